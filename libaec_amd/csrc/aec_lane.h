@@ -1,0 +1,596 @@
+// aec_lane.h -- per-lane building blocks of the MI355X adaptive-entropy codec.
+//
+// Everything here is the work ONE lane does on ONE block (encode) or ONE coded data set
+// (decode).  The functions are __host__ __device__ so the same arithmetic can be exercised
+// by the CPU unit tests (tests/emul) without a GPU; the product only ever calls them from
+// the HIP kernels in aec_enc.hip / aec_dec.hip.
+//
+// Reformulation of the reference's sequential k search (reference src/encode.c:329-410):
+// len(k) = fs(k) + n*(k+1) is convex in k because g(k) = fs(k) - fs(k+1) never increases, so
+// its minimum is attained on one contiguous plateau [klo, khi].  The reference's hill climb
+// started at the previous block's k returns clamp(k_prev, klo, khi) and always the same
+// minimal length.  A block is therefore summarised by (len_min, klo, khi); the carried k is
+// a composition of clamps, which is associative and is resolved by a scan (aec_enc.hip).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define AEC_HD __host__ __device__ __forceinline__
+#else
+#define AEC_HD inline
+#endif
+
+namespace aec {
+
+// ------------------------------------------------------------------------------------
+// stream parameters as the kernels see them
+// ------------------------------------------------------------------------------------
+enum : uint32_t {
+    F_SIGNED = 1, F_3BYTE = 2, F_MSB = 4, F_PREPROCESS = 8, F_RESTRICTED = 16, F_PAD_RSI = 32,
+    F_NOT_ENFORCE = 64
+};
+
+struct Cfg {
+    uint32_t bps;            // bits per sample 1..32
+    uint32_t bs;             // block size in samples (even, <= 64)
+    uint32_t rsi;            // blocks per reference sample interval (1..4096)
+    uint32_t flags;
+    uint32_t id_len;         // 1..5   (reference encode.c:804-859)
+    uint32_t bytes;          // container bytes per sample 1..4
+    uint32_t kmax;           // (1 << id_len) - 3 (encode.c:872); 0 when id_len == 1
+    uint32_t xmin, xmax;     // encode.c:862-870
+    uint32_t segs_per_rsi;   // ceil(rsi / 64): a segment = 64 blocks = one wavefront pass
+    uint32_t pad0;
+    uint64_t total_samples;  // samples in this batch
+    uint64_t total_blocks;   // ceil(total_samples / bs)  (encode.c:676-684 pads the last one)
+    uint64_t total_segs;
+    uint64_t rsi_count;      // ceil(total_blocks / rsi)
+};
+
+enum : uint32_t { OPT_ZERO = 0, OPT_SE = 1, OPT_SPLIT = 2, OPT_UNCOMP = 3, OPT_ZCONT = 4 };
+
+// Per-block summary written by the analysis kernel and consumed by the packing kernel.
+//   [0:12)  CDS length in bits (<= 5 + 32 + 64*32 = 2085)
+//   [12:15) option
+//   [16:21) klo   (split plateau, or for OPT_ZERO the run's unary value, 7 bits [16:23))
+//   [24:29) khi
+AEC_HD uint32_t meta_pack(uint32_t len, uint32_t opt, uint32_t a, uint32_t b)
+{
+    return len | (opt << 12) | (a << 16) | (b << 24);
+}
+AEC_HD uint32_t meta_len(uint32_t m) { return m & 0xFFFu; }
+AEC_HD uint32_t meta_opt(uint32_t m) { return (m >> 12) & 7u; }
+AEC_HD uint32_t meta_a(uint32_t m) { return (m >> 16) & 0xFFu; }
+AEC_HD uint32_t meta_b(uint32_t m) { return (m >> 24) & 0xFFu; }
+
+// k transfer function of a run of blocks: k_out = min(max(k_in, lo), hi)
+struct KClamp {
+    uint32_t lo, hi;
+};
+AEC_HD KClamp kclamp_identity() { return KClamp{0u, 31u}; }
+AEC_HD uint32_t kclamp_apply(KClamp f, uint32_t k) { return k < f.lo ? f.lo : (k > f.hi ? f.hi : k); }
+// first f, then g
+AEC_HD KClamp kclamp_then(KClamp f, KClamp g)
+{
+    return KClamp{kclamp_apply(g, f.lo), kclamp_apply(g, f.hi)};
+}
+
+AEC_HD uint32_t low_mask32(uint32_t n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
+
+AEC_HD uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+AEC_HD int bit_length64(uint64_t v) { return v ? 64 - __builtin_clzll(v) : 0; }
+
+// ------------------------------------------------------------------------------------
+// sample access and the preprocessor (reference encode_accessors.c:61-143, encode.c:235-311)
+// ------------------------------------------------------------------------------------
+AEC_HD uint32_t load_sample_bytes(const uint8_t *p, uint32_t bytes, bool msb)
+{
+    uint32_t v = 0;
+    if (msb) {
+        for (uint32_t i = 0; i < bytes; i++) v = (v << 8) | p[i];
+    } else {
+        for (uint32_t i = bytes; i-- > 0;) v = (v << 8) | p[i];
+    }
+    return v;
+}
+
+AEC_HD uint32_t sign_extend(uint32_t v, uint32_t bps)
+{
+    const uint32_t m = 1u << (bps - 1);
+    return (v ^ m) - m;
+}
+
+// Mapped prediction error of `cur` given its predecessor `prev` (unit-delay predictor).
+// Unsigned flavour: encode.c:255-269.
+AEC_HD uint32_t pp_unsigned(uint32_t prev, uint32_t cur, uint32_t xmax)
+{
+    if (cur >= prev) {
+        const uint32_t delta = cur - prev;
+        return delta <= prev ? 2u * delta : cur;
+    }
+    const uint32_t delta = prev - cur;
+    return delta <= xmax - prev ? 2u * delta - 1u : xmax - cur;
+}
+
+// Signed flavour: encode.c:294-309; inputs already sign extended, arithmetic modulo 2^32.
+AEC_HD uint32_t pp_signed(uint32_t prev_u, uint32_t cur_u, uint32_t xmin, uint32_t xmax)
+{
+    const int32_t prev = (int32_t)prev_u, cur = (int32_t)cur_u;
+    if (cur < prev) {
+        const uint32_t delta = prev_u - cur_u;
+        return delta <= xmax - prev_u ? 2u * delta - 1u : xmax - cur_u;
+    }
+    const uint32_t delta = cur_u - prev_u;
+    return delta <= prev_u - xmin ? 2u * delta : cur_u - xmin;
+}
+
+AEC_HD uint32_t pp_any(uint32_t prev_raw, uint32_t cur_raw, const Cfg &c)
+{
+    if (c.flags & F_SIGNED)
+        return pp_signed(sign_extend(prev_raw, c.bps), sign_extend(cur_raw, c.bps), c.xmin, c.xmax);
+    return pp_unsigned(prev_raw, cur_raw, c.xmax);
+}
+
+// ------------------------------------------------------------------------------------
+// block analysis
+// ------------------------------------------------------------------------------------
+template <int BS, bool WIDE>
+AEC_HD uint64_t fs_sum(const uint32_t *d, uint32_t bs_rt, uint32_t k)
+{
+    const uint32_t bs = BS ? (uint32_t)BS : bs_rt;
+    if (WIDE) {
+        uint64_t s = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < bs; i++) s += (uint64_t)(d[i] >> k);
+        return s;
+    } else {
+        uint32_t s = 0;   // bps <= 16, bs <= 64: at most 64 * 65535 < 2^22
+#pragma unroll
+        for (uint32_t i = 0; i < bs; i++) s += d[i] >> k;
+        return s;
+    }
+}
+
+// Split option: plateau [klo, khi] of minimisers of len(k) over k in [0, kmax] and the minimal
+// length (reference encode.c:329-410; see the note at the top of this file).
+//   n = number of coded samples (bs - ref); the sum runs over the whole block because the
+//   reference sample slot holds d = 0 (encode.c:254, 323-324).
+template <int BS, bool WIDE>
+AEC_HD void assess_split(const uint32_t *d, uint32_t bs_rt, uint32_t n, uint32_t kmax,
+                         uint32_t &klo, uint32_t &khi, uint32_t &len_min)
+{
+    const uint64_t s0 = fs_sum<BS, WIDE>(d, bs_rt, 0);
+    // smallest k that can possibly satisfy g(k) <= n needs n * 2^(k+2) >= s0
+    int ks = bit_length64(s0) - bit_length64(n) - 2;
+    if (ks < 0) ks = 0;
+    if ((uint32_t)ks > kmax) ks = (int)kmax;
+
+    uint32_t k = (uint32_t)ks;
+    uint64_t f_cur = k ? fs_sum<BS, WIDE>(d, bs_rt, k) : s0;
+    bool have_lo = false;
+    klo = khi = kmax;
+    len_min = 0;
+    for (;;) {
+        if (k >= kmax) {
+            if (!have_lo) {
+                klo = kmax;
+                len_min = (uint32_t)(f_cur + (uint64_t)n * (k + 1));
+            }
+            khi = kmax;
+            break;
+        }
+        const uint64_t f_next = fs_sum<BS, WIDE>(d, bs_rt, k + 1);
+        const uint64_t g = f_cur - f_next;
+        if (!have_lo && g <= n) {
+            have_lo = true;
+            klo = k;
+            len_min = (uint32_t)(f_cur + (uint64_t)n * (k + 1));
+        }
+        if (g < n) {
+            khi = k;
+            break;
+        }
+        k++;
+        f_cur = f_next;
+    }
+}
+
+// Second-extension option length, exact replica of the uint64_t arithmetic and the in-order
+// early exit of reference encode.c:412-434.
+template <int BS>
+AEC_HD uint32_t assess_se(const uint32_t *d, uint32_t bs_rt, uint32_t limit)
+{
+    const uint32_t bs = BS ? (uint32_t)BS : bs_rt;
+    uint32_t len = 1;
+    bool over = false;
+#pragma unroll
+    for (uint32_t i = 0; i < bs; i += 2) {
+        const uint32_t a = d[i], b = d[i + 1];
+        const uint32_t s = a + b;
+        if (!over) {
+            if (s < a) {
+                // a + b >= 2^32: replicate the wrapping 64-bit product (encode.c:428-429)
+                const uint64_t s64 = (uint64_t)a + (uint64_t)b;
+                const uint64_t l64 = (uint64_t)len + s64 * (s64 + 1) / 2 + b + 1;
+                if (l64 > limit) over = true; else len = (uint32_t)l64;
+            } else if (s >= 32768u) {
+                over = true;    // s(s+1)/2 >= 2^29 > any limit (limit <= 64*32)
+            } else {
+                len += s * (s + 1) / 2 + b + 1;
+                if (len > limit) over = true;
+            }
+        }
+    }
+    return over ? 0xFFFFFFFFu : len;
+}
+
+struct BlockChoice {
+    uint32_t opt;    // OPT_SE / OPT_SPLIT / OPT_UNCOMP
+    uint32_t bits;   // whole CDS length: id + optional reference sample + payload
+    uint32_t klo, khi;
+};
+
+// reference encode.c:585-612 m_select_code_option (plus the CDS framing of 520-563)
+template <int BS, bool WIDE>
+AEC_HD BlockChoice choose_option(const uint32_t *d, const Cfg &c, uint32_t ref)
+{
+    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
+    const uint32_t n = bs - ref;
+    const uint32_t uncomp_len = n * c.bps;         // encode.c:270, 746: (bs - ref) * bps
+    BlockChoice r;
+    uint32_t split_len = 0xFFFFFFFFu;
+    r.klo = 0;
+    r.khi = 31;
+    if (c.id_len > 1)
+        assess_split<BS, WIDE>(d, bs, n, c.kmax, r.klo, r.khi, split_len);
+    const uint32_t se_len = assess_se<BS>(d, bs, uncomp_len);
+    const uint32_t head = c.id_len + ref * c.bps;
+    if (split_len < uncomp_len) {
+        if (split_len < se_len) { r.opt = OPT_SPLIT; r.bits = head + split_len; }
+        else                    { r.opt = OPT_SE;    r.bits = head + se_len; }
+    } else {
+        if (uncomp_len <= se_len) { r.opt = OPT_UNCOMP; r.bits = c.id_len + bs * c.bps; }
+        else                      { r.opt = OPT_SE;     r.bits = head + se_len; }
+    }
+    return r;
+}
+
+// Zero-block run bookkeeping inside one segment (reference encode.c:614-659, 565-583).
+//   zmask   bit l set <=> block l of the segment is all zero (only bits < nv may be set)
+//   l       this block (must be a zero block)
+//   nv      blocks in the segment (the segment ends at a 64-block boundary or at the RSI end)
+// Returns 0 for a block swallowed by a run that started earlier, else the run length; `fs`
+// receives the unary value of the run's CDS.
+AEC_HD uint32_t zero_run_at(uint64_t zmask, uint32_t l, uint32_t nv, uint32_t &fs)
+{
+    if (l > 0 && ((zmask >> (l - 1)) & 1)) return 0;
+    const uint64_t rest = ~(zmask >> l);                  // first 0 bit = end of run
+    uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+    if (run > nv - l) run = nv - l;
+    const bool closes = (l + run == nv);                  // encode.c:649
+    if (closes && run > 4) fs = 4;                        // ROS, encode.c:650-651, 574-575
+    else if (run >= 5)     fs = run;                      // encode.c:576-577
+    else                   fs = run - 1;                  // encode.c:578-579
+    return run;
+}
+
+// ------------------------------------------------------------------------------------
+// bit emission: MSB-first writer over a zero-initialised array of 32-bit words whose
+// bit 31 is the earliest stream bit.  Sink::or_word(idx, value) ORs into word idx
+// (an LDS atomic on the device, a plain |= in the host tests).
+// ------------------------------------------------------------------------------------
+template <class Sink>
+struct BitWriter {
+    Sink &sink;
+    uint64_t acc;
+    uint32_t n;      // pending bits in acc (low n bits), < 32 between calls
+    uint32_t word;   // next word to be written
+
+    AEC_HD BitWriter(Sink &s, uint32_t bit_offset)
+        : sink(s), acc(0), n(bit_offset & 31u), word(bit_offset >> 5) {}
+
+    AEC_HD void put(uint32_t v, uint32_t nb)   // nb <= 32, v < 2^nb
+    {
+        acc = (acc << nb) | v;
+        n += nb;
+        if (n >= 32) {
+            n -= 32;
+            sink.or_word(word++, (uint32_t)(acc >> n));
+        }
+    }
+    AEC_HD void unary(uint32_t zeros)          // `zeros` 0 bits then a 1 (encode.c:85-104)
+    {
+        if (zeros < 32) {
+            put(1u, zeros + 1u);
+        } else {
+            if (n) sink.or_word(word, (uint32_t)(acc << (32 - n)));
+            const uint32_t pos = n + zeros;
+            word += pos >> 5;
+            n = pos & 31u;
+            acc = 0;
+            put(1u, 1u);
+        }
+    }
+    AEC_HD void finish()
+    {
+        if (n) sink.or_word(word, (uint32_t)(acc << (32 - n)));
+    }
+};
+
+// Emit one block's CDS (reference encode.c:520-583).  d[0] of a reference block is ignored
+// for SPLIT/SE payloads exactly as the reference does (sample slot 0 holds 0 / is skipped).
+template <int BS, class Sink>
+AEC_HD void emit_block(BitWriter<Sink> &w, const uint32_t *d, const Cfg &c, uint32_t opt,
+                       uint32_t k_or_fs, uint32_t ref, uint32_t ref_sample)
+{
+    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
+    if (opt == OPT_SPLIT) {
+        const uint32_t k = k_or_fs;
+        w.put(k + 1u, c.id_len);
+        if (ref) w.put(ref_sample, c.bps);
+#pragma unroll
+        for (uint32_t i = 0; i < bs; i++)
+            if (i >= ref) w.unary(d[i] >> k);
+        if (k) {
+            const uint32_t m = low_mask32(k);
+#pragma unroll
+            for (uint32_t i = 0; i < bs; i++)
+                if (i >= ref) w.put(d[i] & m, k);
+        }
+    } else if (opt == OPT_SE) {
+        w.put(1u, c.id_len + 1u);
+        if (ref) w.put(ref_sample, c.bps);
+#pragma unroll
+        for (uint32_t i = 0; i < bs; i += 2) {
+            const uint32_t s = d[i] + d[i + 1];
+            w.unary(s * (s + 1u) / 2u + d[i + 1]);
+        }
+    } else if (opt == OPT_UNCOMP) {
+        const uint32_t m = low_mask32(c.bps);
+        w.put((1u << c.id_len) - 1u, c.id_len);
+#pragma unroll
+        for (uint32_t i = 0; i < bs; i++)
+            w.put((i == 0 && ref) ? ref_sample : (d[i] & m), c.bps);
+    } else if (opt == OPT_ZERO) {
+        w.put(0u, c.id_len + 1u);
+        if (ref) w.put(ref_sample, c.bps);
+        w.unary(k_or_fs);
+    }
+    w.finish();
+}
+
+// ------------------------------------------------------------------------------------
+// bit reader: stream = big-endian 32-bit words at a 4-byte aligned base
+// ------------------------------------------------------------------------------------
+struct BitReader {
+    const uint32_t *words;
+    uint64_t nwords;     // words that may be read
+    uint64_t end_bit;    // bits that belong to the stream (reads beyond it see zeros)
+    uint64_t pos;        // absolute position of the next unread bit
+    uint64_t win;        // unread bits, left aligned; bits below the top `cnt` are zero
+    uint32_t cnt;        // valid bits in win; (pos + cnt) is always a multiple of 32
+    uint64_t next_word;
+
+    AEC_HD uint32_t fetch(uint64_t idx) const { return idx < nwords ? bswap32(words[idx]) : 0u; }
+
+    AEC_HD void init(const uint32_t *w, uint64_t nw, uint64_t endb, uint64_t start_bit)
+    {
+        words = w; nwords = nw; end_bit = endb; pos = start_bit;
+        const uint32_t sh = (uint32_t)(start_bit & 31u);
+        next_word = (start_bit >> 5) + 1;
+        win = (uint64_t)fetch(start_bit >> 5) << (32 + sh);
+        cnt = 32 - sh;
+    }
+    AEC_HD void refill()   // requires cnt <= 32
+    {
+        win |= (uint64_t)fetch(next_word++) << (32 - cnt);
+        cnt += 32;
+    }
+    AEC_HD uint32_t get(uint32_t n)   // n <= 32
+    {
+        if (n == 0) return 0;
+        if (cnt < n) refill();
+        const uint32_t v = (uint32_t)(win >> (64 - n));
+        win <<= n;
+        cnt -= n;
+        pos += n;
+        return v;
+    }
+    AEC_HD void skip(uint64_t n)
+    {
+        if (n <= cnt) {
+            win = n >= 64 ? 0 : win << n;
+            cnt -= (uint32_t)n;
+            pos += n;
+        } else {
+            init(words, nwords, end_bit, pos + n);
+        }
+    }
+    // counts zeros up to the next 1 (reference decode.c:288-340); false if the stream ends first
+    AEC_HD bool unary(uint32_t &zeros)
+    {
+        uint32_t z = 0;
+        for (;;) {
+            if (win != 0) {
+                const uint32_t c = (uint32_t)__builtin_clzll(win);
+                win = c >= 63 ? 0 : win << (c + 1);
+                cnt -= c + 1;
+                pos += c + 1;
+                zeros = z + c;
+                return true;
+            }
+            z += cnt;
+            pos += cnt;
+            cnt = 0;
+            if (pos >= end_bit) return false;
+            refill();
+        }
+    }
+    // skips `n` unary codes; false if the stream ends first
+    AEC_HD bool skip_unary(uint32_t n)
+    {
+        while (n) {
+            if (cnt == 0) {
+                if (pos >= end_bit) return false;
+                refill();
+            }
+            const uint32_t ones = (uint32_t)__builtin_popcountll(win);
+            if (ones < n) {
+                n -= ones;
+                pos += cnt;
+                cnt = 0;
+                win = 0;
+            } else {
+                uint32_t z;
+                for (; n; n--) unary(z);
+            }
+        }
+        return true;
+    }
+    AEC_HD bool overrun() const { return pos > end_bit; }
+};
+
+// Inverse of the preprocessor (reference decode.c:91-135), one step.
+AEC_HD uint32_t unpp_unsigned(uint32_t x, uint32_t d, uint32_t xmax)
+{
+    const uint32_t med = xmax / 2 + 1;
+    const uint32_t half = (d >> 1) + (d & 1);
+    const uint32_t mask = (x & med) ? xmax : 0;
+    if (half <= (mask ^ x)) return x + ((d & 1) ? ~(d >> 1) : (d >> 1));
+    return mask ^ d;
+}
+AEC_HD uint32_t unpp_signed(uint32_t xu, uint32_t d, uint32_t xmax)
+{
+    const int32_t x = (int32_t)xu;
+    const uint32_t half = (d >> 1) + (d & 1);
+    const uint32_t step = (d & 1) ? ~(d >> 1) : (d >> 1);
+    if (x < 0) {
+        if (half <= xmax + xu + 1u) return xu + step;
+        return d - xmax - 1u;
+    }
+    if (half <= xmax - xu) return xu + step;
+    return xmax - d;
+}
+
+// second-extension code value m -> (a + b, m - tri(a + b)); reference decode.c:679-692 builds
+// the same mapping as a 91-entry table.  false for m > 90 (outside the table).
+AEC_HD bool se_lookup(uint32_t m, uint32_t &sum, uint32_t &second)
+{
+    if (m > 90) return false;
+    uint32_t s = 0, tri = 0;
+    while (tri + s + 1 <= m) { tri += s + 1; s++; }
+    sum = s;
+    second = m - tri;
+    return true;
+}
+
+// Decode status codes shared by the kernels and the host
+enum : uint32_t { DEC_OK = 0, DEC_NEED_INPUT = 1, DEC_DATA_ERROR = 2 };
+
+// Parses one CDS.  d receives the block's samples for SPLIT / SE / UNCOMP (d[0] is the
+// reference sample on a reference block).  For a zero run `nzero_blocks` receives the number
+// of blocks covered and d is untouched (only d[0] = reference sample if ref).
+//   blk_in_rsi = index of this block inside its RSI (needed for ROS, decode.c:528-530)
+template <int BS>
+AEC_HD uint32_t parse_cds(BitReader &r, uint32_t *d, const Cfg &c, uint32_t ref,
+                          uint32_t blk_in_rsi, uint32_t &nzero_blocks)
+{
+    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
+    nzero_blocks = 0;
+    const uint32_t id = r.get(c.id_len);
+    if (id == 0) {                                       // decode.c:634-644, 618-632
+        const uint32_t sel = r.get(1);
+        if (ref) d[0] = r.get(c.bps);
+        if (sel) {                                       // decode.c:589-616
+            uint32_t i = ref;
+#pragma unroll
+            for (uint32_t j = 0; j < bs / 2; j++) {
+                uint32_t m, s, second;
+                if (!r.unary(m)) return DEC_NEED_INPUT;
+                if (!se_lookup(m, s, second)) return r.overrun() ? DEC_NEED_INPUT : DEC_DATA_ERROR;
+                if ((i & 1u) == 0) d[i++] = s - second;
+                d[i++] = second;
+            }
+        } else {                                         // decode.c:518-558
+            uint32_t fs;
+            if (!r.unary(fs)) return DEC_NEED_INPUT;
+            uint32_t nz = fs + 1;
+            if (nz == 5) {
+                const uint32_t left_rsi = c.rsi - blk_in_rsi;
+                const uint32_t left_seg = 64 - (blk_in_rsi % 64);
+                nz = left_rsi < left_seg ? left_rsi : left_seg;
+            } else if (nz > 5) {
+                nz--;
+            }
+            if (r.overrun()) return DEC_NEED_INPUT;
+            if (nz > c.rsi - blk_in_rsi) return DEC_DATA_ERROR;   // decode.c:543-544
+            nzero_blocks = nz;
+        }
+    } else if (id == (1u << c.id_len) - 1u) {            // decode.c:659-677
+#pragma unroll
+        for (uint32_t i = 0; i < bs; i++) d[i] = r.get(c.bps);
+    } else {                                             // decode.c:462-502
+        const uint32_t k = id - 1;
+        if (ref) d[0] = r.get(c.bps);
+#pragma unroll
+        for (uint32_t i = 0; i < bs; i++)
+            if (i >= ref) {
+                uint32_t z;
+                if (!r.unary(z)) return DEC_NEED_INPUT;
+                d[i] = z << k;
+            }
+        if (k) {
+#pragma unroll
+            for (uint32_t i = 0; i < bs; i++)
+                if (i >= ref) d[i] += r.get(k);
+        }
+    }
+    return r.overrun() ? DEC_NEED_INPUT : DEC_OK;
+}
+
+// Skips one CDS without materialising samples (RSI index pass).  Returns blocks covered in
+// `nblocks` (1, or the zero-run length).
+AEC_HD uint32_t skip_cds(BitReader &r, const Cfg &c, uint32_t ref, uint32_t blk_in_rsi,
+                         uint32_t &nblocks)
+{
+    nblocks = 1;
+    const uint32_t id = r.get(c.id_len);
+    if (id == 0) {
+        const uint32_t sel = r.get(1);
+        if (ref) r.skip(c.bps);
+        if (sel) {
+            // every SE code must be a valid table entry; validate while skipping
+            for (uint32_t j = 0; j < c.bs / 2; j++) {
+                uint32_t m;
+                if (!r.unary(m)) return DEC_NEED_INPUT;
+                if (m > 90) return r.overrun() ? DEC_NEED_INPUT : DEC_DATA_ERROR;
+            }
+        } else {
+            uint32_t fs;
+            if (!r.unary(fs)) return DEC_NEED_INPUT;
+            uint32_t nz = fs + 1;
+            if (nz == 5) {
+                const uint32_t left_rsi = c.rsi - blk_in_rsi;
+                const uint32_t left_seg = 64 - (blk_in_rsi % 64);
+                nz = left_rsi < left_seg ? left_rsi : left_seg;
+            } else if (nz > 5) {
+                nz--;
+            }
+            if (r.overrun()) return DEC_NEED_INPUT;
+            if (nz > c.rsi - blk_in_rsi) return DEC_DATA_ERROR;
+            nblocks = nz;
+        }
+    } else if (id == (1u << c.id_len) - 1u) {
+        r.skip((uint64_t)c.bs * c.bps);
+    } else {
+        const uint32_t k = id - 1;
+        if (ref) r.skip(c.bps);
+        if (!r.skip_unary(c.bs - ref)) return DEC_NEED_INPUT;
+        r.skip((uint64_t)(c.bs - ref) * k);
+    }
+    return r.overrun() ? DEC_NEED_INPUT : DEC_OK;
+}
+
+}  // namespace aec

@@ -1,0 +1,194 @@
+// emul.cpp -- CPU harness for libaec_amd/csrc/aec_lane.h (TEST INFRASTRUCTURE).
+// Runs the per-lane device functions lane by lane with the wave-level glue (ballots,
+// prefix sums, k-clamp scan, word assembly) written as plain loops, so the arithmetic and the
+// parallel reformulation can be checked against the oracle without a GPU.  Not linked into
+// the product library.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../libaec_amd/csrc/aec_lane.h"
+#include "../../libaec_amd/csrc/aec_cfg.h"
+
+using namespace aec;
+
+struct VecSink {
+    std::vector<uint32_t> &w;
+    void or_word(uint32_t i, uint32_t v) { if (i >= w.size()) w.resize(i + 1, 0); w[i] |= v; }
+};
+
+template <bool WIDE>
+static int encode_t(const Cfg &c, const uint8_t *in, uint8_t *out, size_t cap, uint32_t start_bit,
+                    uint32_t k_in, uint64_t *total_bits, uint32_t *k_out, uint32_t *meta_out,
+                    uint64_t *rsi_off)
+{
+    const bool pp = c.flags & F_PREPROCESS, msb = c.flags & F_MSB;
+    const uint32_t mask = low_mask32(c.bps);
+    uint64_t bitpos = start_bit;
+    uint32_t kcur = k_in;
+    memset(out, 0, cap);
+    std::vector<uint32_t> d(64 * 64);
+    for (uint64_t sg = 0; sg < c.total_segs; sg++) {
+        const uint64_t r = sg / c.segs_per_rsi;
+        const uint32_t s = (uint32_t)(sg % c.segs_per_rsi);
+        const uint32_t b0 = s * 64;
+        uint64_t nb_rsi = c.total_blocks - r * c.rsi;
+        if (nb_rsi > c.rsi) nb_rsi = c.rsi;
+        const uint32_t nv = (uint32_t)((nb_rsi - b0) < 64 ? (nb_rsi - b0) : 64);
+        const uint64_t samp0 = (r * c.rsi + b0) * (uint64_t)c.bs;
+        auto raw = [&](uint64_t i) {
+            if (i >= c.total_samples) i = c.total_samples - 1;
+            return load_sample_bytes(in + i * c.bytes, c.bytes, msb);
+        };
+        if (s == 0 && rsi_off) rsi_off[r] = bitpos;
+        const uint32_t ref_sample = raw(r * c.rsi * (uint64_t)c.bs) & mask;
+        // phase A: preprocess
+        for (uint32_t i = 0; i < nv * c.bs; i++) {
+            const uint64_t gi = samp0 + i;
+            uint32_t v;
+            if (!pp) v = raw(gi);
+            else if (b0 == 0 && i == 0) v = 0;
+            else v = pp_any(raw(gi - 1), raw(gi), c);
+            d[i] = v;
+        }
+        // phase B: per lane analysis
+        uint32_t meta[64]; uint64_t zmask = 0;
+        BlockChoice ch[64];
+        for (uint32_t l = 0; l < nv; l++) {
+            bool z = true;
+            for (uint32_t i = 0; i < c.bs; i++) if (d[l * c.bs + i]) z = false;
+            if (z) zmask |= 1ull << l;
+        }
+        KClamp segc = kclamp_identity();
+        uint32_t kprev[64];
+        for (uint32_t l = 0; l < nv; l++) {
+            const uint32_t ref = (pp && b0 == 0 && l == 0) ? 1 : 0;
+            kprev[l] = kclamp_apply(segc, kcur);
+            if ((zmask >> l) & 1) {
+                uint32_t fs;
+                const uint32_t run = zero_run_at(zmask, l, nv, fs);
+                if (run == 0) meta[l] = meta_pack(0, OPT_ZCONT, 0, 0);
+                else meta[l] = meta_pack(c.id_len + 1 + ref * c.bps + fs + 1, OPT_ZERO, fs, 0);
+            } else {
+                ch[l] = choose_option<0, WIDE>(&d[l * c.bs], c, ref);
+                meta[l] = meta_pack(ch[l].bits, ch[l].opt, ch[l].klo, ch[l].khi);
+                if (c.id_len > 1) segc = kclamp_then(segc, KClamp{ch[l].klo, ch[l].khi});
+            }
+            if (meta_out) meta_out[(r * c.rsi + b0) + l] = meta[l];
+        }
+        // pack
+        uint32_t lead = (uint32_t)(bitpos & 31);
+        std::vector<uint32_t> words;
+        VecSink sink{words};
+        uint32_t off = lead;
+        for (uint32_t l = 0; l < nv; l++) {
+            const uint32_t ref = (pp && b0 == 0 && l == 0) ? 1 : 0;
+            const uint32_t opt = meta_opt(meta[l]);
+            if (opt == OPT_ZCONT) continue;
+            uint32_t karg = opt == OPT_ZERO ? meta_a(meta[l])
+                           : kclamp_apply(KClamp{meta_a(meta[l]), meta_b(meta[l])}, kprev[l]);
+            BitWriter<VecSink> w(sink, off);
+            emit_block<0>(w, &d[l * c.bs], c, opt, karg, ref, ref_sample);
+            off += meta_len(meta[l]);
+        }
+        kcur = kclamp_apply(segc, kcur);
+        const uint64_t gw = bitpos >> 5;
+        for (size_t w = 0; w < words.size(); w++) {
+            const uint32_t v = bswap32(words[w]);
+            const size_t byte = (gw + w) * 4;
+            for (int b = 0; b < 4; b++)
+                if (byte + b < cap) out[byte + b] |= (uint8_t)(v >> (8 * b));
+        }
+        bitpos += off - lead;
+    }
+    if (rsi_off) rsi_off[c.rsi_count] = bitpos;
+    *total_bits = bitpos - start_bit;
+    *k_out = kcur;
+    return 0;
+}
+
+extern "C" int emul_encode(const uint32_t *p /*bps,bs,rsi,flags*/, const uint8_t *in, size_t in_len,
+                           uint8_t *out, size_t cap, uint32_t start_bit, uint32_t k_in,
+                           uint64_t *total_bits, uint32_t *k_out, uint32_t *meta_out, uint64_t *rsi_off)
+{
+    Cfg c;
+    int rc = make_cfg(p[0], p[1], p[2], p[3], in_len, true, &c);
+    if (rc) return rc;
+    return c.bps > 16 ? encode_t<true>(c, in, out, cap, start_bit, k_in, total_bits, k_out, meta_out, rsi_off)
+                      : encode_t<false>(c, in, out, cap, start_bit, k_in, total_bits, k_out, meta_out, rsi_off);
+}
+
+// decode every RSI from its bit offset; returns status, writes whole blocks
+extern "C" int emul_decode(const uint32_t *p, const uint8_t *in, size_t in_len, const uint64_t *rsi_off,
+                           uint64_t nrsi, uint64_t total_blocks, uint8_t *out, size_t cap)
+{
+    Cfg c;
+    int rc = make_cfg(p[0], p[1], p[2], p[3], 0, false, &c);
+    if (rc) return rc;
+    const bool pp = c.flags & F_PREPROCESS, msb = c.flags & F_MSB;
+    std::vector<uint32_t> words((in_len + 3) / 4 + 1, 0);
+    memcpy(words.data(), in, in_len);
+    uint32_t d[64];
+    for (uint64_t r = 0; r < nrsi; r++) {
+        BitReader br;
+        br.init(words.data(), words.size(), (uint64_t)in_len * 8, rsi_off[r]);
+        uint64_t nb = total_blocks - r * c.rsi;
+        if (nb > c.rsi) nb = c.rsi;
+        uint32_t x = 0;
+        uint64_t o = r * c.rsi * (uint64_t)c.bs;
+        uint32_t b = 0;
+        while (b < nb) {
+            const uint32_t ref = (pp && b == 0) ? 1 : 0;
+            uint32_t nz;
+            const uint32_t st = parse_cds<0>(br, d, c, ref, b, nz);
+            if (st != DEC_OK) return (int)st;
+            uint32_t nblk = nz ? nz : 1;
+            // a rest-of-segment run in a short final RSI is closed by the end of the data, not by
+            // the nominal RSI length: never produce more blocks than the caller expects
+            if (nblk > nb - b) nblk = (uint32_t)(nb - b);
+            for (uint32_t j = 0; j < nblk * c.bs; j++) {
+                uint32_t v;
+                const uint32_t dv = nz ? ((j == 0 && ref) ? d[0] : 0) : d[j];
+                if (!pp) v = dv;
+                else if (ref && j == 0) v = x = (c.flags & F_SIGNED) ? sign_extend(dv, c.bps) : dv;
+                else v = x = (c.flags & F_SIGNED) ? unpp_signed(x, dv, c.xmax) : unpp_unsigned(x, dv, c.xmax);
+                uint8_t *q = out + (o + j) * c.bytes;
+                if ((o + j + 1) * c.bytes > cap) return -100;
+                for (uint32_t t = 0; t < c.bytes; t++)
+                    q[t] = (uint8_t)(v >> (8 * (msb ? c.bytes - 1 - t : t)));
+            }
+            o += (uint64_t)nblk * c.bs;
+            b += nblk;
+        }
+    }
+    return 0;
+}
+
+// serial RSI index: walks the stream from bit `start_bit` (an RSI start) and records offsets
+extern "C" int emul_index(const uint32_t *p, const uint8_t *in, size_t in_len, uint64_t start_bit,
+                          uint64_t *rsi_off, uint64_t max_rsi, uint64_t *n_rsi, uint64_t *tail_blocks,
+                          uint64_t *end_bit)
+{
+    Cfg c;
+    int rc = make_cfg(p[0], p[1], p[2], p[3], 0, false, &c);
+    if (rc) return rc;
+    const bool pp = c.flags & F_PREPROCESS;
+    std::vector<uint32_t> words((in_len + 3) / 4 + 1, 0);
+    memcpy(words.data(), in, in_len);
+    BitReader br;
+    br.init(words.data(), words.size(), (uint64_t)in_len * 8, start_bit);
+    uint64_t r = 0; uint32_t b = 0; uint64_t good = start_bit;
+    int status = DEC_OK;
+    for (;;) {
+        if (b == 0) { if (r >= max_rsi) break; rsi_off[r] = good; }
+        uint32_t nblk;
+        BitReader save = br;
+        const uint32_t st = skip_cds(br, c, (pp && b == 0) ? 1 : 0, b, nblk);
+        if (st != DEC_OK) { br = save; status = st == DEC_NEED_INPUT ? 0 : (int)st; break; }
+        good = br.pos;
+        b += nblk;
+        if (b >= c.rsi) { b = 0; r++; }
+    }
+    *n_rsi = r; *tail_blocks = b; *end_bit = good;
+    return status;
+}

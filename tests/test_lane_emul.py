@@ -1,0 +1,161 @@
+"""CPU check of the per-lane device functions (libaec_amd/csrc/aec_lane.h) and of the parallel
+reformulation (plateau clamp for k, segment-local zero runs, word assembly) through the host
+harness tests/emul/emul.cpp, against the oracle and the reference-produced golden vectors."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import (AEC_DATA_3BYTE, AEC_DATA_MSB, AEC_DATA_PREPROCESS, AEC_DATA_SIGNED,
+                     AEC_NOT_ENFORCE, AEC_RESTRICTED, OPT_SE, OPT_SPLIT, OPT_UNCOMP, OPT_ZERO,
+                     OPT_ZERO_CONT, ROOT, bytes_per_sample, max_encoded_size, oracle_decode,
+                     oracle_encode, pack_samples, random_walk_samples)
+
+EMUL_DIR = os.path.join(ROOT, "tests", "emul")
+EMUL_SO = os.path.join(EMUL_DIR, "_build", "libemul.so")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    os.makedirs(os.path.dirname(EMUL_SO), exist_ok=True)
+    srcs = [os.path.join(EMUL_DIR, "emul.cpp"),
+            os.path.join(ROOT, "libaec_amd", "csrc", "aec_lane.h"),
+            os.path.join(ROOT, "libaec_amd", "csrc", "aec_cfg.h")]
+    if not os.path.exists(EMUL_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMUL_SO) for s in srcs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+                        "-o", EMUL_SO, srcs[0]], check=True)
+    lib = C.CDLL(EMUL_SO)
+    lib.emul_encode.restype = C.c_int
+    lib.emul_decode.restype = C.c_int
+    lib.emul_index.restype = C.c_int
+    return lib
+
+
+def emul_encode(lib, data, bps, bs, rsi, flags, start_bit=0, k_in=0):
+    a = np.ascontiguousarray(data, dtype=np.uint8)
+    cap = max_encoded_size(a.size, bps, bs, flags) + 16
+    out = np.zeros(cap, np.uint8)
+    nb = bytes_per_sample(bps, flags)
+    nblk = (a.size // nb + bs - 1) // bs
+    nrsi = (nblk + rsi - 1) // rsi
+    meta = np.zeros(max(nblk, 1), np.uint32)
+    offs = np.zeros(nrsi + 1, np.uint64)
+    p = (C.c_uint32 * 4)(bps, bs, rsi, flags)
+    tb, ko = C.c_uint64(0), C.c_uint32(0)
+    rc = lib.emul_encode(p, C.c_void_p(a.ctypes.data), C.c_size_t(a.size), C.c_void_p(out.ctypes.data),
+                         C.c_size_t(cap), C.c_uint32(start_bit), C.c_uint32(k_in), C.byref(tb),
+                         C.byref(ko), C.c_void_p(meta.ctypes.data), C.c_void_p(offs.ctypes.data))
+    return rc, out, tb.value, ko.value, meta[:nblk], offs
+
+
+def stream_bytes(out, total_bits, start_bit=0):
+    n = max(1, (start_bit + total_bits + 7) // 8) if start_bit + total_bits else 1
+    return out[:n].tobytes()
+
+
+def check_case(lib, name, bps, bs, rsi, flags, data, expect):
+    rc, out, tb, ko, meta, offs = emul_encode(lib, data, bps, bs, rsi, flags)
+    assert rc == 0, name
+    assert stream_bytes(out, tb) == expect, name
+    # per-block summary must agree with the sequential oracle
+    rc, enc, trace, o_offs, o_bits = oracle_encode(data, bps, bs, rsi, flags, want_trace=True)
+    assert o_bits == tb, name
+    assert np.array_equal(offs[:-1], o_offs), name
+    assert np.array_equal(meta & 0xFFF, trace["bits"]), name
+    opt_map = {0: OPT_ZERO, 1: OPT_SE, 2: OPT_SPLIT, 3: OPT_UNCOMP, 4: OPT_ZERO_CONT}
+    assert [opt_map[int(o)] for o in (meta >> 12) & 7] == trace["option"].tolist(), name
+    if len(trace):
+        assert ko == trace["k"][-1], name
+    # decode from the RSI offsets
+    nb = bytes_per_sample(bps, flags)
+    nblk = (data.size // nb + bs - 1) // bs
+    dec = np.zeros(nblk * bs * nb + 8, np.uint8)
+    p = (C.c_uint32 * 4)(bps, bs, rsi, flags)
+    enc_a = np.frombuffer(expect, dtype=np.uint8)
+    rc = lib.emul_decode(p, C.c_void_p(enc_a.ctypes.data), C.c_size_t(enc_a.size),
+                         C.c_void_p(offs.ctypes.data), C.c_uint64(len(offs) - 1), C.c_uint64(nblk),
+                         C.c_void_p(dec.ctypes.data), C.c_size_t(dec.size))
+    assert rc == 0, name
+    rc, odec, _ = oracle_decode(expect, bps, bs, rsi, flags, nblk * bs * nb)
+    assert dec[:nblk * bs * nb].tobytes() == odec, name
+    # serial index pass finds the same RSI offsets
+    ioffs = np.zeros(len(offs) + 2, np.uint64)
+    n_rsi, tail, endb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    rc = lib.emul_index(p, C.c_void_p(enc_a.ctypes.data), C.c_size_t(enc_a.size), C.c_uint64(0),
+                        C.c_void_p(ioffs.ctypes.data), C.c_uint64(len(ioffs)), C.byref(n_rsi),
+                        C.byref(tail), C.byref(endb))
+    assert rc == 0, name
+    # a rest-of-segment zero run that closes a short final RSI is indistinguishable from one
+    # reaching the nominal segment end, so the walker may count up to 63 phantom blocks there
+    assert nblk <= n_rsi.value * rsi + tail.value <= nblk + 63, (name, n_rsi.value, tail.value, nblk)
+    assert endb.value == tb, name
+    nfound = min(n_rsi.value + (1 if tail.value else 0), len(offs) - 1)
+    assert np.array_equal(ioffs[:nfound], offs[:nfound]), name
+
+
+def test_golden_through_lane_functions(emul, golden):
+    for i in range(len(golden)):
+        name, bps, bs, rsi, flags, data, expect, _ = golden.case(i)
+        if bps == 1 and flags & AEC_DATA_SIGNED:
+            continue
+        check_case(emul, name, bps, bs, rsi, flags, data, expect)
+
+
+def test_random_sweep_vs_oracle(emul):
+    rng = np.random.default_rng(4242)
+    for it in range(600):
+        bps = int(rng.integers(1, 33))
+        flags = 0
+        if rng.random() < 0.75:
+            flags |= AEC_DATA_PREPROCESS
+        if rng.random() < 0.5:
+            flags |= AEC_DATA_MSB
+        if rng.random() < 0.4 and bps > 1:
+            flags |= AEC_DATA_SIGNED
+        if rng.random() < 0.3:
+            flags |= AEC_DATA_3BYTE
+        if bps <= 4 and rng.random() < 0.5:
+            flags |= AEC_RESTRICTED
+        if rng.random() < 0.2:
+            flags |= AEC_NOT_ENFORCE
+            bs = int(rng.integers(1, 33)) * 2
+        else:
+            bs = int(rng.choice([8, 16, 32, 64]))
+        rsi = int(rng.choice([1, 2, 3, 5, 17, 63, 64, 65, 128, 130, 300]))
+        n = int(rng.integers(1, 5000))
+        mode = rng.integers(0, 3)
+        if mode == 0:
+            vals = random_walk_samples(rng, n, bps, flags, scale=float(rng.choice([0.3, 1, 5, 50, 1000])),
+                                       zero_frac=float(rng.choice([0.05, 0.6])))
+        elif mode == 1:
+            lo = -(1 << (bps - 1)) if flags & AEC_DATA_SIGNED else 0
+            hi = (1 << (bps - 1)) - 1 if flags & AEC_DATA_SIGNED else (1 << bps) - 1
+            vals = rng.integers(lo, hi + 1, size=n)
+        else:   # long constant stretches: zero runs that close at segment / RSI ends (ROS)
+            vals = np.repeat(rng.integers(0, 1 << min(bps, 7), size=n // 97 + 1), 97)[:n]
+        data = pack_samples(vals, bps, flags)
+        rc, expect, *_ = oracle_encode(data, bps, bs, rsi, flags)
+        assert rc == 0
+        check_case(emul, f"it{it}-n{bps}-j{bs}-r{rsi}-f{flags}-len{n}", bps, bs, rsi, flags, data, expect)
+
+
+def test_carry_in_matches_split_stream(emul):
+    """Encoding a stream in two batches with (bit offset, k) carried over must give the bytes
+    of the one-shot encode -- what the streaming front-end and the multi-GPU split rely on."""
+    rng = np.random.default_rng(9)
+    bps, bs, rsi, flags = 16, 16, 8, AEC_DATA_PREPROCESS
+    vals = random_walk_samples(rng, bs * rsi * 6, bps, flags, scale=2.0, zero_frac=0.3)
+    data = pack_samples(vals, bps, flags)
+    rc, whole, *_ = oracle_encode(data, bps, bs, rsi, flags)
+    cut = bs * rsi * 2 * 2     # 2 RSIs, in bytes
+    rc, o1, tb1, k1, *_ = emul_encode(emul, data[:cut], bps, bs, rsi, flags)
+    rc, o2, tb2, k2, *_ = emul_encode(emul, data[cut:], bps, bs, rsi, flags, start_bit=tb1 % 8, k_in=k1)
+    nb1 = tb1 // 8
+    merged = bytearray(o1[:nb1].tobytes())
+    tail = bytearray(stream_bytes(o2, tb2, tb1 % 8))
+    if tb1 % 8:
+        tail[0] |= int(o1[nb1])
+    merged += tail
+    assert bytes(merged) == whole
