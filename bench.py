@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- encode+decode throughput of the MI355X adaptive entropy coder.
+
+One "step" = one pass of the hot path over the rank's resident input: encode the whole shard
+(analyze -> scan -> clear -> pack) and decode it again from the encoder's RSI offset table.
+Workload = BASELINE.json configs[1] shape: 4 GiB of synthetic low-entropy 16-bit samples per
+GPU, block 16, rsi 128, AEC_DATA_PREPROCESS (generator: libaec_amd/csrc/datagen.c, seed
+0x5EED0000 + rank).  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 every rank codes its own shard as an independent stream (weak scaling) and the
+compressed shards are reassembled on every rank by ONE RCCL all-gather per step, issued on a side
+stream so that it overlaps the local decode.
+
+Rank 0 prints one JSON line: metric/value (whole-job GB/s of input bytes through encode+decode),
+`roofline` for the dominant kernel (HIP-event time measured in this run) and `cpu_baseline`
+(the reference libaec -- or the oracle port if oracle/_ref is absent -- timed on one host core on
+a bounded prefix of the same input).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+BPS, BS, RSI = 16, 16, 128
+FLAGS = 8               # AEC_DATA_PREPROCESS
+
+
+def generate(kind, nbytes, shard, threads):
+    lib = C.CDLL(os.path.join(ROOT, "libaec_amd", "lib", "libaec_datagen.so"))
+    a = np.empty(nbytes, dtype=np.uint8)
+    lib.aec_gen_fill_parallel(C.c_uint(kind), C.c_uint64(shard), C.c_void_p(a.ctypes.data),
+                              C.c_size_t(nbytes // 2), C.c_uint(threads))
+    return a
+
+
+def cpu_baseline(sample):
+    """Reference libaec (oracle/_ref) if it travelled with the repo, else the oracle port;
+    one thread, in memory, encode + decode of `sample`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    kind = "reference" if helpers.have_ref() else "port"
+    t0 = time.perf_counter()
+    if kind == "reference":
+        rc, enc = helpers.ref_encode(sample, BPS, BS, RSI, FLAGS)
+    else:
+        rc, enc, *_ = helpers.oracle_encode(sample, BPS, BS, RSI, FLAGS)
+    t1 = time.perf_counter()
+    if kind == "reference":
+        rc2, dec = helpers.ref_decode(enc, BPS, BS, RSI, FLAGS, sample.size)
+    else:
+        rc2, dec, _ = helpers.oracle_decode(enc, BPS, BS, RSI, FLAGS, sample.size)
+    t2 = time.perf_counter()
+    assert rc == 0 and rc2 == 0 and dec == sample.tobytes()
+    n = sample.size
+    return {"value": round(n / (t2 - t0) / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": kind,
+            "sample": f"first {n >> 20} MiB of the rank-0 input, aec_buffer_encode + aec_buffer_decode "
+                      f"in memory, 1 thread",
+            "encode_GBps": round(n / (t1 - t0) / 1e9, 4), "decode_GBps": round(n / (t2 - t1) / 1e9, 4),
+            "compressed_bytes": len(enc)}, enc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size-mib", type=int, default=4096, help="input bytes per GPU (MiB)")
+    ap.add_argument("--cpu-sample-mib", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of compressed shards")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (the codec has no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from libaec_amd import gpu
+
+    nbytes = args.size_mib << 20
+    threads = max(1, (os.cpu_count() or 8) // max(1, world))
+    host = generate(0, nbytes, rank, threads)
+
+    codec = gpu.Codec(BPS, BS, RSI, FLAGS)
+    codec.reserve(nbytes)
+    d_in = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    step = 256 << 20
+    for o in range(0, nbytes, step):
+        d_in[o:o + step].copy_(torch.from_numpy(host[o:o + step]))
+    n_rsi, n_blk = codec.rsi_count(nbytes), codec.block_count(nbytes)
+    d_out = torch.empty(codec.encode_bound(nbytes), dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n_rsi + 1, dtype=torch.int64, device=dev)
+    d_eres = torch.zeros(16, dtype=torch.uint8, device=dev)
+    d_dres = torch.zeros(48, dtype=torch.uint8, device=dev)
+    d_dec = torch.empty(nbytes + 16, dtype=torch.uint8, device=dev)
+
+    # ---- untimed: one encode to learn the compressed size, correctness of the timed configuration
+    codec.encode_async(d_in, nbytes, d_out, d_off, d_eres)
+    eres = d_eres.cpu().numpy().view(gpu.ENC_RESULT_DTYPE)[0]
+    assert not eres["overflow"]
+    cbytes = (int(eres["total_bits"]) + 7) // 8
+    codec.decode_async(d_out, cbytes, d_off, n_rsi, n_blk, d_dec, d_dres)
+    dres = d_dres.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]
+    assert dres["status"] == 0, "decode reported an error"
+    assert torch.equal(d_dec[:nbytes], d_in), "round trip differs"
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        sample = host[: min(nbytes, args.cpu_sample_mib << 20)]
+        cpu, enc_cpu = cpu_baseline(sample)
+        # the GPU stream's prefix must be the CPU stream (whole RSIs code to a prefix of the stream)
+        nfull = len(enc_cpu) - 1
+        assert d_out[:nfull].cpu().numpy().tobytes() == enc_cpu[:nfull], "GPU stream != CPU reference stream"
+    del host
+
+    gather = world > 1 and not args.no_gather
+    if gather:
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([cbytes], dtype=torch.int64, device=dev))
+        pad = (max(int(s.item()) for s in sizes) + 4095) // 4096 * 4096
+        d_all = torch.empty(world * pad, dtype=torch.uint8, device=dev)
+        comm = torch.cuda.Stream(device=dev)
+
+    def one_step():
+        codec.encode_async(d_in, nbytes, d_out, d_off, d_eres)
+        if gather:
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready)
+                dist.all_gather_into_tensor(d_all, d_out[:pad])
+        codec.decode_async(d_out, cbytes, d_off, n_rsi, n_blk, d_dec, d_dres)
+        if gather:
+            torch.cuda.current_stream().wait_stream(comm)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel device time of this run (HIP events recorded by the library on the same stream)
+    lib = gpu._lib()
+    lib.aec_gpu_profile.argtypes = [C.c_void_p, C.c_int]
+    lib.aec_gpu_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.aec_gpu_profile(codec.ctx, 1)
+    acc = np.zeros(5)
+    reps = max(3, min(args.steps, 10))
+    for _ in range(reps):
+        codec.encode_async(d_in, nbytes, d_out, d_off, d_eres)
+        codec.decode_async(d_out, cbytes, d_off, n_rsi, n_blk, d_dec, d_dres)
+        ms = (C.c_float * 5)()
+        lib.aec_gpu_phase_ms(codec.ctx, ms)
+        acc += np.array(list(ms))
+    lib.aec_gpu_profile(codec.ctx, 0)
+    phase = dict(zip(["analyze", "scan", "clear", "pack", "decode"], (acc / reps).tolist()))
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * nbytes / (elapsed / args.steps) / 1e9
+        algo = {"analyze": nbytes, "pack": nbytes + cbytes, "decode": nbytes + cbytes}
+        dom = max(algo, key=lambda k: phase[k])
+        achieved = algo[dom] / (phase[dom] * 1e-3) / 1e9
+        enc_ms = phase["analyze"] + phase["scan"] + phase["clear"] + phase["pack"]
+        out = {
+            "metric": "encode+decode GB/s (input bytes)",
+            "value": round(value, 3),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"lowent16 {args.size_mib} MiB per GPU, 16-bit LSB unsigned, block 16, rsi 128, "
+                                   f"AEC_DATA_PREPROCESS; step = encode + decode (RSI offset table)"
+                                   + ("; + RCCL all-gather of compressed shards" if gather else ""),
+                       "bits_per_sample": BPS, "block_size": BS, "rsi": RSI, "flags": FLAGS,
+                       "input_bytes_per_gpu": nbytes, "compressed_bytes_rank0": cbytes,
+                       "ratio": round(nbytes / cbytes, 3), "bit_exact_vs_cpu": cpu is not None,
+                       "parallelism": f"{world} independent shard stream(s)"},
+            "roofline": {"bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": algo[dom], "kernel_ms": round(phase[dom], 4)},
+            "cpu_baseline": cpu,
+            "phases_ms": {k: round(v, 4) for k, v in phase.items()},
+            "encode_GBps": round(nbytes / (enc_ms * 1e-3) / 1e9, 2),
+            "decode_GBps": round(nbytes / (phase["decode"] * 1e-3) / 1e9, 2),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

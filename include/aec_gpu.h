@@ -1,0 +1,113 @@
+/*
+ * aec_gpu.h -- device-resident batch interface of the MI355X adaptive entropy coder.
+ *
+ * The libaec ABI (libaec.h) hands over host buffers; these entry points are what sits directly
+ * under it and what a GPU-resident caller (an HDF5 VOL/filter that keeps chunks in HBM, the
+ * benchmark, the multi-GPU driver) binds instead: all pointers marked d_ are HIP device
+ * pointers, every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) and
+ * returns; results are written to device memory.  No reference counterpart: the reference is
+ * CPU-only (this replaces the per-RSI loops of reference src/encode.c:709-754 and
+ * src/decode.c:797-831 for a whole batch of RSIs at once).
+ */
+#ifndef AEC_GPU_H
+#define AEC_GPU_H 1
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AEC_GPU_API __attribute__((visibility("default")))
+
+typedef struct aec_gpu_ctx aec_gpu_ctx;
+
+/* same four values a caller puts into struct aec_stream (reference src/libaec.h:84-94) */
+typedef struct aec_gpu_params {
+    unsigned int bits_per_sample;
+    unsigned int block_size;
+    unsigned int rsi;
+    unsigned int flags;
+} aec_gpu_params;
+
+typedef struct aec_gpu_enc_result {
+    uint64_t total_bits;  /* stream bits produced by the call (without the carried-in start bits) */
+    uint32_t k_out;       /* encoder's carried k after the last block (reference state->k) */
+    uint32_t overflow;    /* 1: out_cap was too small, output clipped */
+} aec_gpu_enc_result;
+
+typedef struct aec_gpu_dec_result {
+    uint64_t n_rsi;        /* index pass: complete RSIs found */
+    uint64_t tail_blocks;  /* index pass: complete blocks of the trailing partial RSI */
+    uint64_t end_bit;      /* index pass: bit position after the last complete coded data set */
+    uint32_t status;       /* 0 ok, 1 input ended inside a coded data set, 2 corrupt stream */
+    uint32_t pad;
+    uint64_t bad_rsi;      /* lowest RSI with status != 0 */
+} aec_gpu_dec_result;
+
+/* Context = workspace on the current HIP device.  One context per host thread / stream. */
+AEC_GPU_API int aec_gpu_create(aec_gpu_ctx **ctx);
+AEC_GPU_API void aec_gpu_destroy(aec_gpu_ctx *ctx);
+
+/* AEC_OK or AEC_CONF_ERROR for a parameter set (same rules as aec_encode_init / aec_decode_init) */
+AEC_GPU_API int aec_gpu_check_params(const aec_gpu_params *p, int for_encode);
+
+/* Output capacity (bytes, multiple of 16) that can never overflow for in_bytes of input. */
+AEC_GPU_API size_t aec_gpu_encode_bound(const aec_gpu_params *p, size_t in_bytes);
+/* Number of RSIs / blocks in_bytes of input make (entries in the offset table = n_rsi + 1). */
+AEC_GPU_API uint64_t aec_gpu_rsi_count(const aec_gpu_params *p, size_t in_bytes);
+AEC_GPU_API uint64_t aec_gpu_block_count(const aec_gpu_params *p, size_t in_bytes);
+
+/* Grow the context's workspace for inputs up to in_bytes now (allocation synchronises the
+ * device; doing it here keeps the enqueue calls below free of allocations). */
+AEC_GPU_API int aec_gpu_reserve(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes);
+
+/*
+ * Encode in_bytes at d_in (16-byte aligned) into d_out (16-byte aligned, out_cap a multiple of
+ * 16).  The stream continues at bit `start_bit` (0..7) of d_out[0] with carried k `k_in` (both
+ * 0 for a new stream); bits before start_bit are left zero for the caller to merge.  All whole
+ * samples are coded; a final partial block is padded as aec_encode(AEC_FLUSH) does.  The final
+ * zero padding to a byte boundary is implicit (the buffer is cleared up to the last word).
+ * d_rsi_bit_offsets (optional) receives rsi_count + 1 absolute bit positions: the start of every
+ * RSI and the end of the stream.  d_result receives an aec_gpu_enc_result.
+ */
+AEC_GPU_API int aec_gpu_encode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                     size_t in_bytes, void *d_out, size_t out_cap,
+                                     unsigned int start_bit, unsigned int k_in,
+                                     uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result,
+                                     void *stream);
+
+/*
+ * Decode n_rsi RSIs whose start bits are d_rsi_bit_offsets[0..n_rsi) (relative to d_in, which
+ * must be 4-byte aligned and readable up to the next multiple of 4) into d_out, producing
+ * `total_blocks` whole blocks (the last RSI may be short).  d_out needs
+ * total_blocks * block_size * bytes_per_sample bytes and 16-byte alignment.
+ */
+AEC_GPU_API int aec_gpu_decode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                     size_t in_bytes, const uint64_t *d_rsi_bit_offsets,
+                                     uint64_t n_rsi, uint64_t total_blocks, void *d_out,
+                                     aec_gpu_dec_result *d_result, void *stream);
+
+/*
+ * Find the RSI start offsets of a stream that comes without an offset table: a serial walk from
+ * bit start_bit (an RSI boundary) that stops at the end of the input, after max_rsi RSIs, or at
+ * a corrupt coded data set.  d_rsi_bit_offsets needs max_rsi entries.
+ */
+AEC_GPU_API int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                    size_t in_bytes, uint64_t start_bit, uint64_t *d_rsi_bit_offsets,
+                                    uint64_t max_rsi, aec_gpu_dec_result *d_result, void *stream);
+
+/*
+ * Measurement hooks (bench.py): with profiling enabled the context records HIP events on the
+ * caller's stream around its kernels; aec_gpu_phase_ms waits for them and returns the device
+ * time of the LAST encode (analyze, scan, clear, pack) and decode call in milliseconds
+ * (-1 for a phase that has not run).
+ */
+AEC_GPU_API int aec_gpu_profile(aec_gpu_ctx *ctx, int enable);
+AEC_GPU_API int aec_gpu_phase_ms(aec_gpu_ctx *ctx, float ms[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AEC_GPU_H */

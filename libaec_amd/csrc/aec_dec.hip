@@ -1,0 +1,271 @@
+// aec_dec.hip -- gfx950 decoder kernels for the CCSDS 121.0-B-2 adaptive entropy coder.
+//
+//   k_decode  ONE LANE PER RSI.  A coded data set can only be located by parsing its
+//             predecessor (the stream has no lengths, reference src/decode.c:402-421), so the
+//             bit-serial dependency is kept inside a lane: the lane walks its RSI block by block
+//             with a 64-bit window (reference decode.c:222-340), runs the inverse predictor
+//             (decode.c:67-141), which is a serial chain as well, and stores whole blocks in the
+//             caller's byte order (decode.c:144-189).  Parallelism comes from the RSIs: 4 GiB of
+//             16-bit / block 16 / rsi 128 data is one million independent lanes.
+//   k_index   serial walk over one stream that only finds the RSI start offsets (no samples
+//             are produced); needed for streams that arrive without the encoder's RSI offset
+//             table.  One lane per stream.
+#include <hip/hip_runtime.h>
+
+#include "aec_kernels.h"
+#include "aec_lane.h"
+
+namespace aec {
+
+namespace {
+
+// Inverse predictor + byte-order store of one block (BS > 0: registers, vector stores).
+template <int BS, int BYTES>
+__device__ __forceinline__ void store_block(uint8_t *dst, const uint32_t *d, const Cfg &c, bool ref,
+                                            uint32_t &x)
+{
+    const bool pp = c.flags & F_PREPROCESS, sgn = c.flags & F_SIGNED, msb = c.flags & F_MSB;
+    uint32_t v[BS];
+#pragma unroll
+    for (int i = 0; i < BS; i++) {
+        if (!pp) {
+            v[i] = d[i];
+        } else if (i == 0 && ref) {
+            x = sgn ? sign_extend(d[0], c.bps) : d[0];           // decode.c:78-86
+            v[i] = x;
+        } else {
+            x = sgn ? unpp_signed(x, d[i], c.xmax) : unpp_unsigned(x, d[i], c.xmax);
+            v[i] = x;
+        }
+    }
+    if (BYTES == 4) {
+        uint4 *o = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+        for (int q = 0; q < BS / 4; q++) {
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) w[j] = msb ? bswap32(v[4 * q + j]) : v[4 * q + j];
+            o[q] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    } else if (BYTES == 2) {
+        uint32_t w[BS / 2];
+#pragma unroll
+        for (int j = 0; j < BS / 2; j++) {
+            uint32_t a = v[2 * j] & 0xFFFFu, b = v[2 * j + 1] & 0xFFFFu;
+            if (msb) {
+                a = (a >> 8) | ((a & 0xFFu) << 8);
+                b = (b >> 8) | ((b & 0xFFu) << 8);
+            }
+            w[j] = a | (b << 16);
+        }
+        if (BS >= 8) {
+            uint4 *o = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+            for (int q = 0; q < BS / 8; q++) o[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        }
+    } else if (BYTES == 1) {
+        uint32_t w[BS / 4];
+#pragma unroll
+        for (int j = 0; j < BS / 4; j++)
+            w[j] = (v[4 * j] & 0xFFu) | ((v[4 * j + 1] & 0xFFu) << 8) | ((v[4 * j + 2] & 0xFFu) << 16) |
+                   (v[4 * j + 3] << 24);
+        uint2 *o = reinterpret_cast<uint2 *>(dst);
+#pragma unroll
+        for (int q = 0; q < BS / 8; q++) o[q] = make_uint2(w[2 * q], w[2 * q + 1]);
+    } else {   // 3-byte containers: byte stores
+#pragma unroll
+        for (int i = 0; i < BS; i++) {
+            const uint32_t s = v[i];
+            dst[3 * i + 0] = (uint8_t)(msb ? s >> 16 : s);
+            dst[3 * i + 1] = (uint8_t)(s >> 8);
+            dst[3 * i + 2] = (uint8_t)(msb ? s : s >> 16);
+        }
+    }
+}
+
+// generic block size / container: sample by sample
+__device__ __forceinline__ void store_block_generic(uint8_t *dst, const uint32_t *d, const Cfg &c, bool ref,
+                                                    uint32_t &x)
+{
+    const bool pp = c.flags & F_PREPROCESS, sgn = c.flags & F_SIGNED, msb = c.flags & F_MSB;
+    for (uint32_t i = 0; i < c.bs; i++) {
+        uint32_t v;
+        if (!pp) v = d[i];
+        else if (i == 0 && ref) v = x = sgn ? sign_extend(d[0], c.bps) : d[0];
+        else v = x = sgn ? unpp_signed(x, d[i], c.xmax) : unpp_unsigned(x, d[i], c.xmax);
+        for (uint32_t t = 0; t < c.bytes; t++)
+            dst[i * c.bytes + t] = (uint8_t)(v >> (8 * (msb ? c.bytes - 1 - t : t)));
+    }
+}
+
+__device__ __forceinline__ void report(DecResult *res, uint32_t status, uint64_t rsi)
+{
+    // worst status wins (DATA_ERROR > NEED_INPUT > OK); remember the lowest failing RSI
+    atomicMax(&res->status, status);
+    atomicMin(reinterpret_cast<unsigned long long *>(&res->bad_rsi), (unsigned long long)rsi);
+}
+
+template <int BS, int BYTES>
+__global__ void __launch_bounds__(256)
+k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
+         const uint64_t *__restrict__ rsi_off, uint64_t n_rsi, uint64_t total_blocks,
+         uint8_t *__restrict__ out, DecResult *res)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rsi) return;
+    constexpr int DN = BS ? BS : (int)kMaxBlockSize;
+    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
+    const bool pp = c.flags & F_PREPROCESS;
+
+    uint64_t nb = total_blocks - r * c.rsi;
+    if (nb > c.rsi) nb = c.rsi;
+    const size_t blk_bytes = (size_t)bs * c.bytes;
+    uint8_t *dst = out + (size_t)r * c.rsi * blk_bytes;
+
+    BitReader br;
+    br.init(words, nwords, end_bit, rsi_off[r]);
+    uint32_t d[DN];
+    uint32_t x = 0;
+    uint32_t b = 0;
+    while (b < nb) {
+        const uint32_t ref = (pp && b == 0) ? 1u : 0u;
+        uint32_t nz = 0;
+        const uint32_t st = parse_cds<BS>(br, d, c, ref, b, nz);
+        if (st != DEC_OK) {
+            report(res, st, r);
+            return;
+        }
+        if (nz == 0) {
+            if (BS) store_block<DN, (BYTES ? BYTES : 1)>(dst, d, c, ref != 0, x);
+            else store_block_generic(dst, d, c, ref != 0, x);
+            dst += blk_bytes;
+            b++;
+        } else {
+            // zero run: d = 0 for every sample (the reference sample, if any, sits in d[0]).
+            // A rest-of-segment run closing a short final RSI is clipped to the data.
+            uint32_t run = nz;
+            if (run > nb - b) run = (uint32_t)(nb - b);
+            const uint32_t keep = d[0];
+#pragma unroll
+            for (int i = 0; i < DN; i++) d[i] = 0;
+            for (uint32_t j = 0; j < run; j++) {
+                const bool rf = ref && j == 0;
+                if (rf) d[0] = keep;
+                if (BS) store_block<DN, (BYTES ? BYTES : 1)>(dst, d, c, rf, x);
+                else store_block_generic(dst, d, c, rf, x);
+                d[0] = 0;
+                dst += blk_bytes;
+            }
+            b += run;
+        }
+    }
+}
+
+// serial RSI index (one active lane)
+__global__ void __launch_bounds__(64)
+k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
+        uint64_t start_bit, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool pp = c.flags & F_PREPROCESS;
+    BitReader br;
+    br.init(words, nwords, end_bit, start_bit);
+    uint64_t r = 0, good = start_bit;
+    uint32_t b = 0, status = DEC_OK;
+    for (;;) {
+        if (b == 0) {
+            if (r >= max_rsi) break;
+            if ((c.flags & F_PAD_RSI) && (good & 7u)) {      // reference decode.c:407-408
+                good = (good + 7u) & ~7ull;
+                br.init(words, nwords, end_bit, good);
+            }
+            rsi_off[r] = good;
+        }
+        uint32_t nblk = 1;
+        const uint32_t st = skip_cds(br, c, (pp && b == 0) ? 1u : 0u, b, nblk);
+        if (st != DEC_OK) {
+            status = st;
+            break;
+        }
+        good = br.pos;
+        b += nblk;
+        if (b >= c.rsi) {
+            b = 0;
+            r++;
+        }
+    }
+    res->n_rsi = r;
+    res->tail_blocks = b;
+    res->end_bit = good;
+    if (status == DEC_DATA_ERROR) {
+        res->status = DEC_DATA_ERROR;
+        res->bad_rsi = r;
+    }
+}
+
+__global__ void k_dec_result_init(DecResult *res)
+{
+    res->n_rsi = 0;
+    res->tail_blocks = 0;
+    res->end_bit = 0;
+    res->status = DEC_OK;
+    res->pad = 0;
+    res->bad_rsi = ~0ull;
+}
+
+template <int BS>
+void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
+                         const uint64_t *rsi_off, uint64_t n_rsi, uint64_t total_blocks, uint8_t *out,
+                         DecResult *res, hipStream_t st)
+{
+    const dim3 block(64), grid((uint32_t)((n_rsi + 63) / 64));
+#define AEC_GO(B)                                                                                   \
+    hipLaunchKernelGGL((k_decode<BS, B>), grid, block, 0, st, c, words, nwords, end_bit, rsi_off, n_rsi, \
+                       total_blocks, out, res)
+    switch (c.bytes) {
+    case 1: AEC_GO(1); break;
+    case 2: AEC_GO(2); break;
+    case 3: AEC_GO(3); break;
+    default: AEC_GO(4); break;
+    }
+#undef AEC_GO
+}
+
+}  // namespace
+
+void launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
+                   uint64_t n_rsi, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res, hipStream_t st,
+                   const PhaseEvents *prof)
+{
+    hipLaunchKernelGGL(k_dec_result_init, dim3(1), dim3(1), 0, st, d_res);
+    if (n_rsi == 0) return;
+    if (prof) (void)hipEventRecord(prof->ev[5], st);
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
+    const uint64_t nwords = (in_bytes + 3) / 4;
+    const uint64_t end_bit = (uint64_t)in_bytes * 8;
+    // vector stores need 16-byte aligned blocks
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
+    const uint32_t bs = vec_ok ? c.bs : 0;
+    switch (bs) {
+    case 8: launch_decode_bytes<8>(c, words, nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, st); break;
+    case 16: launch_decode_bytes<16>(c, words, nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, st); break;
+    case 32: launch_decode_bytes<32>(c, words, nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, st); break;
+    case 64: launch_decode_bytes<64>(c, words, nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, st); break;
+    default:
+        hipLaunchKernelGGL((k_decode<0, 0>), dim3((uint32_t)((n_rsi + 63) / 64)), dim3(64), 0, st, c, words,
+                           nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res);
+        break;
+    }
+    if (prof) (void)hipEventRecord(prof->ev[6], st);
+}
+
+void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
+                  uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dec_result_init, dim3(1), dim3(1), 0, st, d_res);
+    hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, reinterpret_cast<const uint32_t *>(d_in),
+                       (uint64_t)((in_bytes + 3) / 4), (uint64_t)in_bytes * 8, start_bit, d_rsi_off, max_rsi,
+                       d_res);
+}
+
+}  // namespace aec

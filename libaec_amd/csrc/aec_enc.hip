@@ -1,0 +1,653 @@
+// aec_enc.hip -- gfx950 encoder kernels for the CCSDS 121.0-B-2 adaptive entropy coder.
+//
+// Work decomposition (MI355X: 64-lane wavefronts, 160 KiB LDS per CU):
+//   segment  = up to 64 consecutive blocks of one RSI = one wavefront pass, ONE LANE PER BLOCK.
+//              It is exactly the CCSDS zero-run segment (reference src/encode.c:649), so zero-block
+//              aggregation is a 64-bit ballot per wavefront and never crosses a wavefront.
+//   phase A  (lane = 16-byte chunk) coalesced global loads, byte-order fix-up, unit-delay
+//            predictor + sign map (reference encode.c:235-311, encode_accessors.c:145-269),
+//            results written to padded LDS rows [block][sample].
+//   phase B  (lane = block) option / k-plateau / length selection (encode.c:313-434, 585-659).
+//
+//   k_analyze   phase A+B, writes a 4-byte summary per block and (bits, k clamp) per segment.
+//   k_scan_*    device-wide exclusive scan of segment bit lengths (absolute bit offsets) and of
+//               the k clamp composition (replaces the serial state->k / state->bits carry).
+//   k_clear     zeroes exactly the output words the stream will occupy.
+//   k_pack      phase A again (input is re-read; the per-block summaries are not recomputed),
+//               per-lane bit emission into an LDS image of the segment via ds_or_b32, then a
+//               coalesced byte-swapped copy to HBM; only the first/last word of a segment can be
+//               shared with a neighbour and uses a global atomic OR.
+//
+// HBM traffic per input byte: 2 reads of the input + 4/(bs*bytes) summary write+read + 1 clear
+// + 1 write of the compressed stream.  Algorithmic bytes are N + C.
+#include <hip/hip_runtime.h>
+
+#include "aec_kernels.h"
+#include "aec_lane.h"
+
+namespace aec {
+
+namespace {
+
+constexpr uint32_t kWave = 64;
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct LdsSink {
+    uint32_t *w;
+    __device__ __forceinline__ void or_word(uint32_t i, uint32_t v)
+    {
+        __hip_atomic_fetch_or(&w[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t o = 1; o < kWave; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// ordered inclusive scan of k clamps packed as lo | hi << 8
+__device__ __forceinline__ uint32_t clamp_pack(KClamp c) { return c.lo | (c.hi << 8); }
+__device__ __forceinline__ KClamp clamp_unpack(uint32_t p) { return KClamp{p & 0xFFu, (p >> 8) & 0xFFu}; }
+
+__device__ __forceinline__ uint32_t wave_incl_clamp(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t o = 1; o < kWave; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o);
+        if (lane >= o) v = clamp_pack(kclamp_then(clamp_unpack(t), clamp_unpack(v)));
+    }
+    return v;
+}
+
+struct Seg {
+    uint64_t rsi_idx;   // RSI this segment belongs to
+    uint64_t blk0;      // global index of its first block
+    uint64_t samp0;     // global index of its first sample
+    uint32_t b0;        // index of its first block inside the RSI (multiple of 64)
+    uint32_t nv;        // blocks in the segment (1..64)
+    bool full;          // every sample of the segment exists (no end-of-data padding)
+};
+
+__device__ __forceinline__ Seg seg_geom(const Cfg &c, uint64_t sg)
+{
+    Seg g;
+    g.rsi_idx = sg / c.segs_per_rsi;
+    const uint32_t s = (uint32_t)(sg - g.rsi_idx * c.segs_per_rsi);
+    g.b0 = s * 64u;
+    uint64_t nb = c.total_blocks - g.rsi_idx * c.rsi;
+    if (nb > c.rsi) nb = c.rsi;
+    const uint64_t left = nb - g.b0;
+    g.nv = left < 64 ? (uint32_t)left : 64u;
+    g.blk0 = g.rsi_idx * c.rsi + g.b0;
+    g.samp0 = g.blk0 * c.bs;
+    g.full = g.samp0 + (uint64_t)g.nv * c.bs <= c.total_samples;
+    return g;
+}
+
+// ---- phase A, fast path: whole 16-byte chunks, segment 16-byte aligned in HBM ----------------
+template <int BS, int BYTES>
+__device__ __forceinline__ void load_segment_fast(const Cfg &c, const uint8_t *in, const Seg &g,
+                                                  uint32_t *rows, uint32_t lane)
+{
+    constexpr uint32_t SPC = 16 / BYTES;           // samples per chunk
+    constexpr uint32_t STRIDE = BS + 4;
+    const bool msb = c.flags & F_MSB, pp = c.flags & F_PREPROCESS;
+    const uint32_t nchunks = g.nv * (uint32_t)BS * BYTES / 16u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + g.samp0 * BYTES);
+
+    uint32_t carry = 0;
+    if (g.b0 != 0) carry = load_sample_bytes(in + (g.samp0 - 1) * BYTES, BYTES, msb);
+
+    for (uint32_t base = 0; base < nchunks; base += kWave) {
+        const uint32_t ci = base + lane;
+        const bool act = ci < nchunks;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (act) v = src[ci];
+        const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+        uint32_t x[SPC];
+        if (BYTES == 4) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) x[j] = msb ? bswap32(vw[j]) : vw[j];
+        } else if (BYTES == 2) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t h = (vw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                x[j] = msb ? ((h >> 8) | ((h & 0xFFu) << 8)) : h;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++) x[j] = (vw[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+        }
+        const uint32_t last = x[SPC - 1];
+        uint32_t prev = __shfl_up(last, 1);
+        if (lane == 0) prev = carry;
+        carry = __shfl(last, 63);
+        if (act) {
+            uint32_t dd[SPC];
+#pragma unroll
+            for (uint32_t j = 0; j < SPC; j++) {
+                const uint32_t p = j ? x[j - 1] : prev;
+                dd[j] = pp ? pp_any(p, x[j], c) : x[j];
+            }
+            if (pp && g.b0 == 0 && ci == 0) dd[0] = 0;   // reference sample slot, encode.c:254
+#pragma unroll
+            for (uint32_t q = 0; q < SPC / 4; q++) {
+                const uint32_t i = ci * SPC + q * 4;
+                const uint32_t row = i / BS, col = i % BS;
+                *reinterpret_cast<uint4 *>(&rows[row * STRIDE + col]) =
+                    make_uint4(dd[4 * q], dd[4 * q + 1], dd[4 * q + 2], dd[4 * q + 3]);
+            }
+        }
+    }
+}
+
+// ---- phase A, generic path: lane = sample, byte loads, end-of-data padding -------------------
+__device__ __forceinline__ void load_segment_generic(const Cfg &c, const uint8_t *in, const Seg &g,
+                                                     uint32_t *rows, uint32_t stride, uint32_t lane)
+{
+    const bool msb = c.flags & F_MSB, pp = c.flags & F_PREPROCESS;
+    const uint32_t ns = g.nv * c.bs;
+    const uint64_t last = c.total_samples - 1;
+    for (uint32_t i = lane; i < ns; i += kWave) {
+        const uint64_t gi = g.samp0 + i;
+        const uint64_t gc = gi < last ? gi : last;            // encode.c:676-684: repeat last sample
+        const uint32_t cur = load_sample_bytes(in + gc * c.bytes, c.bytes, msb);
+        uint32_t dv;
+        if (!pp) {
+            dv = cur;
+        } else if (g.b0 == 0 && i == 0) {
+            dv = 0;
+        } else {
+            const uint64_t gp = gi - 1 < last ? gi - 1 : last;
+            dv = pp_any(load_sample_bytes(in + gp * c.bytes, c.bytes, msb), cur, c);
+        }
+        rows[(i / c.bs) * stride + (i % c.bs)] = dv;
+    }
+}
+
+template <int BS, int BYTES>
+__device__ __forceinline__ void load_segment(const Cfg &c, const uint8_t *in, const Seg &g,
+                                             uint32_t *rows, uint32_t stride, uint32_t lane, bool fast_ok)
+{
+    if (BS > 0 && BYTES != 3 && BYTES != 0) {
+        if (fast_ok && g.full) {
+            load_segment_fast<(BS > 0 ? BS : 8), (BYTES == 1 || BYTES == 2 || BYTES == 4) ? BYTES : 1>(
+                c, in, g, rows, lane);
+            return;
+        }
+    }
+    load_segment_generic(c, in, g, rows, stride, lane);
+}
+
+// copy a block's LDS row into registers (BS > 0) or alias the row (BS == 0)
+template <int BS>
+struct BlockRegs {
+    uint32_t v[BS];
+    __device__ __forceinline__ const uint32_t *load(const uint32_t *row)
+    {
+#pragma unroll
+        for (int q = 0; q < BS / 4; q++) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(row + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        return v;
+    }
+};
+template <>
+struct BlockRegs<0> {
+    __device__ __forceinline__ const uint32_t *load(const uint32_t *row) { return row; }
+};
+
+template <int BS>
+__device__ __forceinline__ bool block_is_zero(const uint32_t *d, uint32_t bs_rt)
+{
+    const uint32_t bs = BS ? (uint32_t)BS : bs_rt;
+    uint32_t any = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < bs; i++) any |= d[i];
+    return any == 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// K1: analysis
+// ----------------------------------------------------------------------------------------------
+template <int BS, int BYTES>
+__global__ void __launch_bounds__(256)
+k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ meta,
+          uint32_t *__restrict__ seg_bits, uint16_t *__restrict__ seg_clamp, uint32_t segs_per_wave,
+          uint32_t fast_ok)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
+    const uint32_t stride = bs + 4;
+    uint32_t *rows = smem + (size_t)wave * 64u * stride;
+    const bool pp = c.flags & F_PREPROCESS;
+    constexpr bool WIDE_T = (BYTES >= 3);
+
+    const uint64_t gwave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    uint64_t sg = gwave * segs_per_wave;
+    uint64_t sg_end = sg + segs_per_wave;
+    if (sg_end > c.total_segs) sg_end = c.total_segs;
+
+    for (; sg < sg_end; sg++) {
+        const Seg g = seg_geom(c, sg);
+        load_segment<BS, BYTES>(c, in, g, rows, stride, lane, fast_ok != 0);
+        wave_lds_fence();
+
+        BlockRegs<BS> regs;
+        const bool valid = lane < g.nv;
+        // every lane loads a row (idle lanes re-read the last valid one) so that the block lives in
+        // registers instead of behind a conditionally assigned pointer
+        const uint32_t *d = regs.load(rows + (valid ? lane : g.nv - 1) * stride);
+        const bool zero = valid && block_is_zero<BS>(d, bs);
+        const uint64_t zmask = __ballot(zero);
+
+        uint32_t m = meta_pack(0, OPT_ZCONT, 0, 0);
+        KClamp kc = kclamp_identity();
+        if (valid) {
+            const uint32_t ref = (pp && g.b0 == 0 && lane == 0) ? 1u : 0u;
+            if (zero) {
+                uint32_t fs = 0;
+                const uint32_t run = zero_run_at(zmask, lane, g.nv, fs);
+                if (run) m = meta_pack(c.id_len + 1 + ref * c.bps + fs + 1, OPT_ZERO, fs, 0);
+            } else {
+                BlockChoice ch;
+                if (BS == 0)
+                    ch = (c.bps > 16) ? choose_option<BS, true>(d, c, ref) : choose_option<BS, false>(d, c, ref);
+                else
+                    ch = choose_option<BS, WIDE_T>(d, c, ref);
+                m = meta_pack(ch.bits, ch.opt, ch.klo, ch.khi);
+                if (c.id_len > 1) kc = KClamp{ch.klo, ch.khi};
+            }
+            meta[g.blk0 + lane] = m;
+        }
+        const uint32_t tot = wave_incl_sum(meta_len(m), lane);
+        const uint32_t cl = wave_incl_clamp(clamp_pack(kc), lane);
+        if (lane == 63) {
+            seg_bits[sg] = tot;
+            seg_clamp[sg] = (uint16_t)cl;
+        }
+        wave_lds_fence();
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K2: scan of (bits, clamp) over segments -- reduce / scan partials / apply
+// ----------------------------------------------------------------------------------------------
+struct ScanVal {
+    uint64_t bits;
+    uint32_t cl;   // packed clamp
+};
+__device__ __forceinline__ ScanVal scan_then(ScanVal a, ScanVal b)
+{
+    return ScanVal{a.bits + b.bits, clamp_pack(kclamp_then(clamp_unpack(a.cl), clamp_unpack(b.cl)))};
+}
+__device__ __forceinline__ ScanVal scan_identity() { return ScanVal{0, clamp_pack(kclamp_identity())}; }
+
+// ordered inclusive scan across the 256 threads of a workgroup; returns this thread's
+// EXCLUSIVE prefix and the workgroup total
+__device__ __forceinline__ ScanVal block_excl_scan(ScanVal v, ScanVal &total, ScanVal *sh /*[4]*/)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    ScanVal inc = v;
+#pragma unroll
+    for (uint32_t o = 1; o < kWave; o <<= 1) {
+        ScanVal t;
+        t.bits = __shfl_up((unsigned long long)inc.bits, o);
+        t.cl = __shfl_up(inc.cl, o);
+        if (lane >= o) inc = scan_then(t, inc);
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    ScanVal wprefix = scan_identity();
+    for (uint32_t w = 0; w < wave; w++) wprefix = scan_then(wprefix, sh[w]);
+    total = scan_identity();
+    for (uint32_t w = 0; w < (blockDim.x >> 6); w++) total = scan_then(total, sh[w]);
+    ScanVal exc;
+    exc.bits = __shfl_up((unsigned long long)inc.bits, 1);
+    exc.cl = __shfl_up(inc.cl, 1);
+    if (lane == 0) exc = scan_identity();
+    __syncthreads();
+    return scan_then(wprefix, exc);
+}
+
+constexpr uint32_t kScanItems = 8;   // kScanChunk = 256 * 8
+
+__global__ void __launch_bounds__(256)
+k_scan_reduce(const uint32_t *__restrict__ seg_bits, const uint16_t *__restrict__ seg_clamp,
+              uint64_t nseg, ScanPartial *__restrict__ partials)
+{
+    __shared__ ScanVal sh[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * kScanItems;
+    ScanVal acc = scan_identity();
+#pragma unroll
+    for (uint32_t i = 0; i < kScanItems; i++) {
+        const uint64_t s = base + i;
+        if (s < nseg) acc = scan_then(acc, ScanVal{seg_bits[s], seg_clamp[s]});
+    }
+    ScanVal total;
+    block_excl_scan(acc, total, sh);
+    if (threadIdx.x == 0) {
+        const KClamp k = clamp_unpack(total.cl);
+        partials[blockIdx.x] = ScanPartial{total.bits, k.lo, k.hi};
+    }
+}
+
+// single workgroup: exclusive scan of the chunk partials in place, final totals to *res
+__global__ void __launch_bounds__(256)
+k_scan_partials(ScanPartial *partials, uint64_t nchunks, uint32_t start_bit, uint32_t k_in,
+                EncResult *res)
+{
+    __shared__ ScanVal sh[4];
+    const uint64_t per = (nchunks + 255) / 256;
+    const uint64_t lo = (uint64_t)threadIdx.x * per;
+    uint64_t hi = lo + per;
+    if (hi > nchunks) hi = nchunks;
+    ScanVal acc = scan_identity();
+    for (uint64_t i = lo; i < hi; i++)
+        acc = scan_then(acc, ScanVal{partials[i].bits, clamp_pack(KClamp{partials[i].lo, partials[i].hi})});
+    ScanVal total;
+    ScanVal run = block_excl_scan(acc, total, sh);
+    for (uint64_t i = lo; i < hi; i++) {
+        const ScanVal cur{partials[i].bits, clamp_pack(KClamp{partials[i].lo, partials[i].hi})};
+        const KClamp k = clamp_unpack(run.cl);
+        partials[i] = ScanPartial{run.bits, k.lo, k.hi};
+        run = scan_then(run, cur);
+    }
+    if (threadIdx.x == 0) {
+        res->total_bits = total.bits;
+        res->k_out = kclamp_apply(clamp_unpack(total.cl), k_in);
+        res->overflow = 0;
+    }
+    (void)start_bit;
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_apply(const uint32_t *__restrict__ seg_bits, const uint16_t *__restrict__ seg_clamp,
+             uint64_t nseg, const ScanPartial *__restrict__ partials, uint32_t start_bit, uint32_t k_in,
+             uint32_t segs_per_rsi, uint64_t rsi_count, uint64_t *__restrict__ seg_start,
+             uint8_t *__restrict__ seg_kin, uint64_t *__restrict__ rsi_off,
+             const EncResult *__restrict__ res)
+{
+    __shared__ ScanVal sh[4];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * kScanItems;
+    ScanVal item[kScanItems];
+    ScanVal acc = scan_identity();
+#pragma unroll
+    for (uint32_t i = 0; i < kScanItems; i++) {
+        const uint64_t s = base + i;
+        item[i] = (s < nseg) ? ScanVal{seg_bits[s], seg_clamp[s]} : scan_identity();
+        acc = scan_then(acc, item[i]);
+    }
+    ScanVal total;
+    ScanVal run = block_excl_scan(acc, total, sh);
+    const ScanPartial cp = partials[blockIdx.x];
+    run = scan_then(ScanVal{cp.bits, clamp_pack(KClamp{cp.lo, cp.hi})}, run);
+#pragma unroll
+    for (uint32_t i = 0; i < kScanItems; i++) {
+        const uint64_t s = base + i;
+        if (s < nseg) {
+            const uint64_t bit = (uint64_t)start_bit + run.bits;
+            seg_start[s] = bit;
+            seg_kin[s] = (uint8_t)kclamp_apply(clamp_unpack(run.cl), k_in);
+            if (rsi_off && (s % segs_per_rsi) == 0) rsi_off[s / segs_per_rsi] = bit;
+        }
+        run = scan_then(run, item[i]);
+    }
+    if (rsi_off && blockIdx.x == 0 && threadIdx.x == 0)
+        rsi_off[rsi_count] = (uint64_t)start_bit + res->total_bits;
+}
+
+// ----------------------------------------------------------------------------------------------
+// clear: zero the words the stream will occupy (grid-stride, 16 bytes per lane)
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_clear(uint32_t *__restrict__ out_words, uint64_t cap_words, uint32_t start_bit, EncResult *res)
+{
+    uint64_t nwords = ((uint64_t)start_bit + res->total_bits + 31) / 32 + 1;
+    if (nwords > cap_words) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 &&
+            ((uint64_t)start_bit + res->total_bits + 7) / 8 > cap_words * 4)
+            res->overflow = 1;
+        nwords = cap_words;
+    }
+    const uint64_t nvec = nwords / 4;
+    uint4 *v = reinterpret_cast<uint4 *>(out_words);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        v[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x < 4) {
+        const uint64_t w = nvec * 4 + threadIdx.x;
+        if (w < nwords) out_words[w] = 0;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K3: pack
+// ----------------------------------------------------------------------------------------------
+template <int BS, int BYTES>
+__global__ void __launch_bounds__(256)
+k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__ meta,
+       const uint64_t *__restrict__ seg_start, const uint8_t *__restrict__ seg_kin,
+       uint32_t *__restrict__ out_words, uint64_t cap_words, uint32_t segs_per_wave, uint32_t obuf_words,
+       uint32_t fast_ok)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
+    const uint32_t stride = bs + 4;
+    const uint32_t per_wave = 64u * stride + obuf_words;
+    uint32_t *rows = smem + (size_t)wave * per_wave;
+    uint32_t *obuf = rows + 64u * stride;
+    const bool pp = c.flags & F_PREPROCESS, msb = c.flags & F_MSB;
+
+    const uint64_t gwave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    uint64_t sg = gwave * segs_per_wave;
+    uint64_t sg_end = sg + segs_per_wave;
+    if (sg_end > c.total_segs) sg_end = c.total_segs;
+
+    for (; sg < sg_end; sg++) {
+        const Seg g = seg_geom(c, sg);
+        load_segment<BS, BYTES>(c, in, g, rows, stride, lane, fast_ok != 0);
+
+        const bool valid = lane < g.nv;
+        const uint32_t m = valid ? meta[g.blk0 + lane] : meta_pack(0, OPT_ZCONT, 0, 0);
+        const uint32_t len = meta_len(m), opt = meta_opt(m);
+        const uint32_t incl = wave_incl_sum(len, lane);
+        const uint32_t total = __shfl(incl, 63);
+        const uint32_t excl = incl - len;
+
+        const bool updates_k = valid && opt != OPT_ZERO && opt != OPT_ZCONT && c.id_len > 1;
+        const KClamp kc = updates_k ? KClamp{meta_a(m), meta_b(m)} : kclamp_identity();
+        const uint32_t incl_c = wave_incl_clamp(clamp_pack(kc), lane);
+        uint32_t excl_c = __shfl_up(incl_c, 1);
+        if (lane == 0) excl_c = clamp_pack(kclamp_identity());
+        const uint32_t kin = seg_kin[sg];
+        const uint32_t k = kclamp_apply(kc, kclamp_apply(clamp_unpack(excl_c), kin));
+
+        const uint64_t start = seg_start[sg];
+        const uint32_t lead = (uint32_t)(start & 31u);
+        const uint32_t nwords = (lead + total + 31u) >> 5;
+        for (uint32_t w = lane; w < nwords; w += kWave) obuf[w] = 0;
+        wave_lds_fence();
+
+        if (valid && opt != OPT_ZCONT) {
+            const uint32_t ref = (pp && g.b0 == 0 && lane == 0) ? 1u : 0u;
+            uint32_t ref_sample = 0;
+            if (ref)
+                ref_sample = load_sample_bytes(in + g.samp0 * c.bytes, c.bytes, msb) & low_mask32(c.bps);
+            BlockRegs<BS> regs;
+            const uint32_t *d = regs.load(rows + lane * stride);
+            LdsSink sink{obuf};
+            BitWriter<LdsSink> bw(sink, lead + excl);
+            emit_block<BS>(bw, d, c, opt, opt == OPT_ZERO ? meta_a(m) : k, ref, ref_sample);
+        }
+        wave_lds_fence();
+
+        const uint64_t gw = start >> 5;
+        const uint32_t tail = (lead + total) & 31u;
+        for (uint32_t w = lane; w < nwords; w += kWave) {
+            const uint32_t v = obuf[w];
+            const uint64_t idx = gw + w;
+            if (v != 0 && idx < cap_words) {
+                const bool shared = (w == 0 && lead != 0) || (w == nwords - 1 && tail != 0);
+                const uint32_t sv = bswap32(v);
+                if (shared)
+                    __hip_atomic_fetch_or(&out_words[idx], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    out_words[idx] = sv;
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// dispatch
+// ----------------------------------------------------------------------------------------------
+struct LaunchGeom {
+    uint32_t waves_per_block;
+    uint32_t segs_per_wave;
+    uint32_t grid;
+    size_t lds_bytes;
+    uint32_t obuf_words;
+};
+
+LaunchGeom make_geom(const Cfg &c, bool with_obuf)
+{
+    LaunchGeom g;
+    const uint32_t stride = c.bs + 4;
+    const uint32_t maxlen = c.id_len + c.bs * c.bps + 2 + c.bps;
+    g.obuf_words = with_obuf ? ((64u * maxlen + 62u) / 32u + 4u) & ~3u : 0u;
+    const size_t per_wave = ((size_t)64 * stride + g.obuf_words) * 4;
+    uint32_t wpb = (uint32_t)(65536 / per_wave);
+    if (wpb > 4) wpb = 4;
+    if (wpb < 1) wpb = 1;
+    g.waves_per_block = wpb;
+    g.lds_bytes = per_wave * wpb;
+    // a wave walks a short run of consecutive segments (at least one RSI's worth up to 4)
+    uint32_t spw = c.segs_per_rsi < 4 ? c.segs_per_rsi : 4;
+    if (c.total_segs < (uint64_t)spw * wpb * 1024) spw = 1;   // small inputs: spread over the chip
+    g.segs_per_wave = spw;
+    const uint64_t waves = (c.total_segs + spw - 1) / spw;
+    g.grid = (uint32_t)((waves + wpb - 1) / wpb);
+    return g;
+}
+
+template <int BS, int BYTES>
+void launch_analyze_t(const Cfg &c, const uint8_t *in, const EncWorkspace &ws, uint32_t fast_ok,
+                      hipStream_t st)
+{
+    const LaunchGeom g = make_geom(c, false);
+    hipLaunchKernelGGL((k_analyze<BS, BYTES>), dim3(g.grid), dim3(64 * g.waves_per_block), g.lds_bytes, st,
+                       c, in, ws.meta, ws.seg_bits, ws.seg_clamp, g.segs_per_wave, fast_ok);
+}
+
+template <int BS, int BYTES>
+void launch_pack_t(const Cfg &c, const uint8_t *in, const EncWorkspace &ws, uint32_t *out_words,
+                   uint64_t cap_words, uint32_t fast_ok, hipStream_t st)
+{
+    const LaunchGeom g = make_geom(c, true);
+    hipLaunchKernelGGL((k_pack<BS, BYTES>), dim3(g.grid), dim3(64 * g.waves_per_block), g.lds_bytes, st,
+                       c, in, ws.meta, ws.seg_start, ws.seg_kin, out_words, cap_words, g.segs_per_wave,
+                       g.obuf_words, fast_ok);
+}
+
+template <int BS>
+void dispatch_bytes(bool pack, const Cfg &c, const uint8_t *in, const EncWorkspace &ws,
+                    uint32_t *out_words, uint64_t cap_words, uint32_t fast_ok, hipStream_t st)
+{
+#define AEC_GO(B)                                                                     \
+    do {                                                                              \
+        if (pack) launch_pack_t<BS, B>(c, in, ws, out_words, cap_words, fast_ok, st); \
+        else launch_analyze_t<BS, B>(c, in, ws, fast_ok, st);                         \
+    } while (0)
+    switch (c.bytes) {
+    case 1: AEC_GO(1); break;
+    case 2: AEC_GO(2); break;
+    case 3: AEC_GO(3); break;
+    default: AEC_GO(4); break;
+    }
+#undef AEC_GO
+}
+
+void dispatch(bool pack, const Cfg &c, const uint8_t *in, const EncWorkspace &ws, uint32_t *out_words,
+              uint64_t cap_words, uint32_t fast_ok, hipStream_t st)
+{
+    switch (c.bs) {
+    case 8: dispatch_bytes<8>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
+    case 16: dispatch_bytes<16>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
+    case 32: dispatch_bytes<32>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
+    case 64: dispatch_bytes<64>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
+    default:
+        if (pack) launch_pack_t<0, 0>(c, in, ws, out_words, cap_words, 0, st);
+        else launch_analyze_t<0, 0>(c, in, ws, 0, st);
+        break;
+    }
+}
+
+}  // namespace
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t enc_workspace_bytes(const Cfg &c, size_t *off_meta, size_t *off_bits, size_t *off_clamp,
+                           size_t *off_start, size_t *off_kin, size_t *off_part)
+{
+    size_t o = 0;
+    const uint64_t nseg = c.total_segs ? c.total_segs : 1;
+    const uint64_t nchunks = (nseg + kScanChunk - 1) / kScanChunk + 1;
+    *off_meta = o;  o = align_up(o + (c.total_blocks + 1) * 4, 256);
+    *off_bits = o;  o = align_up(o + nseg * 4, 256);
+    *off_clamp = o; o = align_up(o + nseg * 2, 256);
+    *off_start = o; o = align_up(o + nseg * 8, 256);
+    *off_kin = o;   o = align_up(o + nseg, 256);
+    *off_part = o;  o = align_up(o + nchunks * sizeof(ScanPartial), 256);
+    return o;
+}
+
+void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out_cap,
+                   uint32_t start_bit, uint32_t k_in, const EncWorkspace &ws, uint64_t *d_rsi_off,
+                   EncResult *d_res, hipStream_t st, const PhaseEvents *prof)
+{
+    auto mark = [&](int i) { if (prof) (void)hipEventRecord(prof->ev[i], st); };
+    uint32_t *out_words = reinterpret_cast<uint32_t *>(d_out);
+    const uint64_t cap_words = out_cap / 4;
+    const uint64_t nseg = c.total_segs;
+    const uint64_t nchunks = (nseg + kScanChunk - 1) / kScanChunk;
+    // fast loads need every segment to start on a 16-byte boundary of a 16-byte aligned buffer
+    const uint32_t fast_ok = ((reinterpret_cast<uintptr_t>(d_in) & 15u) == 0 &&
+                              ((uint64_t)c.rsi * c.bs * c.bytes) % 16 == 0) ? 1u : 0u;
+
+    mark(0);
+    if (nseg) dispatch(false, c, d_in, ws, nullptr, 0, fast_ok, st);
+    mark(1);
+    if (nchunks)
+        hipLaunchKernelGGL(k_scan_reduce, dim3((uint32_t)nchunks), dim3(256), 0, st, ws.seg_bits,
+                           ws.seg_clamp, nseg, ws.partials);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, st, ws.partials, nchunks, start_bit, k_in,
+                       d_res);
+    if (nchunks)
+        hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)nchunks), dim3(256), 0, st, ws.seg_bits,
+                           ws.seg_clamp, nseg, ws.partials, start_bit, k_in, c.segs_per_rsi, c.rsi_count,
+                           ws.seg_start, ws.seg_kin, d_rsi_off, d_res);
+    else if (d_rsi_off)
+        (void)hipMemsetAsync(d_rsi_off, 0, sizeof(uint64_t), st);   // empty batch: single entry
+    mark(2);
+    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, st, out_words, cap_words, start_bit, d_res);
+    mark(3);
+    if (nseg) dispatch(true, c, d_in, ws, out_words, cap_words, fast_ok, st);
+    mark(4);
+}
+
+}  // namespace aec

@@ -1,0 +1,181 @@
+// aec_gpu.hip -- device-resident batch API (include/aec_gpu.h): context, workspace, enqueue.
+// No reference counterpart; this is the host-side seam between the libaec ABI front-end
+// (aec_abi.cpp) / GPU-resident callers and the kernels in aec_enc.hip / aec_dec.hip.
+#include <hip/hip_runtime.h>
+
+#include <new>
+
+#include "../../include/aec_gpu.h"
+#include "aec_cfg.h"
+#include "aec_kernels.h"
+
+using namespace aec;
+
+struct aec_gpu_ctx {
+    int device;
+    void *ws;          // encoder workspace
+    size_t ws_bytes;
+    bool profiling;    // record PhaseEvents around the kernels of the next calls
+    PhaseEvents ev;
+};
+
+static_assert(sizeof(aec_gpu_enc_result) == sizeof(EncResult), "result layout");
+static_assert(sizeof(aec_gpu_dec_result) == sizeof(DecResult), "result layout");
+
+static int cfg_from(const aec_gpu_params *p, size_t in_bytes, bool enc, Cfg *c)
+{
+    return make_cfg(p->bits_per_sample, p->block_size, p->rsi, p->flags, in_bytes, enc, c);
+}
+
+extern "C" {
+
+int aec_gpu_create(aec_gpu_ctx **out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RC_MEM_ERROR;
+    aec_gpu_ctx *ctx = new (std::nothrow) aec_gpu_ctx;
+    if (!ctx) return RC_MEM_ERROR;
+    ctx->device = dev;
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    ctx->profiling = false;
+    for (auto &e : ctx->ev.ev) e = nullptr;
+    *out = ctx;
+    return RC_OK;
+}
+
+void aec_gpu_destroy(aec_gpu_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    for (auto &e : ctx->ev.ev)
+        if (e) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+int aec_gpu_check_params(const aec_gpu_params *p, int for_encode)
+{
+    Cfg c;
+    return cfg_from(p, 0, for_encode != 0, &c);
+}
+
+size_t aec_gpu_encode_bound(const aec_gpu_params *p, size_t in_bytes)
+{
+    Cfg c;
+    if (cfg_from(p, in_bytes, true, &c) != RC_OK) return 0;
+    return (max_encoded_bytes(c) + 15 + 16) & ~(size_t)15;
+}
+
+uint64_t aec_gpu_rsi_count(const aec_gpu_params *p, size_t in_bytes)
+{
+    Cfg c;
+    if (cfg_from(p, in_bytes, true, &c) != RC_OK) return 0;
+    return c.rsi_count;
+}
+
+uint64_t aec_gpu_block_count(const aec_gpu_params *p, size_t in_bytes)
+{
+    Cfg c;
+    if (cfg_from(p, in_bytes, true, &c) != RC_OK) return 0;
+    return c.total_blocks;
+}
+
+int aec_gpu_reserve(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes)
+{
+    Cfg c;
+    const int rc = cfg_from(p, in_bytes, true, &c);
+    if (rc != RC_OK) return rc;
+    size_t o[6];
+    const size_t need = enc_workspace_bytes(c, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5]);
+    if (need > ctx->ws_bytes) {
+        if (ctx->ws) (void)hipFree(ctx->ws);
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+        if (hipMalloc(&ctx->ws, need) != hipSuccess) return RC_MEM_ERROR;
+        ctx->ws_bytes = need;
+    }
+    return RC_OK;
+}
+
+int aec_gpu_encode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                         void *d_out, size_t out_cap, unsigned int start_bit, unsigned int k_in,
+                         uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result, void *stream)
+{
+    Cfg c;
+    int rc = cfg_from(p, in_bytes, true, &c);
+    if (rc != RC_OK) return rc;
+    if (start_bit > 7 || k_in > 31 || (reinterpret_cast<uintptr_t>(d_out) & 15u) || (out_cap & 15u) ||
+        out_cap < 16)
+        return RC_CONF_ERROR;
+    rc = aec_gpu_reserve(ctx, p, in_bytes);
+    if (rc != RC_OK) return rc;
+    size_t o[6];
+    enc_workspace_bytes(c, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5]);
+    uint8_t *base = static_cast<uint8_t *>(ctx->ws);
+    EncWorkspace ws;
+    ws.meta = reinterpret_cast<uint32_t *>(base + o[0]);
+    ws.seg_bits = reinterpret_cast<uint32_t *>(base + o[1]);
+    ws.seg_clamp = reinterpret_cast<uint16_t *>(base + o[2]);
+    ws.seg_start = reinterpret_cast<uint64_t *>(base + o[3]);
+    ws.seg_kin = base + o[4];
+    ws.partials = reinterpret_cast<ScanPartial *>(base + o[5]);
+    launch_encode(c, static_cast<const uint8_t *>(d_in), static_cast<uint8_t *>(d_out), out_cap, start_bit,
+                  k_in, ws, d_rsi_bit_offsets, reinterpret_cast<EncResult *>(d_result),
+                  static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
+}
+
+int aec_gpu_decode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                         const uint64_t *d_rsi_bit_offsets, uint64_t n_rsi, uint64_t total_blocks,
+                         void *d_out, aec_gpu_dec_result *d_result, void *stream)
+{
+    Cfg c;
+    const int rc = cfg_from(p, 0, false, &c);
+    if (rc != RC_OK) return rc;
+    if (reinterpret_cast<uintptr_t>(d_in) & 3u) return RC_CONF_ERROR;
+    if (n_rsi && (total_blocks > n_rsi * c.rsi || total_blocks <= (n_rsi - 1) * c.rsi)) return RC_CONF_ERROR;
+    launch_decode(c, static_cast<const uint8_t *>(d_in), in_bytes, d_rsi_bit_offsets, n_rsi, total_blocks,
+                  static_cast<uint8_t *>(d_out), reinterpret_cast<DecResult *>(d_result),
+                  static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
+}
+
+int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                        uint64_t start_bit, uint64_t *d_rsi_bit_offsets, uint64_t max_rsi,
+                        aec_gpu_dec_result *d_result, void *stream)
+{
+    (void)ctx;
+    Cfg c;
+    const int rc = cfg_from(p, 0, false, &c);
+    if (rc != RC_OK) return rc;
+    if (reinterpret_cast<uintptr_t>(d_in) & 3u) return RC_CONF_ERROR;
+    launch_index(c, static_cast<const uint8_t *>(d_in), in_bytes, start_bit, d_rsi_bit_offsets, max_rsi,
+                 reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream));
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
+}
+
+int aec_gpu_profile(aec_gpu_ctx *ctx, int enable)
+{
+    if (enable) {
+        for (auto &e : ctx->ev.ev)
+            if (!e && hipEventCreate(&e) != hipSuccess) return RC_MEM_ERROR;
+    }
+    ctx->profiling = enable != 0;
+    return RC_OK;
+}
+
+int aec_gpu_phase_ms(aec_gpu_ctx *ctx, float *ms /*[5]: analyze, scan, clear, pack, decode*/)
+{
+    static const int pair[5][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {5, 6}};
+    for (int i = 0; i < 5; i++) {
+        ms[i] = -1.0f;
+        hipEvent_t a = ctx->ev.ev[pair[i][0]], b = ctx->ev.ev[pair[i][1]];
+        if (!a || !b) continue;
+        if (hipEventSynchronize(b) != hipSuccess) continue;
+        float t = 0;
+        if (hipEventElapsedTime(&t, a, b) == hipSuccess) ms[i] = t;
+    }
+    return RC_OK;
+}
+
+}  // extern "C"

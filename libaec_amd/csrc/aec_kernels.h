@@ -1,0 +1,71 @@
+// aec_kernels.h -- host-visible launchers of the gfx950 kernels (aec_enc.hip, aec_dec.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "aec_cfg.h"
+
+namespace aec {
+
+// One entry per 2048 segments for the three-phase scan of (bit length, k clamp).
+struct ScanPartial {
+    uint64_t bits;
+    uint32_t lo, hi;
+};
+
+// Result record the encoder leaves in device memory (and the host mirrors from pinned memory).
+struct EncResult {
+    uint64_t total_bits;   // bits produced by this batch (excluding the carried-in start bits)
+    uint32_t k_out;        // encoder's k after the last block (reference state->k)
+    uint32_t overflow;     // 1 when the output capacity was too small (stores were clipped)
+};
+
+struct DecResult {
+    uint64_t n_rsi;        // index pass: complete RSIs found
+    uint64_t tail_blocks;  // index pass: blocks of the trailing incomplete RSI
+    uint64_t end_bit;      // index pass: bit after the last complete CDS
+    uint32_t status;       // DEC_OK / DEC_NEED_INPUT / DEC_DATA_ERROR (worst over all lanes)
+    uint32_t pad;
+    uint64_t bad_rsi;      // first RSI that reported a non-OK status
+};
+
+struct EncWorkspace {
+    uint32_t *meta;          // [total_blocks]   per-block summary (aec_lane.h meta_pack)
+    uint32_t *seg_bits;      // [total_segs]     bits per segment
+    uint16_t *seg_clamp;     // [total_segs]     k clamp per segment, lo | hi << 8
+    uint64_t *seg_start;     // [total_segs]     absolute start bit per segment
+    uint8_t *seg_kin;        // [total_segs]     k carried into the segment
+    ScanPartial *partials;   // [ceil(total_segs / 2048) + 1]
+};
+
+// Optional per-phase timing: when non-null the launchers record these events around the phases.
+//   encode: ev[0] | analyze | ev[1] | scan x3 | ev[2] | clear | ev[3] | pack | ev[4]
+//   decode: ev[5] | decode | ev[6]
+struct PhaseEvents {
+    hipEvent_t ev[7];
+};
+
+static const uint32_t kScanChunk = 2048;   // segments per scan workgroup (256 threads x 8)
+
+size_t enc_workspace_bytes(const Cfg &c, size_t *off_meta, size_t *off_bits, size_t *off_clamp,
+                           size_t *off_start, size_t *off_kin, size_t *off_part);
+
+// Enqueues analyze -> scan -> clear -> pack on `stream`.  d_out must be 4-byte aligned and hold
+// out_cap bytes; bit `start_bit` (0..7) of d_out[0] is where the stream continues, k_in is the
+// carried k.  d_rsi_off (optional) receives rsi_count + 1 absolute bit offsets.
+void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out_cap,
+                   uint32_t start_bit, uint32_t k_in, const EncWorkspace &ws, uint64_t *d_rsi_off,
+                   EncResult *d_res, hipStream_t stream, const PhaseEvents *prof = nullptr);
+
+// Enqueues the RSI-parallel decoder: one lane per RSI, offsets in bits from d_in.
+//   total_blocks  blocks to produce (the last RSI may be short); d_out holds whole blocks
+void launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
+                   uint64_t n_rsi, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res,
+                   hipStream_t stream, const PhaseEvents *prof = nullptr);
+
+// Enqueues the serial RSI index pass over one stream starting at start_bit (an RSI boundary).
+void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
+                  uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t stream);
+
+}  // namespace aec

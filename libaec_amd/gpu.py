@@ -1,0 +1,156 @@
+"""Device-resident batch interface (include/aec_gpu.h) for torch tensors living in HBM.
+
+torch is used for device memory and streams only; every codec operation is a kernel launched
+by libaec.so.0 on the tensor's device through the C entry points declared in aec_gpu.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .api import library
+
+
+class Params(C.Structure):
+    _fields_ = [("bits_per_sample", C.c_uint), ("block_size", C.c_uint), ("rsi", C.c_uint),
+                ("flags", C.c_uint)]
+
+
+ENC_RESULT_DTYPE = np.dtype([("total_bits", "<u8"), ("k_out", "<u4"), ("overflow", "<u4")])
+DEC_RESULT_DTYPE = np.dtype([("n_rsi", "<u8"), ("tail_blocks", "<u8"), ("end_bit", "<u8"),
+                             ("status", "<u4"), ("pad", "<u4"), ("bad_rsi", "<u8")])
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    lib = library()
+    if not _bound:
+        vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+        pp = C.POINTER(Params)
+        lib.aec_gpu_create.restype = C.c_int
+        lib.aec_gpu_create.argtypes = [C.POINTER(vp)]
+        lib.aec_gpu_destroy.restype = None
+        lib.aec_gpu_destroy.argtypes = [vp]
+        lib.aec_gpu_check_params.restype = C.c_int
+        lib.aec_gpu_check_params.argtypes = [pp, C.c_int]
+        lib.aec_gpu_encode_bound.restype = sz
+        lib.aec_gpu_encode_bound.argtypes = [pp, sz]
+        lib.aec_gpu_rsi_count.restype = u64
+        lib.aec_gpu_rsi_count.argtypes = [pp, sz]
+        lib.aec_gpu_block_count.restype = u64
+        lib.aec_gpu_block_count.argtypes = [pp, sz]
+        lib.aec_gpu_reserve.restype = C.c_int
+        lib.aec_gpu_reserve.argtypes = [vp, pp, sz]
+        lib.aec_gpu_encode_async.restype = C.c_int
+        lib.aec_gpu_encode_async.argtypes = [vp, pp, vp, sz, vp, sz, C.c_uint, C.c_uint, vp, vp, vp]
+        lib.aec_gpu_decode_async.restype = C.c_int
+        lib.aec_gpu_decode_async.argtypes = [vp, pp, vp, sz, vp, u64, u64, vp, vp, vp]
+        lib.aec_gpu_index_async.restype = C.c_int
+        lib.aec_gpu_index_async.argtypes = [vp, pp, vp, sz, u64, vp, u64, vp, vp]
+        _bound = True
+    return lib
+
+
+class Codec:
+    """One aec_gpu context (workspace) on the current torch device."""
+
+    def __init__(self, bits_per_sample, block_size, rsi, flags):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("libaec_amd.gpu needs a HIP device (no CPU implementation)")
+        self.torch = torch
+        self.lib = _lib()
+        self.p = Params(bits_per_sample, block_size, rsi, flags)
+        rc = self.lib.aec_gpu_check_params(C.byref(self.p), 1)
+        if rc != 0:
+            raise ValueError(f"invalid stream parameters (aec_gpu_check_params -> {rc})")
+        self.ctx = C.c_void_p()
+        torch.cuda.current_device()
+        torch.zeros(1, device="cuda")          # make sure the HIP context of this device is current
+        rc = self.lib.aec_gpu_create(C.byref(self.ctx))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_create failed ({rc})")
+
+    def close(self):
+        if self.ctx:
+            self.lib.aec_gpu_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- sizes ---------------------------------------------------------------------------------
+    def encode_bound(self, in_bytes):
+        return int(self.lib.aec_gpu_encode_bound(C.byref(self.p), in_bytes))
+
+    def rsi_count(self, in_bytes):
+        return int(self.lib.aec_gpu_rsi_count(C.byref(self.p), in_bytes))
+
+    def block_count(self, in_bytes):
+        return int(self.lib.aec_gpu_block_count(C.byref(self.p), in_bytes))
+
+    def reserve(self, in_bytes):
+        rc = self.lib.aec_gpu_reserve(self.ctx, C.byref(self.p), in_bytes)
+        if rc != 0:
+            raise MemoryError(f"aec_gpu_reserve({in_bytes}) failed ({rc})")
+
+    def _stream(self, stream):
+        return C.c_void_p(stream if stream is not None else self.torch.cuda.current_stream().cuda_stream)
+
+    # ---- enqueue -------------------------------------------------------------------------------
+    def encode_async(self, d_in, in_bytes, d_out, d_offsets, d_result, start_bit=0, k_in=0, stream=None):
+        """d_in/d_out: uint8 CUDA tensors; d_offsets: int64 tensor with rsi_count+1 entries or None;
+        d_result: uint8 tensor of >= 16 bytes."""
+        rc = self.lib.aec_gpu_encode_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes, C.c_void_p(d_out.data_ptr()),
+            d_out.numel(), start_bit, k_in,
+            C.c_void_p(d_offsets.data_ptr()) if d_offsets is not None else None,
+            C.c_void_p(d_result.data_ptr()), self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_encode_async failed ({rc})")
+
+    def decode_async(self, d_in, in_bytes, d_offsets, n_rsi, total_blocks, d_out, d_result, stream=None):
+        rc = self.lib.aec_gpu_decode_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes,
+            C.c_void_p(d_offsets.data_ptr()), n_rsi, total_blocks, C.c_void_p(d_out.data_ptr()),
+            C.c_void_p(d_result.data_ptr()), self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_decode_async failed ({rc})")
+
+    def index_async(self, d_in, in_bytes, start_bit, d_offsets, max_rsi, d_result, stream=None):
+        rc = self.lib.aec_gpu_index_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes, start_bit,
+            C.c_void_p(d_offsets.data_ptr()), max_rsi, C.c_void_p(d_result.data_ptr()),
+            self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_index_async failed ({rc})")
+
+    # ---- convenience (synchronising) -------------------------------------------------------------
+    def encode(self, d_in, start_bit=0, k_in=0):
+        """Encode a uint8 CUDA tensor.  Returns (d_out, n_bytes, total_bits, k_out, d_offsets)."""
+        torch = self.torch
+        n = d_in.numel()
+        d_out = torch.empty(self.encode_bound(n), dtype=torch.uint8, device=d_in.device)
+        d_off = torch.empty(self.rsi_count(n) + 1, dtype=torch.int64, device=d_in.device)
+        d_res = torch.zeros(16, dtype=torch.uint8, device=d_in.device)
+        self.encode_async(d_in, n, d_out, d_off, d_res, start_bit, k_in)
+        res = d_res.cpu().numpy().view(ENC_RESULT_DTYPE)[0]
+        if res["overflow"]:
+            raise RuntimeError("encode overflow")
+        bits = int(res["total_bits"])
+        nbytes = max(1, (start_bit + bits + 7) // 8) if (start_bit + bits) else 1
+        return d_out, nbytes, bits, int(res["k_out"]), d_off
+
+    def decode(self, d_in, in_bytes, d_offsets, n_rsi, total_blocks):
+        torch = self.torch
+        bps = self.p.bits_per_sample
+        nb = 4 if bps > 16 and not (bps <= 24 and self.p.flags & 2) else (3 if bps > 16 else (2 if bps > 8 else 1))
+        d_out = torch.empty(total_blocks * self.p.block_size * nb + 16, dtype=torch.uint8, device=d_in.device)
+        d_res = torch.zeros(48, dtype=torch.uint8, device=d_in.device)
+        self.decode_async(d_in, in_bytes, d_offsets, n_rsi, total_blocks, d_out, d_res)
+        res = d_res.cpu().numpy().view(DEC_RESULT_DTYPE)[0]
+        return d_out[: total_blocks * self.p.block_size * nb], int(res["status"])

@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol the
+headers under include/ declare, lays out struct aec_stream like the reference, and fails loudly
+(no CPU fallback) when no HIP device is present."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from helpers import ROOT
+
+INCLUDE = os.path.join(ROOT, "include")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from libaec_amd import api
+    return api.library()
+
+
+def declared_functions():
+    names = []
+    for h in sorted(os.listdir(INCLUDE)):
+        text = open(os.path.join(INCLUDE, h)).read()
+        names += re.findall(r"(?:LIBAEC_API|AEC_GPU_API|SZLIB_API)\s+[\w\s\*]+?\b(\w+)\s*\(", text)
+    return names
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert {"aec_encode_init", "aec_encode", "aec_encode_end", "aec_decode_init", "aec_decode",
+            "aec_decode_end", "aec_buffer_encode", "aec_buffer_decode"} <= set(names)
+    assert "aec_gpu_encode_async" in names and "aec_gpu_decode_async" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported"
+
+
+def test_no_reference_internal_symbols_leak():
+    from libaec_amd import api
+    out = subprocess.run(["nm", "-D", "--defined-only", api.library_path()], capture_output=True,
+                         text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert not {s for s in exported if s.startswith("aec_get_")}
+    assert all(s.startswith(("aec_", "SZ_")) for s in exported), exported
+
+
+def test_soname():
+    from libaec_amd import api
+    out = subprocess.run(["readelf", "-d", api.library_path()], capture_output=True, text=True).stdout
+    assert "libaec.so.0" in out
+
+
+def test_stream_struct_layout():
+    """reference src/libaec.h:67-97 on x86-64: 6 x 8 + 4 x 4 + 8 = 72 bytes."""
+    from libaec_amd.api import AecStream
+    assert C.sizeof(AecStream) == 72
+    assert AecStream.bits_per_sample.offset == 48 and AecStream.state.offset == 64
+
+
+def test_parameter_validation_needs_no_gpu(lib):
+    """aec_gpu_check_params mirrors reference encode.c:777-794, 843-851 and runs on the host."""
+    from libaec_amd.gpu import Params, _lib
+    l = _lib()
+
+    def chk(bps, bs, rsi, flags, enc=1):
+        return l.aec_gpu_check_params(C.byref(Params(bps, bs, rsi, flags)), enc)
+    assert chk(16, 16, 128, 8) == 0
+    assert chk(0, 16, 128, 0) == -1 and chk(33, 16, 128, 0) == -1
+    assert chk(8, 12, 128, 0) == -1 and chk(8, 12, 128, 64) == 0 and chk(8, 13, 128, 64) == -1
+    assert chk(8, 16, 4097, 0) == -1
+    assert chk(8, 8, 128, 16) == -1 and chk(4, 8, 128, 16) == 0        # RESTRICTED needs bps <= 4
+    assert l.aec_gpu_encode_bound(C.byref(Params(16, 16, 128, 8)), 1 << 20) >= (1 << 20) // 32 * (4 + 256) // 8
+
+
+def test_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from libaec_amd import api
+    rc, out = api.aec_buffer_encode(bytes(64), 16, 16, 128, api.AEC_DATA_PREPROCESS)
+    assert rc == api.AEC_MEM_ERROR and out == b""
+    from libaec_amd import gpu
+    with pytest.raises(RuntimeError):
+        gpu.Codec(16, 16, 128, 8)
