@@ -110,7 +110,7 @@ def main():
     d_out = torch.empty(codec.encode_bound(nbytes), dtype=torch.uint8, device=dev)
     d_off = torch.empty(n_rsi + 1, dtype=torch.int64, device=dev)
     d_eres = torch.zeros(16, dtype=torch.uint8, device=dev)
-    d_dres = torch.zeros(48, dtype=torch.uint8, device=dev)
+    d_dres = torch.zeros(40, dtype=torch.uint8, device=dev)
     d_dec = torch.empty(nbytes + 16, dtype=torch.uint8, device=dev)
 
     # ---- untimed: one encode to learn the compressed size, correctness of the timed configuration

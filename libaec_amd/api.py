@@ -55,11 +55,32 @@ class AecStream(C.Structure):
 _lib = None
 
 
+def _preload_process_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm ships its own libamdhip64.so (same
+    SONAME libamdhip64.so.7 as /opt/rocm's); if libaec.so.0 were loaded first it would bind the
+    system copy and a later `import torch` would bring in a second runtime, after which HIP calls
+    of one of them fail.  Loading torch's copy first makes both resolve to the same object."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def library():
     """Load the HIP-backed libaec.  Raises if it has not been built (no fallback)."""
     global _lib
     if _lib is None:
         path = library_path()
+        _preload_process_hip_runtime()
         if not os.path.exists(path):
             raise RuntimeError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

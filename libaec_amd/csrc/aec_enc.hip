@@ -90,7 +90,10 @@ __device__ __forceinline__ Seg seg_geom(const Cfg &c, uint64_t sg)
     g.nv = left < 64 ? (uint32_t)left : 64u;
     g.blk0 = g.rsi_idx * c.rsi + g.b0;
     g.samp0 = g.blk0 * c.bs;
-    g.full = g.samp0 + (uint64_t)g.nv * c.bs <= c.total_samples;
+    // "full": every sample exists and the segment is a whole number of 16-byte chunks (a short
+    // final RSI may end on half a chunk)
+    g.full = g.samp0 + (uint64_t)g.nv * c.bs <= c.total_samples &&
+             ((uint64_t)g.nv * c.bs * c.bytes) % 16 == 0;
     return g;
 }
 

@@ -109,6 +109,7 @@ int aec_gpu_encode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *
         return RC_CONF_ERROR;
     rc = aec_gpu_reserve(ctx, p, in_bytes);
     if (rc != RC_OK) return rc;
+    (void)hipGetLastError();   // only launch errors of THIS call are reported below
     size_t o[6];
     enc_workspace_bytes(c, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5]);
     uint8_t *base = static_cast<uint8_t *>(ctx->ws);
@@ -134,6 +135,7 @@ int aec_gpu_decode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *
     if (rc != RC_OK) return rc;
     if (reinterpret_cast<uintptr_t>(d_in) & 3u) return RC_CONF_ERROR;
     if (n_rsi && (total_blocks > n_rsi * c.rsi || total_blocks <= (n_rsi - 1) * c.rsi)) return RC_CONF_ERROR;
+    (void)hipGetLastError();
     launch_decode(c, static_cast<const uint8_t *>(d_in), in_bytes, d_rsi_bit_offsets, n_rsi, total_blocks,
                   static_cast<uint8_t *>(d_out), reinterpret_cast<DecResult *>(d_result),
                   static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr);
@@ -149,6 +151,7 @@ int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d
     const int rc = cfg_from(p, 0, false, &c);
     if (rc != RC_OK) return rc;
     if (reinterpret_cast<uintptr_t>(d_in) & 3u) return RC_CONF_ERROR;
+    (void)hipGetLastError();
     launch_index(c, static_cast<const uint8_t *>(d_in), in_bytes, start_bit, d_rsi_bit_offsets, max_rsi,
                  reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream));
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;

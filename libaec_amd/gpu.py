@@ -150,7 +150,7 @@ class Codec:
         bps = self.p.bits_per_sample
         nb = 4 if bps > 16 and not (bps <= 24 and self.p.flags & 2) else (3 if bps > 16 else (2 if bps > 8 else 1))
         d_out = torch.empty(total_blocks * self.p.block_size * nb + 16, dtype=torch.uint8, device=d_in.device)
-        d_res = torch.zeros(48, dtype=torch.uint8, device=d_in.device)
+        d_res = torch.zeros(DEC_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=d_in.device)
         self.decode_async(d_in, in_bytes, d_offsets, n_rsi, total_blocks, d_out, d_res)
         res = d_res.cpu().numpy().view(DEC_RESULT_DTYPE)[0]
         return d_out[: total_blocks * self.p.block_size * nb], int(res["status"])

@@ -217,7 +217,7 @@ def test_device_api_offsets_index_and_carry(gpu):
     assert status == 0 and d_dec.cpu().numpy().tobytes() == data.tobytes()
     # serial index pass over the bare stream finds the same table
     d_idx = torch.zeros(nrsi + 8, dtype=torch.int64, device="cuda")
-    d_res = torch.zeros(48, dtype=torch.uint8, device="cuda")
+    d_res = torch.zeros(40, dtype=torch.uint8, device="cuda")
     codec.index_async(d_out, nbytes, 0, d_idx, nrsi + 8, d_res)
     res = d_res.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]
     assert res["status"] <= 1 and int(res["n_rsi"]) == nrsi and int(res["end_bit"]) == bits
