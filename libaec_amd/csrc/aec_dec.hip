@@ -105,58 +105,178 @@ __device__ __forceinline__ void report(DecResult *res, uint32_t status, uint64_t
     atomicMin(reinterpret_cast<unsigned long long *>(&res->bad_rsi), (unsigned long long)rsi);
 }
 
+// ---- compressed-stream staging ------------------------------------------------------------------
+// Every lane owns one column of a small LDS ring: word i (relative to the lane's 16-byte aligned
+// base a0) lives at ring[((slot0 + i) & mask) * 64 + lane], so a wave-wide access at any per-lane
+// index is bank-conflict free.  The ring is topped up at ONE wave-synchronous point per block
+// iteration with 16-byte global loads issued an iteration ahead (issue early / write late), so the
+// bit reader itself only ever touches LDS and never waits on HBM.
+struct RingSrc {
+    const uint32_t *col;   // ring + lane
+    uint32_t slot0, mask;
+    uint32_t limit;        // words landed (relative index); reads at or beyond it starve
+    uint32_t starve;
+    __device__ __forceinline__ uint32_t word(uint32_t i)
+    {
+        starve |= (i >= limit) ? 1u : 0u;      // the slot read is always inside the ring
+        return col[((slot0 + i) & mask) * 64u];
+    }
+    // words i and i+1; row mask+1 mirrors row 0 so the pair is always two adjacent rows
+    __device__ __forceinline__ void word2(uint32_t i, uint32_t &w0, uint32_t &w1)
+    {
+        starve |= (i + 1 >= limit) ? 1u : 0u;
+        const uint32_t *q = col + ((slot0 + i) & mask) * 64u;
+        w0 = q[0];
+        w1 = q[64];
+    }
+    __device__ __forceinline__ bool starved() const { return starve != 0; }
+};
+
+// four consecutive stream words starting at absolute index idx (multiple of 4), host order;
+// zeros past the end of the buffer
+__device__ __forceinline__ uint4 load_words4(const uint32_t *__restrict__ words, uint64_t idx, uint64_t nwords)
+{
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (idx + 4 <= nwords) {
+        v = *reinterpret_cast<const uint4 *>(words + idx);
+    } else {
+        if (idx < nwords) v.x = words[idx];
+        if (idx + 1 < nwords) v.y = words[idx + 1];
+        if (idx + 2 < nwords) v.z = words[idx + 2];
+    }
+    return make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+}
+
+// rel is a multiple of 4 and slot0 a multiple of 4, so the four rows never wrap inside a chunk
+__device__ __forceinline__ void ring_put4(uint32_t *col, uint32_t slot0, uint32_t mask, uint32_t rel, uint4 v)
+{
+    const uint32_t row = (slot0 + rel) & mask;
+    uint32_t *q = col + row * 64u;
+    q[0] = v.x;
+    q[64] = v.y;
+    q[128] = v.z;
+    q[192] = v.w;
+    if (row == 0) col[(mask + 1u) * 64u] = v.x;   // mirror of row 0 for word2()
+}
+
+constexpr int kPend = 2;   // 16-byte loads kept in flight per lane across one block iteration
+
 template <int BS, int BYTES>
 __global__ void __launch_bounds__(256)
 k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
          const uint64_t *__restrict__ rsi_off, uint64_t n_rsi, uint64_t total_blocks,
-         uint8_t *__restrict__ out, DecResult *res)
+         uint8_t *__restrict__ out, DecResult *res, uint32_t ring_words, uint32_t maxw)
 {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rsi) return;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *col = smem + (size_t)wave * (ring_words + 1u) * 64u + lane;
+    const uint32_t mask = ring_words - 1;
+
+    const uint64_t r = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 64u + lane;
+    const bool active = r < n_rsi;
     constexpr int DN = BS ? BS : (int)kMaxBlockSize;
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const bool pp = c.flags & F_PREPROCESS;
 
-    uint64_t nb = total_blocks - r * c.rsi;
-    if (nb > c.rsi) nb = c.rsi;
+    uint32_t nb = 0;
+    uint64_t start = 0;
+    if (active) {
+        uint64_t left = total_blocks - r * c.rsi;
+        nb = left > c.rsi ? c.rsi : (uint32_t)left;
+        start = rsi_off[r];
+    }
     const size_t blk_bytes = (size_t)bs * c.bytes;
     uint8_t *dst = out + (size_t)r * c.rsi * blk_bytes;
 
-    BitReader br;
-    br.init(words, nwords, end_bit, rsi_off[r]);
-    uint32_t d[DN];
-    uint32_t x = 0;
-    uint32_t b = 0;
-    while (b < nb) {
-        const uint32_t ref = (pp && b == 0) ? 1u : 0u;
-        uint32_t nz = 0;
-        const uint32_t st = parse_cds<BS>(br, d, c, ref, b, nz);
-        if (st != DEC_OK) {
-            report(res, st, r);
-            return;
-        }
-        if (nz == 0) {
-            if (BS) store_block<DN, (BYTES ? BYTES : 1)>(dst, d, c, ref != 0, x);
-            else store_block_generic(dst, d, c, ref != 0, x);
-            dst += blk_bytes;
-            b++;
-        } else {
-            // zero run: d = 0 for every sample (the reference sample, if any, sits in d[0]).
-            // A rest-of-segment run closing a short final RSI is clipped to the data.
-            uint32_t run = nz;
-            if (run > nb - b) run = (uint32_t)(nb - b);
-            const uint32_t keep = d[0];
+    const uint64_t a0 = (start >> 5) & ~3ull;        // lane base word, 16-byte aligned
+    const uint32_t slot0 = (uint32_t)a0 & mask;
+    uint32_t landed = 0;
+    for (; landed < ring_words; landed += 4)          // prologue: fill the whole ring
+        ring_put4(col, slot0, mask, landed, load_words4(words, a0 + landed, nwords));
+
+    RingSrc src{col, slot0, mask, landed, 0u};
+    const uint64_t left_bits = end_bit - a0 * 32u;
+    const uint32_t end_p = left_bits > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)left_bits;
+    uint32_t p = (uint32_t)(start - a0 * 32u);        // fast path: bit position relative to a0
+    WinReader<RingSrc> br;                            // generic path: sequential reader
+    if (BS == 0) br.init(src, a0 * 32u, end_bit, p);
+
+    uint4 pend[kPend];
+    bool pv[kPend];
 #pragma unroll
-            for (int i = 0; i < DN; i++) d[i] = 0;
-            for (uint32_t j = 0; j < run; j++) {
-                const bool rf = ref && j == 0;
-                if (rf) d[0] = keep;
-                if (BS) store_block<DN, (BYTES ? BYTES : 1)>(dst, d, c, rf, x);
-                else store_block_generic(dst, d, c, rf, x);
-                d[0] = 0;
-                dst += blk_bytes;
+    for (int j = 0; j < kPend; j++) { pend[j] = make_uint4(0, 0, 0, 0); pv[j] = false; }
+
+    uint32_t d[DN];
+    uint32_t x = 0, zrun = 0;
+    bool ok = true;
+
+    for (uint32_t b = 0; __any(b < nb && ok); b++) {
+        const bool live = b < nb && ok;
+        // ---- top up the ring (wave-synchronous) ----
+#pragma unroll
+        for (int j = 0; j < kPend; j++)
+            if (pv[j]) {
+                ring_put4(col, slot0, mask, landed, pend[j]);
+                landed += 4;
             }
-            b += run;
+        const uint32_t next = BS ? (p >> 5) : br.next;             // first word still needed
+        while (__any(live && landed - next < maxw)) {              // rare: a lane fell behind
+            if (live && landed - next < maxw) {
+                ring_put4(col, slot0, mask, landed, load_words4(words, a0 + landed, nwords));
+                landed += 4;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kPend; j++) {
+            pv[j] = live && (landed + 4u * j + 4u - next <= ring_words);
+            if (pv[j]) pend[j] = load_words4(words, a0 + landed + 4u * j, nwords);
+        }
+
+        // ---- one block per lane ----
+        const uint32_t ref = (pp && b == 0) ? 1u : 0u;             // wave-uniform
+        if (BS) {
+            src.limit = landed;
+            uint32_t nz = 0;
+            const bool parse = live && zrun == 0;
+            // lanes inside a zero run (and finished lanes) get d = 0 from the same code path
+            const uint32_t st = decode_block<(BS ? BS : 2)>(src, p, end_p, d, c, ref, b, parse, nz);
+            if (parse) {
+                if (st != DEC_OK) {
+                    report(res, st, r);
+                    ok = false;
+                } else if (nz) {
+                    zrun = nz;
+                }
+            }
+            if (live && ok) {
+                store_block<DN, (BYTES ? BYTES : 1)>(dst, d, c, ref != 0 && parse, x);
+                dst += blk_bytes;
+                zrun -= zrun ? 1u : 0u;
+            }
+        } else if (live) {
+            br.src.limit = landed;
+            bool rf = ref != 0;
+            if (zrun == 0) {
+                uint32_t nz = 0;
+                const uint32_t st = parse_cds<0>(br, d, c, ref, b, nz);
+                if (st != DEC_OK) {
+                    report(res, st, r);
+                    ok = false;
+                } else if (nz) {
+                    const uint32_t keep = d[0];
+                    for (int i = 0; i < DN; i++) d[i] = 0;
+                    if (rf) d[0] = keep;
+                    zrun = nz - 1;
+                }
+            } else {
+                zrun--;
+                rf = false;
+            }
+            if (ok) {
+                store_block_generic(dst, d, c, rf, x);
+                dst += blk_bytes;
+                if (rf) d[0] = 0;
+            }
         }
     }
 }
@@ -213,15 +333,42 @@ __global__ void k_dec_result_init(DecResult *res)
     res->bad_rsi = ~0ull;
 }
 
+struct DecGeom {
+    uint32_t ring_words, maxw, waves, grid;
+    size_t lds_bytes;
+};
+
+// Ring capacity: a coded data set never exceeds id_len + 1 + bps + bs*bps bits; with loads landing
+// one iteration late the ring must hold two of them plus alignment slack (see k_decode).
+DecGeom dec_geom(const Cfg &c, uint64_t n_rsi)
+{
+    DecGeom g;
+    const uint32_t maxbits = c.id_len + 1 + c.bps + c.bs * c.bps;
+    g.maxw = maxbits / 32 + 3;
+    uint32_t rw = 16;
+    while (rw < 2 * g.maxw + 8) rw <<= 1;
+    g.ring_words = rw;
+    const size_t per_wave = (size_t)(rw + 1) * 64 * 4;
+    uint32_t waves = (uint32_t)(65536 / per_wave);
+    if (waves > 4) waves = 4;
+    if (waves < 1) waves = 1;
+    g.waves = waves;
+    g.lds_bytes = per_wave * waves;
+    const uint64_t nwaves = (n_rsi + 63) / 64;
+    g.grid = (uint32_t)((nwaves + waves - 1) / waves);
+    return g;
+}
+
 template <int BS>
 void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          const uint64_t *rsi_off, uint64_t n_rsi, uint64_t total_blocks, uint8_t *out,
                          DecResult *res, hipStream_t st)
 {
-    const dim3 block(64), grid((uint32_t)((n_rsi + 63) / 64));
+    const DecGeom g = dec_geom(c, n_rsi);
+    const dim3 block(64 * g.waves), grid(g.grid);
 #define AEC_GO(B)                                                                                   \
-    hipLaunchKernelGGL((k_decode<BS, B>), grid, block, 0, st, c, words, nwords, end_bit, rsi_off, n_rsi, \
-                       total_blocks, out, res)
+    hipLaunchKernelGGL((k_decode<BS, B>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, rsi_off, \
+                       n_rsi, total_blocks, out, res, g.ring_words, g.maxw)
     switch (c.bytes) {
     case 1: AEC_GO(1); break;
     case 2: AEC_GO(2); break;
@@ -252,9 +399,12 @@ void launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uin
     case 32: launch_decode_bytes<32>(c, words, nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, st); break;
     case 64: launch_decode_bytes<64>(c, words, nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, st); break;
     default:
-        hipLaunchKernelGGL((k_decode<0, 0>), dim3((uint32_t)((n_rsi + 63) / 64)), dim3(64), 0, st, c, words,
-                           nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res);
+    {
+        const DecGeom g = dec_geom(c, n_rsi);
+        hipLaunchKernelGGL((k_decode<0, 0>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
+                           end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, g.ring_words, g.maxw);
         break;
+    }
     }
     if (prof) (void)hipEventRecord(prof->ev[6], st);
 }

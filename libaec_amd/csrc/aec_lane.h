@@ -452,6 +452,84 @@ struct BitReader {
     AEC_HD bool overrun() const { return pos > end_bit; }
 };
 
+// Lean window reader used by the RSI-parallel decoder.  Src::word(i) returns the i-th 32-bit
+// big-endian word (already in host order) counted from a per-lane base, or 0 past what is
+// available (Src then remembers that it starved).  Between operations at least 32 unread bits sit
+// in the window, so a field of up to 32 bits or a short unary code never needs a refill first.
+template <class Src>
+struct WinReader {
+    Src src;
+    uint64_t win;       // unread bits, left aligned; bits below the top `cnt` are zero
+    uint32_t cnt;       // valid bits in win (32..64 between operations)
+    uint32_t next;      // index (relative to the lane base) of the word held in `nextw`
+    uint32_t nextw;     // word `next`, fetched ahead so that a refill is pure register work
+    uint64_t base_bit;  // absolute bit position of relative word 0
+    uint64_t end_bit;   // bits that belong to the stream
+
+    AEC_HD void init(const Src &s, uint64_t base, uint64_t endb, uint32_t start_rel_bit)
+    {
+        src = s; base_bit = base; end_bit = endb;
+        next = start_rel_bit >> 5;
+        const uint32_t sh = start_rel_bit & 31u;
+        const uint32_t w0 = src.word(next), w1 = src.word(next + 1);
+        next += 2;
+        nextw = src.word(next);
+        win = (((uint64_t)w0 << 32) | w1) << sh;
+        cnt = 64 - sh;
+    }
+    AEC_HD uint64_t pos() const { return base_bit + (uint64_t)next * 32u - cnt; }
+    // Restores cnt >= 32 after at most 32 bits were consumed.  Written without control flow: the
+    // appended word is masked out when no refill is due, and the look-ahead word is re-read from
+    // the (LDS) source unconditionally.
+    AEC_HD void top()
+    {
+        const bool take = cnt < 32;
+        const uint64_t add = (uint64_t)nextw << ((32u - cnt) & 63u);
+        win |= take ? add : 0;
+        cnt += take ? 32u : 0u;
+        next += take ? 1u : 0u;
+        nextw = src.word(next);
+    }
+    AEC_HD uint32_t get(uint32_t n)   // 1 <= n <= 32
+    {
+        const uint32_t v = (uint32_t)(win >> (64 - n));
+        win <<= n;
+        cnt -= n;
+        top();
+        return v;
+    }
+    AEC_HD bool unary(uint32_t &zeros)
+    {
+        const uint32_t hi = (uint32_t)(win >> 32);
+        if (__builtin_expect(hi != 0, 1)) {  // common case: the 1 bit is within 32 bits
+            const uint32_t z = (uint32_t)__builtin_clz(hi);
+            win <<= z + 1;
+            cnt -= z + 1;
+            top();
+            zeros = z;
+            return true;
+        }
+        uint32_t total = 0;
+        for (;;) {
+            if (win != 0) {
+                const uint32_t c = (uint32_t)__builtin_clzll(win);
+                win = c >= 63 ? 0 : win << (c + 1);
+                cnt -= c + 1;
+                if (cnt < 32) top();
+                if (cnt < 32) top();
+                zeros = total + c;
+                return true;
+            }
+            total += cnt;
+            cnt = 0;
+            zeros = 0;
+            if (pos() >= end_bit) return false;
+            top();
+        }
+    }
+    AEC_HD bool overrun() const { return pos() > end_bit || src.starved(); }
+};
+
 // Inverse of the preprocessor (reference decode.c:91-135), one step.
 AEC_HD uint32_t unpp_unsigned(uint32_t x, uint32_t d, uint32_t xmax)
 {
@@ -493,12 +571,16 @@ enum : uint32_t { DEC_OK = 0, DEC_NEED_INPUT = 1, DEC_DATA_ERROR = 2 };
 // reference sample on a reference block).  For a zero run `nzero_blocks` receives the number
 // of blocks covered and d is untouched (only d[0] = reference sample if ref).
 //   blk_in_rsi = index of this block inside its RSI (needed for ROS, decode.c:528-530)
-template <int BS>
-AEC_HD uint32_t parse_cds(BitReader &r, uint32_t *d, const Cfg &c, uint32_t ref,
+template <int BS, class Reader>
+AEC_HD uint32_t parse_cds(Reader &r, uint32_t *d, const Cfg &c, uint32_t ref,
                           uint32_t blk_in_rsi, uint32_t &nzero_blocks)
 {
+    // No early exits inside the sample loops: a lane that runs out of input keeps going on zeros
+    // (every read is bounded by the reader) and reports once at the end, which keeps the 64 lanes
+    // of a wavefront on one control path.
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     nzero_blocks = 0;
+    bool short_input = false, corrupt = false;
     const uint32_t id = r.get(c.id_len);
     if (id == 0) {                                       // decode.c:634-644, 618-632
         const uint32_t sel = r.get(1);
@@ -507,15 +589,15 @@ AEC_HD uint32_t parse_cds(BitReader &r, uint32_t *d, const Cfg &c, uint32_t ref,
             uint32_t i = ref;
 #pragma unroll
             for (uint32_t j = 0; j < bs / 2; j++) {
-                uint32_t m, s, second;
-                if (!r.unary(m)) return DEC_NEED_INPUT;
-                if (!se_lookup(m, s, second)) return r.overrun() ? DEC_NEED_INPUT : DEC_DATA_ERROR;
+                uint32_t m = 0, s = 0, second = 0;
+                if (!r.unary(m)) short_input = true;
+                else if (!se_lookup(m, s, second)) corrupt = true;
                 if ((i & 1u) == 0) d[i++] = s - second;
                 d[i++] = second;
             }
         } else {                                         // decode.c:518-558
-            uint32_t fs;
-            if (!r.unary(fs)) return DEC_NEED_INPUT;
+            uint32_t fs = 0;
+            if (!r.unary(fs)) short_input = true;
             uint32_t nz = fs + 1;
             if (nz == 5) {
                 const uint32_t left_rsi = c.rsi - blk_in_rsi;
@@ -524,8 +606,7 @@ AEC_HD uint32_t parse_cds(BitReader &r, uint32_t *d, const Cfg &c, uint32_t ref,
             } else if (nz > 5) {
                 nz--;
             }
-            if (r.overrun()) return DEC_NEED_INPUT;
-            if (nz > c.rsi - blk_in_rsi) return DEC_DATA_ERROR;   // decode.c:543-544
+            if (nz > c.rsi - blk_in_rsi) corrupt = true;   // decode.c:543-544
             nzero_blocks = nz;
         }
     } else if (id == (1u << c.id_len) - 1u) {            // decode.c:659-677
@@ -537,8 +618,8 @@ AEC_HD uint32_t parse_cds(BitReader &r, uint32_t *d, const Cfg &c, uint32_t ref,
 #pragma unroll
         for (uint32_t i = 0; i < bs; i++)
             if (i >= ref) {
-                uint32_t z;
-                if (!r.unary(z)) return DEC_NEED_INPUT;
+                uint32_t z = 0;
+                if (!r.unary(z)) short_input = true;
                 d[i] = z << k;
             }
         if (k) {
@@ -547,7 +628,168 @@ AEC_HD uint32_t parse_cds(BitReader &r, uint32_t *d, const Cfg &c, uint32_t ref,
                 if (i >= ref) d[i] += r.get(k);
         }
     }
-    return r.overrun() ? DEC_NEED_INPUT : DEC_OK;
+    if (r.overrun() || short_input) return DEC_NEED_INPUT;
+    return corrupt ? DEC_DATA_ERROR : DEC_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Phase-structured block decoder (fast path of the RSI-parallel decode kernel).
+//
+// Instead of one sequential reader it works on a bit position `p` and a word source that can
+// return ANY two consecutive words cheaply (an LDS ring on the device):
+//   1. header        id, low-entropy selector, reference sample
+//   2. unary phase   all fundamental sequences of the block, two codes per 32-bit peek; codes
+//                    longer than 15 zeros take a (rare) slow step, entered wave-uniformly
+//   3. field phase   the k-bit (or bps-bit) fields are at p + i*k: independent direct reads
+//   4. combine       d[i] = (fs << k) + field; second extension / zero run fixed up last
+// All code options run through the same phases with per-lane counts, so a wavefront whose lanes
+// hold different options does not serialise.  Src::word2(i, w0, w1) yields words i and i+1.
+// AEC_ANY(x) is __any(x) on the device (wave-uniform entry to the rare paths) and x on the host.
+// ------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AEC_ANY(x) __any(x)
+#else
+#define AEC_ANY(x) (x)
+#endif
+
+template <class Src>
+AEC_HD uint32_t peek32(Src &src, uint32_t p)
+{
+    uint32_t w0, w1;
+    src.word2(p >> 5, w0, w1);
+    return (uint32_t)((((((uint64_t)w0) << 32) | w1) << (p & 31u)) >> 32);
+}
+
+AEC_HD uint32_t clz32_or32(uint32_t v) { return v ? (uint32_t)__builtin_clz(v) : 32u; }
+
+// general unary read at p for codes of any length; stops at end_p (stream end)
+template <class Src>
+AEC_HD uint32_t unary_slow(Src &src, uint32_t &p, uint32_t end_p, bool &short_input)
+{
+    uint32_t zeros = 0;
+    for (;;) {
+        const uint32_t h = peek32(src, p);
+        if (h != 0) {
+            const uint32_t z = (uint32_t)__builtin_clz(h);
+            p += z + 1;
+            return zeros + z;
+        }
+        zeros += 32;
+        p += 32;
+        if (p >= end_p) {
+            short_input = true;
+            return 0;
+        }
+    }
+}
+
+template <int BS, class Src>
+AEC_HD uint32_t decode_block(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d, const Cfg &c,
+                             uint32_t ref, uint32_t blk_in_rsi, bool live, uint32_t &nzero_blocks)
+{
+    static_assert(BS >= 2 && BS % 2 == 0, "templated block sizes only");
+    const uint32_t idmax = (1u << c.id_len) - 1u;
+    bool short_input = false, corrupt = false;
+    nzero_blocks = 0;
+
+    // ---- 1. header --------------------------------------------------------------------------
+    uint32_t h = peek32(src, p);
+    const uint32_t id = h >> (32 - c.id_len);
+    const bool lowent = live && id == 0;
+    const bool unc = live && id == idmax;
+    const bool split = live && !lowent && !unc;
+    const uint32_t sel = (h >> (31 - c.id_len)) & 1u;
+    const bool se = lowent && sel;
+    const bool zero = lowent && !sel;
+    const uint32_t k = split ? id - 1u : 0u;
+    p += live ? c.id_len + (lowent ? 1u : 0u) : 0u;
+    uint32_t refv = 0;
+    if (ref) {                                           // wave-uniform: first block of the RSIs
+        refv = peek32(src, p) >> (32 - c.bps);
+        p += (live && !unc) ? c.bps : 0u;
+    }
+
+    // ---- 2. unary phase: code for sample slot i lives in u[i] ---------------------------------
+    const uint32_t nfs = split ? (uint32_t)BS - ref : (se ? (uint32_t)BS / 2 : (zero ? 1u : 0u));
+    uint32_t u[BS];
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)BS; i += 2) {
+        const bool a1 = i >= ref && i - ref < nfs;
+        const bool a2 = i + 1 - ref < nfs;               // i + 1 >= 1 >= ref always
+        h = peek32(src, p);
+        uint32_t z1 = clz32_or32(h);
+        const uint32_t h2 = z1 >= 31 ? 0u : h << (z1 + 1);
+        uint32_t z2 = clz32_or32(h2);
+        const bool slow = (a1 && z1 > 15) || (a2 && (z2 > 15 || !a1 && z1 > 15));
+        uint32_t adv = 0;
+        if (AEC_ANY(slow)) {                             // rare: a long fundamental sequence
+            if (slow) {
+                uint32_t q = p;
+                if (a1) z1 = unary_slow(src, q, end_p, short_input);
+                if (a2) z2 = unary_slow(src, q, end_p, short_input);
+                adv = q - p;
+            }
+        }
+        if (!slow) {
+            // without code 1 the second code starts at p itself
+            if (!a1) z2 = z1;
+            adv = (a1 ? z1 + 1 : 0u) + (a2 ? z2 + 1 : 0u);
+        }
+        p += adv;
+        u[i] = a1 ? z1 : 0u;
+        u[i + 1] = a2 ? z2 : 0u;
+    }
+
+    // ---- 3. field phase ---------------------------------------------------------------------
+    const uint32_t kk = split ? k : (unc ? c.bps : 0u);
+    const uint32_t nf = split ? (uint32_t)BS - ref : (unc ? (uint32_t)BS : 0u);
+    const uint32_t off = split ? ref : 0u;
+    const uint32_t fsh = (32u - kk) & 31u;
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)BS; i++) {
+        const bool act = kk != 0 && i >= off && i - off < nf;
+        const uint32_t v = peek32(src, act ? p + (i - off) * kk : p);
+        const uint32_t f = act ? v >> fsh : 0u;
+        d[i] = (u[i] << k) + f;                          // k == 0 for uncompressed lanes
+    }
+    p += nf * kk;
+    if (ref && !unc) d[0] = refv;
+
+    // ---- 4. second extension / zero run (rare, divergent) ------------------------------------
+    if (AEC_ANY(se)) {
+        if (se) {
+            uint32_t i = ref;
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)BS / 2; j++) {
+                const uint32_t m = u[(ref ? 1 : 0) + j];
+                uint32_t s = 0, second = 0;
+                if (!se_lookup(m, s, second)) corrupt = true;
+                if ((i & 1u) == 0) d[i++] = s - second;
+                d[i++] = second;
+            }
+            if (ref) d[0] = refv;
+        }
+    }
+    if (AEC_ANY(zero)) {
+        if (zero) {
+            uint32_t nz = u[ref ? 1 : 0] + 1;
+            if (nz == 5) {
+                const uint32_t left_rsi = c.rsi - blk_in_rsi;
+                const uint32_t left_seg = 64 - (blk_in_rsi % 64);
+                nz = left_rsi < left_seg ? left_rsi : left_seg;
+            } else if (nz > 5) {
+                nz--;
+            }
+            if (nz > c.rsi - blk_in_rsi) corrupt = true;  // decode.c:543-544
+            nzero_blocks = nz;
+#pragma unroll
+            for (uint32_t i = 0; i < (uint32_t)BS; i++) d[i] = 0;
+            if (ref) d[0] = refv;
+        }
+    }
+    if (!live) return DEC_OK;
+    if (short_input || p > end_p || src.starved()) return DEC_NEED_INPUT;
+    return corrupt ? DEC_DATA_ERROR : DEC_OK;
 }
 
 // Skips one CDS without materialising samples (RSI index pass).  Returns blocks covered in

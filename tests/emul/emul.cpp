@@ -12,6 +12,15 @@
 
 using namespace aec;
 
+// word source over plain memory for WinReader (the device uses an LDS ring instead)
+struct MemSrc {
+    const uint32_t *w;
+    uint64_t n, base;
+    uint32_t word(uint32_t i) const { const uint64_t idx = base + i; return idx < n ? bswap32(w[idx]) : 0u; }
+    void word2(uint32_t i, uint32_t &w0, uint32_t &w1) const { w0 = word(i); w1 = word(i + 1); }
+    bool starved() const { return false; }
+};
+
 struct VecSink {
     std::vector<uint32_t> &w;
     void or_word(uint32_t i, uint32_t v) { if (i >= w.size()) w.resize(i + 1, 0); w[i] |= v; }
@@ -118,6 +127,46 @@ extern "C" int emul_encode(const uint32_t *p /*bps,bs,rsi,flags*/, const uint8_t
                       : encode_t<false>(c, in, out, cap, start_bit, k_in, total_bits, k_out, meta_out, rsi_off);
 }
 
+// phase-structured block decoder (aec_lane.h decode_block), templated block sizes only
+template <int BS>
+static int decode_fast(const Cfg &c, const std::vector<uint32_t> &words, size_t in_len, const uint64_t *rsi_off,
+                       uint64_t nrsi, uint64_t total_blocks, uint8_t *out, size_t cap)
+{
+    const bool pp = c.flags & F_PREPROCESS, msb = c.flags & F_MSB;
+    uint32_t d[BS];
+    for (uint64_t r = 0; r < nrsi; r++) {
+        const uint64_t a0 = (rsi_off[r] >> 5) & ~3ull;
+        MemSrc src{words.data(), words.size(), a0};
+        uint32_t p = (uint32_t)(rsi_off[r] - a0 * 32);
+        const uint32_t end_p = (uint32_t)((uint64_t)in_len * 8 - a0 * 32);
+        uint64_t nb = total_blocks - r * c.rsi;
+        if (nb > c.rsi) nb = c.rsi;
+        uint32_t x = 0, zrun = 0;
+        uint64_t o = r * c.rsi * (uint64_t)c.bs;
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint32_t ref = (pp && b == 0) ? 1 : 0;
+            uint32_t nz = 0;
+            const bool parse = zrun == 0;
+            const uint32_t st = decode_block<BS>(src, p, end_p, d, c, ref, b, parse, nz);
+            if (parse && st != DEC_OK) return (int)st;
+            if (parse && nz) zrun = nz;
+            for (uint32_t j = 0; j < (uint32_t)BS; j++) {
+                uint32_t v;
+                if (!pp) v = d[j];
+                else if (ref && parse && j == 0) v = x = (c.flags & F_SIGNED) ? sign_extend(d[0], c.bps) : d[0];
+                else v = x = (c.flags & F_SIGNED) ? unpp_signed(x, d[j], c.xmax) : unpp_unsigned(x, d[j], c.xmax);
+                if ((o + j + 1) * c.bytes > cap) return -100;
+                uint8_t *q = out + (o + j) * c.bytes;
+                for (uint32_t t = 0; t < c.bytes; t++)
+                    q[t] = (uint8_t)(v >> (8 * (msb ? c.bytes - 1 - t : t)));
+            }
+            o += BS;
+            if (zrun) zrun--;
+        }
+    }
+    return 0;
+}
+
 // decode every RSI from its bit offset; returns status, writes whole blocks
 extern "C" int emul_decode(const uint32_t *p, const uint8_t *in, size_t in_len, const uint64_t *rsi_off,
                            uint64_t nrsi, uint64_t total_blocks, uint8_t *out, size_t cap)
@@ -128,10 +177,19 @@ extern "C" int emul_decode(const uint32_t *p, const uint8_t *in, size_t in_len, 
     const bool pp = c.flags & F_PREPROCESS, msb = c.flags & F_MSB;
     std::vector<uint32_t> words((in_len + 3) / 4 + 1, 0);
     memcpy(words.data(), in, in_len);
+    switch (c.bs) {
+    case 8: return decode_fast<8>(c, words, in_len, rsi_off, nrsi, total_blocks, out, cap);
+    case 16: return decode_fast<16>(c, words, in_len, rsi_off, nrsi, total_blocks, out, cap);
+    case 32: return decode_fast<32>(c, words, in_len, rsi_off, nrsi, total_blocks, out, cap);
+    case 64: return decode_fast<64>(c, words, in_len, rsi_off, nrsi, total_blocks, out, cap);
+    default: break;
+    }
     uint32_t d[64];
     for (uint64_t r = 0; r < nrsi; r++) {
-        BitReader br;
-        br.init(words.data(), words.size(), (uint64_t)in_len * 8, rsi_off[r]);
+        WinReader<MemSrc> br;
+        const uint64_t a0 = (rsi_off[r] >> 5) & ~3ull;
+        br.init(MemSrc{words.data(), words.size(), a0}, a0 * 32, (uint64_t)in_len * 8,
+                (uint32_t)(rsi_off[r] - a0 * 32));
         uint64_t nb = total_blocks - r * c.rsi;
         if (nb > c.rsi) nb = c.rsi;
         uint32_t x = 0;
