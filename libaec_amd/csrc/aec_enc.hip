@@ -22,6 +22,8 @@
 // + 1 write of the compressed stream.  Algorithmic bytes are N + C.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "aec_kernels.h"
 #include "aec_lane.h"
 
@@ -30,6 +32,20 @@ namespace aec {
 namespace {
 
 constexpr uint32_t kWave = 64;
+
+// LDS rows [block][sample] of preprocessed samples.  Samples of at most 16 bits are kept as
+// uint16 (half the LDS, which is what bounds the waves per CU of k_pack); wider ones as uint32.
+// A row is padded by 16 bytes so that one-lane-per-row ds_read_b128 accesses are conflict free.
+template <int BS, int BYTES>
+struct Rows {
+    static constexpr bool HALF = BS > 0 && (BYTES == 1 || BYTES == 2);
+    __host__ __device__ static constexpr uint32_t stride_words(uint32_t bs) { return HALF ? bs / 2 + 4 : bs + 4; }
+    __device__ static __forceinline__ void put(uint32_t *rows, uint32_t stride_w, uint32_t row, uint32_t col, uint32_t v)
+    {
+        if (HALF) reinterpret_cast<uint16_t *>(rows + row * stride_w)[col] = (uint16_t)v;
+        else rows[row * stride_w + col] = v;
+    }
+};
 
 __device__ __forceinline__ void wave_lds_fence()
 {
@@ -45,28 +61,42 @@ struct LdsSink {
     }
 };
 
-__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, uint32_t lane)
+// Wave-wide inclusive scan on the DPP network (row_shr within 16-lane rows, then row_bcast:15/31
+// across rows): six cross-lane moves, no LDS traffic and no waits (the __shfl_up based version
+// costs a dozen ds_bpermute round trips per scan).  op(earlier, later) may be non-commutative.
+template <class Op>
+__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v, uint32_t ident, Op op)
 {
-#pragma unroll
-    for (uint32_t o = 1; o < kWave; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
+    uint32_t t;
+    t = __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false); v = op(t, v);   // row_shr:1
+    t = __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false); v = op(t, v);   // row_shr:2
+    t = __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false); v = op(t, v);   // row_shr:4
+    t = __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false); v = op(t, v);   // row_shr:8
+    t = __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xa, 0xf, false); v = op(t, v);   // row_bcast:15
+    t = __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xc, 0xf, false); v = op(t, v);   // row_bcast:31
     return v;
+}
+// value of lane-1 (lane 0 receives `fill`)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t fill)
+{
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);               // wave_shr:1
+}
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return __builtin_amdgcn_readlane(v, 63); }
+
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, uint32_t)
+{
+    return wave_scan_dpp(v, 0u, [](uint32_t a, uint32_t b) { return a + b; });
 }
 
 // ordered inclusive scan of k clamps packed as lo | hi << 8
 __device__ __forceinline__ uint32_t clamp_pack(KClamp c) { return c.lo | (c.hi << 8); }
 __device__ __forceinline__ KClamp clamp_unpack(uint32_t p) { return KClamp{p & 0xFFu, (p >> 8) & 0xFFu}; }
 
-__device__ __forceinline__ uint32_t wave_incl_clamp(uint32_t v, uint32_t lane)
+__device__ __forceinline__ uint32_t wave_incl_clamp(uint32_t v, uint32_t)
 {
-#pragma unroll
-    for (uint32_t o = 1; o < kWave; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o);
-        if (lane >= o) v = clamp_pack(kclamp_then(clamp_unpack(t), clamp_unpack(v)));
-    }
-    return v;
+    return wave_scan_dpp(v, clamp_pack(kclamp_identity()), [](uint32_t a, uint32_t b) {
+        return clamp_pack(kclamp_then(clamp_unpack(a), clamp_unpack(b)));
+    });
 }
 
 struct Seg {
@@ -81,7 +111,8 @@ struct Seg {
 __device__ __forceinline__ Seg seg_geom(const Cfg &c, uint64_t sg)
 {
     Seg g;
-    g.rsi_idx = sg / c.segs_per_rsi;
+    // 32-bit division whenever possible (a 64-bit one costs ~100 instructions per segment)
+    g.rsi_idx = (sg >> 32) ? sg / c.segs_per_rsi : (uint64_t)((uint32_t)sg / c.segs_per_rsi);
     const uint32_t s = (uint32_t)(sg - g.rsi_idx * c.segs_per_rsi);
     g.b0 = s * 64u;
     uint64_t nb = c.total_blocks - g.rsi_idx * c.rsi;
@@ -98,63 +129,125 @@ __device__ __forceinline__ Seg seg_geom(const Cfg &c, uint64_t sg)
 }
 
 // ---- phase A, fast path: whole 16-byte chunks, segment 16-byte aligned in HBM ----------------
+// Split into ISSUE (global loads into registers) and FINISH (byte order, predictor, LDS rows) so
+// that the loads of segment i+1 are in flight while segment i is analysed / packed: a wavefront
+// otherwise exposes a full HBM round trip several times per segment.
+template <int BYTES>
+__device__ __forceinline__ uint32_t load_sample_typed(const uint8_t *p, bool msb)
+{
+    if (BYTES == 1) return *p;
+    if (BYTES == 2) {
+        const uint32_t v = *reinterpret_cast<const uint16_t *>(p);
+        return msb ? ((v >> 8) | ((v & 0xFFu) << 8)) : v;
+    }
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+    return msb ? bswap32(v) : v;
+}
+
 template <int BS, int BYTES>
-__device__ __forceinline__ void load_segment_fast(const Cfg &c, const uint8_t *in, const Seg &g,
-                                                  uint32_t *rows, uint32_t lane)
+struct FastSeg {
+    static constexpr uint32_t CHUNKS = (uint32_t)BS * BYTES * 64u / 16u;       // per full segment
+    static constexpr uint32_t NIT = (CHUNKS + 63u) / 64u;                      // chunk rounds per lane
+    uint4 v[NIT];
+    uint32_t carry;   // sample just before the segment (raw, caller's byte order resolved)
+};
+
+// max_chunk = index of the last whole 16-byte chunk of the input (addresses are clamped to it, so
+// the loads are unconditional and can be issued for a segment that later takes the generic path)
+template <int BS, int BYTES>
+__device__ __forceinline__ void fast_issue(const Cfg &c, const uint8_t *in, const Seg &g, uint32_t lane,
+                                           uint64_t max_chunk, FastSeg<BS, BYTES> &f)
+{
+    const bool msb = c.flags & F_MSB;
+    const uint4 *src = reinterpret_cast<const uint4 *>(in);
+    const uint64_t first = g.samp0 * BYTES / 16u;
+#pragma unroll
+    for (uint32_t it = 0; it < FastSeg<BS, BYTES>::NIT; it++) {
+        uint64_t ci = first + it * kWave + lane;
+        if (ci > max_chunk) ci = max_chunk;
+        f.v[it] = src[ci];
+    }
+    const uint64_t prev = g.samp0 ? g.samp0 - 1 : 0;
+    f.carry = load_sample_typed<BYTES>(in + prev * BYTES, msb);
+}
+
+template <int BS, int BYTES>
+__device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const FastSeg<BS, BYTES> &f,
+                                            uint32_t *rows, uint32_t lane)
 {
     constexpr uint32_t SPC = 16 / BYTES;           // samples per chunk
-    constexpr uint32_t STRIDE = BS + 4;
+    constexpr uint32_t STRIDE = Rows<BS, BYTES>::stride_words(BS);
     const bool msb = c.flags & F_MSB, pp = c.flags & F_PREPROCESS;
     const uint32_t nchunks = g.nv * (uint32_t)BS * BYTES / 16u;
-    const uint4 *src = reinterpret_cast<const uint4 *>(in + g.samp0 * BYTES);
+    uint32_t carry = f.carry;
 
-    uint32_t carry = 0;
-    if (g.b0 != 0) carry = load_sample_bytes(in + (g.samp0 - 1) * BYTES, BYTES, msb);
-
-    for (uint32_t base = 0; base < nchunks; base += kWave) {
-        const uint32_t ci = base + lane;
+#pragma unroll
+    for (uint32_t it = 0; it < FastSeg<BS, BYTES>::NIT; it++) {
+        const uint32_t ci = it * kWave + lane;
         const bool act = ci < nchunks;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (act) v = src[ci];
+        const uint4 v = f.v[it];
         const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
         uint32_t x[SPC];
         if (BYTES == 4) {
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) x[j] = msb ? bswap32(vw[j]) : vw[j];
         } else if (BYTES == 2) {
+            uint32_t sw[4];
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) {
-                const uint32_t h = (vw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                x[j] = msb ? ((h >> 8) | ((h & 0xFFu) << 8)) : h;
-            }
+            for (uint32_t j = 0; j < 4; j++)   // swap the bytes of both halves at once for MSB data
+                sw[j] = msb ? (((vw[j] & 0x00FF00FFu) << 8) | ((vw[j] >> 8) & 0x00FF00FFu)) : vw[j];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) x[j] = (j & 1) ? sw[j >> 1] >> 16 : sw[j >> 1] & 0xFFFFu;
         } else {
 #pragma unroll
             for (uint32_t j = 0; j < 16; j++) x[j] = (vw[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
         }
         const uint32_t last = x[SPC - 1];
-        uint32_t prev = __shfl_up(last, 1);
-        if (lane == 0) prev = carry;
-        carry = __shfl(last, 63);
+        const uint32_t prev = wave_shr1(last, carry);
+        carry = wave_last(last);
         if (act) {
             uint32_t dd[SPC];
+            // the three flavours are selected once per chunk (wave-uniform), not per sample
+            if (!pp) {
 #pragma unroll
-            for (uint32_t j = 0; j < SPC; j++) {
-                const uint32_t p = j ? x[j - 1] : prev;
-                dd[j] = pp ? pp_any(p, x[j], c) : x[j];
+                for (uint32_t j = 0; j < SPC; j++) dd[j] = x[j];
+            } else if (c.flags & F_SIGNED) {
+                uint32_t pv = sign_extend(prev, c.bps);
+#pragma unroll
+                for (uint32_t j = 0; j < SPC; j++) {
+                    const uint32_t cv = sign_extend(x[j], c.bps);
+                    dd[j] = pp_signed(pv, cv, c.xmin, c.xmax);
+                    pv = cv;
+                }
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < SPC; j++) dd[j] = pp_unsigned(j ? x[j - 1] : prev, x[j], c.xmax);
             }
             if (pp && g.b0 == 0 && ci == 0) dd[0] = 0;   // reference sample slot, encode.c:254
+            if (Rows<BS, BYTES>::HALF) {
 #pragma unroll
-            for (uint32_t q = 0; q < SPC / 4; q++) {
-                const uint32_t i = ci * SPC + q * 4;
-                const uint32_t row = i / BS, col = i % BS;
-                *reinterpret_cast<uint4 *>(&rows[row * STRIDE + col]) =
-                    make_uint4(dd[4 * q], dd[4 * q + 1], dd[4 * q + 2], dd[4 * q + 3]);
+                for (uint32_t q = 0; q < SPC / 8; q++) {
+                    const uint32_t i = ci * SPC + q * 8;
+                    const uint32_t row = i / BS, col = i % BS;
+                    *reinterpret_cast<uint4 *>(&rows[row * STRIDE + col / 2]) =
+                        make_uint4(dd[8 * q] | (dd[8 * q + 1] << 16), dd[8 * q + 2] | (dd[8 * q + 3] << 16),
+                                   dd[8 * q + 4] | (dd[8 * q + 5] << 16), dd[8 * q + 6] | (dd[8 * q + 7] << 16));
+                }
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < SPC / 4; q++) {
+                    const uint32_t i = ci * SPC + q * 4;
+                    const uint32_t row = i / BS, col = i % BS;
+                    *reinterpret_cast<uint4 *>(&rows[row * STRIDE + col]) =
+                        make_uint4(dd[4 * q], dd[4 * q + 1], dd[4 * q + 2], dd[4 * q + 3]);
+                }
             }
         }
     }
 }
 
 // ---- phase A, generic path: lane = sample, byte loads, end-of-data padding -------------------
+template <int BS, int BYTES>
 __device__ __forceinline__ void load_segment_generic(const Cfg &c, const uint8_t *in, const Seg &g,
                                                      uint32_t *rows, uint32_t stride, uint32_t lane)
 {
@@ -174,40 +267,85 @@ __device__ __forceinline__ void load_segment_generic(const Cfg &c, const uint8_t
             const uint64_t gp = gi - 1 < last ? gi - 1 : last;
             dv = pp_any(load_sample_bytes(in + gp * c.bytes, c.bytes, msb), cur, c);
         }
-        rows[(i / c.bs) * stride + (i % c.bs)] = dv;
+        Rows<BS, BYTES>::put(rows, stride, i / c.bs, i % c.bs, dv);
     }
 }
 
+// Segment feeder: owns the prefetched registers of the NEXT segment.  fast == templated block
+// size, 1/2/4-byte containers, 16-byte aligned RSIs; everything else takes the generic loader.
 template <int BS, int BYTES>
-__device__ __forceinline__ void load_segment(const Cfg &c, const uint8_t *in, const Seg &g,
-                                             uint32_t *rows, uint32_t stride, uint32_t lane, bool fast_ok)
-{
-    if (BS > 0 && BYTES != 3 && BYTES != 0) {
-        if (fast_ok && g.full) {
-            load_segment_fast<(BS > 0 ? BS : 8), (BYTES == 1 || BYTES == 2 || BYTES == 4) ? BYTES : 1>(
-                c, in, g, rows, lane);
-            return;
+struct Feeder {
+    static constexpr bool FAST_T = BS > 0 && (BYTES == 1 || BYTES == 2 || BYTES == 4);
+    static constexpr int FBS = FAST_T ? BS : 8, FBY = FAST_T ? BYTES : 1;
+    // prefetch across segments only while it is cheap in registers (<= 4 x 16 bytes per lane)
+    static constexpr bool PIPE = FAST_T && FastSeg<FBS, FBY>::NIT <= 4;
+    FastSeg<(PIPE ? FBS : 8), (PIPE ? FBY : 1)> pre;
+    bool fast;            // run-time half of the decision (alignment, at least one whole chunk)
+    uint64_t max_chunk;
+
+    __device__ __forceinline__ void init(const Cfg &c, uint32_t fast_ok)
+    {
+        const uint64_t total_bytes = c.total_samples * c.bytes;
+        fast = FAST_T && fast_ok && total_bytes >= 16;
+        max_chunk = total_bytes >= 16 ? total_bytes / 16 - 1 : 0;
+    }
+    __device__ __forceinline__ void prefetch(const Cfg &c, const uint8_t *in, const Seg &g, uint32_t lane)
+    {
+        if (PIPE) {
+            if (fast) fast_issue<(PIPE ? FBS : 8), (PIPE ? FBY : 1)>(c, in, g, lane, max_chunk, pre);
         }
     }
-    load_segment_generic(c, in, g, rows, stride, lane);
-}
+    // consumes the registers prefetched for g (call prefetch(next) BEFORE this to overlap)
+    __device__ __forceinline__ void feed(const Cfg &c, const uint8_t *in, const Seg &g,
+                                         const FastSeg<(PIPE ? FBS : 8), (PIPE ? FBY : 1)> &cur, uint32_t *rows,
+                                         uint32_t stride, uint32_t lane)
+    {
+        if (PIPE) {
+            if (fast && g.full) {
+                fast_finish<(PIPE ? FBS : 8), (PIPE ? FBY : 1)>(c, g, cur, rows, lane);
+                return;
+            }
+        } else if (FAST_T) {
+            if (fast && g.full) {          // big blocks: load and use in place
+                FastSeg<FBS, FBY> now;
+                fast_issue<FBS, FBY>(c, in, g, lane, max_chunk, now);
+                fast_finish<FBS, FBY>(c, g, now, rows, lane);
+                return;
+            }
+        }
+        load_segment_generic<BS, BYTES>(c, in, g, rows, stride, lane);
+    }
+};
 
 // copy a block's LDS row into registers (BS > 0) or alias the row (BS == 0)
-template <int BS>
+template <int BS, bool HALF>
 struct BlockRegs {
     uint32_t v[BS];
     __device__ __forceinline__ const uint32_t *load(const uint32_t *row)
     {
+        if (HALF) {
 #pragma unroll
-        for (int q = 0; q < BS / 4; q++) {
-            const uint4 t = *reinterpret_cast<const uint4 *>(row + 4 * q);
-            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            for (int q = 0; q < BS / 8; q++) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(row + 4 * q);
+                const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    v[8 * q + 2 * j] = w[j] & 0xFFFFu;
+                    v[8 * q + 2 * j + 1] = w[j] >> 16;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < BS / 4; q++) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(row + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
         }
         return v;
     }
 };
-template <>
-struct BlockRegs<0> {
+template <bool HALF>
+struct BlockRegs<0, HALF> {
     __device__ __forceinline__ const uint32_t *load(const uint32_t *row) { return row; }
 };
 
@@ -225,6 +363,11 @@ __device__ __forceinline__ bool block_is_zero(const uint32_t *d, uint32_t bs_rt)
 // K1: analysis
 // ----------------------------------------------------------------------------------------------
 template <int BS, int BYTES>
+__device__ __forceinline__ void analyze_body(const Cfg &c, const Seg &g, uint32_t *rows, uint32_t stride,
+                                             uint32_t lane, uint64_t sg, uint32_t *__restrict__ meta,
+                                             uint32_t *__restrict__ seg_bits, uint16_t *__restrict__ seg_clamp);
+
+template <int BS, int BYTES>
 __global__ void __launch_bounds__(256)
 k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ meta,
           uint32_t *__restrict__ seg_bits, uint16_t *__restrict__ seg_clamp, uint32_t segs_per_wave,
@@ -233,7 +376,7 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
-    const uint32_t stride = bs + 4;
+    const uint32_t stride = Rows<BS, BYTES>::stride_words(bs);
     uint32_t *rows = smem + (size_t)wave * 64u * stride;
     const bool pp = c.flags & F_PREPROCESS;
     constexpr bool WIDE_T = (BYTES >= 3);
@@ -243,12 +386,32 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
     uint64_t sg_end = sg + segs_per_wave;
     if (sg_end > c.total_segs) sg_end = c.total_segs;
 
+    Feeder<BS, BYTES> feeder;
+    feeder.init(c, fast_ok);
+    Seg g = seg_geom(c, sg < sg_end ? sg : 0);
+    if (sg < sg_end) feeder.prefetch(c, in, g, lane);
     for (; sg < sg_end; sg++) {
-        const Seg g = seg_geom(c, sg);
-        load_segment<BS, BYTES>(c, in, g, rows, stride, lane, fast_ok != 0);
+        const auto cur = feeder.pre;
+        const Seg gcur = g;
+        if (sg + 1 < sg_end) g = seg_geom(c, sg + 1);
+        feeder.prefetch(c, in, g, lane);          // next segment's loads fly during this one
+        feeder.feed(c, in, gcur, cur, rows, stride, lane);
+        analyze_body<BS, BYTES>(c, gcur, rows, stride, lane, sg, meta, seg_bits, seg_clamp);
+    }
+}
+
+template <int BS, int BYTES>
+__device__ __forceinline__ void analyze_body(const Cfg &c, const Seg &g, uint32_t *rows, uint32_t stride,
+                                             uint32_t lane, uint64_t sg, uint32_t *__restrict__ meta,
+                                             uint32_t *__restrict__ seg_bits, uint16_t *__restrict__ seg_clamp)
+{
+    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
+    const bool pp = c.flags & F_PREPROCESS;
+    constexpr bool WIDE_T = (BYTES >= 3);
+    {
         wave_lds_fence();
 
-        BlockRegs<BS> regs;
+        BlockRegs<BS, Rows<BS, BYTES>::HALF> regs;
         const bool valid = lane < g.nv;
         // every lane loads a row (idle lanes re-read the last valid one) so that the block lives in
         // registers instead of behind a conditionally assigned pointer
@@ -275,9 +438,9 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
             }
             meta[g.blk0 + lane] = m;
         }
-        const uint32_t tot = wave_incl_sum(meta_len(m), lane);
-        const uint32_t cl = wave_incl_clamp(clamp_pack(kc), lane);
-        if (lane == 63) {
+        const uint32_t tot = wave_last(wave_incl_sum(meta_len(m), lane));
+        const uint32_t cl = wave_last(wave_incl_clamp(clamp_pack(kc), lane));
+        if (lane == 0) {
             seg_bits[sg] = tot;
             seg_clamp[sg] = (uint16_t)cl;
         }
@@ -444,12 +607,12 @@ __global__ void __launch_bounds__(256)
 k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__ meta,
        const uint64_t *__restrict__ seg_start, const uint8_t *__restrict__ seg_kin,
        uint32_t *__restrict__ out_words, uint64_t cap_words, uint32_t segs_per_wave, uint32_t obuf_words,
-       uint32_t fast_ok)
+       uint32_t fast_ok, uint32_t dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
-    const uint32_t stride = bs + 4;
+    const uint32_t stride = Rows<BS, BYTES>::stride_words(bs);
     const uint32_t per_wave = 64u * stride + obuf_words;
     uint32_t *rows = smem + (size_t)wave * per_wave;
     uint32_t *obuf = rows + 64u * stride;
@@ -460,51 +623,83 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
     uint64_t sg_end = sg + segs_per_wave;
     if (sg_end > c.total_segs) sg_end = c.total_segs;
 
+    Feeder<BS, BYTES> feeder;
+    feeder.init(c, fast_ok);
+    Seg gnext = seg_geom(c, sg < sg_end ? sg : 0);
+    if (sg < sg_end) feeder.prefetch(c, in, gnext, lane);
+    uint32_t pending = 0;        // open tail word of the previous segment (stream bit order)
+    bool first_seg = true, carried_shared = false;
     for (; sg < sg_end; sg++) {
-        const Seg g = seg_geom(c, sg);
-        load_segment<BS, BYTES>(c, in, g, rows, stride, lane, fast_ok != 0);
-
+        const auto cur = feeder.pre;
+        const Seg g = gnext;
+        // everything this segment needs from HBM is requested before the first wait
         const bool valid = lane < g.nv;
         const uint32_t m = valid ? meta[g.blk0 + lane] : meta_pack(0, OPT_ZCONT, 0, 0);
+        const uint32_t kin = seg_kin[sg];
+        const uint64_t start = seg_start[sg];
+        uint32_t ref_sample = 0;
+        if (pp && g.b0 == 0 && lane == 0)
+            ref_sample = load_sample_bytes(in + g.samp0 * c.bytes, c.bytes, msb) & low_mask32(c.bps);
+        if (sg + 1 < sg_end) gnext = seg_geom(c, sg + 1);
+        feeder.prefetch(c, in, gnext, lane);      // next segment's loads fly during this one
+        if (!(dbg & 4)) feeder.feed(c, in, g, cur, rows, stride, lane);
+
         const uint32_t len = meta_len(m), opt = meta_opt(m);
         const uint32_t incl = wave_incl_sum(len, lane);
-        const uint32_t total = __shfl(incl, 63);
+        const uint32_t total = wave_last(incl);
         const uint32_t excl = incl - len;
 
         const bool updates_k = valid && opt != OPT_ZERO && opt != OPT_ZCONT && c.id_len > 1;
         const KClamp kc = updates_k ? KClamp{meta_a(m), meta_b(m)} : kclamp_identity();
         const uint32_t incl_c = wave_incl_clamp(clamp_pack(kc), lane);
-        uint32_t excl_c = __shfl_up(incl_c, 1);
-        if (lane == 0) excl_c = clamp_pack(kclamp_identity());
-        const uint32_t kin = seg_kin[sg];
+        const uint32_t excl_c = wave_shr1(incl_c, clamp_pack(kclamp_identity()));
         const uint32_t k = kclamp_apply(kc, kclamp_apply(clamp_unpack(excl_c), kin));
 
-        const uint64_t start = seg_start[sg];
         const uint32_t lead = (uint32_t)(start & 31u);
         const uint32_t nwords = (lead + total + 31u) >> 5;
-        for (uint32_t w = lane; w < nwords; w += kWave) obuf[w] = 0;
+        // image of the segment; its first word continues the previous segment of this wave, whose
+        // open tail word was kept in `pending` instead of being written out
+        for (uint32_t w = lane; w < nwords; w += kWave) obuf[w] = (w == 0) ? pending : 0u;
         wave_lds_fence();
 
-        if (valid && opt != OPT_ZCONT) {
+        if (!(dbg & 1)) {
+            const bool emits = valid && opt != OPT_ZCONT;
             const uint32_t ref = (pp && g.b0 == 0 && lane == 0) ? 1u : 0u;
-            uint32_t ref_sample = 0;
-            if (ref)
-                ref_sample = load_sample_bytes(in + g.samp0 * c.bytes, c.bytes, msb) & low_mask32(c.bps);
-            BlockRegs<BS> regs;
-            const uint32_t *d = regs.load(rows + lane * stride);
+            const uint32_t karg = opt == OPT_ZERO ? meta_a(m) : k;
+            BlockRegs<BS, Rows<BS, BYTES>::HALF> regs;
+            const uint32_t *d = regs.load(rows + (valid ? lane : 0u) * stride);
             LdsSink sink{obuf};
             BitWriter<LdsSink> bw(sink, lead + excl);
-            emit_block<BS>(bw, d, c, opt, opt == OPT_ZERO ? meta_a(m) : k, ref, ref_sample);
+            bool done = !emits;
+            if (BS > 0 && BS <= 16) {
+                // small blocks: unary and field regions assembled in registers (aec_lane.h emit_small)
+                uint32_t ubits = 0, fbits = 0;
+                const bool small = emits && small_eligible(c, bs, opt, karg, ref, len, ubits, fbits);
+                emit_small<(BS > 0 && BS <= 16 ? BS : 8)>(bw, d, c, opt, karg, ref, ref_sample, ubits, fbits, small);
+                done = done || small;
+            }
+            if (__any(!done)) {
+                if (!done) emit_block<BS>(bw, d, c, opt, karg, ref, ref_sample);
+            }
         }
         wave_lds_fence();
 
+        // Copy the image out.  Only a word this wave does not own alone needs an atomic: the first
+        // word of the wave's first segment (shared with the previous wave) and the open tail word of
+        // its last segment.  An open tail in between is carried to the next segment in `pending`.
         const uint64_t gw = start >> 5;
         const uint32_t tail = (lead + total) & 31u;
-        for (uint32_t w = lane; w < nwords; w += kWave) {
+        const bool last_seg = sg + 1 == sg_end;
+        const bool carry_tail = tail != 0 && !last_seg && nwords > 0;
+        // word 0 also holds bits of another wave only in the wave's first segment, or when a one-word
+        // segment carried that word along
+        const bool left_shared = first_seg ? lead != 0 : carried_shared;
+        for (uint32_t w = lane; w < nwords && !(dbg & 2); w += kWave) {
             const uint32_t v = obuf[w];
             const uint64_t idx = gw + w;
-            if (v != 0 && idx < cap_words) {
-                const bool shared = (w == 0 && lead != 0) || (w == nwords - 1 && tail != 0);
+            const bool is_tail = w == nwords - 1 && tail != 0;
+            if (v != 0 && idx < cap_words && !(is_tail && carry_tail)) {
+                const bool shared = (w == 0 && left_shared) || is_tail;
                 const uint32_t sv = bswap32(v);
                 if (shared)
                     __hip_atomic_fetch_or(&out_words[idx], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -512,6 +707,9 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
                     out_words[idx] = sv;
             }
         }
+        pending = carry_tail ? obuf[nwords - 1] : 0u;     // uniform: every lane reads the same word
+        carried_shared = carry_tail && nwords == 1 && left_shared;
+        first_seg = false;
         wave_lds_fence();
     }
 }
@@ -530,7 +728,8 @@ struct LaunchGeom {
 LaunchGeom make_geom(const Cfg &c, bool with_obuf)
 {
     LaunchGeom g;
-    const uint32_t stride = c.bs + 4;
+    const bool templated = c.bs == 8 || c.bs == 16 || c.bs == 32 || c.bs == 64;
+    const uint32_t stride = (templated && c.bytes <= 2) ? c.bs / 2 + 4 : c.bs + 4;   // Rows<>::stride_words
     const uint32_t maxlen = c.id_len + c.bs * c.bps + 2 + c.bps;
     g.obuf_words = with_obuf ? ((64u * maxlen + 62u) / 32u + 4u) & ~3u : 0u;
     const size_t per_wave = ((size_t)64 * stride + g.obuf_words) * 4;
@@ -539,9 +738,11 @@ LaunchGeom make_geom(const Cfg &c, bool with_obuf)
     if (wpb < 1) wpb = 1;
     g.waves_per_block = wpb;
     g.lds_bytes = per_wave * wpb;
-    // a wave walks a short run of consecutive segments (at least one RSI's worth up to 4)
-    uint32_t spw = c.segs_per_rsi < 4 ? c.segs_per_rsi : 4;
-    if (c.total_segs < (uint64_t)spw * wpb * 1024) spw = 1;   // small inputs: spread over the chip
+    // A wave walks a run of consecutive segments: interior word boundaries then stay inside the
+    // wave (no atomics) and the next segment's loads overlap the current one.  Small inputs are
+    // spread over the chip instead.
+    uint32_t spw = 8;
+    while (spw > 1 && c.total_segs < (uint64_t)spw * wpb * 2048) spw >>= 1;
     g.segs_per_wave = spw;
     const uint64_t waves = (c.total_segs + spw - 1) / spw;
     g.grid = (uint32_t)((waves + wpb - 1) / wpb);
@@ -564,7 +765,7 @@ void launch_pack_t(const Cfg &c, const uint8_t *in, const EncWorkspace &ws, uint
     const LaunchGeom g = make_geom(c, true);
     hipLaunchKernelGGL((k_pack<BS, BYTES>), dim3(g.grid), dim3(64 * g.waves_per_block), g.lds_bytes, st,
                        c, in, ws.meta, ws.seg_start, ws.seg_kin, out_words, cap_words, g.segs_per_wave,
-                       g.obuf_words, fast_ok);
+                       g.obuf_words, fast_ok, (uint32_t)(getenv("AEC_DBG_PACK") ? atoi(getenv("AEC_DBG_PACK")) : 0));
 }
 
 template <int BS>

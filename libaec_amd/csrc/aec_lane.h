@@ -21,6 +21,14 @@
 #define AEC_HD inline
 #endif
 
+// AEC_ANY(x): wave-uniform "some lane needs this" test used to enter rare paths once per
+// wavefront on the device; on the host (one lane at a time) it is just x.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AEC_ANY(x) __any(x)
+#else
+#define AEC_ANY(x) (x)
+#endif
+
 namespace aec {
 
 // ------------------------------------------------------------------------------------
@@ -103,27 +111,28 @@ AEC_HD uint32_t sign_extend(uint32_t v, uint32_t bps)
 }
 
 // Mapped prediction error of `cur` given its predecessor `prev` (unit-delay predictor).
-// Unsigned flavour: encode.c:255-269.
+// Both flavours are written as selects (no control flow) so that the 64 lanes of a wavefront,
+// which see different signs of the difference, stay on one instruction stream.
+// Unsigned flavour: reference encode.c:255-269.
 AEC_HD uint32_t pp_unsigned(uint32_t prev, uint32_t cur, uint32_t xmax)
 {
-    if (cur >= prev) {
-        const uint32_t delta = cur - prev;
-        return delta <= prev ? 2u * delta : cur;
-    }
-    const uint32_t delta = prev - cur;
-    return delta <= xmax - prev ? 2u * delta - 1u : xmax - cur;
+    const bool up = cur >= prev;
+    const uint32_t delta = up ? cur - prev : prev - cur;
+    const uint32_t room = up ? prev : xmax - prev;          // how far the mapping stays two-sided
+    const uint32_t folded = 2u * delta - (up ? 0u : 1u);
+    const uint32_t clipped = up ? cur : xmax - cur;
+    return delta <= room ? folded : clipped;
 }
 
-// Signed flavour: encode.c:294-309; inputs already sign extended, arithmetic modulo 2^32.
+// Signed flavour: reference encode.c:294-309; inputs already sign extended, arithmetic modulo 2^32.
 AEC_HD uint32_t pp_signed(uint32_t prev_u, uint32_t cur_u, uint32_t xmin, uint32_t xmax)
 {
-    const int32_t prev = (int32_t)prev_u, cur = (int32_t)cur_u;
-    if (cur < prev) {
-        const uint32_t delta = prev_u - cur_u;
-        return delta <= xmax - prev_u ? 2u * delta - 1u : xmax - cur_u;
-    }
-    const uint32_t delta = cur_u - prev_u;
-    return delta <= prev_u - xmin ? 2u * delta : cur_u - xmin;
+    const bool down = (int32_t)cur_u < (int32_t)prev_u;
+    const uint32_t delta = down ? prev_u - cur_u : cur_u - prev_u;
+    const uint32_t room = down ? xmax - prev_u : prev_u - xmin;
+    const uint32_t folded = 2u * delta - (down ? 1u : 0u);
+    const uint32_t clipped = down ? xmax - cur_u : cur_u - xmin;
+    return delta <= room ? folded : clipped;
 }
 
 AEC_HD uint32_t pp_any(uint32_t prev_raw, uint32_t cur_raw, const Cfg &c)
@@ -359,6 +368,60 @@ AEC_HD void emit_block(BitWriter<Sink> &w, const uint32_t *d, const Cfg &c, uint
         w.unary(k_or_fs);
     }
     w.finish();
+}
+
+// Fast emission for small blocks (BS <= 16): when the unary region (fundamental sequences /
+// second-extension codes / the zero-run code) and the k-bit field region of a CDS each fit in
+// 64 bits, both are assembled in registers with straight-line code and leave through at most
+// four word puts, instead of two bit-writer calls per sample.  For the split option at its
+// optimal k the unary region is at most 3*n bits (fs(k) <= 2n follows from g(k) <= n), so with
+// n <= 16 only k = kmax blocks can miss the fast path.  Returns the eligibility test so the
+// caller can route the remaining lanes through emit_block().
+AEC_HD bool small_eligible(const Cfg &c, uint32_t bs, uint32_t opt, uint32_t k, uint32_t ref, uint32_t len,
+                           uint32_t &ubits, uint32_t &fbits)
+{
+    const uint32_t n = bs - ref;
+    const uint32_t head = c.id_len + (opt == OPT_SPLIT ? 0u : 1u) + ref * c.bps;
+    fbits = opt == OPT_SPLIT ? n * k : 0u;
+    ubits = len - head - fbits;
+    return (opt == OPT_SPLIT || opt == OPT_SE || opt == OPT_ZERO) && ubits <= 64 && fbits <= 64 && len >= head;
+}
+
+template <int BS, class Sink>
+AEC_HD void emit_small(BitWriter<Sink> &w, const uint32_t *d, const Cfg &c, uint32_t opt, uint32_t k_or_fs,
+                       uint32_t ref, uint32_t ref_sample, uint32_t ubits, uint32_t fbits, bool live)
+{
+    const bool is_split = live && opt == OPT_SPLIT, is_se = live && opt == OPT_SE;
+    const bool is_zero = live && opt == OPT_ZERO;
+    const uint32_t k = is_split ? k_or_fs : 0u;
+    const uint32_t km = low_mask32(k);
+    uint64_t ua = is_zero ? 1u : 0u;     // unary region, right aligned
+    uint64_t fa = 0;                     // field region, right aligned
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)BS; i++) {
+        const bool act = is_split && i >= ref;
+        const uint32_t t = d[i] >> k;
+        ua = (ua << (act ? (t + 1u) & 63u : 0u)) | (act ? 1u : 0u);
+        fa = (fa << (act ? k : 0u)) | (act ? d[i] & km : 0u);
+    }
+    if (AEC_ANY(is_se)) {
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)BS; i += 2) {
+            const uint32_t sum = d[i] + d[i + 1];
+            const uint32_t m = sum * (sum + 1u) / 2u + d[i + 1];
+            ua = (ua << (is_se ? (m + 1u) & 63u : 0u)) | (is_se ? 1u : 0u);
+        }
+    }
+    if (live) {
+        const uint32_t idv = is_split ? k + 1u : (is_se ? 1u : 0u);
+        w.put(idv, c.id_len + (is_split ? 0u : 1u));
+        if (ref) w.put(ref_sample, c.bps);
+        if (ubits > 32) w.put((uint32_t)(ua >> 32), ubits - 32);
+        w.put((uint32_t)ua, ubits > 32 ? 32u : ubits);
+        if (fbits > 32) w.put((uint32_t)(fa >> 32), fbits - 32);
+        if (fbits) w.put((uint32_t)fa, fbits > 32 ? 32u : fbits);
+        w.finish();
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -646,12 +709,6 @@ AEC_HD uint32_t parse_cds(Reader &r, uint32_t *d, const Cfg &c, uint32_t ref,
 // hold different options does not serialise.  Src::word2(i, w0, w1) yields words i and i+1.
 // AEC_ANY(x) is __any(x) on the device (wave-uniform entry to the rare paths) and x on the host.
 // ------------------------------------------------------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-#define AEC_ANY(x) __any(x)
-#else
-#define AEC_ANY(x) (x)
-#endif
-
 template <class Src>
 AEC_HD uint32_t peek32(Src &src, uint32_t p)
 {
@@ -720,7 +777,7 @@ AEC_HD uint32_t decode_block(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d,
         uint32_t z1 = clz32_or32(h);
         const uint32_t h2 = z1 >= 31 ? 0u : h << (z1 + 1);
         uint32_t z2 = clz32_or32(h2);
-        const bool slow = (a1 && z1 > 15) || (a2 && (z2 > 15 || !a1 && z1 > 15));
+        const bool slow = (a1 && z1 > 15) || (a2 && (z2 > 15 || (!a1 && z1 > 15)));
         uint32_t adv = 0;
         if (AEC_ANY(slow)) {                             // rare: a long fundamental sequence
             if (slow) {

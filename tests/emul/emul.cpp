@@ -97,7 +97,12 @@ static int encode_t(const Cfg &c, const uint8_t *in, uint8_t *out, size_t cap, u
             uint32_t karg = opt == OPT_ZERO ? meta_a(meta[l])
                            : kclamp_apply(KClamp{meta_a(meta[l]), meta_b(meta[l])}, kprev[l]);
             BitWriter<VecSink> w(sink, off);
-            emit_block<0>(w, &d[l * c.bs], c, opt, karg, ref, ref_sample);
+            uint32_t ubits = 0, fbits = 0;
+            const bool small = (c.bs == 8 || c.bs == 16) &&
+                               small_eligible(c, c.bs, opt, karg, ref, meta_len(meta[l]), ubits, fbits);
+            if (small && c.bs == 8) emit_small<8>(w, &d[l * c.bs], c, opt, karg, ref, ref_sample, ubits, fbits, true);
+            else if (small) emit_small<16>(w, &d[l * c.bs], c, opt, karg, ref, ref_sample, ubits, fbits, true);
+            else emit_block<0>(w, &d[l * c.bs], c, opt, karg, ref, ref_sample);
             off += meta_len(meta[l]);
         }
         kcur = kclamp_apply(segc, kcur);
