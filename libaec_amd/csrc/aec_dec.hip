@@ -129,11 +129,21 @@ struct RingSrc {
         w0 = q[0];
         w1 = q[64];
     }
+    // words i, i+1, i+2 (rows mask+1 and mask+2 mirror rows 0 and 1)
+    __device__ __forceinline__ void word3(uint32_t i, uint32_t &w0, uint32_t &w1, uint32_t &w2)
+    {
+        starve |= (i + 2 >= limit) ? 1u : 0u;
+        const uint32_t *q = col + ((slot0 + i) & mask) * 64u;
+        w0 = q[0];
+        w1 = q[64];
+        w2 = q[128];
+    }
     __device__ __forceinline__ bool starved() const { return starve != 0; }
 };
 
-// four consecutive stream words starting at absolute index idx (multiple of 4), host order;
-// zeros past the end of the buffer
+// four consecutive stream words starting at absolute index idx (multiple of 4), RAW byte order
+// (the swap to host order happens when they are written to the ring, so that a load issued one
+// iteration ahead is not waited for at issue time); zeros past the end of the buffer
 __device__ __forceinline__ uint4 load_words4(const uint32_t *__restrict__ words, uint64_t idx, uint64_t nwords)
 {
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -144,7 +154,7 @@ __device__ __forceinline__ uint4 load_words4(const uint32_t *__restrict__ words,
         if (idx + 1 < nwords) v.y = words[idx + 1];
         if (idx + 2 < nwords) v.z = words[idx + 2];
     }
-    return make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+    return v;
 }
 
 // rel is a multiple of 4 and slot0 a multiple of 4, so the four rows never wrap inside a chunk
@@ -152,11 +162,15 @@ __device__ __forceinline__ void ring_put4(uint32_t *col, uint32_t slot0, uint32_
 {
     const uint32_t row = (slot0 + rel) & mask;
     uint32_t *q = col + row * 64u;
-    q[0] = v.x;
-    q[64] = v.y;
-    q[128] = v.z;
-    q[192] = v.w;
-    if (row == 0) col[(mask + 1u) * 64u] = v.x;   // mirror of row 0 for word2()
+    const uint32_t x = bswap32(v.x), y = bswap32(v.y);
+    q[0] = x;
+    q[64] = y;
+    q[128] = bswap32(v.z);
+    q[192] = bswap32(v.w);
+    if (row == 0) {                               // mirrors of rows 0 and 1 for word2() / word3()
+        col[(mask + 1u) * 64u] = x;
+        col[(mask + 2u) * 64u] = y;
+    }
 }
 
 constexpr int kPend = 2;   // 16-byte loads kept in flight per lane across one block iteration
@@ -169,7 +183,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t *col = smem + (size_t)wave * (ring_words + 1u) * 64u + lane;
+    uint32_t *col = smem + (size_t)wave * (ring_words + 2u) * 64u + lane;
     const uint32_t mask = ring_words - 1;
 
     const uint64_t r = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 64u + lane;
@@ -212,24 +226,28 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
 
     for (uint32_t b = 0; __any(b < nb && ok); b++) {
         const bool live = b < nb && ok;
-        // ---- top up the ring (wave-synchronous) ----
+        // Order inside one iteration: (rare) synchronous refill -> decode -> land the 16-byte loads
+        // issued one iteration ago -> store the block -> issue the next loads.  At the landing
+        // point everything still outstanding (those loads, the previous block's stores) was
+        // issued at least one whole block decode earlier, so the vmcnt wait there is free.
+        {
+            const uint32_t next = BS ? (p >> 5) : br.next;         // first word still needed
+            if (__any(live && landed - next < maxw)) {             // rare: a lane fell behind
 #pragma unroll
-        for (int j = 0; j < kPend; j++)
-            if (pv[j]) {
-                ring_put4(col, slot0, mask, landed, pend[j]);
-                landed += 4;
+                for (int j = 0; j < kPend; j++) {                  // in-flight chunks come first
+                    if (pv[j]) {
+                        ring_put4(col, slot0, mask, landed, pend[j]);
+                        landed += 4;
+                    }
+                    pv[j] = false;
+                }
+                while (__any(live && landed - next < maxw)) {
+                    if (live && landed - next < maxw) {
+                        ring_put4(col, slot0, mask, landed, load_words4(words, a0 + landed, nwords));
+                        landed += 4;
+                    }
+                }
             }
-        const uint32_t next = BS ? (p >> 5) : br.next;             // first word still needed
-        while (__any(live && landed - next < maxw)) {              // rare: a lane fell behind
-            if (live && landed - next < maxw) {
-                ring_put4(col, slot0, mask, landed, load_words4(words, a0 + landed, nwords));
-                landed += 4;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kPend; j++) {
-            pv[j] = live && (landed + 4u * j + 4u - next <= ring_words);
-            if (pv[j]) pend[j] = load_words4(words, a0 + landed + 4u * j, nwords);
         }
 
         // ---- one block per lane ----
@@ -248,10 +266,22 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                     zrun = nz;
                 }
             }
+#pragma unroll
+            for (int j = 0; j < kPend; j++)                        // land last iteration's loads
+                if (pv[j]) {
+                    ring_put4(col, slot0, mask, landed, pend[j]);
+                    landed += 4;
+                }
             if (live && ok) {
                 store_block<DN, (BYTES ? BYTES : 1)>(dst, d, c, ref != 0 && parse, x);
                 dst += blk_bytes;
                 zrun -= zrun ? 1u : 0u;
+            }
+            const uint32_t next = p >> 5;
+#pragma unroll
+            for (int j = 0; j < kPend; j++) {                      // issue the next loads
+                pv[j] = live && ok && (landed + 4u * j + 4u - next <= ring_words);
+                if (pv[j]) pend[j] = load_words4(words, a0 + landed + 4u * j, nwords);
             }
         } else if (live) {
             br.src.limit = landed;
@@ -344,11 +374,11 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi)
 {
     DecGeom g;
     const uint32_t maxbits = c.id_len + 1 + c.bps + c.bs * c.bps;
-    g.maxw = maxbits / 32 + 3;
+    g.maxw = maxbits / 32 + 5;   // + look-ahead of the 64-bit peeks
     uint32_t rw = 16;
-    while (rw < 2 * g.maxw + 8) rw <<= 1;
+    while (rw < 2 * g.maxw + 3) rw <<= 1;
     g.ring_words = rw;
-    const size_t per_wave = (size_t)(rw + 1) * 64 * 4;
+    const size_t per_wave = (size_t)(rw + 2) * 64 * 4;
     uint32_t waves = (uint32_t)(65536 / per_wave);
     if (waves > 4) waves = 4;
     if (waves < 1) waves = 1;

@@ -22,8 +22,6 @@
 // + 1 write of the compressed stream.  Algorithmic bytes are N + C.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "aec_kernels.h"
 #include "aec_lane.h"
 
@@ -607,7 +605,7 @@ __global__ void __launch_bounds__(256)
 k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__ meta,
        const uint64_t *__restrict__ seg_start, const uint8_t *__restrict__ seg_kin,
        uint32_t *__restrict__ out_words, uint64_t cap_words, uint32_t segs_per_wave, uint32_t obuf_words,
-       uint32_t fast_ok, uint32_t dbg)
+       uint32_t fast_ok)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -642,7 +640,7 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
             ref_sample = load_sample_bytes(in + g.samp0 * c.bytes, c.bytes, msb) & low_mask32(c.bps);
         if (sg + 1 < sg_end) gnext = seg_geom(c, sg + 1);
         feeder.prefetch(c, in, gnext, lane);      // next segment's loads fly during this one
-        if (!(dbg & 4)) feeder.feed(c, in, g, cur, rows, stride, lane);
+        feeder.feed(c, in, g, cur, rows, stride, lane);
 
         const uint32_t len = meta_len(m), opt = meta_opt(m);
         const uint32_t incl = wave_incl_sum(len, lane);
@@ -662,7 +660,7 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
         for (uint32_t w = lane; w < nwords; w += kWave) obuf[w] = (w == 0) ? pending : 0u;
         wave_lds_fence();
 
-        if (!(dbg & 1)) {
+        {
             const bool emits = valid && opt != OPT_ZCONT;
             const uint32_t ref = (pp && g.b0 == 0 && lane == 0) ? 1u : 0u;
             const uint32_t karg = opt == OPT_ZERO ? meta_a(m) : k;
@@ -694,7 +692,7 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
         // word 0 also holds bits of another wave only in the wave's first segment, or when a one-word
         // segment carried that word along
         const bool left_shared = first_seg ? lead != 0 : carried_shared;
-        for (uint32_t w = lane; w < nwords && !(dbg & 2); w += kWave) {
+        for (uint32_t w = lane; w < nwords; w += kWave) {
             const uint32_t v = obuf[w];
             const uint64_t idx = gw + w;
             const bool is_tail = w == nwords - 1 && tail != 0;
@@ -765,7 +763,7 @@ void launch_pack_t(const Cfg &c, const uint8_t *in, const EncWorkspace &ws, uint
     const LaunchGeom g = make_geom(c, true);
     hipLaunchKernelGGL((k_pack<BS, BYTES>), dim3(g.grid), dim3(64 * g.waves_per_block), g.lds_bytes, st,
                        c, in, ws.meta, ws.seg_start, ws.seg_kin, out_words, cap_words, g.segs_per_wave,
-                       g.obuf_words, fast_ok, (uint32_t)(getenv("AEC_DBG_PACK") ? atoi(getenv("AEC_DBG_PACK")) : 0));
+                       g.obuf_words, fast_ok);
 }
 
 template <int BS>

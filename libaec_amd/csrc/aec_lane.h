@@ -717,6 +717,18 @@ AEC_HD uint32_t peek32(Src &src, uint32_t p)
     return (uint32_t)((((((uint64_t)w0) << 32) | w1) << (p & 31u)) >> 32);
 }
 
+// 64 stream bits starting at bit position p (Src::word3 yields three consecutive words)
+template <class Src>
+AEC_HD uint64_t peek64(Src &src, uint32_t p)
+{
+    uint32_t w0, w1, w2;
+    src.word3(p >> 5, w0, w1, w2);
+    const uint32_t sh = p & 31u;
+    const uint32_t hi = (uint32_t)((((((uint64_t)w0) << 32) | w1) << sh) >> 32);
+    const uint32_t lo = (uint32_t)((((((uint64_t)w1) << 32) | w2) << sh) >> 32);
+    return (((uint64_t)hi) << 32) | lo;
+}
+
 AEC_HD uint32_t clz32_or32(uint32_t v) { return v ? (uint32_t)__builtin_clz(v) : 32u; }
 
 // general unary read at p for codes of any length; stops at end_p (stream end)
@@ -767,47 +779,73 @@ AEC_HD uint32_t decode_block(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d,
     }
 
     // ---- 2. unary phase: code for sample slot i lives in u[i] ---------------------------------
+    // Eight slots per 64-bit peek: each code is located with one clz on the upper half and one
+    // 64-bit shift.  (For the split option at its optimal k the whole unary region of a block is
+    // at most 3*n bits, see emit_small.)  A group that does not fit 64 bits, or holds a code with
+    // 32 or more zeros, is redone code by code -- entered wave-uniformly, practically never.
     const uint32_t nfs = split ? (uint32_t)BS - ref : (se ? (uint32_t)BS / 2 : (zero ? 1u : 0u));
     uint32_t u[BS];
+    constexpr uint32_t GRP = BS < 8 ? (uint32_t)BS : 8u;
 #pragma unroll
-    for (uint32_t i = 0; i < (uint32_t)BS; i += 2) {
-        const bool a1 = i >= ref && i - ref < nfs;
-        const bool a2 = i + 1 - ref < nfs;               // i + 1 >= 1 >= ref always
-        h = peek32(src, p);
-        uint32_t z1 = clz32_or32(h);
-        const uint32_t h2 = z1 >= 31 ? 0u : h << (z1 + 1);
-        uint32_t z2 = clz32_or32(h2);
-        const bool slow = (a1 && z1 > 15) || (a2 && (z2 > 15 || (!a1 && z1 > 15)));
-        uint32_t adv = 0;
-        if (AEC_ANY(slow)) {                             // rare: a long fundamental sequence
-            if (slow) {
+    for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += GRP) {
+        uint64_t U = peek64(src, p);
+        uint32_t used = 0;
+        bool bad = false;
+#pragma unroll
+        for (uint32_t j = 0; j < GRP; j++) {
+            const uint32_t i = g0 + j;
+            const bool act = i >= ref && i - ref < nfs;
+            const uint32_t z = clz32_or32((uint32_t)(U >> 32));
+            bad = bad || (act && z >= 32);
+            const uint32_t n1 = act ? z + 1u : 0u;
+            U <<= (n1 & 63u);
+            used += n1;
+            u[i] = act ? z : 0u;
+        }
+        if (AEC_ANY(bad)) {
+            if (bad) {
                 uint32_t q = p;
-                if (a1) z1 = unary_slow(src, q, end_p, short_input);
-                if (a2) z2 = unary_slow(src, q, end_p, short_input);
-                adv = q - p;
+#pragma unroll
+                for (uint32_t j = 0; j < GRP; j++) {
+                    const uint32_t i = g0 + j;
+                    if (i >= ref && i - ref < nfs) u[i] = unary_slow(src, q, end_p, short_input);
+                }
+                used = q - p;
             }
         }
-        if (!slow) {
-            // without code 1 the second code starts at p itself
-            if (!a1) z2 = z1;
-            adv = (a1 ? z1 + 1 : 0u) + (a2 ? z2 + 1 : 0u);
-        }
-        p += adv;
-        u[i] = a1 ? z1 : 0u;
-        u[i + 1] = a2 ? z2 : 0u;
+        p += used;
     }
 
     // ---- 3. field phase ---------------------------------------------------------------------
     const uint32_t kk = split ? k : (unc ? c.bps : 0u);
     const uint32_t nf = split ? (uint32_t)BS - ref : (unc ? (uint32_t)BS : 0u);
     const uint32_t off = split ? ref : 0u;
-    const uint32_t fsh = (32u - kk) & 31u;
+    if (AEC_ANY(kk > 8)) {
+        // wide fields (uncompressed blocks, large k): one 32-bit peek per sample
+        const uint32_t fsh = (32u - kk) & 31u;
 #pragma unroll
-    for (uint32_t i = 0; i < (uint32_t)BS; i++) {
-        const bool act = kk != 0 && i >= off && i - off < nf;
-        const uint32_t v = peek32(src, act ? p + (i - off) * kk : p);
-        const uint32_t f = act ? v >> fsh : 0u;
-        d[i] = (u[i] << k) + f;                          // k == 0 for uncompressed lanes
+        for (uint32_t i = 0; i < (uint32_t)BS; i++) {
+            const bool act = kk != 0 && i >= off && i - off < nf;
+            const uint32_t v = peek32(src, act ? p + (i - off) * kk : p);
+            const uint32_t f = act ? v >> fsh : 0u;
+            d[i] = (u[i] << k) + f;                      // k == 0 for uncompressed lanes
+        }
+    } else {
+        // narrow fields: eight of them per 64-bit peek
+        const uint32_t km = low_mask32(kk);
+#pragma unroll
+        for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += GRP) {
+            const bool gact = kk != 0 && g0 + GRP > off && g0 < nf + off;
+            const uint32_t base = gact ? p + g0 * kk - off * kk : p;
+            const uint64_t F = peek64(src, base);
+#pragma unroll
+            for (uint32_t j = 0; j < GRP; j++) {
+                const uint32_t i = g0 + j;
+                const bool act = kk != 0 && i >= off && i - off < nf;
+                const uint32_t f = (uint32_t)(F >> ((64u - (j + 1u) * kk) & 63u)) & km;
+                d[i] = (u[i] << k) + (act ? f : 0u);
+            }
+        }
     }
     p += nf * kk;
     if (ref && !unc) d[0] = refv;

@@ -18,6 +18,7 @@ struct MemSrc {
     uint64_t n, base;
     uint32_t word(uint32_t i) const { const uint64_t idx = base + i; return idx < n ? bswap32(w[idx]) : 0u; }
     void word2(uint32_t i, uint32_t &w0, uint32_t &w1) const { w0 = word(i); w1 = word(i + 1); }
+    void word3(uint32_t i, uint32_t &w0, uint32_t &w1, uint32_t &w2) const { w0 = word(i); w1 = word(i + 1); w2 = word(i + 2); }
     bool starved() const { return false; }
 };
 
