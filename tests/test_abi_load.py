@@ -34,8 +34,12 @@ def test_every_declared_symbol_is_exported(lib):
     assert {"aec_encode_init", "aec_encode", "aec_encode_end", "aec_decode_init", "aec_decode",
             "aec_decode_end", "aec_buffer_encode", "aec_buffer_decode"} <= set(names)
     assert "aec_gpu_encode_async" in names and "aec_gpu_decode_async" in names
+    from libaec_amd import szip
+    sz = C.CDLL(szip.library_path())
+    assert {"SZ_BufftoBuffCompress", "SZ_BufftoBuffDecompress", "SZ_encoder_enabled", "SZ_Compress"} <= set(names)
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/ but not exported"
+        owner = sz if n.startswith("SZ_") else lib
+        assert hasattr(owner, n), f"{n} declared in include/ but not exported"
 
 
 def test_no_reference_internal_symbols_leak():
@@ -48,9 +52,12 @@ def test_no_reference_internal_symbols_leak():
 
 
 def test_soname():
-    from libaec_amd import api
+    """reference src/CMakeLists.txt:3-5, 13-15: libaec.so.0 and libsz.so.2"""
+    from libaec_amd import api, szip
     out = subprocess.run(["readelf", "-d", api.library_path()], capture_output=True, text=True).stdout
     assert "libaec.so.0" in out
+    out = subprocess.run(["readelf", "-d", szip.library_path()], capture_output=True, text=True).stdout
+    assert "libsz.so.2" in out and "libaec.so.0" in out
 
 
 def test_stream_struct_layout():
