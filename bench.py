@@ -10,9 +10,10 @@ GPU, block 16, rsi 128, AEC_DATA_PREPROCESS (generator: libaec_amd/csrc/datagen.
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-With N > 1 every rank codes its own shard as an independent stream (weak scaling) and the
-compressed shards are reassembled on every rank by ONE RCCL all-gather per step, issued on a side
-stream so that it overlaps the local decode.
+With N > 1 the ranks code ONE stream (weak scaling: 4 GiB per rank): every rank plans its shard,
+the ranks exchange three numbers (bits, k clamp), each emits its shard at the global bit offset,
+and ONE RCCL all-gather per step plus a local stitch reassemble the byte-exact stream on every
+rank, on a side stream that overlaps the decode of the local shard (libaec_amd/shard.py).
 
 Rank 0 prints one JSON line: metric/value (whole-job GB/s of input bytes through encode+decode),
 `roofline` for the dominant kernel (HIP-event time measured in this run) and `cpu_baseline`
@@ -79,7 +80,10 @@ def main():
     ap.add_argument("--size-mib", type=int, default=4096, help="input bytes per GPU (MiB)")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of compressed shards")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N > 1: independent shard streams, no exchange and no all-gather")
+    ap.add_argument("--shard-path", action="store_true",
+                    help="run the plan/exchange/emit/gather/stitch path even with one GPU")
     args = ap.parse_args()
 
     import torch
@@ -109,7 +113,7 @@ def main():
     n_rsi, n_blk = codec.rsi_count(nbytes), codec.block_count(nbytes)
     d_out = torch.empty(codec.encode_bound(nbytes), dtype=torch.uint8, device=dev)
     d_off = torch.empty(n_rsi + 1, dtype=torch.int64, device=dev)
-    d_eres = torch.zeros(16, dtype=torch.uint8, device=dev)
+    d_eres = torch.zeros(gpu.ENC_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     d_dres = torch.zeros(40, dtype=torch.uint8, device=dev)
     d_dec = torch.empty(nbytes + 16, dtype=torch.uint8, device=dev)
 
@@ -132,25 +136,60 @@ def main():
         assert d_out[:nfull].cpu().numpy().tobytes() == enc_cpu[:nfull], "GPU stream != CPU reference stream"
     del host
 
-    gather = world > 1 and not args.no_gather
-    if gather:
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([cbytes], dtype=torch.int64, device=dev))
-        pad = (max(int(s.item()) for s in sizes) + 4095) // 4096 * 4096
-        d_all = torch.empty(world * pad, dtype=torch.uint8, device=dev)
+    # ---- N > 1: ONE stream over all ranks (libaec_amd/shard.py): plan -> exchange 3 numbers ->
+    # emit at the global bit offset -> one RCCL all-gather of the slices -> local stitch.  The
+    # all-gather + stitch run on a side stream and overlap the decode of the local shard.
+    from libaec_amd import shard
+    sharded = (world > 1 and not args.no_gather) or args.shard_path
+    if sharded:
+        def exchange(bits, lo, hi):
+            if world > 1:
+                return shard.exchange_plans(bits, lo, hi, device=dev)
+            return [(bits, lo, hi)]
+
+        def gather(local, slot):
+            if world > 1:
+                return shard.gather_slices(local, slot)
+            return local[:slot].clone()
+
+        codec.encode_plan_async(d_in, nbytes, d_eres)
+        r0 = d_eres.cpu().numpy().view(gpu.ENC_RESULT_DTYPE)[0]
+        plans0 = exchange(int(r0["total_bits"]), int(r0["k_lo"]), int(r0["k_hi"]))
+        slot = shard.slot_bytes(plans0)
+        assert slot <= d_out.numel()
+        d_stream = torch.zeros(sum((b + 7) // 8 for b, _, _ in plans0) + 64, dtype=torch.uint8, device=dev)
         comm = torch.cuda.Stream(device=dev)
 
     def one_step():
-        codec.encode_async(d_in, nbytes, d_out, d_off, d_eres)
-        if gather:
-            ready = torch.cuda.Event()
-            ready.record()
-            with torch.cuda.stream(comm):
-                comm.wait_event(ready)
-                dist.all_gather_into_tensor(d_all, d_out[:pad])
-        codec.decode_async(d_out, cbytes, d_off, n_rsi, n_blk, d_dec, d_dres)
-        if gather:
-            torch.cuda.current_stream().wait_stream(comm)
+        if not sharded:
+            codec.encode_async(d_in, nbytes, d_out, d_off, d_eres)
+            codec.decode_async(d_out, cbytes, d_off, n_rsi, n_blk, d_dec, d_dres)
+            return
+        codec.encode_plan_async(d_in, nbytes, d_eres)
+        r = d_eres.cpu().numpy().view(gpu.ENC_RESULT_DTYPE)[0]            # 24 bytes, one sync
+        plans = exchange(int(r["total_bits"]), int(r["k_lo"]), int(r["k_hi"]))
+        start, k_in = shard.carry_in(plans, rank)
+        codec.encode_emit_async(d_in, nbytes, d_out, d_off, d_eres, start % 8, k_in)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready)
+            shard.stitch(gather(d_out, slot), slot, plans, out=d_stream)
+        mine = (start % 8 + plans[rank][0] + 7) // 8
+        codec.decode_async(d_out, mine, d_off, n_rsi, n_blk, d_dec, d_dres)
+        torch.cuda.current_stream().wait_stream(comm)
+
+    if sharded:
+        # correctness of the sharded configuration before timing it: local round trip, and on one
+        # rank the stitched stream must be exactly the single-device stream
+        one_step()
+        torch.cuda.synchronize()
+        assert torch.equal(d_dec[:nbytes], d_in), "sharded round trip differs"
+        if world == 1:
+            ref_out = torch.empty_like(d_out)
+            codec.encode_async(d_in, nbytes, ref_out, d_off, d_eres)
+            assert torch.equal(ref_out[:cbytes], d_stream[:cbytes]), "stitched stream != single stream"
+            del ref_out
 
     for _ in range(args.warmup):
         one_step()
@@ -210,11 +249,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"lowent16 {args.size_mib} MiB per GPU, 16-bit LSB unsigned, block 16, rsi 128, "
                                    f"AEC_DATA_PREPROCESS; step = encode + decode (RSI offset table)"
-                                   + ("; + RCCL all-gather of compressed shards" if gather else ""),
+                                   + ("; one stream over all ranks: plan, exchange, emit at the global bit "
+                                      "offset, RCCL all-gather + stitch overlapped with decode" if sharded else ""),
                        "bits_per_sample": BPS, "block_size": BS, "rsi": RSI, "flags": FLAGS,
                        "input_bytes_per_gpu": nbytes, "compressed_bytes_rank0": cbytes,
                        "ratio": round(nbytes / cbytes, 3), "bit_exact_vs_cpu": cpu is not None,
-                       "parallelism": f"{world} independent shard stream(s)"},
+                       "parallelism": (f"{world} rank(s), one bit-exact stream" if sharded
+                                       else f"{world} independent shard stream(s)")},
             "roofline": {"bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": algo[dom], "kernel_ms": round(phase[dom], 4)},

@@ -35,6 +35,7 @@ typedef struct aec_gpu_enc_result {
     uint64_t total_bits;  /* stream bits produced by the call (without the carried-in start bits) */
     uint32_t k_out;       /* encoder's carried k after the last block (reference state->k) */
     uint32_t overflow;    /* 1: out_cap was too small, output clipped */
+    uint32_t k_lo, k_hi;  /* the call's k transfer function: k_out = min(max(k_in, k_lo), k_hi) */
 } aec_gpu_enc_result;
 
 typedef struct aec_gpu_dec_result {
@@ -77,6 +78,21 @@ AEC_GPU_API int aec_gpu_encode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, 
                                      unsigned int start_bit, unsigned int k_in,
                                      uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result,
                                      void *stream);
+
+/*
+ * The same work in two steps for callers that code ONE stream on several devices: PLAN analyses
+ * the input and leaves total_bits and (k_lo, k_hi) in d_result without needing start_bit / k_in;
+ * after the caller has combined the plans of all preceding parts (sum of total_bits; composition of
+ * the k clamps) EMIT writes the part at its global bit offset.  Both calls must use the same
+ * context, parameters and input, with no other encode on that context in between.
+ */
+AEC_GPU_API int aec_gpu_encode_plan_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                          size_t in_bytes, aec_gpu_enc_result *d_result, void *stream);
+AEC_GPU_API int aec_gpu_encode_emit_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                          size_t in_bytes, void *d_out, size_t out_cap,
+                                          unsigned int start_bit, unsigned int k_in,
+                                          uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result,
+                                          void *stream);
 
 /*
  * Decode n_rsi RSIs whose start bits are d_rsi_bit_offsets[0..n_rsi) (relative to d_in, which

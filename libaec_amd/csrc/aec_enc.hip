@@ -530,9 +530,12 @@ k_scan_partials(ScanPartial *partials, uint64_t nchunks, uint32_t start_bit, uin
         run = scan_then(run, cur);
     }
     if (threadIdx.x == 0) {
+        const KClamp t = clamp_unpack(total.cl);
         res->total_bits = total.bits;
-        res->k_out = kclamp_apply(clamp_unpack(total.cl), k_in);
+        res->k_out = kclamp_apply(t, k_in);
         res->overflow = 0;
+        res->k_lo = t.lo;
+        res->k_hi = t.hi;
     }
     (void)start_bit;
 }
@@ -541,8 +544,7 @@ __global__ void __launch_bounds__(256)
 k_scan_apply(const uint32_t *__restrict__ seg_bits, const uint16_t *__restrict__ seg_clamp,
              uint64_t nseg, const ScanPartial *__restrict__ partials, uint32_t start_bit, uint32_t k_in,
              uint32_t segs_per_rsi, uint64_t rsi_count, uint64_t *__restrict__ seg_start,
-             uint8_t *__restrict__ seg_kin, uint64_t *__restrict__ rsi_off,
-             const EncResult *__restrict__ res)
+             uint8_t *__restrict__ seg_kin, uint64_t *__restrict__ rsi_off, EncResult *res)
 {
     __shared__ ScanVal sh[4];
     const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * kScanItems;
@@ -569,8 +571,10 @@ k_scan_apply(const uint32_t *__restrict__ seg_bits, const uint16_t *__restrict__
         }
         run = scan_then(run, item[i]);
     }
-    if (rsi_off && blockIdx.x == 0 && threadIdx.x == 0)
-        rsi_off[rsi_count] = (uint64_t)start_bit + res->total_bits;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        res->k_out = kclamp_apply(KClamp{res->k_lo, res->k_hi}, k_in);   // k_in is only known now
+        if (rsi_off) rsi_off[rsi_count] = (uint64_t)start_bit + res->total_bits;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -820,7 +824,7 @@ size_t enc_workspace_bytes(const Cfg &c, size_t *off_meta, size_t *off_bits, siz
 
 void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out_cap,
                    uint32_t start_bit, uint32_t k_in, const EncWorkspace &ws, uint64_t *d_rsi_off,
-                   EncResult *d_res, hipStream_t st, const PhaseEvents *prof)
+                   EncResult *d_res, hipStream_t st, const PhaseEvents *prof, uint32_t phases)
 {
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(prof->ev[i], st); };
     uint32_t *out_words = reinterpret_cast<uint32_t *>(d_out);
@@ -831,25 +835,29 @@ void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out
     const uint32_t fast_ok = ((reinterpret_cast<uintptr_t>(d_in) & 15u) == 0 &&
                               ((uint64_t)c.rsi * c.bs * c.bytes) % 16 == 0) ? 1u : 0u;
 
-    mark(0);
-    if (nseg) dispatch(false, c, d_in, ws, nullptr, 0, fast_ok, st);
-    mark(1);
-    if (nchunks)
-        hipLaunchKernelGGL(k_scan_reduce, dim3((uint32_t)nchunks), dim3(256), 0, st, ws.seg_bits,
-                           ws.seg_clamp, nseg, ws.partials);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, st, ws.partials, nchunks, start_bit, k_in,
-                       d_res);
-    if (nchunks)
-        hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)nchunks), dim3(256), 0, st, ws.seg_bits,
-                           ws.seg_clamp, nseg, ws.partials, start_bit, k_in, c.segs_per_rsi, c.rsi_count,
-                           ws.seg_start, ws.seg_kin, d_rsi_off, d_res);
-    else if (d_rsi_off)
-        (void)hipMemsetAsync(d_rsi_off, 0, sizeof(uint64_t), st);   // empty batch: single entry
-    mark(2);
-    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, st, out_words, cap_words, start_bit, d_res);
-    mark(3);
-    if (nseg) dispatch(true, c, d_in, ws, out_words, cap_words, fast_ok, st);
-    mark(4);
+    if (phases & ENC_PLAN) {
+        mark(0);
+        if (nseg) dispatch(false, c, d_in, ws, nullptr, 0, fast_ok, st);
+        mark(1);
+        if (nchunks)
+            hipLaunchKernelGGL(k_scan_reduce, dim3((uint32_t)nchunks), dim3(256), 0, st, ws.seg_bits,
+                               ws.seg_clamp, nseg, ws.partials);
+        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, st, ws.partials, nchunks, start_bit, k_in,
+                           d_res);
+    }
+    if (phases & ENC_EMIT) {
+        if (nchunks)
+            hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)nchunks), dim3(256), 0, st, ws.seg_bits,
+                               ws.seg_clamp, nseg, ws.partials, start_bit, k_in, c.segs_per_rsi, c.rsi_count,
+                               ws.seg_start, ws.seg_kin, d_rsi_off, d_res);
+        else if (d_rsi_off)
+            (void)hipMemsetAsync(d_rsi_off, 0, sizeof(uint64_t), st);   // empty batch: single entry
+        mark(2);
+        hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, st, out_words, cap_words, start_bit, d_res);
+        mark(3);
+        if (nseg) dispatch(true, c, d_in, ws, out_words, cap_words, fast_ok, st);
+        mark(4);
+    }
 }
 
 }  // namespace aec

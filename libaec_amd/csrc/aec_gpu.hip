@@ -97,15 +97,15 @@ int aec_gpu_reserve(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes)
     return RC_OK;
 }
 
-int aec_gpu_encode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+static int encode_phases(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
                          void *d_out, size_t out_cap, unsigned int start_bit, unsigned int k_in,
-                         uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result, void *stream)
+                         uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result, void *stream, uint32_t phases)
 {
     Cfg c;
     int rc = cfg_from(p, in_bytes, true, &c);
     if (rc != RC_OK) return rc;
-    if (start_bit > 7 || k_in > 31 || (reinterpret_cast<uintptr_t>(d_out) & 15u) || (out_cap & 15u) ||
-        out_cap < 16)
+    if (start_bit > 7 || k_in > 31) return RC_CONF_ERROR;
+    if ((phases & ENC_EMIT) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) || (out_cap & 15u) || out_cap < 16))
         return RC_CONF_ERROR;
     rc = aec_gpu_reserve(ctx, p, in_bytes);
     if (rc != RC_OK) return rc;
@@ -122,8 +122,30 @@ int aec_gpu_encode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *
     ws.partials = reinterpret_cast<ScanPartial *>(base + o[5]);
     launch_encode(c, static_cast<const uint8_t *>(d_in), static_cast<uint8_t *>(d_out), out_cap, start_bit,
                   k_in, ws, d_rsi_bit_offsets, reinterpret_cast<EncResult *>(d_result),
-                  static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr);
+                  static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr, phases);
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
+}
+
+int aec_gpu_encode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                         void *d_out, size_t out_cap, unsigned int start_bit, unsigned int k_in,
+                         uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result, void *stream)
+{
+    return encode_phases(ctx, p, d_in, in_bytes, d_out, out_cap, start_bit, k_in, d_rsi_bit_offsets, d_result,
+                         stream, ENC_ALL);
+}
+
+int aec_gpu_encode_plan_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                              aec_gpu_enc_result *d_result, void *stream)
+{
+    return encode_phases(ctx, p, d_in, in_bytes, nullptr, 0, 0, 0, nullptr, d_result, stream, ENC_PLAN);
+}
+
+int aec_gpu_encode_emit_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                              void *d_out, size_t out_cap, unsigned int start_bit, unsigned int k_in,
+                              uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result, void *stream)
+{
+    return encode_phases(ctx, p, d_in, in_bytes, d_out, out_cap, start_bit, k_in, d_rsi_bit_offsets, d_result,
+                         stream, ENC_EMIT);
 }
 
 int aec_gpu_decode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,

@@ -19,6 +19,7 @@ struct EncResult {
     uint64_t total_bits;   // bits produced by this batch (excluding the carried-in start bits)
     uint32_t k_out;        // encoder's k after the last block (reference state->k)
     uint32_t overflow;     // 1 when the output capacity was too small (stores were clipped)
+    uint32_t k_lo, k_hi;   // the batch's k transfer function: k_out = min(max(k_in, k_lo), k_hi)
 };
 
 struct DecResult {
@@ -54,9 +55,16 @@ size_t enc_workspace_bytes(const Cfg &c, size_t *off_meta, size_t *off_bits, siz
 // Enqueues analyze -> scan -> clear -> pack on `stream`.  d_out must be 4-byte aligned and hold
 // out_cap bytes; bit `start_bit` (0..7) of d_out[0] is where the stream continues, k_in is the
 // carried k.  d_rsi_off (optional) receives rsi_count + 1 absolute bit offsets.
+//
+// The work splits at the point where a batch needs to know what precedes it: PLAN (analyze + the
+// local part of the scan) yields total_bits and (k_lo, k_hi) without knowing start_bit / k_in;
+// EMIT (offset scan, clear, pack) needs them.  A multi-GPU single stream runs PLAN on every rank,
+// exchanges the three numbers, then EMIT at the global bit offset.
+enum : uint32_t { ENC_PLAN = 1, ENC_EMIT = 2, ENC_ALL = 3 };
 void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out_cap,
                    uint32_t start_bit, uint32_t k_in, const EncWorkspace &ws, uint64_t *d_rsi_off,
-                   EncResult *d_res, hipStream_t stream, const PhaseEvents *prof = nullptr);
+                   EncResult *d_res, hipStream_t stream, const PhaseEvents *prof = nullptr,
+                   uint32_t phases = ENC_ALL);
 
 // Enqueues the RSI-parallel decoder: one lane per RSI, offsets in bits from d_in.
 //   total_blocks  blocks to produce (the last RSI may be short); d_out holds whole blocks

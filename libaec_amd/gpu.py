@@ -15,7 +15,8 @@ class Params(C.Structure):
                 ("flags", C.c_uint)]
 
 
-ENC_RESULT_DTYPE = np.dtype([("total_bits", "<u8"), ("k_out", "<u4"), ("overflow", "<u4")])
+ENC_RESULT_DTYPE = np.dtype([("total_bits", "<u8"), ("k_out", "<u4"), ("overflow", "<u4"),
+                             ("k_lo", "<u4"), ("k_hi", "<u4")])
 DEC_RESULT_DTYPE = np.dtype([("n_rsi", "<u8"), ("tail_blocks", "<u8"), ("end_bit", "<u8"),
                              ("status", "<u4"), ("pad", "<u4"), ("bad_rsi", "<u8")])
 
@@ -44,6 +45,10 @@ def _lib():
         lib.aec_gpu_reserve.argtypes = [vp, pp, sz]
         lib.aec_gpu_encode_async.restype = C.c_int
         lib.aec_gpu_encode_async.argtypes = [vp, pp, vp, sz, vp, sz, C.c_uint, C.c_uint, vp, vp, vp]
+        lib.aec_gpu_encode_plan_async.restype = C.c_int
+        lib.aec_gpu_encode_plan_async.argtypes = [vp, pp, vp, sz, vp, vp]
+        lib.aec_gpu_encode_emit_async.restype = C.c_int
+        lib.aec_gpu_encode_emit_async.argtypes = [vp, pp, vp, sz, vp, sz, C.c_uint, C.c_uint, vp, vp, vp]
         lib.aec_gpu_decode_async.restype = C.c_int
         lib.aec_gpu_decode_async.argtypes = [vp, pp, vp, sz, vp, u64, u64, vp, vp, vp]
         lib.aec_gpu_index_async.restype = C.c_int
@@ -113,6 +118,23 @@ class Codec:
         if rc != 0:
             raise RuntimeError(f"aec_gpu_encode_async failed ({rc})")
 
+    def encode_plan_async(self, d_in, in_bytes, d_result, stream=None):
+        """first half of an encode: leaves total_bits and (k_lo, k_hi) in d_result"""
+        rc = self.lib.aec_gpu_encode_plan_async(self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes,
+                                                C.c_void_p(d_result.data_ptr()), self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_encode_plan_async failed ({rc})")
+
+    def encode_emit_async(self, d_in, in_bytes, d_out, d_offsets, d_result, start_bit, k_in, stream=None):
+        """second half: writes the stream at bit `start_bit` of d_out[0] with carried k `k_in`"""
+        rc = self.lib.aec_gpu_encode_emit_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes, C.c_void_p(d_out.data_ptr()),
+            d_out.numel(), start_bit, k_in,
+            C.c_void_p(d_offsets.data_ptr()) if d_offsets is not None else None,
+            C.c_void_p(d_result.data_ptr()), self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_encode_emit_async failed ({rc})")
+
     def decode_async(self, d_in, in_bytes, d_offsets, n_rsi, total_blocks, d_out, d_result, stream=None):
         rc = self.lib.aec_gpu_decode_async(
             self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes,
@@ -136,7 +158,7 @@ class Codec:
         n = d_in.numel()
         d_out = torch.empty(self.encode_bound(n), dtype=torch.uint8, device=d_in.device)
         d_off = torch.empty(self.rsi_count(n) + 1, dtype=torch.int64, device=d_in.device)
-        d_res = torch.zeros(16, dtype=torch.uint8, device=d_in.device)
+        d_res = torch.zeros(ENC_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=d_in.device)
         self.encode_async(d_in, n, d_out, d_off, d_res, start_bit, k_in)
         res = d_res.cpu().numpy().view(ENC_RESULT_DTYPE)[0]
         if res["overflow"]:
