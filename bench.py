@@ -46,6 +46,22 @@ def generate(kind, nbytes, shard, threads):
     return a
 
 
+def measured_traffic(kernel, size_mib):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary taken on this
+    workload size (profiles/*/traffic_*.json, written by tests/prof_traffic.sh: FETCH_SIZE and
+    WRITE_SIZE in separate passes, gfx950 FETCH correction applied where the access is wide)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_*.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("size_mib") == size_mib and kernel in d.get("kernels", {}):
+            best = (d["kernels"][kernel]["traffic"], os.path.relpath(f, ROOT))
+    return best
+
+
 def cpu_baseline(sample):
     """Reference libaec (oracle/_ref) if it travelled with the repo, else the oracle port;
     one thread, in memory, encode + decode of `sample`."""
@@ -233,6 +249,7 @@ def main():
         algo = {"analyze": nbytes, "pack": nbytes + cbytes, "decode": nbytes + cbytes}
         dom = max(algo, key=lambda k: phase[k])
         achieved = algo[dom] / (phase[dom] * 1e-3) / 1e9
+        traffic = measured_traffic(f"k_{dom}", args.size_mib)
         enc_ms = phase["analyze"] + phase["scan"] + phase["clear"] + phase["pack"]
         out = {
             "metric": "encode+decode GB/s (input bytes)",
@@ -257,7 +274,9 @@ def main():
                        "parallelism": (f"{world} rank(s), one bit-exact stream" if sharded
                                        else f"{world} independent shard stream(s)")},
             "roofline": {"bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
                          "algorithmic_bytes_per_launch": algo[dom], "kernel_ms": round(phase[dom], 4)},
             "cpu_baseline": cpu,
             "phases_ms": {k: round(v, 4) for k, v in phase.items()},
