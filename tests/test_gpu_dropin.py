@@ -1,0 +1,45 @@
+"""Binary drop-in: the reference's OWN programs -- its CLI src/aec.c and its tests
+tests/check_buffer_sizes.c, tests/check_long_fs.c -- compiled unchanged (oracle/Makefile target
+`dropin`, against the reference's header) but linked to libaec_amd/lib/libaec.so.0, run on the GPU."""
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+from helpers import ORACLE_DIR
+
+pytestmark = pytest.mark.gpu
+
+DROPIN = os.path.join(ORACLE_DIR, "_ref", "dropin")
+
+
+def _need(name):
+    path = os.path.join(DROPIN, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not built (reference tree absent at build time)")
+    return path
+
+
+def test_reference_cli_on_product_library(tmp_path, typical_rz):
+    """BASELINE config 1 through the reference's CLI: decode data/typical.rz (reference src/benc.sh:7
+    parameters), re-encode byte-identically, and re-encode at block 16 / rsi 128."""
+    aec = _need("aec")
+    rz, dat, rz2, rz3 = (str(tmp_path / n) for n in ("t.rz", "t.dat", "t2.rz", "t3.rz"))
+    open(rz, "wb").write(typical_rz)
+    subprocess.run([aec, "-d", "-n16", "-j64", "-r256", "-m", rz, dat], check=True, timeout=120)
+    dec = open(dat, "rb").read()
+    assert len(dec) == 1 << 20 and hashlib.sha256(dec).hexdigest().startswith("e6e1bf684916")
+    subprocess.run([aec, "-n16", "-j64", "-r256", "-m", dat, rz2], check=True, timeout=120)
+    assert open(rz2, "rb").read() == typical_rz
+    subprocess.run([aec, "-n16", "-j16", "-r128", "-m", dat, rz3], check=True, timeout=120)
+    enc = open(rz3, "rb").read()
+    assert len(enc) == 740174 and hashlib.sha256(enc).hexdigest().startswith("60f1f251f7e6")
+
+
+@pytest.mark.parametrize("prog", ["check_buffer_sizes", "check_long_fs"])
+def test_reference_test_programs_on_product_library(prog):
+    """reference tests/check_buffer_sizes.c:49-77 and tests/check_long_fs.c:8-29 (exit code 99 = fail)"""
+    out = subprocess.run([_need(prog)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "PASS" in out.stdout and "FAIL" not in out.stdout
