@@ -36,13 +36,21 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 
 BPS, BS, RSI = 16, 16, 128
 FLAGS = 8               # AEC_DATA_PREPROCESS
+KIND = 0                # datagen.c: 0 lowent16, 1 lowent32s, 2 chunks8
+
+# BASELINE.json configs; the headline metric is quoted on c2 (default)
+CONFIGS = {
+    "c2": ("lowent16", 0, 16, 16, 128, 8),               # 16-bit LSB unsigned, block 16, rsi 128, PP
+    "c3": ("lowent32s", 1, 32, 32, 4096, 8 | 4 | 1),      # 32-bit signed MSB, block 32, rsi 4096, PP
+    "c5": ("chunks8", 2, 8, 8, 128, 8),                   # 8-bit, block 8, rsi 128, PP (SZIP chunk shape)
+}
 
 
 def generate(kind, nbytes, shard, threads):
     lib = C.CDLL(os.path.join(ROOT, "libaec_amd", "lib", "libaec_datagen.so"))
     a = np.empty(nbytes, dtype=np.uint8)
     lib.aec_gen_fill_parallel(C.c_uint(kind), C.c_uint64(shard), C.c_void_p(a.ctypes.data),
-                              C.c_size_t(nbytes // 2), C.c_uint(threads))
+                              C.c_size_t(nbytes // {0: 2, 1: 4, 2: 1}[kind]), C.c_uint(threads))
     return a
 
 
@@ -95,12 +103,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size-mib", type=int, default=4096, help="input bytes per GPU (MiB)")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="BASELINE.json configuration (the headline metric is quoted on c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: independent shard streams, no exchange and no all-gather")
     ap.add_argument("--shard-path", action="store_true",
                     help="run the plan/exchange/emit/gather/stitch path even with one GPU")
     args = ap.parse_args()
+    global BPS, BS, RSI, FLAGS, KIND
+    wl_name, KIND, BPS, BS, RSI, FLAGS = CONFIGS[args.config]
 
     import torch
     import torch.distributed as dist
@@ -118,7 +130,7 @@ def main():
 
     nbytes = args.size_mib << 20
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
-    host = generate(0, nbytes, rank, threads)
+    host = generate(KIND, nbytes, rank, threads)
 
     codec = gpu.Codec(BPS, BS, RSI, FLAGS)
     codec.reserve(nbytes)
@@ -264,8 +276,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"lowent16 {args.size_mib} MiB per GPU, 16-bit LSB unsigned, block 16, rsi 128, "
-                                   f"AEC_DATA_PREPROCESS; step = encode + decode (RSI offset table)"
+            "config": {"workload": f"{args.config}: {wl_name} {args.size_mib} MiB per GPU, {BPS}-bit, block {BS}, rsi {RSI}, "
+                                   f"flags {FLAGS}; step = encode + decode (RSI offset table)"
                                    + ("; one stream over all ranks: plan, exchange, emit at the global bit "
                                       "offset, RCCL all-gather + stitch overlapped with decode" if sharded else ""),
                        "bits_per_sample": BPS, "block_size": BS, "rsi": RSI, "flags": FLAGS,
