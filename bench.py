@@ -2,7 +2,8 @@
 """bench.py -- encode+decode throughput of the MI355X adaptive entropy coder.
 
 One "step" = one pass of the hot path over the rank's resident input: encode the whole shard
-(analyze -> scan -> clear -> pack) and decode it again from the encoder's RSI offset table.
+(analyze -> scan -> clear -> pack) and decode it again from the encoder's segment table
+(start bit + preceding sample per 64 blocks; one decoder lane per segment).
 Workload = BASELINE.json configs[1] shape: 4 GiB of synthetic low-entropy 16-bit samples per
 GPU, block 16, rsi 128, AEC_DATA_PREPROCESS (generator: libaec_amd/csrc/datagen.c, seed
 0x5EED0000 + rank).  Inputs are resident in HBM before the timed region.
@@ -144,13 +145,21 @@ def main():
     d_eres = torch.zeros(gpu.ENC_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     d_dres = torch.zeros(40, dtype=torch.uint8, device=dev)
     d_dec = torch.empty(nbytes + 16, dtype=torch.uint8, device=dev)
+    # the encoder also leaves its segment table (start bit + preceding sample per 64 blocks), which
+    # lets the decoder run one lane per segment instead of one per RSI
+    n_seg = codec.segment_count(nbytes)
+    d_seg = torch.zeros(n_seg * 16, dtype=torch.uint8, device=dev)
+    codec.set_segment_table(d_seg)
+
+    def decode_async(in_bytes):
+        codec.decode_segments_async(d_out, in_bytes, d_seg, n_seg, n_blk, d_dec, d_dres)
 
     # ---- untimed: one encode to learn the compressed size, correctness of the timed configuration
     codec.encode_async(d_in, nbytes, d_out, d_off, d_eres)
     eres = d_eres.cpu().numpy().view(gpu.ENC_RESULT_DTYPE)[0]
     assert not eres["overflow"]
     cbytes = (int(eres["total_bits"]) + 7) // 8
-    codec.decode_async(d_out, cbytes, d_off, n_rsi, n_blk, d_dec, d_dres)
+    decode_async(cbytes)
     dres = d_dres.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]
     assert dres["status"] == 0, "decode reported an error"
     assert torch.equal(d_dec[:nbytes], d_in), "round trip differs"
@@ -191,7 +200,7 @@ def main():
     def one_step():
         if not sharded:
             codec.encode_async(d_in, nbytes, d_out, d_off, d_eres)
-            codec.decode_async(d_out, cbytes, d_off, n_rsi, n_blk, d_dec, d_dres)
+            decode_async(cbytes)
             return
         codec.encode_plan_async(d_in, nbytes, d_eres)
         r = d_eres.cpu().numpy().view(gpu.ENC_RESULT_DTYPE)[0]            # 24 bytes, one sync
@@ -204,7 +213,7 @@ def main():
             comm.wait_event(ready)
             shard.stitch(gather(d_out, slot), slot, plans, out=d_stream)
         mine = (start % 8 + plans[rank][0] + 7) // 8
-        codec.decode_async(d_out, mine, d_off, n_rsi, n_blk, d_dec, d_dres)
+        decode_async(mine)
         torch.cuda.current_stream().wait_stream(comm)
 
     if sharded:
@@ -247,7 +256,7 @@ def main():
     reps = max(3, min(args.steps, 10))
     for _ in range(reps):
         codec.encode_async(d_in, nbytes, d_out, d_off, d_eres)
-        codec.decode_async(d_out, cbytes, d_off, n_rsi, n_blk, d_dec, d_dres)
+        decode_async(cbytes)
         ms = (C.c_float * 5)()
         lib.aec_gpu_phase_ms(codec.ctx, ms)
         acc += np.array(list(ms))
@@ -277,7 +286,7 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {wl_name} {args.size_mib} MiB per GPU, {BPS}-bit, block {BS}, rsi {RSI}, "
-                                   f"flags {FLAGS}; step = encode + decode (RSI offset table)"
+                                   f"flags {FLAGS}; step = encode + decode (segment table)"
                                    + ("; one stream over all ranks: plan, exchange, emit at the global bit "
                                       "offset, RCCL all-gather + stitch overlapped with decode" if sharded else ""),
                        "bits_per_sample": BPS, "block_size": BS, "rsi": RSI, "flags": FLAGS,

@@ -47,6 +47,16 @@ typedef struct aec_gpu_dec_result {
     uint64_t bad_rsi;      /* lowest RSI with status != 0 */
 } aec_gpu_dec_result;
 
+/* Entry of the segment table: a segment = 64 consecutive blocks of one RSI (the last segment of
+ * an RSI may be shorter).  Start bit of its first coded data set and the raw sample preceding it
+ * are all a decoder needs to start there, so decoding parallelises over segments instead of RSIs:
+ * the difference between 8192 and 524288 work items for 4 GiB of 32-bit / block 32 / rsi 4096. */
+typedef struct aec_gpu_seg_entry {
+    uint64_t bit;
+    uint32_t prev;
+    uint32_t pad;
+} aec_gpu_seg_entry;
+
 /* Context = workspace on the current HIP device.  One context per host thread / stream. */
 AEC_GPU_API int aec_gpu_create(aec_gpu_ctx **ctx);
 AEC_GPU_API void aec_gpu_destroy(aec_gpu_ctx *ctx);
@@ -104,6 +114,18 @@ AEC_GPU_API int aec_gpu_decode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, 
                                      size_t in_bytes, const uint64_t *d_rsi_bit_offsets,
                                      uint64_t n_rsi, uint64_t total_blocks, void *d_out,
                                      aec_gpu_dec_result *d_result, void *stream);
+
+/*
+ * Segment-granular variant of the offset table.  After aec_gpu_set_segment_table(ctx, d_table) every
+ * encode / emit call on ctx also fills d_table with aec_gpu_segment_count() entries (pass NULL to
+ * stop).  aec_gpu_decode_segments_async decodes from such a table, one lane per segment.
+ */
+AEC_GPU_API uint64_t aec_gpu_segment_count(const aec_gpu_params *p, size_t in_bytes);
+AEC_GPU_API void aec_gpu_set_segment_table(aec_gpu_ctx *ctx, aec_gpu_seg_entry *d_table);
+AEC_GPU_API int aec_gpu_decode_segments_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                              size_t in_bytes, const aec_gpu_seg_entry *d_seg_table,
+                                              uint64_t n_seg, uint64_t total_blocks, void *d_out,
+                                              aec_gpu_dec_result *d_result, void *stream);
 
 /*
  * Find the RSI start offsets of a stream that comes without an offset table: a serial walk from

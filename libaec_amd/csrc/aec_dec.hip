@@ -175,11 +175,13 @@ __device__ __forceinline__ void ring_put4(uint32_t *col, uint32_t slot0, uint32_
 
 constexpr int kPend = 2;   // 16-byte loads kept in flight per lane across one block iteration
 
-template <int BS, int BYTES>
+// SEG = false: work item = RSI, start bits from rsi_off.  SEG = true: work item = segment (64
+// blocks), start bit and preceding sample from the encoder's segment table.
+template <int BS, int BYTES, bool SEG>
 __global__ void __launch_bounds__(256)
 k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
-         const uint64_t *__restrict__ rsi_off, uint64_t n_rsi, uint64_t total_blocks,
-         uint8_t *__restrict__ out, DecResult *res, uint32_t ring_words, uint32_t maxw)
+         const uint64_t *__restrict__ rsi_off, const SegEntry *__restrict__ seg_table, uint64_t n_rsi,
+         uint64_t total_blocks, uint8_t *__restrict__ out, DecResult *res, uint32_t ring_words, uint32_t maxw)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -192,15 +194,28 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const bool pp = c.flags & F_PREPROCESS;
 
-    uint32_t nb = 0;
-    uint64_t start = 0;
+    uint32_t nb = 0, b0 = 0, x = 0;
+    uint64_t start = 0, first_blk = 0;
     if (active) {
-        uint64_t left = total_blocks - r * c.rsi;
-        nb = left > c.rsi ? c.rsi : (uint32_t)left;
-        start = rsi_off[r];
+        if (SEG) {
+            const uint64_t rsi_idx = (r >> 32) ? r / c.segs_per_rsi : (uint64_t)((uint32_t)r / c.segs_per_rsi);
+            b0 = (uint32_t)(r - rsi_idx * c.segs_per_rsi) * 64u;
+            uint64_t left = total_blocks - rsi_idx * c.rsi;
+            if (left > c.rsi) left = c.rsi;
+            nb = left - b0 > 64 ? 64u : (uint32_t)(left - b0);
+            const SegEntry e = seg_table[r];
+            start = e.bit;
+            x = (c.flags & F_SIGNED) ? sign_extend(e.prev, c.bps) : e.prev;
+            first_blk = rsi_idx * c.rsi + b0;
+        } else {
+            uint64_t left = total_blocks - r * c.rsi;
+            nb = left > c.rsi ? c.rsi : (uint32_t)left;
+            start = rsi_off[r];
+            first_blk = r * c.rsi;
+        }
     }
     const size_t blk_bytes = (size_t)bs * c.bytes;
-    uint8_t *dst = out + (size_t)r * c.rsi * blk_bytes;
+    uint8_t *dst = out + (size_t)first_blk * blk_bytes;
 
     const uint64_t a0 = (start >> 5) & ~3ull;        // lane base word, 16-byte aligned
     const uint32_t slot0 = (uint32_t)a0 & mask;
@@ -221,7 +236,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     for (int j = 0; j < kPend; j++) { pend[j] = make_uint4(0, 0, 0, 0); pv[j] = false; }
 
     uint32_t d[DN];
-    uint32_t x = 0, zrun = 0;
+    uint32_t zrun = 0;
     bool ok = true;
 
     for (uint32_t b = 0; __any(b < nb && ok); b++) {
@@ -251,13 +266,13 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
         }
 
         // ---- one block per lane ----
-        const uint32_t ref = (pp && b == 0) ? 1u : 0u;             // wave-uniform
+        const uint32_t ref = (pp && b0 + b == 0) ? 1u : 0u;        // per lane in SEG mode
         if (BS) {
             src.limit = landed;
             uint32_t nz = 0;
             const bool parse = live && zrun == 0;
             // lanes inside a zero run (and finished lanes) get d = 0 from the same code path
-            const uint32_t st = decode_block<(BS ? BS : 2)>(src, p, end_p, d, c, ref, b, parse, nz);
+            const uint32_t st = decode_block<(BS ? BS : 2)>(src, p, end_p, d, c, ref, b0 + b, parse, nz);
             if (parse) {
                 if (st != DEC_OK) {
                     report(res, st, r);
@@ -288,7 +303,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             bool rf = ref != 0;
             if (zrun == 0) {
                 uint32_t nz = 0;
-                const uint32_t st = parse_cds<0>(br, d, c, ref, b, nz);
+                const uint32_t st = parse_cds<0>(br, d, c, ref, b0 + b, nz);
                 if (st != DEC_OK) {
                     report(res, st, r);
                     ok = false;
@@ -389,16 +404,16 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi)
     return g;
 }
 
-template <int BS>
+template <int BS, bool SEG>
 void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
-                         const uint64_t *rsi_off, uint64_t n_rsi, uint64_t total_blocks, uint8_t *out,
-                         DecResult *res, hipStream_t st)
+                         const uint64_t *rsi_off, const SegEntry *seg_table, uint64_t n_rsi,
+                         uint64_t total_blocks, uint8_t *out, DecResult *res, hipStream_t st)
 {
     const DecGeom g = dec_geom(c, n_rsi);
     const dim3 block(64 * g.waves), grid(g.grid);
 #define AEC_GO(B)                                                                                   \
-    hipLaunchKernelGGL((k_decode<BS, B>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, rsi_off, \
-                       n_rsi, total_blocks, out, res, g.ring_words, g.maxw)
+    hipLaunchKernelGGL((k_decode<BS, B, SEG>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
+                       rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw)
     switch (c.bytes) {
     case 1: AEC_GO(1); break;
     case 2: AEC_GO(2); break;
@@ -410,12 +425,13 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
 
 }  // namespace
 
-void launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
-                   uint64_t n_rsi, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res, hipStream_t st,
-                   const PhaseEvents *prof)
+template <bool SEG>
+static void launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
+                              const SegEntry *d_seg, uint64_t n_items, uint64_t total_blocks, uint8_t *d_out,
+                              DecResult *d_res, hipStream_t st, const PhaseEvents *prof)
 {
     hipLaunchKernelGGL(k_dec_result_init, dim3(1), dim3(1), 0, st, d_res);
-    if (n_rsi == 0) return;
+    if (n_items == 0) return;
     if (prof) (void)hipEventRecord(prof->ev[5], st);
     const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
     const uint64_t nwords = (in_bytes + 3) / 4;
@@ -424,19 +440,33 @@ void launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uin
     const bool vec_ok = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
     const uint32_t bs = vec_ok ? c.bs : 0;
     switch (bs) {
-    case 8: launch_decode_bytes<8>(c, words, nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, st); break;
-    case 16: launch_decode_bytes<16>(c, words, nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, st); break;
-    case 32: launch_decode_bytes<32>(c, words, nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, st); break;
-    case 64: launch_decode_bytes<64>(c, words, nwords, end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, st); break;
+    case 8: launch_decode_bytes<8, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st); break;
+    case 16: launch_decode_bytes<16, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st); break;
+    case 32: launch_decode_bytes<32, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st); break;
+    case 64: launch_decode_bytes<64, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st); break;
     default:
     {
-        const DecGeom g = dec_geom(c, n_rsi);
-        hipLaunchKernelGGL((k_decode<0, 0>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
-                           end_bit, d_rsi_off, n_rsi, total_blocks, d_out, d_res, g.ring_words, g.maxw);
+        const DecGeom g = dec_geom(c, n_items);
+        hipLaunchKernelGGL((k_decode<0, 0, SEG>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
+                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw);
         break;
     }
     }
     if (prof) (void)hipEventRecord(prof->ev[6], st);
+}
+
+void launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
+                   uint64_t n_rsi, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res, hipStream_t st,
+                   const PhaseEvents *prof)
+{
+    launch_decode_any<false>(c, d_in, in_bytes, d_rsi_off, nullptr, n_rsi, total_blocks, d_out, d_res, st, prof);
+}
+
+void launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const SegEntry *d_seg_table,
+                            uint64_t n_seg, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res,
+                            hipStream_t st, const PhaseEvents *prof)
+{
+    launch_decode_any<true>(c, d_in, in_bytes, nullptr, d_seg_table, n_seg, total_blocks, d_out, d_res, st, prof);
 }
 
 void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,

@@ -577,6 +577,23 @@ k_scan_apply(const uint32_t *__restrict__ seg_bits, const uint16_t *__restrict__
     }
 }
 
+// segment table for segment-parallel decoding: start bit + preceding raw sample per segment
+__global__ void __launch_bounds__(256)
+k_seg_table(const Cfg c, const uint8_t *__restrict__ in, const uint64_t *__restrict__ seg_start,
+            SegEntry *__restrict__ table)
+{
+    const uint64_t sg = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sg >= c.total_segs) return;
+    const Seg g = seg_geom(c, sg);
+    uint32_t prev = 0;
+    if (g.b0 != 0) {
+        uint64_t i = g.samp0 - 1;
+        if (i >= c.total_samples) i = c.total_samples - 1;
+        prev = load_sample_bytes(in + i * c.bytes, c.bytes, (c.flags & F_MSB) != 0);
+    }
+    table[sg] = SegEntry{seg_start[sg], prev, 0u};
+}
+
 // ----------------------------------------------------------------------------------------------
 // clear: zero the words the stream will occupy (grid-stride, 16 bytes per lane)
 // ----------------------------------------------------------------------------------------------
@@ -824,7 +841,8 @@ size_t enc_workspace_bytes(const Cfg &c, size_t *off_meta, size_t *off_bits, siz
 
 void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out_cap,
                    uint32_t start_bit, uint32_t k_in, const EncWorkspace &ws, uint64_t *d_rsi_off,
-                   EncResult *d_res, hipStream_t st, const PhaseEvents *prof, uint32_t phases)
+                   EncResult *d_res, hipStream_t st, const PhaseEvents *prof, uint32_t phases,
+                   SegEntry *d_seg_table)
 {
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(prof->ev[i], st); };
     uint32_t *out_words = reinterpret_cast<uint32_t *>(d_out);
@@ -852,6 +870,9 @@ void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out
                                ws.seg_start, ws.seg_kin, d_rsi_off, d_res);
         else if (d_rsi_off)
             (void)hipMemsetAsync(d_rsi_off, 0, sizeof(uint64_t), st);   // empty batch: single entry
+        if (d_seg_table && nseg)
+            hipLaunchKernelGGL(k_seg_table, dim3((uint32_t)((nseg + 255) / 256)), dim3(256), 0, st, c, d_in,
+                               ws.seg_start, d_seg_table);
         mark(2);
         hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, st, out_words, cap_words, start_bit, d_res);
         mark(3);

@@ -17,7 +17,9 @@ struct aec_gpu_ctx {
     size_t ws_bytes;
     bool profiling;    // record PhaseEvents around the kernels of the next calls
     PhaseEvents ev;
+    SegEntry *seg_table;   // where the next encode / emit calls also leave the segment table (or null)
 };
+static_assert(sizeof(aec_gpu_seg_entry) == sizeof(SegEntry), "segment table layout");
 
 static_assert(sizeof(aec_gpu_enc_result) == sizeof(EncResult), "result layout");
 static_assert(sizeof(aec_gpu_dec_result) == sizeof(DecResult), "result layout");
@@ -39,6 +41,7 @@ int aec_gpu_create(aec_gpu_ctx **out)
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     ctx->profiling = false;
+    ctx->seg_table = nullptr;
     for (auto &e : ctx->ev.ev) e = nullptr;
     *out = ctx;
     return RC_OK;
@@ -122,7 +125,7 @@ static int encode_phases(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *
     ws.partials = reinterpret_cast<ScanPartial *>(base + o[5]);
     launch_encode(c, static_cast<const uint8_t *>(d_in), static_cast<uint8_t *>(d_out), out_cap, start_bit,
                   k_in, ws, d_rsi_bit_offsets, reinterpret_cast<EncResult *>(d_result),
-                  static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr, phases);
+                  static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr, phases, ctx->seg_table);
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
@@ -161,6 +164,37 @@ int aec_gpu_decode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *
     launch_decode(c, static_cast<const uint8_t *>(d_in), in_bytes, d_rsi_bit_offsets, n_rsi, total_blocks,
                   static_cast<uint8_t *>(d_out), reinterpret_cast<DecResult *>(d_result),
                   static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr);
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
+}
+
+uint64_t aec_gpu_segment_count(const aec_gpu_params *p, size_t in_bytes)
+{
+    Cfg c;
+    if (cfg_from(p, in_bytes, true, &c) != RC_OK) return 0;
+    return c.total_segs;
+}
+
+void aec_gpu_set_segment_table(aec_gpu_ctx *ctx, aec_gpu_seg_entry *d_table)
+{
+    ctx->seg_table = reinterpret_cast<SegEntry *>(d_table);
+}
+
+int aec_gpu_decode_segments_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                                  const aec_gpu_seg_entry *d_seg_table, uint64_t n_seg, uint64_t total_blocks,
+                                  void *d_out, aec_gpu_dec_result *d_result, void *stream)
+{
+    Cfg c;
+    const int rc = cfg_from(p, 0, false, &c);
+    if (rc != RC_OK) return rc;
+    if (reinterpret_cast<uintptr_t>(d_in) & 3u) return RC_CONF_ERROR;
+    // n_seg must be the segment count of total_blocks
+    const uint64_t full = total_blocks / c.rsi, rem = total_blocks % c.rsi;
+    if (n_seg != full * c.segs_per_rsi + (rem + 63) / 64) return RC_CONF_ERROR;
+    (void)hipGetLastError();
+    launch_decode_segments(c, static_cast<const uint8_t *>(d_in), in_bytes,
+                           reinterpret_cast<const SegEntry *>(d_seg_table), n_seg, total_blocks,
+                           static_cast<uint8_t *>(d_out), reinterpret_cast<DecResult *>(d_result),
+                           static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr);
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 

@@ -31,6 +31,15 @@ struct DecResult {
     uint64_t bad_rsi;      // first RSI that reported a non-OK status
 };
 
+// Entry of the segment table (finer-grained sibling of the RSI offset table): where a segment
+// (64 blocks) starts in the stream and the sample that precedes it, which is all a decoder needs
+// to start in the middle of an RSI.
+struct SegEntry {
+    uint64_t bit;      // absolute start bit of the segment's first CDS
+    uint32_t prev;     // raw sample just before the segment (0 for the first segment of an RSI)
+    uint32_t pad;
+};
+
 struct EncWorkspace {
     uint32_t *meta;          // [total_blocks]   per-block summary (aec_lane.h meta_pack)
     uint32_t *seg_bits;      // [total_segs]     bits per segment
@@ -64,13 +73,19 @@ enum : uint32_t { ENC_PLAN = 1, ENC_EMIT = 2, ENC_ALL = 3 };
 void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out_cap,
                    uint32_t start_bit, uint32_t k_in, const EncWorkspace &ws, uint64_t *d_rsi_off,
                    EncResult *d_res, hipStream_t stream, const PhaseEvents *prof = nullptr,
-                   uint32_t phases = ENC_ALL);
+                   uint32_t phases = ENC_ALL, SegEntry *d_seg_table = nullptr);
 
 // Enqueues the RSI-parallel decoder: one lane per RSI, offsets in bits from d_in.
 //   total_blocks  blocks to produce (the last RSI may be short); d_out holds whole blocks
 void launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
                    uint64_t n_rsi, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res,
                    hipStream_t stream, const PhaseEvents *prof = nullptr);
+
+// Same, one lane per SEGMENT (needs the encoder's segment table): the way to fill the chip when
+// RSIs are large (32-bit, block 32, rsi 4096 = 512 KiB per RSI, only 8192 RSIs in 4 GiB).
+void launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const SegEntry *d_seg_table,
+                            uint64_t n_seg, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res,
+                            hipStream_t stream, const PhaseEvents *prof = nullptr);
 
 // Enqueues the serial RSI index pass over one stream starting at start_bit (an RSI boundary).
 void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,

@@ -773,9 +773,9 @@ AEC_HD uint32_t decode_block(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d,
     const uint32_t k = split ? id - 1u : 0u;
     p += live ? c.id_len + (lowent ? 1u : 0u) : 0u;
     uint32_t refv = 0;
-    if (ref) {                                           // wave-uniform: first block of the RSIs
+    if (AEC_ANY(ref != 0)) {                             // first block of an RSI (per lane)
         refv = peek32(src, p) >> (32 - c.bps);
-        p += (live && !unc) ? c.bps : 0u;
+        p += (live && ref && !unc) ? c.bps : 0u;
     }
 
     // ---- 2. unary phase: code for sample slot i lives in u[i] ---------------------------------
@@ -856,7 +856,7 @@ AEC_HD uint32_t decode_block(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d,
             uint32_t i = ref;
 #pragma unroll
             for (uint32_t j = 0; j < (uint32_t)BS / 2; j++) {
-                const uint32_t m = u[(ref ? 1 : 0) + j];
+                const uint32_t m = ref ? u[1 + j] : u[j];   // j <= BS/2 - 1, so 1 + j < BS
                 uint32_t s = 0, second = 0;
                 if (!se_lookup(m, s, second)) corrupt = true;
                 if ((i & 1u) == 0) d[i++] = s - second;
@@ -867,7 +867,7 @@ AEC_HD uint32_t decode_block(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d,
     }
     if (AEC_ANY(zero)) {
         if (zero) {
-            uint32_t nz = u[ref ? 1 : 0] + 1;
+            uint32_t nz = (ref ? u[1] : u[0]) + 1;
             if (nz == 5) {
                 const uint32_t left_rsi = c.rsi - blk_in_rsi;
                 const uint32_t left_seg = 64 - (blk_in_rsi % 64);

@@ -15,6 +15,7 @@ class Params(C.Structure):
                 ("flags", C.c_uint)]
 
 
+SEG_ENTRY_DTYPE = np.dtype([("bit", "<u8"), ("prev", "<u4"), ("pad", "<u4")])
 ENC_RESULT_DTYPE = np.dtype([("total_bits", "<u8"), ("k_out", "<u4"), ("overflow", "<u4"),
                              ("k_lo", "<u4"), ("k_hi", "<u4")])
 DEC_RESULT_DTYPE = np.dtype([("n_rsi", "<u8"), ("tail_blocks", "<u8"), ("end_bit", "<u8"),
@@ -51,6 +52,12 @@ def _lib():
         lib.aec_gpu_encode_emit_async.argtypes = [vp, pp, vp, sz, vp, sz, C.c_uint, C.c_uint, vp, vp, vp]
         lib.aec_gpu_decode_async.restype = C.c_int
         lib.aec_gpu_decode_async.argtypes = [vp, pp, vp, sz, vp, u64, u64, vp, vp, vp]
+        lib.aec_gpu_segment_count.restype = u64
+        lib.aec_gpu_segment_count.argtypes = [pp, sz]
+        lib.aec_gpu_set_segment_table.restype = None
+        lib.aec_gpu_set_segment_table.argtypes = [vp, vp]
+        lib.aec_gpu_decode_segments_async.restype = C.c_int
+        lib.aec_gpu_decode_segments_async.argtypes = [vp, pp, vp, sz, vp, u64, u64, vp, vp, vp]
         lib.aec_gpu_index_async.restype = C.c_int
         lib.aec_gpu_index_async.argtypes = [vp, pp, vp, sz, u64, vp, u64, vp, vp]
         _bound = True
@@ -97,6 +104,22 @@ class Codec:
 
     def block_count(self, in_bytes):
         return int(self.lib.aec_gpu_block_count(C.byref(self.p), in_bytes))
+
+    def segment_count(self, in_bytes):
+        return int(self.lib.aec_gpu_segment_count(C.byref(self.p), in_bytes))
+
+    def set_segment_table(self, d_table):
+        """d_table: uint8 CUDA tensor of segment_count * 16 bytes (or None): filled by later encodes"""
+        self._seg_table = d_table          # keep it alive
+        self.lib.aec_gpu_set_segment_table(self.ctx, C.c_void_p(d_table.data_ptr()) if d_table is not None else None)
+
+    def decode_segments_async(self, d_in, in_bytes, d_table, n_seg, total_blocks, d_out, d_result, stream=None):
+        rc = self.lib.aec_gpu_decode_segments_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes, C.c_void_p(d_table.data_ptr()),
+            n_seg, total_blocks, C.c_void_p(d_out.data_ptr()), C.c_void_p(d_result.data_ptr()),
+            self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_decode_segments_async failed ({rc})")
 
     def reserve(self, in_bytes):
         rc = self.lib.aec_gpu_reserve(self.ctx, C.byref(self.p), in_bytes)

@@ -282,3 +282,42 @@ def test_full_size_round_trip_config2(gpu):
     assert int(off[pre // (rsi * bs * 2)]) == bits
     d_dec, status = codec.decode(d_out, nbytes, d_off, codec.rsi_count(total), codec.block_count(total))
     assert status == 0 and torch.equal(d_dec, d_in)
+
+
+def test_segment_parallel_decode(gpu):
+    """Decoding one lane per SEGMENT from the encoder's segment table gives the same bytes as
+    decoding one lane per RSI -- for large RSIs (config 3 shape), rsi not a multiple of 64, a short
+    final RSI, zero runs crossing nothing, signed data."""
+    import torch
+    rng = np.random.default_rng(31)
+    cases = [
+        (32, 32, 4096, PP | MSB | SGN, gen(1, 8 << 20)),                     # BASELINE config 3 shape
+        (16, 16, 130, PP, gen(0, (16 * 130 * 2) * 37 + 16 * 2 * 5 + 2)),     # 3 segments per RSI, short tail
+        (8, 8, 128, PP | MSB, gen(2, 1 << 20)),
+        (16, 64, 70, 0, pack_samples(random_walk_samples(rng, 64 * 70 * 5 + 99, 16, 0, scale=0.4, zero_frac=0.6), 16, 0)),
+        (12, 16, 300, PP | SGN, pack_samples(random_walk_samples(rng, 16 * 300 * 3, 12, PP | SGN, scale=30.0), 12, PP | SGN)),
+    ]
+    for bps, bs, rsi, flags, data in cases:
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        codec = gpu.Codec(bps, bs, rsi, flags)
+        d_in = torch.from_numpy(data).cuda()
+        nseg = codec.segment_count(data.size)
+        d_tab = torch.zeros(nseg * 16, dtype=torch.uint8, device="cuda")
+        codec.set_segment_table(d_tab)
+        d_out, nbytes, tb, k_out, d_off = codec.encode(d_in)
+        codec.set_segment_table(None)
+        tab = d_tab.cpu().numpy().view(gpu.SEG_ENTRY_DTYPE)
+        spr = (rsi + 63) // 64
+        assert np.array_equal(tab["bit"][::spr][: len(d_off) - 1], d_off.cpu().numpy()[:-1].astype(np.uint64))
+        nrsi, nblk = codec.rsi_count(data.size), codec.block_count(data.size)
+        d_ref, st = codec.decode(d_out, nbytes, d_off, nrsi, nblk)
+        assert st == 0
+        nb = bytes_per_sample(bps, flags)
+        d_seg = torch.empty(nblk * bs * nb + 16, dtype=torch.uint8, device="cuda")
+        d_res = torch.zeros(40, dtype=torch.uint8, device="cuda")
+        codec.decode_segments_async(d_out, nbytes, d_tab, nseg, nblk, d_seg, d_res)
+        res = d_res.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]
+        assert res["status"] == 0, (bps, bs, rsi, flags)
+        assert torch.equal(d_seg[: nblk * bs * nb], d_ref), (bps, bs, rsi, flags)
+        rc, want, *_ = oracle_encode(data, bps, bs, rsi, flags)
+        assert d_out[:nbytes].cpu().numpy().tobytes() == want
