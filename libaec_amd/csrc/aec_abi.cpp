@@ -194,8 +194,10 @@ int decode_staged(internal_state *s)
     if (nbytes == 0) return AEC_OK;
     const uint64_t start_rel = s->rsi_start_bit - s->stage_base * 8;
     const uint64_t avail_bits = (uint64_t)nbytes * 8 - start_rel;
-    // every RSI needs at least id_len bits, which bounds the table
-    const uint64_t max_rsi = avail_bits / c.id_len + 2;
+    // the shortest possible RSI is all zero blocks: one zero-run CDS (id_len + 2 bits) per segment,
+    // plus the reference sample when the preprocessor is on; that bounds the offset table
+    const uint64_t min_rsi_bits = (uint64_t)c.segs_per_rsi * (c.id_len + 2) + ((c.flags & F_PREPROCESS) ? c.bps : 0);
+    const uint64_t max_rsi = avail_bits / min_rsi_bits + 2;
     if (!s->d_in.ensure(nbytes + 16) || !s->d_off.ensure((max_rsi + 1) * 8)) return AEC_MEM_ERROR;
     if (hipMemcpyAsync(s->d_in.p, s->stage.data(), nbytes, hipMemcpyHostToDevice, s->stream) != hipSuccess)
         return AEC_MEM_ERROR;

@@ -326,15 +326,54 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     }
 }
 
-// serial RSI index (one active lane)
+// ---- serial RSI index -----------------------------------------------------------------------------
+// One wavefront per stream.  The walk itself is serial (every lane executes it redundantly on
+// wave-uniform values), but the stream is served from a 16 KiB LDS window that all 64 lanes refill
+// with coalesced 16-byte loads, so the parser never waits for HBM: a dependent global load per
+// refill of the bit window held the first version at ~5 MB/s of compressed input.
+constexpr uint32_t kIdxWindowWords = 4096;
+
+struct LdsWindowFetch {
+    const uint32_t *lds;    // window of kIdxWindowWords words (host order)
+    uint64_t base;          // stream word index of lds[0]
+    __device__ __forceinline__ uint32_t operator()(uint64_t idx) const
+    {
+        const uint64_t rel = idx - base;
+        return rel < kIdxWindowWords ? lds[rel] : 0u;   // outside: refilled before the next CDS
+    }
+};
+
 __global__ void __launch_bounds__(64)
 k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
         uint64_t start_bit, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ __attribute__((aligned(16))) uint32_t win[kIdxWindowWords];
+    if (blockIdx.x != 0) return;
+    const uint32_t lane = threadIdx.x;
     const bool pp = c.flags & F_PREPROCESS;
-    BitReader br;
-    br.init(words, nwords, end_bit, start_bit);
+    const uint32_t maxw = (c.id_len + 1 + c.bps + c.bs * c.bps) / 32 + 4;   // words one CDS can touch
+
+    uint64_t base = (start_bit >> 5) & ~3ull;
+    auto refill = [&](uint64_t from_word) {
+        base = from_word & ~3ull;
+        for (uint32_t i = lane * 4; i < kIdxWindowWords; i += 64 * 4) {
+            const uint64_t idx = base + i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx + 4 <= nwords) {
+                v = *reinterpret_cast<const uint4 *>(words + idx);
+            } else {
+                if (idx < nwords) v.x = words[idx];
+                if (idx + 1 < nwords) v.y = words[idx + 1];
+                if (idx + 2 < nwords) v.z = words[idx + 2];
+            }
+            *reinterpret_cast<uint4 *>(&win[i]) = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+        }
+        __syncthreads();
+    };
+    refill(base);
+
+    BitReaderT<LdsWindowFetch> br;
+    br.init(LdsWindowFetch{win, base}, end_bit, start_bit);
     uint64_t r = 0, good = start_bit;
     uint32_t b = 0, status = DEC_OK;
     for (;;) {
@@ -342,9 +381,15 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             if (r >= max_rsi) break;
             if ((c.flags & F_PAD_RSI) && (good & 7u)) {      // reference decode.c:407-408
                 good = (good + 7u) & ~7ull;
-                br.init(words, nwords, end_bit, good);
+                br.init(LdsWindowFetch{win, base}, end_bit, good);
             }
-            rsi_off[r] = good;
+            if (lane == 0) rsi_off[r] = good;
+        }
+        // keep the whole next CDS (and the reader's look-ahead) inside the window
+        if ((good >> 5) + maxw + 2 > base + kIdxWindowWords) {
+            __syncthreads();
+            refill(good >> 5);
+            br.init(LdsWindowFetch{win, base}, end_bit, good);
         }
         uint32_t nblk = 1;
         const uint32_t st = skip_cds(br, c, (pp && b == 0) ? 1u : 0u, b, nblk);
@@ -359,12 +404,14 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             r++;
         }
     }
-    res->n_rsi = r;
-    res->tail_blocks = b;
-    res->end_bit = good;
-    if (status == DEC_DATA_ERROR) {
-        res->status = DEC_DATA_ERROR;
-        res->bad_rsi = r;
+    if (lane == 0) {
+        res->n_rsi = r;
+        res->tail_blocks = b;
+        res->end_bit = good;
+        if (status == DEC_DATA_ERROR) {
+            res->status = DEC_DATA_ERROR;
+            res->bad_rsi = r;
+        }
     }
 }
 

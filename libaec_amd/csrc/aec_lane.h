@@ -427,20 +427,33 @@ AEC_HD void emit_small(BitWriter<Sink> &w, const uint32_t *d, const Cfg &c, uint
 // ------------------------------------------------------------------------------------
 // bit reader: stream = big-endian 32-bit words at a 4-byte aligned base
 // ------------------------------------------------------------------------------------
-struct BitReader {
+// Fetch policy of BitReaderT: Fetch::operator()(idx) returns stream word idx in host order, 0 past
+// the end.  MemFetch reads the stream where it lies; the RSI index kernel substitutes a fetcher
+// that serves words from an LDS window refilled by the whole wavefront.
+struct MemFetch {
     const uint32_t *words;
-    uint64_t nwords;     // words that may be read
+    uint64_t nwords;
+    AEC_HD uint32_t operator()(uint64_t idx) const { return idx < nwords ? bswap32(words[idx]) : 0u; }
+};
+
+template <class Fetch>
+struct BitReaderT {
+    Fetch f;
     uint64_t end_bit;    // bits that belong to the stream (reads beyond it see zeros)
     uint64_t pos;        // absolute position of the next unread bit
     uint64_t win;        // unread bits, left aligned; bits below the top `cnt` are zero
     uint32_t cnt;        // valid bits in win; (pos + cnt) is always a multiple of 32
     uint64_t next_word;
 
-    AEC_HD uint32_t fetch(uint64_t idx) const { return idx < nwords ? bswap32(words[idx]) : 0u; }
+    AEC_HD uint32_t fetch(uint64_t idx) const { return f(idx); }
 
     AEC_HD void init(const uint32_t *w, uint64_t nw, uint64_t endb, uint64_t start_bit)
     {
-        words = w; nwords = nw; end_bit = endb; pos = start_bit;
+        init(Fetch{w, nw}, endb, start_bit);
+    }
+    AEC_HD void init(const Fetch &fetcher, uint64_t endb, uint64_t start_bit)
+    {
+        f = fetcher; end_bit = endb; pos = start_bit;
         const uint32_t sh = (uint32_t)(start_bit & 31u);
         next_word = (start_bit >> 5) + 1;
         win = (uint64_t)fetch(start_bit >> 5) << (32 + sh);
@@ -468,7 +481,7 @@ struct BitReader {
             cnt -= (uint32_t)n;
             pos += n;
         } else {
-            init(words, nwords, end_bit, pos + n);
+            init(f, end_bit, pos + n);
         }
     }
     // counts zeros up to the next 1 (reference decode.c:288-340); false if the stream ends first
@@ -514,6 +527,7 @@ struct BitReader {
     }
     AEC_HD bool overrun() const { return pos > end_bit; }
 };
+using BitReader = BitReaderT<MemFetch>;
 
 // Lean window reader used by the RSI-parallel decoder.  Src::word(i) returns the i-th 32-bit
 // big-endian word (already in host order) counted from a per-lane base, or 0 past what is
@@ -889,7 +903,8 @@ AEC_HD uint32_t decode_block(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d,
 
 // Skips one CDS without materialising samples (RSI index pass).  Returns blocks covered in
 // `nblocks` (1, or the zero-run length).
-AEC_HD uint32_t skip_cds(BitReader &r, const Cfg &c, uint32_t ref, uint32_t blk_in_rsi,
+template <class Reader>
+AEC_HD uint32_t skip_cds(Reader &r, const Cfg &c, uint32_t ref, uint32_t blk_in_rsi,
                          uint32_t &nblocks)
 {
     nblocks = 1;
