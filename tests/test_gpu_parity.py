@@ -321,3 +321,37 @@ def test_segment_parallel_decode(gpu):
         assert torch.equal(d_seg[: nblk * bs * nb], d_ref), (bps, bs, rsi, flags)
         rc, want, *_ = oracle_encode(data, bps, bs, rsi, flags)
         assert d_out[:nbytes].cpu().numpy().tobytes() == want
+
+
+def test_pad_rsi_and_restricted_through_abi(api):
+    """Decoder-side AEC_PAD_RSI (reference decode.c:407-408) and the restricted code-option sets
+    (id_len 1 and 2, reference encode.c:843-851) through the libaec ABI."""
+    rng = np.random.default_rng(3)
+    bps, bs, rsi, flags = 16, 16, 8, PP
+    vals = random_walk_samples(rng, bs * rsi * 5, bps, flags, scale=3.0, zero_frac=0.2)
+    data = pack_samples(vals, bps, flags)
+    rb = bs * rsi * 2
+    stream = b"".join(oracle_encode(data[i:i + rb], bps, bs, rsi, flags)[1] for i in range(0, data.size, rb))
+    rc, dec = api.aec_buffer_decode(stream, bps, bs, rsi, flags | 32, data.size)
+    assert rc == AEC_OK and dec == data.tobytes()
+    for bps in (1, 2, 3, 4):
+        fl = PP | AEC_RESTRICTED
+        vals = rng.integers(0, 1 << bps, size=5000)
+        vals[1000:3000] = vals[1000]
+        check_roundtrip(api, f"restricted-{bps}", bps, 16, 10, fl, pack_samples(vals, bps, fl))
+
+
+def test_corrupt_and_truncated_streams(api):
+    """A stream cut inside a coded data set yields the complete CDSes before the cut and AEC_OK;
+    a zero-run that overruns its RSI is AEC_DATA_ERROR (reference decode.c:543-544)."""
+    data = pack_samples(np.arange(4096) * 3 % 4096, 16, PP)
+    rc, enc = api.aec_buffer_encode(data, 16, 16, 16, PP)
+    rc, dec = api.aec_buffer_decode(enc[: len(enc) // 2], 16, 16, 16, PP, data.size)
+    assert rc == AEC_OK and 0 < len(dec) < data.size and len(dec) % 32 == 0
+    assert dec == data.tobytes()[: len(dec)]
+    # all-zero blocks in an RSI of 3: ID 0000 + 0 (zero run) + ref 16 bits + fs code "0000001"
+    # (fs = 6 -> 6 blocks) overruns the 3-block RSI
+    bad = bytes([0b00000000, 0x00, 0x00, 0b00000001, 0x00])
+    rc, _ = api.aec_buffer_decode(bad, 16, 16, 3, PP, 4096)
+    rc_o, _, _ = oracle_decode(bad, 16, 16, 3, PP, 4096)
+    assert rc == rc_o == api.AEC_DATA_ERROR

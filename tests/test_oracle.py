@@ -154,3 +154,20 @@ def test_differential_vs_reference():
             rc_r, dec_r = ref_decode(enc_r, bps, bs, rsi, flags, c)
             rc_o, dec_o, _ = oracle_decode(enc_r, bps, bs, rsi, flags, c)
             assert rc_r == rc_o and (rc_r != AEC_OK or dec_r == dec_o), (it, bps, bs, rsi, flags, n, c)
+
+
+def test_pad_rsi_decode():
+    """AEC_PAD_RSI (decoder side, reference decode.c:407-408): every RSI starts on a byte boundary.
+    The reference encoder never pads (ENABLE_RSI_PADDING is dead code, encode.c:499-505), so such a
+    stream is built by concatenating independently coded RSIs."""
+    rng = np.random.default_rng(3)
+    bps, bs, rsi, flags = 16, 16, 8, AEC_DATA_PREPROCESS
+    vals = random_walk_samples(rng, bs * rsi * 5, bps, flags, scale=3.0, zero_frac=0.2)
+    data = pack_samples(vals, bps, flags)
+    rb = bs * rsi * 2
+    stream = b"".join(oracle_encode(data[i:i + rb], bps, bs, rsi, flags)[1] for i in range(0, data.size, rb))
+    rc, dec, _ = oracle_decode(stream, bps, bs, rsi, flags | 32, data.size)
+    assert rc == AEC_OK and dec == data.tobytes()
+    if have_ref():
+        rc, dec = ref_decode(stream, bps, bs, rsi, flags | 32, data.size)
+        assert rc == AEC_OK and dec == data.tobytes()
