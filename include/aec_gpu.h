@@ -137,6 +137,22 @@ AEC_GPU_API int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, c
                                     uint64_t max_rsi, aec_gpu_dec_result *d_result, void *stream);
 
 /*
+ * Many independent streams in one launch -- the shape of an HDF5 / netCDF dataset stored as SZIP
+ * chunks, where the parallelism of decoding comes from the chunks.  Stream s occupies bytes
+ * [d_chunk_offsets[s], d_chunk_offsets[s+1]) of d_in (n_chunks + 1 entries, every offset a multiple
+ * of 16) and decodes to exactly rsi_per_chunk RSIs.  One wavefront walks each stream and writes its
+ * RSI start bits (absolute in d_in) to d_rsi_bit_offsets[s * rsi_per_chunk ..] and a result record
+ * to d_results[s] (n_rsi < rsi_per_chunk: the stream was shorter than announced; status 2: corrupt).
+ * The filled table then decodes the whole batch with ONE aec_gpu_decode_async call
+ * (n_rsi = n_chunks * rsi_per_chunk), chunk s landing at RSI s * rsi_per_chunk of d_out.
+ */
+AEC_GPU_API int aec_gpu_index_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                          size_t in_bytes, const uint64_t *d_chunk_offsets,
+                                          uint64_t n_chunks, uint64_t rsi_per_chunk,
+                                          uint64_t *d_rsi_bit_offsets, aec_gpu_dec_result *d_results,
+                                          void *stream);
+
+/*
  * Measurement hooks (bench.py): with profiling enabled the context records HIP events on the
  * caller's stream around its kernels; aec_gpu_phase_ms waits for them and returns the device
  * time of the LAST encode (analyze, scan, clear, pack) and decode call in milliseconds

@@ -343,12 +343,24 @@ struct LdsWindowFetch {
     }
 };
 
+// chunk_off == nullptr: one stream [start_bit, end_bit) -> rsi_off[0..max_rsi), res[0].
+// chunk_off != nullptr: workgroup s walks the independent stream that occupies bytes
+// [chunk_off[s], chunk_off[s+1]) of the buffer and writes rsi_off[s*max_rsi ..], res[s]; offsets are
+// absolute bit positions in the buffer, so ONE k_decode launch decodes the RSIs of all streams.
 __global__ void __launch_bounds__(64)
 k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
-        uint64_t start_bit, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res)
+        uint64_t start_bit, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res,
+        const uint64_t *__restrict__ chunk_off)
 {
     __shared__ __attribute__((aligned(16))) uint32_t win[kIdxWindowWords];
-    if (blockIdx.x != 0) return;
+    if (chunk_off) {
+        start_bit = chunk_off[blockIdx.x] * 8u;
+        end_bit = chunk_off[blockIdx.x + 1] * 8u;
+        rsi_off += (uint64_t)blockIdx.x * max_rsi;
+        res += blockIdx.x;
+    } else if (blockIdx.x != 0) {
+        return;
+    }
     const uint32_t lane = threadIdx.x;
     const bool pp = c.flags & F_PREPROCESS;
     const uint32_t maxw = (c.id_len + 1 + c.bps + c.bs * c.bps) / 32 + 4;   // words one CDS can touch
@@ -408,7 +420,11 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         res->n_rsi = r;
         res->tail_blocks = b;
         res->end_bit = good;
-        if (status == DEC_DATA_ERROR) {
+        if (chunk_off) {               // per-stream records are written in full (no init kernel)
+            res->status = status == DEC_DATA_ERROR ? DEC_DATA_ERROR : DEC_OK;
+            res->pad = 0;
+            res->bad_rsi = status == DEC_DATA_ERROR ? r : ~0ull;
+        } else if (status == DEC_DATA_ERROR) {
             res->status = DEC_DATA_ERROR;
             res->bad_rsi = r;
         }
@@ -522,7 +538,17 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
     hipLaunchKernelGGL(k_dec_result_init, dim3(1), dim3(1), 0, st, d_res);
     hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, reinterpret_cast<const uint32_t *>(d_in),
                        (uint64_t)((in_bytes + 3) / 4), (uint64_t)in_bytes * 8, start_bit, d_rsi_off, max_rsi,
-                       d_res);
+                       d_res, (const uint64_t *)nullptr);
+}
+
+void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_chunk_off,
+                        uint64_t n_chunks, uint64_t rsi_per_chunk, uint64_t *d_rsi_off, DecResult *d_res,
+                        hipStream_t st)
+{
+    if (n_chunks == 0) return;
+    hipLaunchKernelGGL(k_index, dim3((uint32_t)n_chunks), dim3(64), 0, st, c,
+                       reinterpret_cast<const uint32_t *>(d_in), (uint64_t)((in_bytes + 3) / 4),
+                       (uint64_t)in_bytes * 8, (uint64_t)0, d_rsi_off, rsi_per_chunk, d_res, d_chunk_off);
 }
 
 }  // namespace aec

@@ -213,6 +213,22 @@ int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
+int aec_gpu_index_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                              const uint64_t *d_chunk_offsets, uint64_t n_chunks, uint64_t rsi_per_chunk,
+                              uint64_t *d_rsi_bit_offsets, aec_gpu_dec_result *d_results, void *stream)
+{
+    (void)ctx;
+    Cfg c;
+    const int rc = cfg_from(p, 0, false, &c);
+    if (rc != RC_OK) return rc;
+    if ((reinterpret_cast<uintptr_t>(d_in) & 15u) || rsi_per_chunk == 0) return RC_CONF_ERROR;
+    (void)hipGetLastError();
+    launch_index_batch(c, static_cast<const uint8_t *>(d_in), in_bytes, d_chunk_offsets, n_chunks, rsi_per_chunk,
+                       d_rsi_bit_offsets, reinterpret_cast<DecResult *>(d_results),
+                       static_cast<hipStream_t>(stream));
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
+}
+
 int aec_gpu_profile(aec_gpu_ctx *ctx, int enable)
 {
     if (enable) {

@@ -91,4 +91,12 @@ void launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, 
 void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
                   uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t stream);
 
+// Index pass over many independent streams stored in one buffer (e.g. the chunks of an HDF5
+// dataset): stream s occupies bytes [chunk_off[s], chunk_off[s+1]) (chunk_off 4-byte aligned values,
+// n_chunks + 1 entries); one wavefront per stream, rsi_per_chunk offsets per stream, absolute bit
+// positions, so the table can go straight into launch_decode for the whole batch.
+void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_chunk_off,
+                        uint64_t n_chunks, uint64_t rsi_per_chunk, uint64_t *d_rsi_off, DecResult *d_res,
+                        hipStream_t stream);
+
 }  // namespace aec

@@ -58,6 +58,8 @@ def _lib():
         lib.aec_gpu_set_segment_table.argtypes = [vp, vp]
         lib.aec_gpu_decode_segments_async.restype = C.c_int
         lib.aec_gpu_decode_segments_async.argtypes = [vp, pp, vp, sz, vp, u64, u64, vp, vp, vp]
+        lib.aec_gpu_index_batch_async.restype = C.c_int
+        lib.aec_gpu_index_batch_async.argtypes = [vp, pp, vp, sz, vp, u64, u64, vp, vp, vp]
         lib.aec_gpu_index_async.restype = C.c_int
         lib.aec_gpu_index_async.argtypes = [vp, pp, vp, sz, u64, vp, u64, vp, vp]
         _bound = True
@@ -173,6 +175,17 @@ class Codec:
             self._stream(stream))
         if rc != 0:
             raise RuntimeError(f"aec_gpu_index_async failed ({rc})")
+
+    def index_batch_async(self, d_in, in_bytes, d_chunk_offsets, n_chunks, rsi_per_chunk, d_offsets, d_results,
+                          stream=None):
+        """d_chunk_offsets: int64 tensor (n_chunks + 1 byte offsets, multiples of 16);
+        d_offsets: int64 tensor (n_chunks * rsi_per_chunk); d_results: uint8 tensor (n_chunks * 40)"""
+        rc = self.lib.aec_gpu_index_batch_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes,
+            C.c_void_p(d_chunk_offsets.data_ptr()), n_chunks, rsi_per_chunk, C.c_void_p(d_offsets.data_ptr()),
+            C.c_void_p(d_results.data_ptr()), self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_index_batch_async failed ({rc})")
 
     # ---- convenience (synchronising) -------------------------------------------------------------
     def encode(self, d_in, start_bit=0, k_in=0):

@@ -60,3 +60,47 @@ def test_sz_hdf5_style_chunks_vs_reference_shim(szip):
             rc, dec = szip.decompress(got, chunk.size, opts, 8, 8, 1024)
             assert rc == 0 and dec == chunk.tobytes()
     assert len(want) < chunk.size // 2
+
+
+def test_batch_of_foreign_chunks_decodes_in_two_launches(szip):
+    """HDF5-style dataset: many independently coded chunks (here coded by the CPU reference / oracle,
+    i.e. streams that come without any offset table).  aec_gpu_index_batch_async walks all chunks
+    concurrently (one wavefront each), one aec_gpu_decode_async call decodes every RSI of the batch."""
+    import time
+    import torch
+    from libaec_amd import gpu
+    from helpers import oracle_encode, ref_encode
+    from test_gpu_parity import gen
+    bps, bs, rsi, flags = 8, 8, 128, 8            # SZ: 8-bit pixels, 8 px/block, 1024 px/scanline, NN
+    chunk_bytes, n_chunks = 256 << 10, 48
+    data = gen(2, chunk_bytes * n_chunks)
+    rpc = chunk_bytes // (bs * rsi)
+    streams, offs, pos = [], [0], 0
+    for s in range(n_chunks):
+        chunk = data[s * chunk_bytes:(s + 1) * chunk_bytes]
+        rc, enc = ref_encode(chunk, bps, bs, rsi, flags) if have_ref() else oracle_encode(chunk, bps, bs, rsi, flags)[:2]
+        assert rc == 0
+        pad = (-len(enc)) % 16
+        streams.append(enc + bytes(pad))
+        pos += len(enc) + pad
+        offs.append(pos)
+    blob = np.frombuffer(b"".join(streams), dtype=np.uint8)
+    codec = gpu.Codec(bps, bs, rsi, flags)
+    d_in = torch.from_numpy(blob.copy()).cuda()
+    d_choff = torch.tensor(offs, dtype=torch.int64, device="cuda")
+    d_off = torch.zeros(n_chunks * rpc, dtype=torch.int64, device="cuda")
+    d_res = torch.zeros(n_chunks * 40, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty(data.size + 16, dtype=torch.uint8, device="cuda")
+    d_dres = torch.zeros(40, dtype=torch.uint8, device="cuda")
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        codec.index_batch_async(d_in, blob.size, d_choff, n_chunks, rpc, d_off, d_res)
+        codec.decode_async(d_in, blob.size, d_off, n_chunks * rpc, n_chunks * rpc * rsi, d_out, d_dres)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    res = d_res.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)
+    assert np.all(res["n_rsi"] == rpc) and np.all(res["status"] == 0)
+    assert d_dres.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]["status"] == 0
+    assert torch.equal(d_out[:data.size].cpu(), torch.from_numpy(data))
+    print(f"batch of {n_chunks} chunks ({data.size >> 20} MiB): {dt * 1e3:.2f} ms -> {data.size / dt / 1e9:.2f} GB/s")
