@@ -19,6 +19,18 @@ namespace aec {
 
 namespace {
 
+// wave-wide inclusive prefix sum on the DPP network (same sequence as aec_enc.hip wave_scan_dpp)
+__device__ __forceinline__ uint32_t wave_incl_sum_dpp(uint32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+    return v;
+}
+
 // Inverse predictor + byte-order store of one block (BS > 0: registers, vector stores).
 template <int BS, int BYTES>
 __device__ __forceinline__ void store_block(uint8_t *dst, const uint32_t *d, const Cfg &c, bool ref,
@@ -384,10 +396,50 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     };
     refill(base);
 
+    // Cooperative walk: the 64 lanes hold 64 consecutive stream words (a 2048-bit window) in
+    // registers; locating the end of a CDS is a masked popcount per lane, one DPP prefix sum, a
+    // ballot and a rank-select inside one word -- about 60 wave instructions per CDS instead of a
+    // bit-serial loop.  Everything below is wave-uniform except W.
+    const uint32_t maxbits = c.id_len + 1 + c.bps + c.bs * c.bps;
+    const bool coop = maxbits + 128u <= 2048u;
+    const uint32_t idmax = (1u << c.id_len) - 1u;
+    uint64_t wbase = 0;          // stream word held by lane 0
+    uint32_t W = 0;
+    auto load_regs = [&](uint64_t first_word) {
+        wbase = first_word;
+        W = LdsWindowFetch{win, base}(first_word + lane);
+    };
+    auto rdlane = [&](uint32_t v, uint32_t l) {
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)l));
+    };
+    auto peek = [&](uint32_t rel) {                     // 32 bits at window bit offset rel
+        const uint32_t w = rel >> 5, sh = rel & 31u;
+        const uint64_t two = ((uint64_t)rdlane(W, w) << 32) | rdlane(W, (w + 1) & 63u);
+        return (uint32_t)((two << sh) >> 32);
+    };
+    // window offset just behind the n-th 1 bit at or after rel; 0xFFFFFFFF if the window has fewer
+    auto skip_ones = [&](uint32_t rel, uint32_t n) -> uint32_t {
+        const uint32_t w = rel >> 5, sh = rel & 31u;
+        const uint32_t m = lane < w ? 0u : (lane == w ? W & (0xFFFFFFFFu >> sh) : W);
+        const uint32_t pc = (uint32_t)__builtin_popcount(m);
+        const uint32_t S = wave_incl_sum_dpp(pc);
+        const uint64_t enough = __ballot(S >= n);
+        if (enough == 0) return 0xFFFFFFFFu;
+        const uint32_t L = (uint32_t)__builtin_ctzll(enough);
+        const uint32_t need = n - (rdlane(S, L) - rdlane(pc, L));      // rank inside word L, 1-based
+        const uint32_t word = rdlane(m, L);
+        const uint32_t j = lane & 31u;
+        const uint32_t bit = (word >> (31u - j)) & 1u;
+        const uint32_t rank = j ? (uint32_t)__builtin_popcount(word >> (32u - j)) : 0u;
+        const uint64_t hit = __ballot(lane < 32u && bit && rank + 1u == need);
+        return L * 32u + (uint32_t)__builtin_ctzll(hit) + 1u;
+    };
+
     BitReaderT<LdsWindowFetch> br;
     br.init(LdsWindowFetch{win, base}, end_bit, start_bit);
     uint64_t r = 0, good = start_bit;
     uint32_t b = 0, status = DEC_OK;
+    if (coop) load_regs(good >> 5);
     for (;;) {
         if (b == 0) {
             if (r >= max_rsi) break;
@@ -397,19 +449,72 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             }
             if (lane == 0) rsi_off[r] = good;
         }
-        // keep the whole next CDS (and the reader's look-ahead) inside the window
-        if ((good >> 5) + maxw + 2 > base + kIdxWindowWords) {
+        // keep the whole next CDS (and the readers' look-ahead) inside the LDS window
+        if ((good >> 5) + (coop ? 66u : maxw + 2u) > base + kIdxWindowWords) {
             __syncthreads();
             refill(good >> 5);
             br.init(LdsWindowFetch{win, base}, end_bit, good);
+            if (coop) load_regs(good >> 5);
         }
+        const uint32_t ref = (pp && b == 0) ? 1u : 0u;
         uint32_t nblk = 1;
-        const uint32_t st = skip_cds(br, c, (pp && b == 0) ? 1u : 0u, b, nblk);
-        if (st != DEC_OK) {
-            status = st;
-            break;
+        bool done = false;
+        if (coop) {
+            uint32_t rel = (uint32_t)(good - wbase * 32u);
+            if (good < wbase * 32u || rel + maxbits + 64u > 2048u) {     // slide the register window
+                load_regs(good >> 5);
+                rel = (uint32_t)(good & 31u);
+            }
+            const uint32_t h = peek(rel);
+            const uint32_t id = h >> (32u - c.id_len);
+            uint32_t q = rel + c.id_len;
+            if (id == 0) {
+                const uint32_t sel = (h >> (31u - c.id_len)) & 1u;
+                q += 1u + ref * c.bps;
+                if (sel) {
+                    q = skip_ones(q, c.bs / 2);
+                } else {
+                    const uint32_t e = skip_ones(q, 1);
+                    if (e != 0xFFFFFFFFu) {
+                        uint32_t nz = e - q;                 // fs + 1
+                        if (nz == 5) {
+                            const uint32_t left_rsi = c.rsi - b, left_seg = 64u - (b % 64u);
+                            nz = left_rsi < left_seg ? left_rsi : left_seg;
+                        } else if (nz > 5) {
+                            nz--;
+                        }
+                        if (nz > c.rsi - b) status = DEC_DATA_ERROR;
+                        nblk = nz;
+                    }
+                    q = e;
+                }
+            } else if (id == idmax) {
+                q += c.bs * c.bps;
+            } else {
+                q += ref * c.bps;
+                q = skip_ones(q, c.bs - ref);
+                if (q != 0xFFFFFFFFu) q += (c.bs - ref) * (id - 1u);
+            }
+            if (q != 0xFFFFFFFFu) {
+                const uint64_t end = wbase * 32u + q;
+                if (status == DEC_DATA_ERROR && end <= end_bit) break;
+                if (end > end_bit) {
+                    status = DEC_NEED_INPUT;
+                    break;
+                }
+                good = end;
+                done = true;
+            }
         }
-        good = br.pos;
+        if (!done) {          // large blocks, or a code reaching beyond the register window
+            if (coop) br.init(LdsWindowFetch{win, base}, end_bit, good);
+            const uint32_t st = skip_cds(br, c, ref, b, nblk);
+            if (st != DEC_OK) {
+                status = st;
+                break;
+            }
+            good = br.pos;
+        }
         b += nblk;
         if (b >= c.rsi) {
             b = 0;
