@@ -12,6 +12,8 @@
 //             table.  One lane per stream.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "aec_kernels.h"
 #include "aec_lane.h"
 
@@ -169,6 +171,15 @@ __device__ __forceinline__ uint4 load_words4(const uint32_t *__restrict__ words,
     return v;
 }
 
+// branch-free variant for the steady-state prefetch: idx is clamped to the last whole 16-byte chunk
+// of the buffer (the words past the end of a stream are never consumed by a valid CDS; the rare
+// exact tail is served by the synchronous refill with load_words4)
+__device__ __forceinline__ uint4 load_words4_nb(const uint32_t *__restrict__ words, uint64_t idx, uint64_t last_chunk)
+{
+    if (idx > last_chunk) idx = last_chunk;
+    return *reinterpret_cast<const uint4 *>(words + idx);
+}
+
 // rel is a multiple of 4 and slot0 a multiple of 4, so the four rows never wrap inside a chunk
 __device__ __forceinline__ void ring_put4(uint32_t *col, uint32_t slot0, uint32_t mask, uint32_t rel, uint4 v)
 {
@@ -193,10 +204,12 @@ template <int BS, int BYTES, bool SEG>
 __global__ void __launch_bounds__(256)
 k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
          const uint64_t *__restrict__ rsi_off, const SegEntry *__restrict__ seg_table, uint64_t n_rsi,
-         uint64_t total_blocks, uint8_t *__restrict__ out, DecResult *res, uint32_t ring_words, uint32_t maxw)
+         uint64_t total_blocks, uint8_t *__restrict__ out, DecResult *res, uint32_t ring_words, uint32_t maxw,
+         uint8_t *__restrict__ dump)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t nwords_vec = nwords >= 4 ? ((nwords + 3) & ~3ull) - 4 : 0;   // last 16-byte chunk
     uint32_t *col = smem + (size_t)wave * (ring_words + 2u) * 64u + lane;
     const uint32_t mask = ring_words - 1;
 
@@ -293,22 +306,29 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                     zrun = nz;
                 }
             }
+            // VMEM order per iteration: land the loads issued one iteration ago, issue the next
+            // loads, then store the block.  Every lane issues every instruction (idle lanes re-read
+            // their base chunk / write to a dump slot), so the instruction count per iteration is
+            // fixed and the wait at the landing point can leave the younger stores outstanding.
 #pragma unroll
-            for (int j = 0; j < kPend; j++)                        // land last iteration's loads
+            for (int j = 0; j < kPend; j++)
                 if (pv[j]) {
                     ring_put4(col, slot0, mask, landed, pend[j]);
                     landed += 4;
                 }
-            if (live && ok) {
-                store_block<DN, (BYTES ? BYTES : 1)>(dst, d, c, ref != 0 && parse, x);
-                dst += blk_bytes;
-                zrun -= zrun ? 1u : 0u;
-            }
             const uint32_t next = p >> 5;
 #pragma unroll
-            for (int j = 0; j < kPend; j++) {                      // issue the next loads
+            for (int j = 0; j < kPend; j++) {
                 pv[j] = live && ok && (landed + 4u * j + 4u - next <= ring_words);
-                if (pv[j]) pend[j] = load_words4(words, a0 + landed + 4u * j, nwords);
+                const uint64_t idx = pv[j] ? a0 + landed + 4u * j : 0;   // idle lanes share one line
+                pend[j] = load_words4_nb(words, idx, nwords_vec);
+            }
+            {
+                const bool st_ok = live && ok;
+                uint8_t *q = st_ok ? dst : dump + (size_t)lane * blk_bytes;
+                store_block<DN, (BYTES ? BYTES : 1)>(q, d, c, ref != 0 && parse, x);
+                dst += st_ok ? blk_bytes : 0;
+                zrun -= (st_ok && zrun) ? 1u : 0u;
             }
         } else if (live) {
             br.src.limit = landed;
@@ -546,6 +566,20 @@ __global__ void k_dec_result_init(DecResult *res)
     res->bad_rsi = ~0ull;
 }
 
+// 64 lanes x one maximal block: where lanes without a block to write send their (always issued)
+// stores.  One buffer per device for the life of the process.
+uint8_t *dump_buffer()
+{
+    static std::mutex mu;
+    static uint8_t *buf[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!buf[dev]) (void)hipMalloc(reinterpret_cast<void **>(&buf[dev]), 64 * kMaxBlockSize * 4);
+    return buf[dev];
+}
+
 struct DecGeom {
     uint32_t ring_words, maxw, waves, grid;
     size_t lds_bytes;
@@ -581,7 +615,7 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
     const dim3 block(64 * g.waves), grid(g.grid);
 #define AEC_GO(B)                                                                                   \
     hipLaunchKernelGGL((k_decode<BS, B, SEG>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
-                       rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw)
+                       rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, dump_buffer())
     switch (c.bytes) {
     case 1: AEC_GO(1); break;
     case 2: AEC_GO(2); break;
@@ -616,7 +650,7 @@ static void launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
     {
         const DecGeom g = dec_geom(c, n_items);
         hipLaunchKernelGGL((k_decode<0, 0, SEG>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
-                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw);
+                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, dump_buffer());
         break;
     }
     }
