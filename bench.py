@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: independent shard streams, no exchange and no all-gather")
+    ap.add_argument("--overlap", action="store_true",
+                    help="pipeline steps over two HIP streams (encode of step i+1 beside decode of step i)")
     ap.add_argument("--shard-path", action="store_true",
                     help="run the plan/exchange/emit/gather/stitch path even with one GPU")
     args = ap.parse_args()
@@ -197,7 +199,33 @@ def main():
         d_stream = torch.zeros(sum((b + 7) // 8 for b, _, _ in plans0) + 64, dtype=torch.uint8, device=dev)
         comm = torch.cuda.Stream(device=dev)
 
+    # Two HIP streams: the encode of step i+1 runs beside the decode of step i (double-buffered
+    # compressed stream and segment table), which fills the bubbles each kernel leaves on its own.
+    overlap = args.overlap and not sharded
+    if overlap:
+        s_enc, s_dec = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        outs = [d_out, torch.empty_like(d_out)]
+        segs = [d_seg, torch.zeros_like(d_seg)]
+        enc_done = [torch.cuda.Event(), torch.cuda.Event()]
+        dec_done = [torch.cuda.Event(), torch.cuda.Event()]
+        step_no = [0]
+        for e in dec_done:
+            e.record()
+
     def one_step():
+        if overlap:
+            i = step_no[0] & 1
+            step_no[0] += 1
+            with torch.cuda.stream(s_enc):
+                s_enc.wait_event(dec_done[i])                 # buffer i is free again
+                codec.set_segment_table(segs[i])
+                codec.encode_async(d_in, nbytes, outs[i], d_off, d_eres)
+                enc_done[i].record()
+            with torch.cuda.stream(s_dec):
+                s_dec.wait_event(enc_done[i])
+                codec.decode_segments_async(outs[i], cbytes, segs[i], n_seg, n_blk, d_dec, d_dres)
+                dec_done[i].record()
+            return
         if not sharded:
             codec.encode_async(d_in, nbytes, d_out, d_off, d_eres)
             decode_async(cbytes)
@@ -228,12 +256,16 @@ def main():
             assert torch.equal(ref_out[:cbytes], d_stream[:cbytes]), "stitched stream != single stream"
             del ref_out
 
+    lib = gpu._lib()
+    lib.aec_gpu_profile.argtypes = [C.c_void_p, C.c_int]
+    lib.aec_gpu_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    lib.aec_gpu_profile(codec.ctx, 1)      # events only; nothing waits on them until the loop is over
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -247,22 +279,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-kernel device time of this run (HIP events recorded by the library on the same stream)
-    lib = gpu._lib()
-    lib.aec_gpu_profile.argtypes = [C.c_void_p, C.c_int]
-    lib.aec_gpu_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
-    lib.aec_gpu_profile(codec.ctx, 1)
-    acc = np.zeros(5)
-    reps = max(3, min(args.steps, 10))
-    for _ in range(reps):
-        codec.encode_async(d_in, nbytes, d_out, d_off, d_eres)
-        decode_async(cbytes)
-        ms = (C.c_float * 5)()
-        lib.aec_gpu_phase_ms(codec.ctx, ms)
-        acc += np.array(list(ms))
+    # ---- per-kernel device time of the timed steps (HIP events recorded by the library, on the
+    # stream the kernels ran on, around every launch of the timed region; read only now)
+    ms = (C.c_float * 5)()
+    lib.aec_gpu_phase_ms(codec.ctx, ms)
     lib.aec_gpu_profile(codec.ctx, 0)
-    phase = dict(zip(["analyze", "scan", "clear", "pack", "decode"], (acc / reps).tolist()))
-    torch.cuda.synchronize()
+    phase = dict(zip(["analyze", "scan", "clear", "pack", "decode"], [float(x) for x in ms]))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

@@ -154,9 +154,11 @@ AEC_GPU_API int aec_gpu_index_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params
 
 /*
  * Measurement hooks (bench.py): with profiling enabled the context records HIP events on the
- * caller's stream around its kernels; aec_gpu_phase_ms waits for them and returns the device
- * time of the LAST encode (analyze, scan, clear, pack) and decode call in milliseconds
- * (-1 for a phase that has not run).
+ * caller's stream around its kernels, one event set per call (a ring of 32), so a timed loop
+ * needs no synchronisation inside it; aec_gpu_phase_ms waits for them and returns the device
+ * time per phase (analyze, scan, clear, pack of the encode calls; decode) in milliseconds,
+ * averaged over the calls made since profiling was enabled (the last 32 at most; -1 for a
+ * phase that has not run).  Enabling profiling again restarts the average.
  */
 AEC_GPU_API int aec_gpu_profile(aec_gpu_ctx *ctx, int enable);
 AEC_GPU_API int aec_gpu_phase_ms(aec_gpu_ctx *ctx, float ms[5]);

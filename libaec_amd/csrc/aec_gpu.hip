@@ -16,7 +16,21 @@ struct aec_gpu_ctx {
     void *ws;          // encoder workspace
     size_t ws_bytes;
     bool profiling;    // record PhaseEvents around the kernels of the next calls
-    PhaseEvents ev;
+    // One event set per call, in a ring, so that a caller can time every launch of a loop without
+    // synchronising inside it; aec_gpu_phase_ms() averages over the sets recorded since profiling
+    // was switched on (the last kProfRing of them).
+    static constexpr unsigned kProfRing = 32;
+    PhaseEvents ev[kProfRing];
+    unsigned enc_calls, dec_calls;
+    // an emit-only call continues the set its plan call opened (its "scan" then spans the host's
+    // plan exchange between the two calls)
+    const PhaseEvents *enc_events(uint32_t phases)
+    {
+        if (!profiling) return nullptr;
+        if ((phases & ENC_PLAN) || enc_calls == 0) enc_calls++;
+        return &ev[(enc_calls - 1) % kProfRing];
+    }
+    const PhaseEvents *dec_events() { return profiling ? &ev[dec_calls++ % kProfRing] : nullptr; }
     SegEntry *seg_table;   // where the next encode / emit calls also leave the segment table (or null)
 };
 static_assert(sizeof(aec_gpu_seg_entry) == sizeof(SegEntry), "segment table layout");
@@ -42,7 +56,9 @@ int aec_gpu_create(aec_gpu_ctx **out)
     ctx->ws_bytes = 0;
     ctx->profiling = false;
     ctx->seg_table = nullptr;
-    for (auto &e : ctx->ev.ev) e = nullptr;
+    ctx->enc_calls = ctx->dec_calls = 0;
+    for (auto &set : ctx->ev)
+        for (auto &e : set.ev) e = nullptr;
     *out = ctx;
     return RC_OK;
 }
@@ -51,8 +67,9 @@ void aec_gpu_destroy(aec_gpu_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->ws) (void)hipFree(ctx->ws);
-    for (auto &e : ctx->ev.ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto &set : ctx->ev)
+        for (auto &e : set.ev)
+            if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -125,7 +142,7 @@ static int encode_phases(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *
     ws.partials = reinterpret_cast<ScanPartial *>(base + o[5]);
     launch_encode(c, static_cast<const uint8_t *>(d_in), static_cast<uint8_t *>(d_out), out_cap, start_bit,
                   k_in, ws, d_rsi_bit_offsets, reinterpret_cast<EncResult *>(d_result),
-                  static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr, phases, ctx->seg_table);
+                  static_cast<hipStream_t>(stream), ctx->enc_events(phases), phases, ctx->seg_table);
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
@@ -163,7 +180,7 @@ int aec_gpu_decode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *
     (void)hipGetLastError();
     launch_decode(c, static_cast<const uint8_t *>(d_in), in_bytes, d_rsi_bit_offsets, n_rsi, total_blocks,
                   static_cast<uint8_t *>(d_out), reinterpret_cast<DecResult *>(d_result),
-                  static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr);
+                  static_cast<hipStream_t>(stream), ctx->dec_events());
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
@@ -194,7 +211,7 @@ int aec_gpu_decode_segments_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, con
     launch_decode_segments(c, static_cast<const uint8_t *>(d_in), in_bytes,
                            reinterpret_cast<const SegEntry *>(d_seg_table), n_seg, total_blocks,
                            static_cast<uint8_t *>(d_out), reinterpret_cast<DecResult *>(d_result),
-                           static_cast<hipStream_t>(stream), ctx->profiling ? &ctx->ev : nullptr);
+                           static_cast<hipStream_t>(stream), ctx->dec_events());
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
@@ -232,8 +249,10 @@ int aec_gpu_index_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const v
 int aec_gpu_profile(aec_gpu_ctx *ctx, int enable)
 {
     if (enable) {
-        for (auto &e : ctx->ev.ev)
-            if (!e && hipEventCreate(&e) != hipSuccess) return RC_MEM_ERROR;
+        for (auto &set : ctx->ev)
+            for (auto &e : set.ev)
+                if (!e && hipEventCreate(&e) != hipSuccess) return RC_MEM_ERROR;
+        ctx->enc_calls = ctx->dec_calls = 0;
     }
     ctx->profiling = enable != 0;
     return RC_OK;
@@ -243,12 +262,17 @@ int aec_gpu_phase_ms(aec_gpu_ctx *ctx, float *ms /*[5]: analyze, scan, clear, pa
 {
     static const int pair[5][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {5, 6}};
     for (int i = 0; i < 5; i++) {
-        ms[i] = -1.0f;
-        hipEvent_t a = ctx->ev.ev[pair[i][0]], b = ctx->ev.ev[pair[i][1]];
-        if (!a || !b) continue;
-        if (hipEventSynchronize(b) != hipSuccess) continue;
-        float t = 0;
-        if (hipEventElapsedTime(&t, a, b) == hipSuccess) ms[i] = t;
+        const unsigned calls = i < 4 ? ctx->enc_calls : ctx->dec_calls;
+        const unsigned sets = calls < aec_gpu_ctx::kProfRing ? calls : aec_gpu_ctx::kProfRing;
+        double sum = 0;
+        unsigned got = 0;
+        for (unsigned s = 0; s < sets; s++) {
+            hipEvent_t a = ctx->ev[s].ev[pair[i][0]], b = ctx->ev[s].ev[pair[i][1]];
+            if (!a || !b || hipEventSynchronize(b) != hipSuccess) continue;
+            float t = 0;
+            if (hipEventElapsedTime(&t, a, b) == hipSuccess) { sum += t; got++; }
+        }
+        ms[i] = got ? static_cast<float>(sum / got) : -1.0f;
     }
     return RC_OK;
 }
