@@ -44,6 +44,9 @@ CONFIGS = {
     "c2": ("lowent16", 0, 16, 16, 128, 8),               # 16-bit LSB unsigned, block 16, rsi 128, PP
     "c3": ("lowent32s", 1, 32, 32, 4096, 8 | 4 | 1),      # 32-bit signed MSB, block 32, rsi 4096, PP
     "c5": ("chunks8", 2, 8, 8, 128, 8),                   # 8-bit, block 8, rsi 128, PP (SZIP chunk shape)
+    # BASELINE.json configs[0]: the reference's own sample (data/typical.rz decoded, 1 MiB of real
+    # 16-bit MSB data, ratio 1.42) tiled to the workload size; -n16 -j64 -r256 -m
+    "typical": ("typical.dat tiled", -1, 16, 64, 256, 8 | 4),
 }
 
 
@@ -53,6 +56,17 @@ def generate(kind, nbytes, shard, threads):
     lib.aec_gen_fill_parallel(C.c_uint(kind), C.c_uint64(shard), C.c_void_p(a.ctypes.data),
                               C.c_size_t(nbytes // {0: 2, 1: 4, 2: 1}[kind]), C.c_uint(threads))
     return a
+
+
+def typical_tiled(nbytes):
+    """The non-synthetic point: tests/golden/typical.rz (the reference's data/typical.rz) decoded
+    by the product library and repeated to `nbytes` (1 MiB = 32 whole RSIs, so tiles stay aligned)."""
+    from libaec_amd import api
+    rz = open(os.path.join(ROOT, "tests", "golden", "typical.rz"), "rb").read()
+    rc, dec = api.aec_buffer_decode(rz, 16, 64, 256, 8 | 4, 1 << 20)
+    assert rc == 0 and len(dec) == 1 << 20
+    one = np.frombuffer(dec, dtype=np.uint8)
+    return np.tile(one, (nbytes + one.size - 1) // one.size)[:nbytes].copy()
 
 
 def measured_traffic(kernel, size_mib):
@@ -97,6 +111,52 @@ def cpu_baseline(sample):
             "compressed_bytes": len(enc)}, enc
 
 
+def cpu_all_cores(host, seconds=10.0):
+    """The reference on every host core: the input cut into contiguous RSI-aligned shards, one
+    independent stream per core (the reference has no threading),
+    driven by the pthread harness oracle/mt_harness.c; passes are repeated to about `seconds`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    mt_so = os.path.join(ROOT, "oracle", "_build", "libaec_mt.so")
+    if not helpers.have_ref() or not os.path.exists(mt_so):
+        return None
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    rsi_bytes = RSI * BS * ((BPS + 7) // 8)
+    per = min(64 << 20, host.size // cores) // rsi_bytes * rsi_bytes
+    if per == 0:
+        return None
+    ref, mt = helpers.ref_lib(), C.CDLL(mt_so)
+    mt.aec_mt_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint,
+                              C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]
+    enc = C.cast(ref.aec_buffer_encode, C.c_void_p)
+    dec = C.cast(ref.aec_buffer_decode, C.c_void_p)
+    reps = max(1, int(seconds * 0.3e9 / per))          # one core does about 0.3 GB/s encode+decode
+    dt = C.c_double(0)
+    rc = mt.aec_mt_run(enc, dec, host.ctypes.data, per, cores, reps, BPS, BS, RSI, FLAGS, C.byref(dt))
+    assert rc == 0, "multi-thread reference run failed"
+    return {"value": round(cores * per * reps / dt.value / 1e9, 3), "unit": "GB/s", "cores": cores,
+            "kind": "reference",
+            "sample": f"{cores} independent streams of {per >> 20} MiB (contiguous RSI-aligned shards of the "
+                      f"rank-0 input), one pthread each, {reps} encode+decode passes in memory"}
+
+
+def abi_end_to_end(host):
+    """PCIe-inclusive rate of the drop-in ABI: aec_buffer_encode / aec_buffer_decode of the product
+    library on HOST buffers (stage, H2D, kernels, D2H; the decode also pays the serial index pass
+    because a bare stream carries no entry points).  Reported beside `value`, never as `value`."""
+    from libaec_amd import api
+    api.aec_buffer_encode(host[: 1 << 20], BPS, BS, RSI, FLAGS)          # warm
+    t0 = time.perf_counter()
+    rc, enc = api.aec_buffer_encode(host, BPS, BS, RSI, FLAGS)
+    t1 = time.perf_counter()
+    rc2, dec = api.aec_buffer_decode(enc, BPS, BS, RSI, FLAGS, host.size)
+    t2 = time.perf_counter()
+    assert rc == 0 and rc2 == 0 and bytes(dec) == host.tobytes()
+    return {"sample_MiB": host.size >> 20, "encode_GBps": round(host.size / (t1 - t0) / 1e9, 3),
+            "decode_GBps": round(host.size / (t2 - t1) / 1e9, 3),
+            "note": "host buffers through libaec.so.0 (pageable memory, H2D + kernels + D2H)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +167,9 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="BASELINE.json configuration (the headline metric is quoted on c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true",
+                    help="also report the reference on all host cores and the PCIe-inclusive ABI rate "
+                         "(about a minute more; not part of the timed region)")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: independent shard streams, no exchange and no all-gather")
     ap.add_argument("--overlap", action="store_true",
@@ -133,7 +196,7 @@ def main():
 
     nbytes = args.size_mib << 20
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
-    host = generate(KIND, nbytes, rank, threads)
+    host = typical_tiled(nbytes) if KIND < 0 else generate(KIND, nbytes, rank, threads)
 
     codec = gpu.Codec(BPS, BS, RSI, FLAGS)
     codec.reserve(nbytes)
@@ -173,7 +236,21 @@ def main():
         # the GPU stream's prefix must be the CPU stream (whole RSIs code to a prefix of the stream)
         nfull = len(enc_cpu) - 1
         assert d_out[:nfull].cpu().numpy().tobytes() == enc_cpu[:nfull], "GPU stream != CPU reference stream"
+    extras = {}
+    if rank == 0 and args.extras:
+        extras["cpu_baseline_all_cores"] = cpu_all_cores(host)
+        extras["abi_end_to_end"] = abi_end_to_end(host[: 256 << 20])
     del host
+
+    # achievable HBM rate beside the spec peak: a plain device copy of the same input (N read + N written)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    d_dec[:nbytes].copy_(d_in)
+    ev0.record()
+    for _ in range(3):
+        d_dec[:nbytes].copy_(d_in)
+    ev1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 2 * nbytes * 3 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
 
     # ---- N > 1: ONE stream over all ranks (libaec_amd/shard.py): plan -> exchange 3 numbers ->
     # emit at the global bit offset -> one RCCL all-gather of the slices -> local stitch.  The
@@ -320,12 +397,15 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
-                         "algorithmic_bytes_per_launch": algo[dom], "kernel_ms": round(phase[dom], 4)},
+                         "algorithmic_bytes_per_launch": algo[dom], "kernel_ms": round(phase[dom], 4),
+                         "device_copy_GBps": round(copy_gbps, 1),
+                         "frac_of_device_copy": round(achieved / copy_gbps, 5)},
             "cpu_baseline": cpu,
             "phases_ms": {k: round(v, 4) for k, v in phase.items()},
             "encode_GBps": round(nbytes / (enc_ms * 1e-3) / 1e9, 2),
             "decode_GBps": round(nbytes / (phase["decode"] * 1e-3) / 1e9, 2),
         }
+        out.update({k: v for k, v in extras.items() if v is not None})
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
