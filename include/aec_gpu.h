@@ -128,10 +128,19 @@ AEC_GPU_API int aec_gpu_decode_segments_async(aec_gpu_ctx *ctx, const aec_gpu_pa
                                               aec_gpu_dec_result *d_result, void *stream);
 
 /*
- * Find the RSI start offsets of a stream that comes without an offset table: a serial walk from
- * bit start_bit (an RSI boundary) that stops at the end of the input, after max_rsi RSIs, or at
- * a corrupt coded data set.  d_rsi_bit_offsets needs max_rsi entries.
+ * Find the RSI start offsets of a stream that comes without an offset table, from bit start_bit
+ * (an RSI boundary) to the end of the input, to max_rsi RSIs, or to a corrupt coded data set.
+ * d_rsi_bit_offsets needs max_rsi entries.  The reference has no counterpart (its decoder walks
+ * the stream CDS by CDS, src/decode.c:402-421).  Here all CUs first tabulate, for every bit
+ * position, the length of an RSI that would start there (speculation through an LDS window:
+ * rank/select over the 1-bits gives the end of a coded data set in O(1)); one wavefront then hops
+ * from RSI start to RSI start over those tables.  RSIs longer than the look-ahead of a window
+ * (about 20 kbit coded), cut by the end of the input or malformed are walked serially, so the
+ * result never depends on the tables.  The look-ahead is sized from the expected coded RSI:
+ * (input bits / max_rsi) unless aec_gpu_set_index_hint gave a better estimate (0 = back to default).
+ * The call may allocate table workspace (up to ~340 MiB for inputs of 8 MiB and more).
  */
+AEC_GPU_API void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits);
 AEC_GPU_API int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
                                     size_t in_bytes, uint64_t start_bit, uint64_t *d_rsi_bit_offsets,
                                     uint64_t max_rsi, aec_gpu_dec_result *d_result, void *stream);

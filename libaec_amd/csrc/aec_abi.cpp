@@ -57,6 +57,9 @@ struct internal_state {
     DevBuf d_in, d_out, d_off, d_res;
     void *h_res;                   // pinned mirror of the device result record
 
+    size_t out_room;               // decoder: avail_out of the current call (sizes the index look-ahead)
+    uint64_t rsi_bits_seen;        // decoder: average coded RSI of the previous batch (0 = none yet)
+
     std::vector<uint8_t> stage;    // input not yet coded
     std::vector<uint8_t> outq;     // produced bytes not yet delivered
     size_t outq_pos;
@@ -203,6 +206,15 @@ int decode_staged(internal_state *s)
         return AEC_MEM_ERROR;
     aec_gpu_dec_result *dres = static_cast<aec_gpu_dec_result *>(s->d_res.p);
     aec_gpu_dec_result *hres = static_cast<aec_gpu_dec_result *>(s->h_res);
+    // Look-ahead of the speculative index = a small multiple of the average coded RSI: measured on
+    // the previous batch of this stream, else estimated from the room the caller offers for output.
+    uint64_t hint = s->rsi_bits_seen;
+    if (!hint) {
+        const uint64_t rsi_bytes = (uint64_t)c.rsi * c.bs * c.bytes;
+        const uint64_t expect = (s->out_room + rsi_bytes - 1) / rsi_bytes;
+        if (expect) hint = avail_bits / expect;
+    }
+    aec_gpu_set_index_hint(s->ctx, hint + hint / 2);
     int rc = aec_gpu_index_async(s->ctx, &s->prm, s->d_in.p, nbytes, start_rel,
                                  static_cast<uint64_t *>(s->d_off.p), max_rsi, dres, s->stream);
     if (rc != RC_OK) return rc;
@@ -210,6 +222,7 @@ int decode_staged(internal_state *s)
         hipStreamSynchronize(s->stream) != hipSuccess)
         return AEC_MEM_ERROR;
     const aec_gpu_dec_result idx = *hres;
+    if (idx.n_rsi) s->rsi_bits_seen = (idx.end_bit - start_rel) / idx.n_rsi;
     const uint64_t n_items = idx.n_rsi + (idx.tail_blocks ? 1 : 0);
     const uint64_t blocks = idx.n_rsi * c.rsi + idx.tail_blocks;
     const size_t blk_bytes = (size_t)c.bs * c.bytes;
@@ -354,6 +367,7 @@ int aec_decode(struct aec_stream *strm, int flush)
         }
         if (!s->new_input) break;         // nothing new to look at
         s->new_input = false;
+        s->out_room = strm->avail_out;
         rc = decode_staged(s);
         if (rc == AEC_DATA_ERROR) s->sticky_error = rc;
     }

@@ -7,9 +7,7 @@
 //             (decode.c:67-141), which is a serial chain as well, and stores whole blocks in the
 //             caller's byte order (decode.c:144-189).  Parallelism comes from the RSIs: 4 GiB of
 //             16-bit / block 16 / rsi 128 data is one million independent lanes.
-//   k_index   serial walk over one stream that only finds the RSI start offsets (no samples
-//             are produced); needed for streams that arrive without the encoder's RSI offset
-//             table.  One lane per stream.
+//   (the index pass for streams that arrive without an offset table lives in aec_idx.hip)
 #include <hip/hip_runtime.h>
 
 #include <mutex>
@@ -358,204 +356,6 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     }
 }
 
-// ---- serial RSI index -----------------------------------------------------------------------------
-// One wavefront per stream.  The walk itself is serial (every lane executes it redundantly on
-// wave-uniform values), but the stream is served from a 16 KiB LDS window that all 64 lanes refill
-// with coalesced 16-byte loads, so the parser never waits for HBM: a dependent global load per
-// refill of the bit window held the first version at ~5 MB/s of compressed input.
-constexpr uint32_t kIdxWindowWords = 4096;
-
-struct LdsWindowFetch {
-    const uint32_t *lds;    // window of kIdxWindowWords words (host order)
-    uint64_t base;          // stream word index of lds[0]
-    __device__ __forceinline__ uint32_t operator()(uint64_t idx) const
-    {
-        const uint64_t rel = idx - base;
-        return rel < kIdxWindowWords ? lds[rel] : 0u;   // outside: refilled before the next CDS
-    }
-};
-
-// chunk_off == nullptr: one stream [start_bit, end_bit) -> rsi_off[0..max_rsi), res[0].
-// chunk_off != nullptr: workgroup s walks the independent stream that occupies bytes
-// [chunk_off[s], chunk_off[s+1]) of the buffer and writes rsi_off[s*max_rsi ..], res[s]; offsets are
-// absolute bit positions in the buffer, so ONE k_decode launch decodes the RSIs of all streams.
-__global__ void __launch_bounds__(64)
-k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
-        uint64_t start_bit, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res,
-        const uint64_t *__restrict__ chunk_off)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t win[kIdxWindowWords];
-    if (chunk_off) {
-        start_bit = chunk_off[blockIdx.x] * 8u;
-        end_bit = chunk_off[blockIdx.x + 1] * 8u;
-        rsi_off += (uint64_t)blockIdx.x * max_rsi;
-        res += blockIdx.x;
-    } else if (blockIdx.x != 0) {
-        return;
-    }
-    const uint32_t lane = threadIdx.x;
-    const bool pp = c.flags & F_PREPROCESS;
-    const uint32_t maxw = (c.id_len + 1 + c.bps + c.bs * c.bps) / 32 + 4;   // words one CDS can touch
-
-    uint64_t base = (start_bit >> 5) & ~3ull;
-    auto refill = [&](uint64_t from_word) {
-        base = from_word & ~3ull;
-        for (uint32_t i = lane * 4; i < kIdxWindowWords; i += 64 * 4) {
-            const uint64_t idx = base + i;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx + 4 <= nwords) {
-                v = *reinterpret_cast<const uint4 *>(words + idx);
-            } else {
-                if (idx < nwords) v.x = words[idx];
-                if (idx + 1 < nwords) v.y = words[idx + 1];
-                if (idx + 2 < nwords) v.z = words[idx + 2];
-            }
-            *reinterpret_cast<uint4 *>(&win[i]) = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
-        }
-        __syncthreads();
-    };
-    refill(base);
-
-    // Cooperative walk: the 64 lanes hold 64 consecutive stream words (a 2048-bit window) in
-    // registers; locating the end of a CDS is a masked popcount per lane, one DPP prefix sum, a
-    // ballot and a rank-select inside one word -- about 60 wave instructions per CDS instead of a
-    // bit-serial loop.  Everything below is wave-uniform except W.
-    const uint32_t maxbits = c.id_len + 1 + c.bps + c.bs * c.bps;
-    const bool coop = maxbits + 128u <= 2048u;
-    const uint32_t idmax = (1u << c.id_len) - 1u;
-    uint64_t wbase = 0;          // stream word held by lane 0
-    uint32_t W = 0;
-    auto load_regs = [&](uint64_t first_word) {
-        wbase = first_word;
-        W = LdsWindowFetch{win, base}(first_word + lane);
-    };
-    auto rdlane = [&](uint32_t v, uint32_t l) {
-        return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)l));
-    };
-    auto peek = [&](uint32_t rel) {                     // 32 bits at window bit offset rel
-        const uint32_t w = rel >> 5, sh = rel & 31u;
-        const uint64_t two = ((uint64_t)rdlane(W, w) << 32) | rdlane(W, (w + 1) & 63u);
-        return (uint32_t)((two << sh) >> 32);
-    };
-    // window offset just behind the n-th 1 bit at or after rel; 0xFFFFFFFF if the window has fewer
-    auto skip_ones = [&](uint32_t rel, uint32_t n) -> uint32_t {
-        const uint32_t w = rel >> 5, sh = rel & 31u;
-        const uint32_t m = lane < w ? 0u : (lane == w ? W & (0xFFFFFFFFu >> sh) : W);
-        const uint32_t pc = (uint32_t)__builtin_popcount(m);
-        const uint32_t S = wave_incl_sum_dpp(pc);
-        const uint64_t enough = __ballot(S >= n);
-        if (enough == 0) return 0xFFFFFFFFu;
-        const uint32_t L = (uint32_t)__builtin_ctzll(enough);
-        const uint32_t need = n - (rdlane(S, L) - rdlane(pc, L));      // rank inside word L, 1-based
-        const uint32_t word = rdlane(m, L);
-        const uint32_t j = lane & 31u;
-        const uint32_t bit = (word >> (31u - j)) & 1u;
-        const uint32_t rank = j ? (uint32_t)__builtin_popcount(word >> (32u - j)) : 0u;
-        const uint64_t hit = __ballot(lane < 32u && bit && rank + 1u == need);
-        return L * 32u + (uint32_t)__builtin_ctzll(hit) + 1u;
-    };
-
-    BitReaderT<LdsWindowFetch> br;
-    br.init(LdsWindowFetch{win, base}, end_bit, start_bit);
-    uint64_t r = 0, good = start_bit;
-    uint32_t b = 0, status = DEC_OK;
-    if (coop) load_regs(good >> 5);
-    for (;;) {
-        if (b == 0) {
-            if (r >= max_rsi) break;
-            if ((c.flags & F_PAD_RSI) && (good & 7u)) {      // reference decode.c:407-408
-                good = (good + 7u) & ~7ull;
-                br.init(LdsWindowFetch{win, base}, end_bit, good);
-            }
-            if (lane == 0) rsi_off[r] = good;
-        }
-        // keep the whole next CDS (and the readers' look-ahead) inside the LDS window
-        if ((good >> 5) + (coop ? 66u : maxw + 2u) > base + kIdxWindowWords) {
-            __syncthreads();
-            refill(good >> 5);
-            br.init(LdsWindowFetch{win, base}, end_bit, good);
-            if (coop) load_regs(good >> 5);
-        }
-        const uint32_t ref = (pp && b == 0) ? 1u : 0u;
-        uint32_t nblk = 1;
-        bool done = false;
-        if (coop) {
-            uint32_t rel = (uint32_t)(good - wbase * 32u);
-            if (good < wbase * 32u || rel + maxbits + 64u > 2048u) {     // slide the register window
-                load_regs(good >> 5);
-                rel = (uint32_t)(good & 31u);
-            }
-            const uint32_t h = peek(rel);
-            const uint32_t id = h >> (32u - c.id_len);
-            uint32_t q = rel + c.id_len;
-            if (id == 0) {
-                const uint32_t sel = (h >> (31u - c.id_len)) & 1u;
-                q += 1u + ref * c.bps;
-                if (sel) {
-                    q = skip_ones(q, c.bs / 2);
-                } else {
-                    const uint32_t e = skip_ones(q, 1);
-                    if (e != 0xFFFFFFFFu) {
-                        uint32_t nz = e - q;                 // fs + 1
-                        if (nz == 5) {
-                            const uint32_t left_rsi = c.rsi - b, left_seg = 64u - (b % 64u);
-                            nz = left_rsi < left_seg ? left_rsi : left_seg;
-                        } else if (nz > 5) {
-                            nz--;
-                        }
-                        if (nz > c.rsi - b) status = DEC_DATA_ERROR;
-                        nblk = nz;
-                    }
-                    q = e;
-                }
-            } else if (id == idmax) {
-                q += c.bs * c.bps;
-            } else {
-                q += ref * c.bps;
-                q = skip_ones(q, c.bs - ref);
-                if (q != 0xFFFFFFFFu) q += (c.bs - ref) * (id - 1u);
-            }
-            if (q != 0xFFFFFFFFu) {
-                const uint64_t end = wbase * 32u + q;
-                if (status == DEC_DATA_ERROR && end <= end_bit) break;
-                if (end > end_bit) {
-                    status = DEC_NEED_INPUT;
-                    break;
-                }
-                good = end;
-                done = true;
-            }
-        }
-        if (!done) {          // large blocks, or a code reaching beyond the register window
-            if (coop) br.init(LdsWindowFetch{win, base}, end_bit, good);
-            const uint32_t st = skip_cds(br, c, ref, b, nblk);
-            if (st != DEC_OK) {
-                status = st;
-                break;
-            }
-            good = br.pos;
-        }
-        b += nblk;
-        if (b >= c.rsi) {
-            b = 0;
-            r++;
-        }
-    }
-    if (lane == 0) {
-        res->n_rsi = r;
-        res->tail_blocks = b;
-        res->end_bit = good;
-        if (chunk_off) {               // per-stream records are written in full (no init kernel)
-            res->status = status == DEC_DATA_ERROR ? DEC_DATA_ERROR : DEC_OK;
-            res->pad = 0;
-            res->bad_rsi = status == DEC_DATA_ERROR ? r : ~0ull;
-        } else if (status == DEC_DATA_ERROR) {
-            res->status = DEC_DATA_ERROR;
-            res->bad_rsi = r;
-        }
-    }
-}
-
 __global__ void k_dec_result_init(DecResult *res)
 {
     res->n_rsi = 0;
@@ -669,25 +469,6 @@ void launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, 
                             hipStream_t st, const PhaseEvents *prof)
 {
     launch_decode_any<true>(c, d_in, in_bytes, nullptr, d_seg_table, n_seg, total_blocks, d_out, d_res, st, prof);
-}
-
-void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
-                  uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st)
-{
-    hipLaunchKernelGGL(k_dec_result_init, dim3(1), dim3(1), 0, st, d_res);
-    hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, reinterpret_cast<const uint32_t *>(d_in),
-                       (uint64_t)((in_bytes + 3) / 4), (uint64_t)in_bytes * 8, start_bit, d_rsi_off, max_rsi,
-                       d_res, (const uint64_t *)nullptr);
-}
-
-void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_chunk_off,
-                        uint64_t n_chunks, uint64_t rsi_per_chunk, uint64_t *d_rsi_off, DecResult *d_res,
-                        hipStream_t st)
-{
-    if (n_chunks == 0) return;
-    hipLaunchKernelGGL(k_index, dim3((uint32_t)n_chunks), dim3(64), 0, st, c,
-                       reinterpret_cast<const uint32_t *>(d_in), (uint64_t)((in_bytes + 3) / 4),
-                       (uint64_t)in_bytes * 8, (uint64_t)0, d_rsi_off, rsi_per_chunk, d_res, d_chunk_off);
 }
 
 }  // namespace aec

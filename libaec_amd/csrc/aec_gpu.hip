@@ -32,6 +32,9 @@ struct aec_gpu_ctx {
     }
     const PhaseEvents *dec_events() { return profiling ? &ev[dec_calls++ % kProfRing] : nullptr; }
     SegEntry *seg_table;   // where the next encode / emit calls also leave the segment table (or null)
+    void *idx_ws;          // speculative index tables (aec_idx.hip), grown on demand
+    size_t idx_ws_bytes;
+    uint64_t idx_hint;     // caller's estimate of the coded RSI size in bits (0 = derive from max_rsi)
 };
 static_assert(sizeof(aec_gpu_seg_entry) == sizeof(SegEntry), "segment table layout");
 
@@ -56,6 +59,9 @@ int aec_gpu_create(aec_gpu_ctx **out)
     ctx->ws_bytes = 0;
     ctx->profiling = false;
     ctx->seg_table = nullptr;
+    ctx->idx_ws = nullptr;
+    ctx->idx_ws_bytes = 0;
+    ctx->idx_hint = 0;
     ctx->enc_calls = ctx->dec_calls = 0;
     for (auto &set : ctx->ev)
         for (auto &e : set.ev) e = nullptr;
@@ -67,6 +73,7 @@ void aec_gpu_destroy(aec_gpu_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
     for (auto &set : ctx->ev)
         for (auto &e : set.ev)
             if (e) (void)hipEventDestroy(e);
@@ -109,6 +116,7 @@ int aec_gpu_reserve(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes)
     const size_t need = enc_workspace_bytes(c, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5]);
     if (need > ctx->ws_bytes) {
         if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
         ctx->ws = nullptr;
         ctx->ws_bytes = 0;
         if (hipMalloc(&ctx->ws, need) != hipSuccess) return RC_MEM_ERROR;
@@ -219,16 +227,33 @@ int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d
                         uint64_t start_bit, uint64_t *d_rsi_bit_offsets, uint64_t max_rsi,
                         aec_gpu_dec_result *d_result, void *stream)
 {
-    (void)ctx;
     Cfg c;
     const int rc = cfg_from(p, 0, false, &c);
     if (rc != RC_OK) return rc;
     if (reinterpret_cast<uintptr_t>(d_in) & 3u) return RC_CONF_ERROR;
     (void)hipGetLastError();
+    // table workspace of the speculative index; a failed allocation only means the serial walk
+    // expected RSIs -> average coded RSI size, which sizes the look-ahead of the speculation
+    const uint64_t in_bits = (uint64_t)in_bytes * 8;
+    const uint64_t hint = ctx->idx_hint ? ctx->idx_hint
+                          : ((max_rsi && in_bits > start_bit) ? (in_bits - start_bit) / max_rsi : 0);
+    const size_t need = index_workspace_bytes(c, in_bytes, start_bit, hint);
+    if (need > ctx->idx_ws_bytes) {
+        if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
+        ctx->idx_ws = nullptr;
+        ctx->idx_ws_bytes = 0;
+    ctx->idx_hint = 0;
+        const size_t want = need + need / 4;
+        if (hipMalloc(&ctx->idx_ws, want) == hipSuccess) ctx->idx_ws_bytes = want;
+        else (void)hipGetLastError();
+    }
     launch_index(c, static_cast<const uint8_t *>(d_in), in_bytes, start_bit, d_rsi_bit_offsets, max_rsi,
-                 reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream));
+                 reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream), ctx->idx_ws,
+                 ctx->idx_ws_bytes, hint);
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
+
+void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits) { ctx->idx_hint = rsi_bits; }
 
 int aec_gpu_index_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
                               const uint64_t *d_chunk_offsets, uint64_t n_chunks, uint64_t rsi_per_chunk,

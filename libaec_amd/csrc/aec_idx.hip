@@ -1,0 +1,614 @@
+// aec_idx.hip -- RSI index pass for streams that arrive without an offset table (gfx950).
+//
+// A coded data set can only be located by parsing its predecessor (the stream has no lengths,
+// reference src/decode.c:402-421), so finding where the RSIs start is a serial walk in the
+// reference.  Here it is split into
+//   k_spec    SPECULATION, fully parallel: a workgroup takes a window of the stream into LDS,
+//             builds rank/select over its 1-bits, tabulates "a CDS starts at bit q: how long is it"
+//             for every q of the window (aec_spec.h), then tries every bit position of the window's
+//             core as an RSI start (ref CDS + table hops over rsi blocks) and finally chains those
+//             RSI hops until they leave the core.  Output per bit position p: T[p] = length of an
+//             RSI starting at p, Xb/Xc[p] = bits / RSIs of the chained hop out of the window.
+//             Nearly all of that work is thrown away -- only the entries at true RSI starts are
+//             ever read -- but it is what turns the walk into table lookups.
+//   k_index   the WALK, one wavefront: at an RSI start it hops over the tables (one lookup per
+//             window); an RSI the tables did not resolve (longer than the look-ahead, cut by the
+//             end of the stream, malformed) is walked CDS by CDS as before: the stream is served
+//             from an LDS window, unary parts are skipped cooperatively (popcount per lane + DPP scan).
+//   k_expand  fills in the RSI starts inside the chained hops, one lane per hop.
+// Long RSIs (raw RSI bits beyond the LDS look-ahead) take the serial walk alone.  The batch form
+// runs one serial walker per independent chunk.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+
+#include "aec_kernels.h"
+#include "aec_lane.h"
+#include "aec_spec.h"
+
+namespace aec {
+
+namespace {
+
+// wave-wide inclusive prefix sum on the DPP network (same sequence as aec_enc.hip wave_scan_dpp)
+__device__ __forceinline__ uint32_t wave_incl_sum_dpp(uint32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+    return v;
+}
+
+// Speculative tables of one chunk of the stream: entries for bit positions [lo, hi).
+struct IdxTables {
+    const uint16_t *T;     // RSI length if an RSI starts here (0 = unresolved)
+    const uint16_t *Xb;    // chained hop out of the window core: bits ...
+    const uint8_t *Xc;     // ... and RSIs covered (0 = none)
+    uint64_t lo, hi;
+};
+
+struct IdxHop {            // a chained hop the walker took: k_expand writes its RSI starts
+    uint64_t pos, r;
+    uint32_t cnt, pad;
+};
+
+struct IdxCarry {          // walker state between the table chunks of one stream
+    uint64_t good, r;
+    uint32_t active, n_hops;
+};
+
+// ---- speculation ------------------------------------------------------------------------------------
+// LDS: win[nw + 2] u32 | rank[nw + 2] u16 | sel[nw + 2] u16 | nxt[W] | hop4[W] | hop16[W] | Tl[core] (u16)
+__global__ void __launch_bounds__(1024)
+k_spec(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
+       uint32_t core, uint32_t look, uint16_t *__restrict__ T, uint16_t *__restrict__ Xb,
+       uint8_t *__restrict__ Xc)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
+    const uint32_t W = core + look, nw = W / 32u;
+    uint32_t *win = spec_lds;
+    uint16_t *rank = reinterpret_cast<uint16_t *>(win + nw + 2);
+    uint16_t *sel = rank + nw + 2;
+    uint16_t *nxt = sel + nw + 2;
+    uint16_t *hop4 = nxt + W;
+    uint16_t *hop16 = hop4 + W;
+    uint16_t *Tl = hop16 + W;
+    const uint64_t rel0 = (uint64_t)blockIdx.x * core;
+    const uint64_t wstart = tab_lo + rel0;
+    if (wstart >= end_bit) return;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint64_t w0 = wstart >> 5;
+    for (uint32_t i = tid; i < nw + 2; i += nt) {
+        const uint64_t idx = w0 + i;
+        win[i] = idx < nwords ? bswap32(words[idx]) : 0u;
+    }
+    __syncthreads();
+    if (tid < 64) {                                   // prefix count of 1-bits per word
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < nw; base += 64) {
+            const uint32_t i = base + tid;
+            const uint32_t pc = i < nw ? (uint32_t)__popc(win[i]) : 0u;
+            const uint32_t incl = wave_incl_sum_dpp(pc);
+            if (i < nw) rank[i + 1] = (uint16_t)(carry + incl);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (tid == 0) rank[0] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nw; i += nt) {         // sampled select: word of every 32nd 1-bit
+        const uint32_t lo = rank[i], hi = rank[i + 1], m = (lo + 31u) >> 5;
+        if (32u * m + 1u > lo && 32u * m + 1u <= hi) sel[m] = (uint16_t)i;
+    }
+    __syncthreads();
+    const uint64_t left = end_bit - wstart;
+    const SpecWin s{win, rank, sel, nw, left < W ? (uint32_t)left : W};
+    // several positions per lane and iteration: the chains of dependent LDS lookups are independent
+    // between positions and the straight-line code lets the scheduler overlap them
+    for (uint32_t q = tid; q < W; q += 2 * nt) {
+        const uint32_t qb = q + nt;
+        const uint16_t ea = q < s.limit ? spec_nxt_entry(s, c, q) : (uint16_t)0;
+        const uint16_t eb = qb < s.limit ? spec_nxt_entry(s, c, qb) : (uint16_t)0;
+        nxt[q] = ea;
+        if (qb < W) nxt[qb] = eb;
+    }
+    __syncthreads();
+    for (uint32_t q = tid; q < W; q += 4 * nt) {
+        uint16_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = q + u * nt < W ? spec_hop4(nxt, c, s.limit, q + u * nt) : (uint16_t)0;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (q + u * nt < W) hop4[q + u * nt] = e[u];
+    }
+    // first CDS of a hypothetical RSI at every core position (carries the reference sample);
+    // parked in Tl until the walk of that position replaces it by the RSI length
+    for (uint32_t q = tid; q < core; q += nt) Tl[q] = q < s.limit ? spec_first_entry(s, c, q) : (uint16_t)0;
+    __syncthreads();
+    for (uint32_t q = tid; q < W; q += 4 * nt) {
+        uint16_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[u] = q + u * nt < W ? spec_hop16(hop4, s.limit, q + u * nt) : (uint16_t)0;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (q + u * nt < W) hop16[q + u * nt] = e[u];
+    }
+    __syncthreads();
+    // RSI walks.  Walk lengths differ wildly between lanes (hypotheses die early or run the full
+    // rsi blocks), so the position loop and the step loop are flattened: every lane keeps kSlots
+    // walks in flight (independent LDS lookups per iteration) and a slot that finishes takes the
+    // lane's next position at once -- a wave is as slow as its lanes' SUMS of steps, not the sum of
+    // per-position maxima.
+    {
+        constexpr int kSlots = 4;
+        const uint32_t per = core / nt;                 // positions per lane: q = tid + k * nt
+        uint32_t wp[kSlots], wpos[kSlots], wb[kSlots], wk[kSlots];
+        bool act[kSlots];
+        auto start = [&](int j) {                       // next position of slot j (k = j, j + kSlots, ...)
+            act[j] = false;
+            while (wk[j] < per) {
+                const uint32_t q = tid + wk[j] * nt;
+                wk[j] += kSlots;
+                if (spec_walk_init(c, Tl[q], q, wpos[j], wb[j])) {
+                    wp[j] = q;
+                    act[j] = true;
+                    return;
+                }
+                Tl[q] = 0;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < kSlots; j++) {
+            wk[j] = (uint32_t)j;
+            start(j);
+        }
+        for (;;) {
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < kSlots; j++) {
+                if (!act[j]) continue;
+                any = true;
+                bool done = wb[j] >= c.rsi, ok = true;
+                if (!done) {
+                    ok = spec_walk_step(c, nxt, hop4, hop16, s.limit, wpos[j], wb[j]);
+                    done = !ok || wb[j] >= c.rsi;
+                }
+                if (done) {
+                    uint32_t t = ok ? wpos[j] - wp[j] : 0u;
+                    if (t > 0xFFFFu) t = 0;
+                    Tl[wp[j]] = (uint16_t)t;      // (global T is written from Tl below, coalesced)
+                    start(j);
+                }
+            }
+            if (!any) break;
+        }
+    }
+    __syncthreads();
+    const bool pad = c.flags & F_PAD_RSI;
+    for (uint32_t q = tid; q < core; q += nt) {
+        uint32_t pos = q, cnt = 0;
+        while (pos < core && pos < s.limit && Tl[pos] && cnt < 255u) {
+            pos += Tl[pos];
+            cnt++;
+            if (pad) pos = (pos + 7u) & ~7u;
+        }
+        T[rel0 + q] = Tl[q];
+        Xb[rel0 + q] = (uint16_t)(pos - q);
+        Xc[rel0 + q] = (uint8_t)cnt;
+    }
+}
+
+// RSI starts inside the chained hops of the walker
+__global__ void k_expand(const IdxCarry *__restrict__ carry, const IdxHop *__restrict__ hops,
+                         const IdxTables tabs, uint32_t pad_rsi, uint64_t *__restrict__ rsi_off)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= carry->n_hops) return;
+    const IdxHop h = hops[i];
+    uint64_t p = h.pos;
+    for (uint32_t j = 0; j < h.cnt; j++) {
+        rsi_off[h.r + j] = p;
+        p += tabs.T[p - tabs.lo];
+        if (pad_rsi) p = (p + 7u) & ~7ull;
+    }
+}
+
+// ---- serial RSI index -----------------------------------------------------------------------------
+// One wavefront per stream.  The walk itself is serial (every lane executes it redundantly on
+// wave-uniform values), but the stream is served from a 16 KiB LDS window that all 64 lanes refill
+// with coalesced 16-byte loads, so the parser never waits for HBM: a dependent global load per
+// refill of the bit window held the first version at ~5 MB/s of compressed input.
+constexpr uint32_t kIdxWindowWords = 4096;
+
+struct LdsWindowFetch {
+    const uint32_t *lds;    // window of kIdxWindowWords words (host order)
+    uint64_t base;          // stream word index of lds[0]
+    __device__ __forceinline__ uint32_t operator()(uint64_t idx) const
+    {
+        const uint64_t rel = idx - base;
+        return rel < kIdxWindowWords ? lds[rel] : 0u;   // outside: refilled before the next CDS
+    }
+};
+
+// chunk_off == nullptr: one stream [start_bit, end_bit) -> rsi_off[0..max_rsi), res[0].
+// chunk_off != nullptr: workgroup s walks the independent stream that occupies bytes
+// [chunk_off[s], chunk_off[s+1]) of the buffer and writes rsi_off[s*max_rsi ..], res[s]; offsets are
+// absolute bit positions in the buffer, so ONE k_decode launch decodes the RSIs of all streams.
+__global__ void __launch_bounds__(64)
+k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
+        uint64_t start_bit, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res,
+        const uint64_t *__restrict__ chunk_off, const IdxTables tabs, IdxHop *__restrict__ hops,
+        uint32_t hop_cap, IdxCarry *carry, uint32_t first, uint32_t last)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t win[kIdxWindowWords];
+    uint64_t r = 0;
+    if (chunk_off) {
+        start_bit = chunk_off[blockIdx.x] * 8u;
+        end_bit = chunk_off[blockIdx.x + 1] * 8u;
+        rsi_off += (uint64_t)blockIdx.x * max_rsi;
+        res += blockIdx.x;
+    } else if (blockIdx.x != 0) {
+        return;
+    }
+    if (carry && !first) {               // continue where the walk over the previous table chunk stopped
+        if (!carry->active) {
+            if (threadIdx.x == 0) carry->n_hops = 0;
+            return;
+        }
+        start_bit = carry->good;
+        r = carry->r;
+    }
+    const uint32_t lane = threadIdx.x;
+    const bool pp = c.flags & F_PREPROCESS;
+    const uint32_t maxw = (c.id_len + 1 + c.bps + c.bs * c.bps) / 32 + 4;   // words one CDS can touch
+
+    uint64_t base = (start_bit >> 5) & ~3ull;
+    auto refill = [&](uint64_t from_word) {
+        base = from_word & ~3ull;
+        for (uint32_t i = lane * 4; i < kIdxWindowWords; i += 64 * 4) {
+            const uint64_t idx = base + i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx + 4 <= nwords) {
+                v = *reinterpret_cast<const uint4 *>(words + idx);
+            } else {
+                if (idx < nwords) v.x = words[idx];
+                if (idx + 1 < nwords) v.y = words[idx + 1];
+                if (idx + 2 < nwords) v.z = words[idx + 2];
+            }
+            *reinterpret_cast<uint4 *>(&win[i]) = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+        }
+        __syncthreads();
+    };
+    refill(base);
+
+    // Cooperative walk: the 64 lanes hold 64 consecutive stream words (a 2048-bit window) in
+    // registers; locating the end of a CDS is a masked popcount per lane, one DPP prefix sum, a
+    // ballot and a rank-select inside one word -- about 60 wave instructions per CDS instead of a
+    // bit-serial loop.  Everything below is wave-uniform except W.
+    const uint32_t maxbits = c.id_len + 1 + c.bps + c.bs * c.bps;
+    const bool coop = maxbits + 128u <= 2048u;
+    const uint32_t idmax = (1u << c.id_len) - 1u;
+    uint64_t wbase = 0;          // stream word held by lane 0
+    uint32_t W = 0;
+    auto load_regs = [&](uint64_t first_word) {
+        wbase = first_word;
+        W = LdsWindowFetch{win, base}(first_word + lane);
+    };
+    auto rdlane = [&](uint32_t v, uint32_t l) {
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)l));
+    };
+    auto peek = [&](uint32_t rel) {                     // 32 bits at window bit offset rel
+        const uint32_t w = rel >> 5, sh = rel & 31u;
+        const uint64_t two = ((uint64_t)rdlane(W, w) << 32) | rdlane(W, (w + 1) & 63u);
+        return (uint32_t)((two << sh) >> 32);
+    };
+    // window offset just behind the n-th 1 bit at or after rel; 0xFFFFFFFF if the window has fewer
+    auto skip_ones = [&](uint32_t rel, uint32_t n) -> uint32_t {
+        const uint32_t w = rel >> 5, sh = rel & 31u;
+        const uint32_t m = lane < w ? 0u : (lane == w ? W & (0xFFFFFFFFu >> sh) : W);
+        const uint32_t pc = (uint32_t)__builtin_popcount(m);
+        const uint32_t S = wave_incl_sum_dpp(pc);
+        const uint64_t enough = __ballot(S >= n);
+        if (enough == 0) return 0xFFFFFFFFu;
+        const uint32_t L = (uint32_t)__builtin_ctzll(enough);
+        const uint32_t need = n - (rdlane(S, L) - rdlane(pc, L));      // rank inside word L, 1-based
+        const uint32_t word = rdlane(m, L);
+        const uint32_t j = lane & 31u;
+        const uint32_t bit = (word >> (31u - j)) & 1u;
+        const uint32_t rank = j ? (uint32_t)__builtin_popcount(word >> (32u - j)) : 0u;
+        const uint64_t hit = __ballot(lane < 32u && bit && rank + 1u == need);
+        return L * 32u + (uint32_t)__builtin_ctzll(hit) + 1u;
+    };
+
+    BitReaderT<LdsWindowFetch> br;
+    br.init(LdsWindowFetch{win, base}, end_bit, start_bit);
+    uint64_t good = start_bit;
+    uint32_t b = 0, status = DEC_OK, nh = 0;
+    if (coop) load_regs(good >> 5);
+    for (;;) {
+        bool hopped = false;
+        if (b == 0) {
+            if (r >= max_rsi) break;
+            if ((c.flags & F_PAD_RSI) && (good & 7u)) {      // reference decode.c:407-408
+                good = (good + 7u) & ~7ull;
+                hopped = true;
+            }
+            // Fast hops over the speculative tables (k_spec): at an RSI start one lookup gives the
+            // end of a chain of whole RSIs leaving the window (Xb/Xc; the RSI starts inside the hop
+            // are filled in by k_expand), or of this RSI alone (T).  An entry of 0 = not resolved
+            // by the tables: that RSI is walked CDS by CDS below.
+            while (tabs.T && r < max_rsi && good >= tabs.lo && good < tabs.hi && good < end_bit) {
+                const uint64_t i = good - tabs.lo;
+                const uint32_t xc = tabs.Xc[i], xb = tabs.Xb[i], t = tabs.T[i];
+                if (xc && r + xc <= max_rsi && nh < hop_cap) {
+                    if (lane == 0) hops[nh] = IdxHop{good, r, xc, 0u};
+                    nh++;
+                    good += xb;
+                    r += xc;
+                } else if (t) {
+                    if (lane == 0) rsi_off[r] = good;
+                    good += t;
+                    r++;
+                    if (c.flags & F_PAD_RSI) good = (good + 7u) & ~7ull;
+                } else {
+                    break;
+                }
+                hopped = true;
+            }
+            if (r >= max_rsi) break;
+            if (carry && !last && good >= tabs.hi) {         // the next table chunk continues from here
+                if (lane == 0) {
+                    carry->good = good;
+                    carry->r = r;
+                    carry->active = 1;
+                    carry->n_hops = nh;
+                }
+                return;
+            }
+            if (lane == 0) rsi_off[r] = good;
+        }
+        // keep the whole next CDS (and the readers' look-ahead) inside the LDS window
+        if ((good >> 5) + (coop ? 66u : maxw + 2u) > base + kIdxWindowWords) {
+            __syncthreads();
+            refill(good >> 5);
+            br.init(LdsWindowFetch{win, base}, end_bit, good);
+            if (coop) load_regs(good >> 5);
+        } else if (hopped) {
+            br.init(LdsWindowFetch{win, base}, end_bit, good);
+        }
+        const uint32_t ref = (pp && b == 0) ? 1u : 0u;
+        uint32_t nblk = 1;
+        bool done = false;
+        if (coop) {
+            uint32_t rel = (uint32_t)(good - wbase * 32u);
+            if (good < wbase * 32u || rel + maxbits + 64u > 2048u) {     // slide the register window
+                load_regs(good >> 5);
+                rel = (uint32_t)(good & 31u);
+            }
+            const uint32_t h = peek(rel);
+            const uint32_t id = h >> (32u - c.id_len);
+            uint32_t q = rel + c.id_len;
+            if (id == 0) {
+                const uint32_t sel = (h >> (31u - c.id_len)) & 1u;
+                q += 1u + ref * c.bps;
+                if (sel) {
+                    q = skip_ones(q, c.bs / 2);
+                } else {
+                    const uint32_t e = skip_ones(q, 1);
+                    if (e != 0xFFFFFFFFu) {
+                        uint32_t nz = e - q;                 // fs + 1
+                        if (nz == 5) {
+                            const uint32_t left_rsi = c.rsi - b, left_seg = 64u - (b % 64u);
+                            nz = left_rsi < left_seg ? left_rsi : left_seg;
+                        } else if (nz > 5) {
+                            nz--;
+                        }
+                        if (nz > c.rsi - b) status = DEC_DATA_ERROR;
+                        nblk = nz;
+                    }
+                    q = e;
+                }
+            } else if (id == idmax) {
+                q += c.bs * c.bps;
+            } else {
+                q += ref * c.bps;
+                q = skip_ones(q, c.bs - ref);
+                if (q != 0xFFFFFFFFu) q += (c.bs - ref) * (id - 1u);
+            }
+            if (q != 0xFFFFFFFFu) {
+                const uint64_t end = wbase * 32u + q;
+                if (status == DEC_DATA_ERROR && end <= end_bit) break;
+                if (end > end_bit) {
+                    status = DEC_NEED_INPUT;
+                    break;
+                }
+                good = end;
+                done = true;
+            }
+        }
+        if (!done) {          // large blocks, or a code reaching beyond the register window
+            if (coop) br.init(LdsWindowFetch{win, base}, end_bit, good);
+            const uint32_t st = skip_cds(br, c, ref, b, nblk);
+            if (st != DEC_OK) {
+                status = st;
+                break;
+            }
+            good = br.pos;
+        }
+        b += nblk;
+        if (b >= c.rsi) {
+            b = 0;
+            r++;
+        }
+    }
+    if (lane == 0 && carry) {
+        carry->active = 0;
+        carry->n_hops = nh;
+    }
+    if (lane == 0) {
+        res->n_rsi = r;
+        res->tail_blocks = b;
+        res->end_bit = good;
+        if (chunk_off) {               // per-stream records are written in full (no init kernel)
+            res->status = status == DEC_DATA_ERROR ? DEC_DATA_ERROR : DEC_OK;
+            res->pad = 0;
+            res->bad_rsi = status == DEC_DATA_ERROR ? r : ~0ull;
+        } else if (status == DEC_DATA_ERROR) {
+            res->status = DEC_DATA_ERROR;
+            res->bad_rsi = r;
+        }
+    }
+}
+
+
+__global__ void k_idx_result_init(DecResult *res)
+{
+    res->n_rsi = 0;
+    res->tail_blocks = 0;
+    res->end_bit = 0;
+    res->status = DEC_OK;
+    res->pad = 0;
+    res->bad_rsi = ~0ull;
+}
+
+struct SpecGeom {
+    bool ok;
+    uint32_t core, look, threads;
+    size_t lds;
+    uint64_t chunk_bits;     // bit positions tabulated per k_spec launch (multiple of core)
+};
+
+constexpr size_t kSpecLdsMax = 160u * 1024u;
+constexpr uint32_t kSpecWMax = 24576;                    // largest window considered (bits)
+constexpr uint64_t kSpecChunkBits = 1ull << 26;          // 8 MiB of stream per table chunk
+
+size_t spec_lds_bytes(uint32_t core, uint32_t look)
+{
+    const uint32_t W = core + look, nw = W / 32;
+    return (size_t)(nw + 2) * 4 + (size_t)(nw + 2) * 2 * 2 + (size_t)W * 2 * 3 + (size_t)core * 2;
+}
+
+// The tables pay off when whole RSIs fit the look-ahead of a window.  `rsi_bits_hint` is the
+// caller's estimate of the average coded RSI (stream bits / expected RSIs; 0 = unknown): the
+// look-ahead is twice that, the rest of the LDS budget is the core.  RSIs longer than the look-ahead
+// are left to the serial walk, so a wrong hint costs speed only.  Small inputs get small cores so
+// that the windows still fill the chip.
+SpecGeom spec_geom(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint)
+{
+    SpecGeom g{};
+    const uint64_t worst = (uint64_t)c.rsi * (c.id_len + (uint64_t)c.bs * c.bps) + c.bps + 64;
+    if (total_bits < 4096) return g;
+    uint64_t look;
+    if (rsi_bits_hint) {
+        if (rsi_bits_hint + rsi_bits_hint / 4 + 256 > kSpecWMax - 2048) return g;
+        look = 2 * rsi_bits_hint + 1024;
+    } else {
+        if (worst > 65000) return g;
+        look = 12288;
+    }
+    if (look > worst) look = worst;
+    if (look > kSpecWMax - 2048) look = kSpecWMax - 2048;
+    if (look < 2048) look = 2048;
+    g.look = (uint32_t)((look + 31) & ~31ull);
+    uint64_t core = (total_bits / 2048 + 1023) & ~1023ull;
+    if (core < 2048) core = 2048;
+    if (core > 16384) core = 16384;
+    if (core > kSpecWMax - g.look) core = (kSpecWMax - g.look) & ~1023ull;
+    while (core >= 2048 && spec_lds_bytes((uint32_t)core, g.look) > kSpecLdsMax) core -= 1024;
+    if (core < 1024) return g;
+    g.core = (uint32_t)core;
+    g.lds = spec_lds_bytes(g.core, g.look);
+    if (g.lds > kSpecLdsMax) return g;
+    const uint32_t W = g.core + g.look;
+    g.threads = W >= 16384 ? 1024 : (W >= 8192 ? 512 : 256);
+    g.chunk_bits = (kSpecChunkBits / g.core) * g.core;
+    g.ok = true;
+    return g;
+}
+
+void allow_big_lds()
+{
+    static std::once_flag once[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    std::call_once(once[dev], [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_spec),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSpecLdsMax);
+    });
+}
+
+}  // namespace
+
+size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
+{
+    const uint64_t end_bit = (uint64_t)in_bytes * 8;
+    if (start_bit >= end_bit) return 0;
+    const SpecGeom g = spec_geom(c, end_bit - start_bit, rsi_bits_hint);
+    if (!g.ok) return 0;
+    const uint64_t lo = start_bit / g.core * g.core;
+    uint64_t span = end_bit - lo;
+    if (span > g.chunk_bits) span = g.chunk_bits;
+    const uint64_t nwin = (span + g.core - 1) / g.core;
+    const uint64_t entries = nwin * g.core;
+    return (size_t)(entries * 5 + (2 * nwin + 16) * sizeof(IdxHop) + 256 + 64);
+}
+
+void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
+                  uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
+                  void *d_ws, size_t ws_bytes, uint64_t rsi_bits_hint)
+{
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
+    const uint64_t nwords = (in_bytes + 3) / 4, end_bit = (uint64_t)in_bytes * 8;
+    hipLaunchKernelGGL(k_idx_result_init, dim3(1), dim3(1), 0, st, d_res);
+    const size_t need = index_workspace_bytes(c, in_bytes, start_bit, rsi_bits_hint);
+    if (!need || !d_ws || ws_bytes < need) {           // serial walk only
+        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off,
+                           max_rsi, d_res, (const uint64_t *)nullptr, IdxTables{}, (IdxHop *)nullptr, 0u,
+                           (IdxCarry *)nullptr, 1u, 1u);
+        return;
+    }
+    allow_big_lds();
+    const SpecGeom g = spec_geom(c, end_bit - start_bit, rsi_bits_hint);
+    const uint64_t lo0 = start_bit / g.core * g.core;
+    uint64_t span = end_bit - lo0;
+    if (span > g.chunk_bits) span = g.chunk_bits;
+    const uint64_t nwin_max = (span + g.core - 1) / g.core, entries = nwin_max * g.core;
+    // workspace: carry | T | Xb | Xc | hops
+    uint8_t *base = static_cast<uint8_t *>(d_ws);
+    IdxCarry *carry = reinterpret_cast<IdxCarry *>(base);
+    uint16_t *T = reinterpret_cast<uint16_t *>(base + 64);
+    uint16_t *Xb = T + entries;
+    uint8_t *Xc = reinterpret_cast<uint8_t *>(Xb + entries);
+    IdxHop *hops = reinterpret_cast<IdxHop *>((reinterpret_cast<uintptr_t>(Xc + entries) + 15) & ~(uintptr_t)15);
+    const uint32_t hop_cap = (uint32_t)(2 * nwin_max + 8);
+    for (uint64_t lo = lo0; lo < end_bit; lo += g.chunk_bits) {
+        uint64_t bits = end_bit - lo;
+        if (bits > g.chunk_bits) bits = g.chunk_bits;
+        const uint32_t nwin = (uint32_t)((bits + g.core - 1) / g.core);
+        const bool first = lo == lo0, last = lo + g.chunk_bits >= end_bit;
+        const IdxTables tabs{T, Xb, Xc, lo, lo + (uint64_t)nwin * g.core};
+        hipLaunchKernelGGL(k_spec, dim3(nwin), dim3(g.threads), g.lds, st, c, words, nwords, end_bit, lo, g.core,
+                           g.look, T, Xb, Xc);
+        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off,
+                           max_rsi, d_res, (const uint64_t *)nullptr, tabs, hops, hop_cap, carry,
+                           first ? 1u : 0u, last ? 1u : 0u);
+        hipLaunchKernelGGL(k_expand, dim3((hop_cap + 255) / 256), dim3(256), 0, st, carry, hops, tabs,
+                           (c.flags & F_PAD_RSI) ? 1u : 0u, d_rsi_off);
+    }
+}
+
+void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_chunk_off,
+                        uint64_t n_chunks, uint64_t rsi_per_chunk, uint64_t *d_rsi_off, DecResult *d_res,
+                        hipStream_t st)
+{
+    if (n_chunks == 0) return;
+    hipLaunchKernelGGL(k_index, dim3((uint32_t)n_chunks), dim3(64), 0, st, c,
+                       reinterpret_cast<const uint32_t *>(d_in), (uint64_t)((in_bytes + 3) / 4),
+                       (uint64_t)in_bytes * 8, (uint64_t)0, d_rsi_off, rsi_per_chunk, d_res, d_chunk_off,
+                       IdxTables{}, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u);
+}
+
+}  // namespace aec

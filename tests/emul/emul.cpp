@@ -256,3 +256,59 @@ extern "C" int emul_index(const uint32_t *p, const uint8_t *in, size_t in_len, u
     *n_rsi = r; *tail_blocks = b; *end_bit = good;
     return status;
 }
+
+// ---- speculative RSI index (aec_spec.h), window by window as k_spec does it --------------------
+#include <algorithm>
+#include "../../libaec_amd/csrc/aec_spec.h"
+
+// Fills T[p] (RSI length for a hypothetical RSI start at bit p, 0 = unresolved), Xb/Xc (chained
+// hop out of the window core: bits, RSI count) for every bit position of the stream.
+extern "C" int emul_spec(const uint32_t *p, const uint8_t *in, size_t in_len, uint32_t core, uint32_t look,
+                         uint16_t *T, uint16_t *Xb, uint8_t *Xc)
+{
+    Cfg c;
+    int rc = make_cfg(p[0], p[1], p[2], p[3], 0, false, &c);
+    if (rc) return rc;
+    const uint64_t end_bit = (uint64_t)in_len * 8;
+    const uint32_t W = core + look, nw = W / 32;
+    std::vector<uint32_t> words((in_len + 3) / 4 + 1, 0);
+    memcpy(words.data(), in, in_len);
+    std::vector<uint32_t> win(nw + 2);
+    std::vector<uint16_t> rank(nw + 1), sel(nw + 2), nxt(W), nxt4(W), nxt16(W), Tl(core);
+    const bool pad = c.flags & F_PAD_RSI;
+    for (uint64_t wstart = 0; wstart < end_bit; wstart += core) {
+        for (uint32_t i = 0; i < nw + 2; i++) {
+            const uint64_t idx = wstart / 32 + i;
+            win[i] = idx < words.size() ? bswap32(words[idx]) : 0u;
+        }
+        rank[0] = 0;
+        for (uint32_t i = 0; i < nw; i++) rank[i + 1] = (uint16_t)(rank[i] + __builtin_popcount(win[i]));
+        for (uint32_t i = 0; i < nw; i++) {
+            const uint32_t lo = rank[i], hi = rank[i + 1], m = (lo + 31u) >> 5;
+            if (32u * m + 1u <= hi && 32u * m + 1u > lo) sel[m] = (uint16_t)i;
+        }
+        SpecWin s{win.data(), rank.data(), sel.data(), nw,
+                  (uint32_t)std::min<uint64_t>(W, end_bit - wstart)};
+        for (uint32_t q = 0; q < W; q++) nxt[q] = q < s.limit ? spec_nxt_entry(s, c, q) : 0;
+        for (uint32_t q = 0; q < W; q++) nxt4[q] = spec_hop4(nxt.data(), c, s.limit, q);
+        for (uint32_t q = 0; q < W; q++) nxt16[q] = spec_hop16(nxt4.data(), s.limit, q);
+        const uint32_t variant = (uint32_t)(wstart / core) % 3u;   // exercise the walk with and without hop tables
+        for (uint32_t q = 0; q < core && wstart + q < end_bit; q++) {
+            const uint32_t t = spec_rsi(s, c, nxt.data(), variant ? nxt4.data() : nullptr,
+                                        variant == 2 ? nxt16.data() : nullptr, q);
+            Tl[q] = (uint16_t)(t <= 0xFFFFu ? t : 0);
+            T[wstart + q] = Tl[q];
+        }
+        for (uint32_t q = 0; q < core && wstart + q < end_bit; q++) {
+            uint32_t pos = q, cnt = 0;
+            while (pos < core && wstart + pos < end_bit && Tl[pos] && cnt < 255) {
+                pos += Tl[pos];
+                cnt++;
+                if (pad) pos = (pos + 7u) & ~7u;
+            }
+            Xb[wstart + q] = (uint16_t)(pos - q);
+            Xc[wstart + q] = (uint8_t)cnt;
+        }
+    }
+    return 0;
+}

@@ -22,7 +22,8 @@ def emul():
     os.makedirs(os.path.dirname(EMUL_SO), exist_ok=True)
     srcs = [os.path.join(EMUL_DIR, "emul.cpp"),
             os.path.join(ROOT, "libaec_amd", "csrc", "aec_lane.h"),
-            os.path.join(ROOT, "libaec_amd", "csrc", "aec_cfg.h")]
+            os.path.join(ROOT, "libaec_amd", "csrc", "aec_cfg.h"),
+            os.path.join(ROOT, "libaec_amd", "csrc", "aec_spec.h")]
     if not os.path.exists(EMUL_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMUL_SO) for s in srcs):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
                         "-o", EMUL_SO, srcs[0]], check=True)
@@ -93,6 +94,39 @@ def check_case(lib, name, bps, bs, rsi, flags, data, expect):
     assert endb.value == tb, name
     nfound = min(n_rsi.value + (1 if tail.value else 0), len(offs) - 1)
     assert np.array_equal(ioffs[:nfound], offs[:nfound]), name
+    check_spec(lib, name, bps, bs, rsi, flags, enc_a, offs, nblk)
+
+
+def check_spec(lib, name, bps, bs, rsi, flags, enc_a, offs, nblk, core=128, look=4096):
+    """Speculative index tables (aec_spec.h): at every true RSI start whose RSI fits in the window
+    the tabulated RSI length must be the true one; the chained window hops must land on true RSI
+    starts.  (Entries at other bit positions are hypotheses nobody reads.)"""
+    nbits = enc_a.size * 8
+    T = np.zeros(nbits + 1, np.uint16)
+    Xb = np.zeros(nbits + 1, np.uint16)
+    Xc = np.zeros(nbits + 1, np.uint8)
+    p = (C.c_uint32 * 4)(bps, bs, rsi, flags)
+    rc = lib.emul_spec(p, C.c_void_p(enc_a.ctypes.data), C.c_size_t(enc_a.size), C.c_uint32(core),
+                       C.c_uint32(look), C.c_void_p(T.ctypes.data), C.c_void_p(Xb.ctypes.data),
+                       C.c_void_p(Xc.ctypes.data))
+    assert rc == 0, name
+    full = nblk // rsi                        # RSIs with all their blocks
+    o = [int(x) for x in offs]
+    for i in range(full):
+        start, true_len = o[i], o[i + 1] - o[i]
+        if (start % core) + true_len <= core + look:
+            assert T[start] == true_len, (name, i, start, int(T[start]), true_len)
+        else:
+            assert T[start] in (0, true_len), (name, i)
+        cnt = int(Xc[start])
+        assert i + cnt <= len(o) - 1, (name, i, cnt)      # (a ROS-closed short last RSI may be hopped too)
+        assert start + int(Xb[start]) == o[i + cnt], (name, i, cnt)
+        if T[start]:
+            assert cnt >= 1, (name, i)
+    if nblk % rsi:
+        # a short last RSI stays unresolved -- unless a rest-of-segment zero run closes it, which no
+        # decoder can tell from a run reaching the nominal RSI end (the serial walk counts it too)
+        assert T[o[full]] in (0, o[full + 1] - o[full]), name
 
 
 def test_golden_through_lane_functions(emul, golden):
