@@ -155,7 +155,9 @@ size_t drain(struct aec_stream *strm, internal_state *s, size_t granule)
 
 // Code `nbytes` of staged input (whole samples) as one GPU batch; append produced whole bytes
 // to the queue and keep the open byte / k as carry.
-int encode_batch(internal_state *s, const uint8_t *data, size_t nbytes)
+// With `strm` given and nothing queued, finished bytes go straight into the caller's buffer (no
+// pass through the queue); only what does not fit, and the open byte, are queued.
+int encode_batch(internal_state *s, const uint8_t *data, size_t nbytes, struct aec_stream *strm = nullptr)
 {
     if (nbytes == 0) return AEC_OK;
     const size_t cap = aec_gpu_encode_bound(&s->prm, nbytes);
@@ -176,21 +178,34 @@ int encode_batch(internal_state *s, const uint8_t *data, size_t nbytes)
     if (res.overflow) return AEC_MEM_ERROR;   // cannot happen: cap is the worst case
     const uint64_t bits = (uint64_t)s->part_bits + res.total_bits;
     const size_t whole = (size_t)(bits / 8), nb = (size_t)((bits + 7) / 8);
-    const size_t at = s->outq.size();
-    s->outq.resize(at + nb);
-    if (nb && hipMemcpy(s->outq.data() + at, s->d_out.p, nb, hipMemcpyDeviceToHost) != hipSuccess)
+    size_t direct = 0;
+    if (strm && s->outq.empty()) direct = whole < strm->avail_out ? whole : strm->avail_out;
+    const uint8_t *d_bytes = static_cast<const uint8_t *>(s->d_out.p);
+    if (direct && hipMemcpy(strm->next_out, d_bytes, direct, hipMemcpyDeviceToHost) != hipSuccess)
         return AEC_MEM_ERROR;
-    if (nb) s->outq[at] |= s->part_byte;
+    const size_t at = s->outq.size();
+    s->outq.resize(at + (nb - direct));
+    if (nb > direct &&
+        hipMemcpy(s->outq.data() + at, d_bytes + direct, nb - direct, hipMemcpyDeviceToHost) != hipSuccess)
+        return AEC_MEM_ERROR;
+    if (direct) strm->next_out[0] |= s->part_byte;
+    else if (nb) s->outq[at] |= s->part_byte;
     s->part_bits = (uint32_t)(bits % 8);
-    s->part_byte = s->part_bits ? s->outq[at + whole] : 0;
-    s->outq.resize(at + whole);
+    s->part_byte = s->part_bits ? s->outq[at + whole - direct] : 0;
+    s->outq.resize(at + whole - direct);
+    if (direct) {
+        strm->next_out += direct;
+        strm->avail_out -= direct;
+    }
     s->k = res.k_out;
     if (res.total_bits) s->any_bits = true;
     return AEC_OK;
 }
 
 // Decode everything decodable in the staged input (see internal_state for the cursor).
-int decode_staged(internal_state *s)
+// Samples go straight into the caller's buffer as far as it has room (the queue is empty whenever
+// this runs); the rest is queued.
+int decode_staged(internal_state *s, struct aec_stream *strm)
 {
     const Cfg &c = s->cfg;
     const size_t nbytes = s->stage.size();
@@ -238,11 +253,24 @@ int decode_staged(internal_state *s)
         if (hres->status != DEC_OK) return AEC_DATA_ERROR;   // the index pass vouched for completeness
         const size_t skip = (size_t)s->delivered * c.bytes;
         const size_t total = (size_t)blocks * blk_bytes;
-        const size_t at = s->outq.size();
-        s->outq.resize(at + (total - skip));
-        if (hipMemcpy(s->outq.data() + at, static_cast<uint8_t *>(s->d_out.p) + skip, total - skip,
-                      hipMemcpyDeviceToHost) != hipSuccess)
-            return AEC_MEM_ERROR;
+        const uint8_t *d_bytes = static_cast<const uint8_t *>(s->d_out.p) + skip;
+        size_t direct = 0;
+        if (s->outq.empty()) {
+            direct = total - skip < strm->avail_out ? total - skip : strm->avail_out;
+            direct -= direct % c.bytes;
+        }
+        if (direct) {
+            if (hipMemcpy(strm->next_out, d_bytes, direct, hipMemcpyDeviceToHost) != hipSuccess) return AEC_MEM_ERROR;
+            strm->next_out += direct;
+            strm->avail_out -= direct;
+        }
+        if (total - skip > direct) {
+            const size_t at = s->outq.size();
+            s->outq.resize(at + (total - skip - direct));
+            if (hipMemcpy(s->outq.data() + at, d_bytes + direct, total - skip - direct, hipMemcpyDeviceToHost) !=
+                hipSuccess)
+                return AEC_MEM_ERROR;
+        }
     }
     // advance the cursor to the start of the (possibly empty) trailing partial RSI
     uint64_t new_start_rel = idx.end_bit;
@@ -289,20 +317,33 @@ int aec_encode(struct aec_stream *strm, int flush)
             break;
         }
         // only whole samples are ever consumed (reference encode.c:673-674)
-        const size_t take = strm->avail_in - strm->avail_in % bytes;
+        size_t take = strm->avail_in - strm->avail_in % bytes;
+        int rc = AEC_OK;
+        if (s->stage.empty() && take >= rsi_bytes) {
+            // whole RSIs offered and nothing staged: code them from the caller's buffer
+            const size_t direct = take / rsi_bytes * rsi_bytes;
+            rc = encode_batch(s, strm->next_in, direct, strm);
+            strm->next_in += direct;
+            strm->avail_in -= direct;
+            if (rc != AEC_OK) {
+                strm->total_in -= strm->avail_in;
+                strm->total_out -= strm->avail_out;
+                return rc;
+            }
+            continue;
+        }
         if (take) {
             s->stage.insert(s->stage.end(), strm->next_in, strm->next_in + take);
             strm->next_in += take;
             strm->avail_in -= take;
         }
         const size_t whole = s->stage.size() / rsi_bytes * rsi_bytes;
-        int rc = AEC_OK;
         if (whole) {
-            rc = encode_batch(s, s->stage.data(), whole);
+            rc = encode_batch(s, s->stage.data(), whole, strm);
             s->stage.erase(s->stage.begin(), s->stage.begin() + (ptrdiff_t)whole);
         } else if (flush == AEC_FLUSH) {
             // last, short RSI (reference encode.c:676-684), then the final byte (686-695)
-            rc = encode_batch(s, s->stage.data(), s->stage.size());
+            rc = encode_batch(s, s->stage.data(), s->stage.size(), strm);
             s->stage.clear();
             if (rc == AEC_OK) {
                 if (s->part_bits || !s->any_bits) s->outq.push_back(s->part_byte);
@@ -368,7 +409,7 @@ int aec_decode(struct aec_stream *strm, int flush)
         if (!s->new_input) break;         // nothing new to look at
         s->new_input = false;
         s->out_room = strm->avail_out;
-        rc = decode_staged(s);
+        rc = decode_staged(s, strm);
         if (rc == AEC_DATA_ERROR) s->sticky_error = rc;
     }
     if (rc != AEC_OK) return rc;          // reference decode.c:818-819 (totals left as they are)

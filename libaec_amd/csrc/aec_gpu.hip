@@ -35,6 +35,8 @@ struct aec_gpu_ctx {
     void *idx_ws;          // speculative index tables (aec_idx.hip), grown on demand
     size_t idx_ws_bytes;
     uint64_t idx_hint;     // caller's estimate of the coded RSI size in bits (0 = derive from max_rsi)
+    IdxSide idx_side;      // side stream + events of the index pass (created on first use)
+    bool idx_side_ok;
 };
 static_assert(sizeof(aec_gpu_seg_entry) == sizeof(SegEntry), "segment table layout");
 
@@ -62,6 +64,8 @@ int aec_gpu_create(aec_gpu_ctx **out)
     ctx->idx_ws = nullptr;
     ctx->idx_ws_bytes = 0;
     ctx->idx_hint = 0;
+    ctx->idx_side = IdxSide{};
+    ctx->idx_side_ok = false;
     ctx->enc_calls = ctx->dec_calls = 0;
     for (auto &set : ctx->ev)
         for (auto &e : set.ev) e = nullptr;
@@ -74,6 +78,13 @@ void aec_gpu_destroy(aec_gpu_ctx *ctx)
     if (!ctx) return;
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
+    if (ctx->idx_side_ok) {
+        (void)hipStreamDestroy(ctx->idx_side.stream);
+        for (int b = 0; b < 2; b++) {
+            (void)hipEventDestroy(ctx->idx_side.spec_done[b]);
+            (void)hipEventDestroy(ctx->idx_side.walk_done[b]);
+        }
+    }
     for (auto &set : ctx->ev)
         for (auto &e : set.ev)
             if (e) (void)hipEventDestroy(e);
@@ -117,6 +128,13 @@ int aec_gpu_reserve(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes)
     if (need > ctx->ws_bytes) {
         if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
+    if (ctx->idx_side_ok) {
+        (void)hipStreamDestroy(ctx->idx_side.stream);
+        for (int b = 0; b < 2; b++) {
+            (void)hipEventDestroy(ctx->idx_side.spec_done[b]);
+            (void)hipEventDestroy(ctx->idx_side.walk_done[b]);
+        }
+    }
         ctx->ws = nullptr;
         ctx->ws_bytes = 0;
         if (hipMalloc(&ctx->ws, need) != hipSuccess) return RC_MEM_ERROR;
@@ -240,16 +258,34 @@ int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d
     const size_t need = index_workspace_bytes(c, in_bytes, start_bit, hint);
     if (need > ctx->idx_ws_bytes) {
         if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
+    if (ctx->idx_side_ok) {
+        (void)hipStreamDestroy(ctx->idx_side.stream);
+        for (int b = 0; b < 2; b++) {
+            (void)hipEventDestroy(ctx->idx_side.spec_done[b]);
+            (void)hipEventDestroy(ctx->idx_side.walk_done[b]);
+        }
+    }
         ctx->idx_ws = nullptr;
         ctx->idx_ws_bytes = 0;
     ctx->idx_hint = 0;
+    ctx->idx_side = IdxSide{};
+    ctx->idx_side_ok = false;
         const size_t want = need + need / 4;
         if (hipMalloc(&ctx->idx_ws, want) == hipSuccess) ctx->idx_ws_bytes = want;
         else (void)hipGetLastError();
     }
+    if (need && !ctx->idx_side_ok) {
+        IdxSide &sd = ctx->idx_side;
+        bool ok = hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) == hipSuccess;
+        for (int b = 0; ok && b < 2; b++)
+            ok = hipEventCreateWithFlags(&sd.spec_done[b], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&sd.walk_done[b], hipEventDisableTiming) == hipSuccess;
+        ctx->idx_side_ok = ok;
+        if (!ok) (void)hipGetLastError();
+    }
     launch_index(c, static_cast<const uint8_t *>(d_in), in_bytes, start_bit, d_rsi_bit_offsets, max_rsi,
                  reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream), ctx->idx_ws,
-                 ctx->idx_ws_bytes, hint);
+                 ctx->idx_ws_bytes, hint, ctx->idx_side_ok ? &ctx->idx_side : nullptr);
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 

@@ -482,7 +482,7 @@ struct SpecGeom {
 
 constexpr size_t kSpecLdsMax = 160u * 1024u;
 constexpr uint32_t kSpecWMax = 24576;                    // largest window considered (bits)
-constexpr uint64_t kSpecChunkBits = 1ull << 26;          // 8 MiB of stream per table chunk
+constexpr uint64_t kSpecChunkBits = 1ull << 25;          // 4 MiB of stream per table chunk
 
 size_t spec_lds_bytes(uint32_t core, uint32_t look)
 {
@@ -542,6 +542,32 @@ void allow_big_lds()
 
 }  // namespace
 
+namespace {
+
+// One set of tables (+ the walker's hop list) for a chunk of `entries` bit positions.
+struct TableSet {
+    uint16_t *T, *Xb;
+    uint8_t *Xc;
+    IdxHop *hops;
+};
+
+size_t table_set_bytes(uint64_t entries, uint64_t nwin)
+{
+    return (size_t)((entries * 5 + 15) / 16 * 16 + (2 * nwin + 16) * sizeof(IdxHop));
+}
+
+TableSet table_set_at(uint8_t *p, uint64_t entries)
+{
+    TableSet t;
+    t.T = reinterpret_cast<uint16_t *>(p);
+    t.Xb = t.T + entries;
+    t.Xc = reinterpret_cast<uint8_t *>(t.Xb + entries);
+    t.hops = reinterpret_cast<IdxHop *>(p + (entries * 5 + 15) / 16 * 16);
+    return t;
+}
+
+}  // namespace
+
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
 {
     const uint64_t end_bit = (uint64_t)in_bytes * 8;
@@ -550,15 +576,15 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
     if (!g.ok) return 0;
     const uint64_t lo = start_bit / g.core * g.core;
     uint64_t span = end_bit - lo;
-    if (span > g.chunk_bits) span = g.chunk_bits;
+    const bool multi = span > g.chunk_bits;
+    if (multi) span = g.chunk_bits;
     const uint64_t nwin = (span + g.core - 1) / g.core;
-    const uint64_t entries = nwin * g.core;
-    return (size_t)(entries * 5 + (2 * nwin + 16) * sizeof(IdxHop) + 256 + 64);
+    return 64 + table_set_bytes(nwin * g.core, nwin) * (multi ? 2 : 1);   // two sets: spec(i+1) beside walk(i)
 }
 
 void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
                   uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
-                  void *d_ws, size_t ws_bytes, uint64_t rsi_bits_hint)
+                  void *d_ws, size_t ws_bytes, uint64_t rsi_bits_hint, const IdxSide *side)
 {
     const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
     const uint64_t nwords = (in_bytes + 3) / 4, end_bit = (uint64_t)in_bytes * 8;
@@ -574,30 +600,44 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
     const SpecGeom g = spec_geom(c, end_bit - start_bit, rsi_bits_hint);
     const uint64_t lo0 = start_bit / g.core * g.core;
     uint64_t span = end_bit - lo0;
-    if (span > g.chunk_bits) span = g.chunk_bits;
+    const bool multi = span > g.chunk_bits;
+    if (multi) span = g.chunk_bits;
     const uint64_t nwin_max = (span + g.core - 1) / g.core, entries = nwin_max * g.core;
-    // workspace: carry | T | Xb | Xc | hops
     uint8_t *base = static_cast<uint8_t *>(d_ws);
     IdxCarry *carry = reinterpret_cast<IdxCarry *>(base);
-    uint16_t *T = reinterpret_cast<uint16_t *>(base + 64);
-    uint16_t *Xb = T + entries;
-    uint8_t *Xc = reinterpret_cast<uint8_t *>(Xb + entries);
-    IdxHop *hops = reinterpret_cast<IdxHop *>((reinterpret_cast<uintptr_t>(Xc + entries) + 15) & ~(uintptr_t)15);
+    const TableSet set[2] = {table_set_at(base + 64, entries),
+                             table_set_at(base + 64 + (multi ? table_set_bytes(entries, nwin_max) : 0), entries)};
     const uint32_t hop_cap = (uint32_t)(2 * nwin_max + 8);
-    for (uint64_t lo = lo0; lo < end_bit; lo += g.chunk_bits) {
+    // With several chunks the walk over chunk i (one wavefront) runs on a side stream beside the
+    // speculation over chunk i + 1 (all CUs) on the caller's stream; events order the two table sets.
+    const bool piped = multi && side && side->stream;
+    hipStream_t wst = piped ? side->stream : st;
+    if (piped)                                           // sets may still be read by an earlier call's walker
+        for (int b = 0; b < 2; b++) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
+    uint32_t i = 0;
+    for (uint64_t lo = lo0; lo < end_bit; lo += g.chunk_bits, i++) {
         uint64_t bits = end_bit - lo;
         if (bits > g.chunk_bits) bits = g.chunk_bits;
-        const uint32_t nwin = (uint32_t)((bits + g.core - 1) / g.core);
+        const uint32_t nwin = (uint32_t)((bits + g.core - 1) / g.core), b = i & 1u;
         const bool first = lo == lo0, last = lo + g.chunk_bits >= end_bit;
-        const IdxTables tabs{T, Xb, Xc, lo, lo + (uint64_t)nwin * g.core};
+        const TableSet &t = set[b];
+        const IdxTables tabs{t.T, t.Xb, t.Xc, lo, lo + (uint64_t)nwin * g.core};
+        if (piped && i >= 2) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
         hipLaunchKernelGGL(k_spec, dim3(nwin), dim3(g.threads), g.lds, st, c, words, nwords, end_bit, lo, g.core,
-                           g.look, T, Xb, Xc);
-        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off,
-                           max_rsi, d_res, (const uint64_t *)nullptr, tabs, hops, hop_cap, carry,
+                           g.look, t.T, t.Xb, t.Xc);
+        if (piped) {
+            (void)hipEventRecord(side->spec_done[b], st);
+            (void)hipStreamWaitEvent(wst, side->spec_done[b], 0);
+        }
+        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, wst, c, words, nwords, end_bit, start_bit, d_rsi_off,
+                           max_rsi, d_res, (const uint64_t *)nullptr, tabs, t.hops, hop_cap, carry,
                            first ? 1u : 0u, last ? 1u : 0u);
-        hipLaunchKernelGGL(k_expand, dim3((hop_cap + 255) / 256), dim3(256), 0, st, carry, hops, tabs,
+        hipLaunchKernelGGL(k_expand, dim3((hop_cap + 255) / 256), dim3(256), 0, wst, carry, t.hops, tabs,
                            (c.flags & F_PAD_RSI) ? 1u : 0u, d_rsi_off);
+        if (piped) (void)hipEventRecord(side->walk_done[b], wst);
     }
+    if (piped)
+        for (int b = 0; b < 2; b++) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
 }
 
 void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_chunk_off,

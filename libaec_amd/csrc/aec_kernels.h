@@ -92,9 +92,16 @@ void launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, 
 // walk hops over speculative per-bit tables built by all CUs (aec_idx.hip).
 // rsi_bits_hint: estimate of the coded size of one RSI (0 = unknown); it sizes the look-ahead.
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint);
+// side (optional): a second stream and four events owned by the caller; with them the walk over one
+// chunk of the tables overlaps the speculation over the next chunk.
+struct IdxSide {
+    hipStream_t stream;
+    hipEvent_t spec_done[2], walk_done[2];
+};
 void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
                   uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t stream,
-                  void *d_ws = nullptr, size_t ws_bytes = 0, uint64_t rsi_bits_hint = 0);
+                  void *d_ws = nullptr, size_t ws_bytes = 0, uint64_t rsi_bits_hint = 0,
+                  const IdxSide *side = nullptr);
 
 // Index pass over many independent streams stored in one buffer (e.g. the chunks of an HDF5
 // dataset): stream s occupies bytes [chunk_off[s], chunk_off[s+1]) (chunk_off 4-byte aligned values,
