@@ -233,6 +233,58 @@ def test_device_api_offsets_index_and_carry(gpu):
     assert bytes(a + b) == want and k2 == k_out
 
 
+@pytest.mark.parametrize("bps,bs,rsi,flags", [
+    (16, 16, 128, PP),            # BASELINE config 2 shape
+    (8, 8, 128, PP),              # config 5 shape
+    (12, 32, 32, PP | MSB),       # bits not a multiple of 8, short RSIs
+    (16, 8, 100, 0),              # no preprocessor (no reference sample), rsi not a multiple of 64
+    (4, 16, 64, PP | AEC_RESTRICTED),
+])
+def test_speculative_index_mixed_content(gpu, bps, bs, rsi, flags):
+    """Index pass over bare streams whose RSIs are wildly different in size: smooth data (RSIs that
+    fit the look-ahead of the speculation windows: table hops), noise (RSIs longer than the
+    look-ahead: serial walk), constant stretches (zero-block runs incl. rest-of-segment codes), in
+    pieces that do not line up with RSIs.  The offsets must be the encoder's, for several stream
+    sizes (one window, several windows, several table chunks) and from a start inside the stream."""
+    import torch
+    rng = np.random.default_rng(bps * 1000 + bs)
+    nb = bytes_per_sample(bps, flags)
+    hi = (1 << bps) - 1
+    for n_samples in (40_000, 1_500_000, 24_000_000):
+        parts, left = [], n_samples
+        while left > 0:
+            n = int(min(left, rng.integers(200, max(300, n_samples // 6))))
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                v = np.cumsum(rng.integers(-3, 4, n)) + hi // 2          # smooth
+            elif kind == 1:
+                v = rng.integers(0, hi + 1, n)                           # noise
+            elif kind == 2:
+                v = np.full(n, int(rng.integers(0, hi + 1)))             # constant
+            else:
+                v = np.cumsum(rng.integers(-40, 41, n)) + hi // 2        # rougher
+            parts.append(np.clip(v, 0, hi))
+            left -= n
+        vals = np.concatenate(parts)[:n_samples]
+        data = np.frombuffer(pack_samples(vals, bps, flags), dtype=np.uint8).copy()
+        codec = gpu.Codec(bps, bs, rsi, flags)
+        d_in = torch.from_numpy(data).cuda()
+        d_out, nbytes, tb, _, d_off = codec.encode(d_in)
+        nrsi = codec.rsi_count(data.size)
+        offs = d_off.cpu().numpy().astype(np.uint64)
+        full = (data.size // nb // bs) // rsi                           # RSIs with all their blocks
+        for first in (0, full // 3):
+            d_idx = torch.zeros(nrsi + 8, dtype=torch.int64, device="cuda")
+            d_res = torch.zeros(40, dtype=torch.uint8, device="cuda")
+            codec.index_async(d_out, nbytes, int(offs[first]), d_idx, nrsi + 8 - first, d_res)
+            res = d_res.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]
+            assert int(res["status"]) <= 1, (n_samples, first)
+            assert full - first <= int(res["n_rsi"]) <= nrsi - first, (n_samples, first, int(res["n_rsi"]))
+            got = d_idx.cpu().numpy()[:full - first].astype(np.uint64)
+            assert np.array_equal(got, offs[first:full]), (n_samples, first)
+            assert int(res["end_bit"]) == tb or int(res["tail_blocks"]) > 0, (n_samples, first)
+
+
 @pytest.mark.parametrize("kind,bps,bs,rsi,flags,expect_len", [
     (0, 16, 16, 128, PP, 11923045),                       # BASELINE configs 2/4 shape
     (1, 32, 32, 4096, PP | MSB | SGN, 16213210),          # config 3
