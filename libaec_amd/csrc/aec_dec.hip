@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256)
 k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
          const uint64_t *__restrict__ rsi_off, const SegEntry *__restrict__ seg_table, uint64_t n_rsi,
          uint64_t total_blocks, uint8_t *__restrict__ out, DecResult *res, uint32_t ring_words, uint32_t maxw,
-         uint8_t *__restrict__ dump)
+         uint32_t needw, uint8_t *__restrict__ dump)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -270,7 +270,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
         // issued at least one whole block decode earlier, so the vmcnt wait there is free.
         {
             const uint32_t next = BS ? (p >> 5) : br.next;         // first word still needed
-            if (__any(live && landed - next < maxw)) {             // rare: a lane fell behind
+            if (__any(live && landed - next < needw)) {            // rare: a lane fell behind
 #pragma unroll
                 for (int j = 0; j < kPend; j++) {                  // in-flight chunks come first
                     if (pv[j]) {
@@ -279,8 +279,8 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                     }
                     pv[j] = false;
                 }
-                while (__any(live && landed - next < maxw)) {
-                    if (live && landed - next < maxw) {
+                while (__any(live && landed - next < needw)) {
+                    if (live && landed - next < needw) {
                         ring_put4(col, slot0, mask, landed, load_words4(words, a0 + landed, nwords));
                         landed += 4;
                     }
@@ -295,7 +295,36 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             uint32_t nz = 0;
             const bool parse = live && zrun == 0;
             // lanes inside a zero run (and finished lanes) get d = 0 from the same code path
-            const uint32_t st = decode_block<(BS ? BS : 2)>(src, p, end_p, d, c, ref, b0 + b, parse, nz);
+            const uint32_t p_save = p;
+            uint32_t st;
+#pragma nounroll
+            for (uint32_t attempt = 0;; attempt++) {
+                st = decode_block<(BS ? BS : 2)>(src, p, end_p, d, c, ref, b0 + b, parse, nz);
+                if (attempt != 0 || needw >= maxw || !__any(parse && src.starved())) break;
+                // Half-size ring (see dec_geom): a CDS longer than the look-ahead kept in steady
+                // state.  Land what is in flight, fill the ring completely from this block's first
+                // word -- that covers any CDS -- and decode the block again (all lanes, same result
+                // for those that had enough).
+                const uint32_t first = p_save >> 5;
+#pragma unroll
+                for (int j = 0; j < kPend; j++) {
+                    if (pv[j]) {
+                        ring_put4(col, slot0, mask, landed, pend[j]);
+                        landed += 4;
+                    }
+                    pv[j] = false;
+                }
+                while (__any(live && landed + 4u - first <= ring_words)) {
+                    if (live && landed + 4u - first <= ring_words) {
+                        ring_put4(col, slot0, mask, landed, load_words4(words, a0 + landed, nwords));
+                        landed += 4;
+                    }
+                }
+                src.limit = landed;
+                src.starve = 0;
+                p = p_save;
+                nz = 0;
+            }
             if (parse) {
                 if (st != DEC_OK) {
                     report(res, st, r);
@@ -381,19 +410,29 @@ uint8_t *dump_buffer()
 }
 
 struct DecGeom {
-    uint32_t ring_words, maxw, waves, grid;
+    uint32_t ring_words, maxw, needw, waves, grid;
     size_t lds_bytes;
 };
 
-// Ring capacity: a coded data set never exceeds id_len + 1 + bps + bs*bps bits; with loads landing
-// one iteration late the ring must hold two of them plus alignment slack (see k_decode).
-DecGeom dec_geom(const Cfg &c, uint64_t n_rsi)
+// Ring capacity: a coded data set never exceeds id_len + 1 + bps + bs*bps bits (maxw words with the
+// look-ahead of the 64-bit peeks); with loads landing one iteration late a ring of two of them plus
+// alignment slack never starves.  LDS is what bounds the waves per SIMD of k_decode, so when the
+// stream averages short coded data sets (avg_cds_bits, from the caller's byte and block counts) and
+// one maximal CDS still fits, the ring is HALF that: steady state keeps needw words ahead, a longer
+// CDS is decoded again after a full refill (k_decode).  Incompressible input keeps the full ring.
+DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits)
 {
     DecGeom g;
     const uint32_t maxbits = c.id_len + 1 + c.bps + c.bs * c.bps;
     g.maxw = maxbits / 32 + 5;   // + look-ahead of the 64-bit peeks
     uint32_t rw = 16;
     while (rw < 2 * g.maxw + 3) rw <<= 1;
+    g.needw = g.maxw;
+    // half ring: after a full refill at least rw/2 - 3 words lie ahead of any position
+    if (rw >= 32 && g.maxw <= rw / 2 - 3 && avg_cds_bits && avg_cds_bits * 4 <= (uint64_t)rw / 2 * 32) {
+        rw /= 2;
+        g.needw = rw / 2;
+    }
     g.ring_words = rw;
     const size_t per_wave = (size_t)(rw + 2) * 64 * 4;
     uint32_t waves = (uint32_t)(65536 / per_wave);
@@ -411,11 +450,11 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
                          const uint64_t *rsi_off, const SegEntry *seg_table, uint64_t n_rsi,
                          uint64_t total_blocks, uint8_t *out, DecResult *res, hipStream_t st)
 {
-    const DecGeom g = dec_geom(c, n_rsi);
+    const DecGeom g = dec_geom(c, n_rsi, total_blocks ? end_bit / total_blocks : 0);
     const dim3 block(64 * g.waves), grid(g.grid);
 #define AEC_GO(B)                                                                                   \
     hipLaunchKernelGGL((k_decode<BS, B, SEG>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
-                       rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, dump_buffer())
+                       rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, g.needw, dump_buffer())
     switch (c.bytes) {
     case 1: AEC_GO(1); break;
     case 2: AEC_GO(2); break;
@@ -448,9 +487,9 @@ static void launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
     case 64: launch_decode_bytes<64, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st); break;
     default:
     {
-        const DecGeom g = dec_geom(c, n_items);
+        const DecGeom g = dec_geom(c, n_items, 0);   // the sample-by-sample reader has no second attempt: full ring
         hipLaunchKernelGGL((k_decode<0, 0, SEG>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
-                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, dump_buffer());
+                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, g.needw, dump_buffer());
         break;
     }
     }

@@ -349,6 +349,15 @@ def test_segment_parallel_decode(gpu):
         (16, 64, 70, 0, pack_samples(random_walk_samples(rng, 64 * 70 * 5 + 99, 16, 0, scale=0.4, zero_frac=0.6), 16, 0)),
         (12, 16, 300, PP | SGN, pack_samples(random_walk_samples(rng, 16 * 300 * 3, 12, PP | SGN, scale=30.0), 12, PP | SGN)),
     ]
+    # short coded data sets on average (the decoder then runs on its half-size ring) with a maximal,
+    # uncompressed one every 37th / 5th block: those are decoded a second time after a full refill
+    for bps, bs, every in ((16, 16, 37), (32, 32, 5), (8, 8, 11)):
+        n = bs * 128 * 40
+        v = np.cumsum(rng.integers(-2, 3, n)) + (1 << (bps - 1))
+        noise = rng.integers(0, 1 << bps, n, dtype=np.uint64)
+        blk = np.arange(n) // bs
+        v = np.where(blk % every == every - 1, noise, np.clip(v, 0, (1 << bps) - 1).astype(np.uint64))
+        cases.append((bps, bs, 128, PP, pack_samples(v, bps, PP)))
     for bps, bs, rsi, flags, data in cases:
         data = np.ascontiguousarray(data, dtype=np.uint8)
         codec = gpu.Codec(bps, bs, rsi, flags)
