@@ -5,7 +5,7 @@
 OUT=$PWD/gpurun_out/$1; SZ=${2:-4096}; R=$PWD
 mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 $R/bench.py --size-mib $SZ --steps 2 --warmup 0 --no-cpu-baseline > $OUT/$c.log 2>&1
+  timeout -s KILL 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -- python3 $R/bench.py --size-mib $SZ --steps 2 --warmup 0 --no-cpu-baseline > $OUT/$c.log 2>&1
 done
 cd $R; python3 - "$OUT" "$SZ" <<'PY'
 import sys, json, glob
