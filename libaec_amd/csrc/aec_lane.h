@@ -767,7 +767,7 @@ AEC_HD uint32_t unary_slow(Src &src, uint32_t &p, uint32_t end_p, bool &short_in
 }
 
 template <int BS, class Src>
-AEC_HD uint32_t decode_block(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d, const Cfg &c,
+AEC_HD uint32_t decode_block_any(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d, const Cfg &c,
                              uint32_t ref, uint32_t blk_in_rsi, bool live, uint32_t &nzero_blocks)
 {
     static_assert(BS >= 2 && BS % 2 == 0, "templated block sizes only");
@@ -899,6 +899,138 @@ AEC_HD uint32_t decode_block(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d,
     if (!live) return DEC_OK;
     if (short_input || p > end_p || src.starved()) return DEC_NEED_INPUT;
     return corrupt ? DEC_DATA_ERROR : DEC_OK;
+}
+
+// Same contract for blocks that are NOT the first of an RSI in any lane (ref == 0 everywhere: every
+// block iteration but the first).  Without the per-lane reference slot the per-code and per-sample
+// predication of decode_block_any disappears:
+//   * unary phase: lanes whose option has no codes in a group of eight (uncompressed, zero blocks,
+//     the upper half of a second-extension block) run the same instructions on an all-ones window,
+//     which decodes as eight codes of value 0 and cannot trip the long-code test; their bit count
+//     is simply not added.  The one code of a zero-block CDS is read in the rare zero branch.
+//   * field phase: the field mask is 0 for k == 0, so no lane needs an "active" test.
+template <int BS, class Src>
+AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d, const Cfg &c,
+                                   uint32_t blk_in_rsi, bool live, uint32_t &nzero_blocks)
+{
+    static_assert(BS >= 2 && BS % 2 == 0, "templated block sizes only");
+    const uint32_t idmax = (1u << c.id_len) - 1u;
+    bool short_input = false, corrupt = false;
+    nzero_blocks = 0;
+
+    // ---- 1. header --------------------------------------------------------------------------
+    const uint32_t h = peek32(src, p);
+    const uint32_t id = h >> (32 - c.id_len);
+    const bool lowent = live && id == 0;
+    const bool unc = live && id == idmax;
+    const bool split = live && !lowent && !unc;
+    const uint32_t sel = (h >> (31 - c.id_len)) & 1u;
+    const bool se = lowent && sel;
+    const bool zero = lowent && !sel;
+    const uint32_t k = split ? id - 1u : 0u;
+    p += live ? c.id_len + (lowent ? 1u : 0u) : 0u;
+
+    // ---- 2. unary phase ---------------------------------------------------------------------
+    uint32_t u[BS];
+    constexpr uint32_t GRP = BS < 8 ? (uint32_t)BS : 8u;
+#pragma unroll
+    for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += GRP) {
+        // (second extension with blocks of 8: its 4 codes are half a group, read in the SE branch)
+        const bool gact = split || (se && BS >= 16 && g0 < (uint32_t)BS / 2);
+        uint64_t U = peek64(src, p);
+        if (!gact) U = ~0ull;
+        uint32_t used = 0, zmax = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < GRP; j++) {
+            const uint32_t z = clz32_or32((uint32_t)(U >> 32));
+            zmax = z > zmax ? z : zmax;
+            U <<= ((z + 1u) & 63u);
+            used += z + 1u;
+            u[g0 + j] = z;
+        }
+        const bool bad = zmax >= 32u;                    // a code of 32+ zeros: redo code by code
+        if (AEC_ANY(bad)) {
+            if (bad) {
+                uint32_t q = p;
+#pragma unroll
+                for (uint32_t j = 0; j < GRP; j++) u[g0 + j] = unary_slow(src, q, end_p, short_input);
+                used = q - p;
+            }
+        }
+        p += gact ? used : 0u;
+    }
+
+    // ---- 3. field phase ---------------------------------------------------------------------
+    const uint32_t kk = split ? k : (unc ? c.bps : 0u);
+    if (AEC_ANY(kk > 8)) {
+        // wide fields (uncompressed blocks, large k): one 32-bit peek per sample
+        const uint32_t fsh = (32u - kk) & 31u;
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)BS; i++) {
+            const uint32_t v = peek32(src, p + i * kk);
+            const uint32_t f = kk != 0 ? v >> fsh : 0u;
+            d[i] = (u[i] << k) + f;                      // k == 0 (and u == 0) for uncompressed lanes
+        }
+    } else {
+        // narrow fields: eight of them per 64-bit peek
+        const uint32_t km = low_mask32(kk);
+#pragma unroll
+        for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += GRP) {
+            const uint64_t F = peek64(src, p + g0 * kk);
+#pragma unroll
+            for (uint32_t j = 0; j < GRP; j++) {
+                const uint32_t f = (uint32_t)(F >> ((64u - (j + 1u) * kk) & 63u)) & km;
+                d[g0 + j] = (u[g0 + j] << k) + f;
+            }
+        }
+    }
+    p += (uint32_t)BS * kk;
+
+    // ---- 4. second extension / zero run (rare, divergent) ------------------------------------
+    if (AEC_ANY(se)) {
+        if (se) {
+            if (BS < 16) {
+#pragma unroll
+                for (uint32_t j = 0; j < (uint32_t)BS / 2; j++) u[j] = unary_slow(src, p, end_p, short_input);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)BS / 2; j++) {
+                uint32_t s = 0, second = 0;
+                if (!se_lookup(u[j], s, second)) corrupt = true;
+                d[2 * j] = s - second;
+                d[2 * j + 1] = second;
+            }
+        }
+    }
+    if (AEC_ANY(zero)) {
+        if (zero) {
+            uint32_t nz = unary_slow(src, p, end_p, short_input) + 1;
+            if (nz == 5) {
+                const uint32_t left_rsi = c.rsi - blk_in_rsi;
+                const uint32_t left_seg = 64 - (blk_in_rsi % 64);
+                nz = left_rsi < left_seg ? left_rsi : left_seg;
+            } else if (nz > 5) {
+                nz--;
+            }
+            if (nz > c.rsi - blk_in_rsi) corrupt = true;  // decode.c:543-544
+            nzero_blocks = nz;
+#pragma unroll
+            for (uint32_t i = 0; i < (uint32_t)BS; i++) d[i] = 0;
+        }
+    }
+    if (!live) return DEC_OK;
+    if (short_input || p > end_p || src.starved()) return DEC_NEED_INPUT;
+    return corrupt ? DEC_DATA_ERROR : DEC_OK;
+}
+
+// One block per lane.  `ref` != 0 marks the first block of an RSI (it carries the reference
+// sample); a wave without such a lane takes the leaner decode_block_noref.
+template <int BS, class Src>
+AEC_HD uint32_t decode_block(Src &src, uint32_t &p, uint32_t end_p, uint32_t *d, const Cfg &c,
+                             uint32_t ref, uint32_t blk_in_rsi, bool live, uint32_t &nzero_blocks)
+{
+    if (AEC_ANY(ref != 0)) return decode_block_any<BS>(src, p, end_p, d, c, ref, blk_in_rsi, live, nzero_blocks);
+    return decode_block_noref<BS>(src, p, end_p, d, c, blk_in_rsi, live, nzero_blocks);
 }
 
 // Skips one CDS without materialising samples (RSI index pass).  Returns blocks covered in
