@@ -213,9 +213,10 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     // and the L2 sees partial-sector writes only; that store path, not decoding, bounded the kernel
     // (TA stalled by TC 77 % of the time; 3.6 ms -> 2.2 ms with the stores pointed at one line).
     // So blocks are parked in an LDS row per lane and every kStgRow bytes the wave writes the rows
-    // out transposed: 4 lanes per row, whole 64-byte sectors per store instruction.
+    // out transposed: 4 lanes per row, whole 64-byte sectors per store instruction.  (Rows of 128
+    // bytes -- whole lines -- were slower: 3.26 ms against 2.75 ms at C2, the LDS costs waves.)
     constexpr int BLK = BS * BYTES;
-    constexpr bool STG = BS != 0 && (BLK == 8 || BLK == 16 || BLK == 32);
+    constexpr bool STG = BS != 0 && (BLK == 16 || BLK == 32);   // (8-byte blocks: measured slower, LDS cost)
     constexpr uint32_t kStgRow = 64, kStgStride = 80;            // 16 bytes of padding: conflict-free rows
     constexpr uint32_t G = STG ? kStgRow / (uint32_t)(BLK ? BLK : 1) : 1u;
     const uint32_t wave_words = (ring_words + 2u) * 64u + (STG ? (64u * kStgStride + 64u * 12u) / 4u : 0u);
@@ -266,15 +267,6 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             const uint32_t have = stg_cnt[row];
             uint8_t *at = stg_base[row] + (size_t)group * kStgRow + chunk;
             uint8_t *q = chunk + 16u <= have ? at : dump + (size_t)lane * 16u;
-            if (BLK == 8) {
-                // an odd number of 8-byte blocks ends in half a chunk; the other half belongs to the
-                // next lane's output
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                typedef __attribute__((address_space(1))) u32x2 global_u32x2;
-                uint8_t *h = (chunk < have && chunk + 16u > have) ? at : dump + (size_t)lane * 16u;
-                const u32x2 hv = {v.x, v.y};
-                *reinterpret_cast<global_u32x2 *>(reinterpret_cast<uintptr_t>(h)) = hv;
-            }
             // (the row's base pointer comes out of LDS: say that it points to global memory, or
             // the store is emitted as a flat instruction)
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -493,8 +485,9 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, bool stage
     uint32_t waves = 1, best = 0;
     for (uint32_t w = 1; w <= 4; w *= 2) {
         if (per_wave * w > 65536) break;
-        const uint32_t fit = (uint32_t)(160 * 1024 / (per_wave * w)) * w;
-        if (fit >= best) {
+        uint32_t fit = (uint32_t)(160 * 1024 / (per_wave * w)) * w;
+        if (fit > 32) fit = 32;                         // a CU holds 32 waves at most
+        if (fit >= best) {                              // ties: the larger workgroup
             best = fit;
             waves = w;
         }
@@ -512,7 +505,7 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
                          uint64_t total_blocks, uint8_t *out, DecResult *res, hipStream_t st)
 {
     const uint32_t blk = (uint32_t)BS * c.bytes;
-    const DecGeom g = dec_geom(c, n_rsi, total_blocks ? end_bit / total_blocks : 0, blk == 8 || blk == 16 || blk == 32);
+    const DecGeom g = dec_geom(c, n_rsi, total_blocks ? end_bit / total_blocks : 0, blk == 16 || blk == 32);
     const dim3 block(64 * g.waves), grid(g.grid);
 #define AEC_GO(B)                                                                                   \
     hipLaunchKernelGGL((k_decode<BS, B, SEG>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
