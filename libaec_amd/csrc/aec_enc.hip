@@ -12,13 +12,13 @@
 //   k_analyze   phase A+B, writes a 4-byte summary per block and (bits, k clamp) per segment.
 //   k_scan_*    device-wide exclusive scan of segment bit lengths (absolute bit offsets) and of
 //               the k clamp composition (replaces the serial state->k / state->bits carry).
-//   k_clear     zeroes exactly the output words the stream will occupy.
+//               (k_scan_apply also zeroes the few output words that two waves of k_pack share)
 //   k_pack      phase A again (input is re-read; the per-block summaries are not recomputed),
 //               per-lane bit emission into an LDS image of the segment via ds_or_b32, then a
 //               coalesced byte-swapped copy to HBM; only the first/last word of a segment can be
 //               shared with a neighbour and uses a global atomic OR.
 //
-// HBM traffic per input byte: 2 reads of the input + 4/(bs*bytes) summary write+read + 1 clear
+// HBM traffic per input byte: 2 reads of the input + 4/(bs*bytes) summary write+read
 // + 1 write of the compressed stream.  Algorithmic bytes are N + C.
 #include <hip/hip_runtime.h>
 
@@ -544,7 +544,8 @@ __global__ void __launch_bounds__(256)
 k_scan_apply(const uint32_t *__restrict__ seg_bits, const uint16_t *__restrict__ seg_clamp,
              uint64_t nseg, const ScanPartial *__restrict__ partials, uint32_t start_bit, uint32_t k_in,
              uint32_t segs_per_rsi, uint64_t rsi_count, uint64_t *__restrict__ seg_start,
-             uint8_t *__restrict__ seg_kin, uint64_t *__restrict__ rsi_off, EncResult *res)
+             uint8_t *__restrict__ seg_kin, uint64_t *__restrict__ rsi_off, EncResult *res,
+             uint32_t *__restrict__ out_words, uint64_t cap_words, uint32_t segs_per_wave)
 {
     __shared__ ScanVal sh[4];
     const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * kScanItems;
@@ -568,12 +569,20 @@ k_scan_apply(const uint32_t *__restrict__ seg_bits, const uint16_t *__restrict__
             seg_start[s] = bit;
             seg_kin[s] = (uint8_t)kclamp_apply(clamp_unpack(run.cl), k_in);
             if (rsi_off && (s % segs_per_rsi) == 0) rsi_off[s / segs_per_rsi] = bit;
+            // k_pack writes every word of the stream with plain stores except the words two of its
+            // waves share -- the one a wave's first segment starts in -- which both OR into: those
+            // (and the last word of the stream, below) are all that has to be zero beforehand
+            if ((s % segs_per_wave) == 0 && (bit >> 5) < cap_words) out_words[bit >> 5] = 0u;
         }
         run = scan_then(run, item[i]);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         res->k_out = kclamp_apply(KClamp{res->k_lo, res->k_hi}, k_in);   // k_in is only known now
         if (rsi_off) rsi_off[rsi_count] = (uint64_t)start_bit + res->total_bits;
+        const uint64_t end = (uint64_t)start_bit + res->total_bits;
+        if ((end + 7) / 8 > cap_words * 4) res->overflow = 1;
+        for (uint64_t w = end >> 5; w <= (end >> 5) + 1; w++)      // open last word (+ one of padding)
+            if (w < cap_words) out_words[w] = 0u;
     }
 }
 
@@ -592,30 +601,6 @@ k_seg_table(const Cfg c, const uint8_t *__restrict__ in, const uint64_t *__restr
         prev = load_sample_bytes(in + i * c.bytes, c.bytes, (c.flags & F_MSB) != 0);
     }
     table[sg] = SegEntry{seg_start[sg], prev, 0u};
-}
-
-// ----------------------------------------------------------------------------------------------
-// clear: zero the words the stream will occupy (grid-stride, 16 bytes per lane)
-// ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_clear(uint32_t *__restrict__ out_words, uint64_t cap_words, uint32_t start_bit, EncResult *res)
-{
-    uint64_t nwords = ((uint64_t)start_bit + res->total_bits + 31) / 32 + 1;
-    if (nwords > cap_words) {
-        if (blockIdx.x == 0 && threadIdx.x == 0 &&
-            ((uint64_t)start_bit + res->total_bits + 7) / 8 > cap_words * 4)
-            res->overflow = 1;
-        nwords = cap_words;
-    }
-    const uint64_t nvec = nwords / 4;
-    uint4 *v = reinterpret_cast<uint4 *>(out_words);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
-         i += (uint64_t)gridDim.x * blockDim.x)
-        v[i] = make_uint4(0, 0, 0, 0);
-    if (blockIdx.x == 0 && threadIdx.x < 4) {
-        const uint64_t w = nvec * 4 + threadIdx.x;
-        if (w < nwords) out_words[w] = 0;
-    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -717,13 +702,13 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
             const uint32_t v = obuf[w];
             const uint64_t idx = gw + w;
             const bool is_tail = w == nwords - 1 && tail != 0;
-            if (v != 0 && idx < cap_words && !(is_tail && carry_tail)) {
+            if (idx < cap_words && !(is_tail && carry_tail)) {
                 const bool shared = (w == 0 && left_shared) || is_tail;
                 const uint32_t sv = bswap32(v);
-                if (shared)
+                if (!shared)
+                    out_words[idx] = sv;                 // (zero words too: nothing clears the buffer)
+                else if (v != 0)
                     __hip_atomic_fetch_or(&out_words[idx], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else
-                    out_words[idx] = sv;
             }
         }
         pending = carry_tail ? obuf[nwords - 1] : 0u;     // uniform: every lane reads the same word
@@ -867,15 +852,17 @@ void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out
         if (nchunks)
             hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)nchunks), dim3(256), 0, st, ws.seg_bits,
                                ws.seg_clamp, nseg, ws.partials, start_bit, k_in, c.segs_per_rsi, c.rsi_count,
-                               ws.seg_start, ws.seg_kin, d_rsi_off, d_res);
-        else if (d_rsi_off)
-            (void)hipMemsetAsync(d_rsi_off, 0, sizeof(uint64_t), st);   // empty batch: single entry
+                               ws.seg_start, ws.seg_kin, d_rsi_off, d_res, out_words, cap_words,
+                               make_geom(c, true).segs_per_wave);
+        else {
+            if (d_rsi_off) (void)hipMemsetAsync(d_rsi_off, 0, sizeof(uint64_t), st);   // empty batch: single entry
+            if (out_cap >= 16) (void)hipMemsetAsync(d_out, 0, 16, st);
+        }
         if (d_seg_table && nseg)
             hipLaunchKernelGGL(k_seg_table, dim3((uint32_t)((nseg + 255) / 256)), dim3(256), 0, st, c, d_in,
                                ws.seg_start, d_seg_table);
         mark(2);
-        hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, st, out_words, cap_words, start_bit, d_res);
-        mark(3);
+        mark(3);   // (the buffer is no longer cleared: k_scan_apply zeroes the few shared words)
         if (nseg) dispatch(true, c, d_in, ws, out_words, cap_words, fast_ok, st);
         mark(4);
     }
