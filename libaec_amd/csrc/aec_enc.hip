@@ -131,14 +131,20 @@ __device__ __forceinline__ Seg seg_geom(const Cfg &c, uint64_t sg)
 // that the loads of segment i+1 are in flight while segment i is analysed / packed: a wavefront
 // otherwise exposes a full HBM round trip several times per segment.
 template <int BYTES>
-__device__ __forceinline__ uint32_t load_sample_typed(const uint8_t *p, bool msb)
+__device__ __forceinline__ uint32_t load_sample_raw(const uint8_t *p)
 {
     if (BYTES == 1) return *p;
-    if (BYTES == 2) {
-        const uint32_t v = *reinterpret_cast<const uint16_t *>(p);
-        return msb ? ((v >> 8) | ((v & 0xFFu) << 8)) : v;
-    }
-    const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+    if (BYTES == 2) return *reinterpret_cast<const uint16_t *>(p);
+    return *reinterpret_cast<const uint32_t *>(p);
+}
+
+// byte order of a sample loaded with load_sample_raw -- applied where the value is CONSUMED: done
+// at the load it makes the prefetch wait for its own data (a full HBM round trip per segment)
+template <int BYTES>
+__device__ __forceinline__ uint32_t sample_byte_order(uint32_t v, bool msb)
+{
+    if (BYTES == 1) return v;
+    if (BYTES == 2) return msb ? ((v >> 8) | ((v & 0xFFu) << 8)) : v;
     return msb ? bswap32(v) : v;
 }
 
@@ -147,7 +153,7 @@ struct FastSeg {
     static constexpr uint32_t CHUNKS = (uint32_t)BS * BYTES * 64u / 16u;       // per full segment
     static constexpr uint32_t NIT = (CHUNKS + 63u) / 64u;                      // chunk rounds per lane
     uint4 v[NIT];
-    uint32_t carry;   // sample just before the segment (raw, caller's byte order resolved)
+    uint32_t carry;   // sample just before the segment, as loaded (byte order not yet resolved)
 };
 
 // max_chunk = index of the last whole 16-byte chunk of the input (addresses are clamped to it, so
@@ -156,7 +162,6 @@ template <int BS, int BYTES>
 __device__ __forceinline__ void fast_issue(const Cfg &c, const uint8_t *in, const Seg &g, uint32_t lane,
                                            uint64_t max_chunk, FastSeg<BS, BYTES> &f)
 {
-    const bool msb = c.flags & F_MSB;
     const uint4 *src = reinterpret_cast<const uint4 *>(in);
     const uint64_t first = g.samp0 * BYTES / 16u;
 #pragma unroll
@@ -166,7 +171,7 @@ __device__ __forceinline__ void fast_issue(const Cfg &c, const uint8_t *in, cons
         f.v[it] = src[ci];
     }
     const uint64_t prev = g.samp0 ? g.samp0 - 1 : 0;
-    f.carry = load_sample_typed<BYTES>(in + prev * BYTES, msb);
+    f.carry = load_sample_raw<BYTES>(in + prev * BYTES);
 }
 
 template <int BS, int BYTES>
@@ -177,7 +182,7 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
     constexpr uint32_t STRIDE = Rows<BS, BYTES>::stride_words(BS);
     const bool msb = c.flags & F_MSB, pp = c.flags & F_PREPROCESS;
     const uint32_t nchunks = g.nv * (uint32_t)BS * BYTES / 16u;
-    uint32_t carry = f.carry;
+    uint32_t carry = sample_byte_order<BYTES>(f.carry, msb);
 
 #pragma unroll
     for (uint32_t it = 0; it < FastSeg<BS, BYTES>::NIT; it++) {
@@ -636,7 +641,8 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
     for (; sg < sg_end; sg++) {
         const auto cur = feeder.pre;
         const Seg g = gnext;
-        // everything this segment needs from HBM is requested before the first wait
+        // everything this segment needs from HBM is requested before the first wait (requesting the
+        // summaries a segment ahead as well was tried: no gain, two registers too many)
         const bool valid = lane < g.nv;
         const uint32_t m = valid ? meta[g.blk0 + lane] : meta_pack(0, OPT_ZCONT, 0, 0);
         const uint32_t kin = seg_kin[sg];
