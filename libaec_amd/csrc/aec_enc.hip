@@ -148,6 +148,27 @@ __device__ __forceinline__ uint32_t sample_byte_order(uint32_t v, bool msb)
     return msb ? bswap32(v) : v;
 }
 
+// ---- two 16-bit samples per instruction ------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 pk(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t unpk(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+// The unsigned predictor mapping (reference encode.c:255-269; aec_lane.h pp_unsigned) for both
+// halves of a word: prev = the two preceding samples, cur = the two samples, xm = (xmax, xmax).
+// With D = |cur - prev|, neg = cur < prev and room = min(prev, xmax - prev) the mapped value is
+// 2D - neg while D <= room and room + D beyond; the first grows twice as fast as the second and
+// they cross exactly at the switch, so it is min(2D - neg, room + D) -- no compare, no select,
+// and everything stays below 2^16 (the doubling saturates, which the min absorbs).
+__device__ __forceinline__ uint32_t pp_unsigned_pk(uint32_t prev, uint32_t cur, uint32_t xm)
+{
+    const u16x2 a = pk(prev), b = pk(cur), one = {1, 1};
+    const u16x2 d = __builtin_elementwise_max(a, b) - __builtin_elementwise_min(a, b);
+    const u16x2 neg = __builtin_elementwise_min(__builtin_elementwise_sub_sat(a, b), one);
+    const u16x2 room = __builtin_elementwise_min(a, pk(xm) - a);
+    const u16x2 folded = __builtin_elementwise_add_sat(d, d - neg);
+    return unpk(__builtin_elementwise_min(folded, room + d));
+}
+
 template <int BS, int BYTES>
 struct FastSeg {
     static constexpr uint32_t CHUNKS = (uint32_t)BS * BYTES * 64u / 16u;       // per full segment
@@ -190,6 +211,42 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
         const bool act = ci < nchunks;
         const uint4 v = f.v[it];
         const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+        if (Rows<BS, BYTES>::HALF && pp && !(c.flags & F_SIGNED)) {
+            // unsigned samples of at most 16 bits: stay packed, two samples per instruction, from the
+            // loaded words to the uint16 rows (pw[] = sample pairs in stream order)
+            constexpr uint32_t NW = SPC / 2;
+            uint32_t pw[NW];
+            if (BYTES == 2) {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++)
+                    pw[j] = msb ? (((vw[j] & 0x00FF00FFu) << 8) | ((vw[j] >> 8) & 0x00FF00FFu)) : vw[j];
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {      // bytes 0,1 and 2,3 widened to 16 bits each
+                    pw[2 * j] = __builtin_amdgcn_perm(0u, vw[j], 0x0c010c00u);
+                    pw[2 * j + 1] = __builtin_amdgcn_perm(0u, vw[j], 0x0c030c02u);
+                }
+            }
+            // the word before this chunk: the neighbour lane's last word, or the carried sample
+            const uint32_t before = wave_shr1(pw[NW - 1], carry << 16);
+            carry = wave_last(pw[NW - 1]) >> 16;
+            if (act) {
+                const uint32_t xm = c.xmax | (c.xmax << 16);
+                uint32_t dw[NW];
+#pragma unroll
+                for (uint32_t j = 0; j < NW; j++)
+                    dw[j] = pp_unsigned_pk(__builtin_amdgcn_alignbit(pw[j], j ? pw[j - 1] : before, 16), pw[j], xm);
+                if (g.b0 == 0 && ci == 0) dw[0] &= 0xFFFF0000u;      // reference sample slot, encode.c:254
+#pragma unroll
+                for (uint32_t q = 0; q < NW / 4; q++) {
+                    const uint32_t i = ci * SPC + q * 8;
+                    const uint32_t row = i / BS, col = i % BS;
+                    *reinterpret_cast<uint4 *>(&rows[row * STRIDE + col / 2]) =
+                        make_uint4(dw[4 * q], dw[4 * q + 1], dw[4 * q + 2], dw[4 * q + 3]);
+                }
+            }
+            continue;
+        }
         uint32_t x[SPC];
         if (BYTES == 4) {
 #pragma unroll
