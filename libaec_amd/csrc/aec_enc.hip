@@ -106,12 +106,27 @@ struct Seg {
     bool full;          // every sample of the segment exists (no end-of-data padding)
 };
 
+// everything that follows from (RSI, segment inside the RSI)
+__device__ __forceinline__ Seg seg_at(const Cfg &c, uint64_t rsi_idx, uint32_t s);
+
 __device__ __forceinline__ Seg seg_geom(const Cfg &c, uint64_t sg)
 {
-    Seg g;
     // 32-bit division whenever possible (a 64-bit one costs ~100 instructions per segment)
-    g.rsi_idx = (sg >> 32) ? sg / c.segs_per_rsi : (uint64_t)((uint32_t)sg / c.segs_per_rsi);
-    const uint32_t s = (uint32_t)(sg - g.rsi_idx * c.segs_per_rsi);
+    const uint64_t rsi_idx = (sg >> 32) ? sg / c.segs_per_rsi : (uint64_t)((uint32_t)sg / c.segs_per_rsi);
+    return seg_at(c, rsi_idx, (uint32_t)(sg - rsi_idx * c.segs_per_rsi));
+}
+
+// the segment after g: a wave walks consecutive segments, so the division is paid once per wave
+__device__ __forceinline__ Seg seg_next(const Cfg &c, const Seg &g)
+{
+    const uint32_t s = g.b0 / 64u + 1u;
+    return s == c.segs_per_rsi ? seg_at(c, g.rsi_idx + 1, 0u) : seg_at(c, g.rsi_idx, s);
+}
+
+__device__ __forceinline__ Seg seg_at(const Cfg &c, uint64_t rsi_idx, uint32_t s)
+{
+    Seg g;
+    g.rsi_idx = rsi_idx;
     g.b0 = s * 64u;
     uint64_t nb = c.total_blocks - g.rsi_idx * c.rsi;
     if (nb > c.rsi) nb = c.rsi;
@@ -453,7 +468,7 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
     for (; sg < sg_end; sg++) {
         const auto cur = feeder.pre;
         const Seg gcur = g;
-        if (sg + 1 < sg_end) g = seg_geom(c, sg + 1);
+        if (sg + 1 < sg_end) g = seg_next(c, g);
         feeder.prefetch(c, in, g, lane);          // next segment's loads fly during this one
         feeder.feed(c, in, gcur, cur, rows, stride, lane);
         analyze_body<BS, BYTES>(c, gcur, rows, stride, lane, sg, meta, seg_bits, seg_clamp);
@@ -707,7 +722,7 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
         uint32_t ref_sample = 0;
         if (pp && g.b0 == 0 && lane == 0)
             ref_sample = load_sample_bytes(in + g.samp0 * c.bytes, c.bytes, msb) & low_mask32(c.bps);
-        if (sg + 1 < sg_end) gnext = seg_geom(c, sg + 1);
+        if (sg + 1 < sg_end) gnext = seg_next(c, gnext);
         feeder.prefetch(c, in, gnext, lane);      // next segment's loads fly during this one
         feeder.feed(c, in, g, cur, rows, stride, lane);
 
