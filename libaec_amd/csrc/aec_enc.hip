@@ -434,6 +434,40 @@ __device__ __forceinline__ bool block_is_zero(const uint32_t *d, uint32_t bs_rt)
     return any == 0;
 }
 
+// Option selection on a block held as BS/2 words of two 16-bit residuals each (uint16 rows):
+// fs(k) = sum of (sample >> k) costs one packed shift and one dot product per PAIR
+// (v_pk_lshrrev_b16, v_dot2_u32_u16 with (1, 1)); the control flow is aec_lane.h's.
+template <int BS>
+__device__ __forceinline__ BlockChoice choose_option_pk(const uint32_t *w, const Cfg &c, uint32_t ref)
+{
+    const uint32_t n = (uint32_t)BS - ref;
+    const u16x2 ones = {1, 1};
+    auto fs = [&](uint32_t k) -> uint64_t {
+        const u16x2 kk = {(unsigned short)k, (unsigned short)k};
+        uint32_t s = 0;
+#pragma unroll
+        for (int j = 0; j < BS / 2; j++) s = __builtin_amdgcn_udot2(pk(w[j]) >> kk, ones, s, false);
+        return s;
+    };
+    uint32_t split_len = 0xFFFFFFFFu, klo = 0, khi = 31;
+    if (c.id_len > 1) assess_split_with(fs, n, c.kmax, klo, khi, split_len);
+    // second extension (aec_lane.h assess_se): a pair is the two halves of a word; their sum stays
+    // below 2^17, so the reference's 64-bit wrap case cannot occur here
+    const uint32_t limit = n * c.bps;
+    uint32_t len = 1;
+    bool over = false;
+#pragma unroll
+    for (int j = 0; j < BS / 2; j++) {
+        const uint32_t b = w[j] >> 16;
+        const uint32_t sum = __builtin_amdgcn_udot2(pk(w[j]), ones, 0u, false);
+        const uint32_t add = sum * (sum + 1u) / 2u + b + 1u;        // only used while sum < 2^15
+        const bool bad = sum >= 32768u || len + add > limit;
+        len = (over || bad) ? len : len + add;
+        over = over || bad;
+    }
+    return choose_from(c, (uint32_t)BS, ref, split_len, over ? 0xFFFFFFFFu : len, klo, khi);
+}
+
 // ----------------------------------------------------------------------------------------------
 // K1: analysis
 // ----------------------------------------------------------------------------------------------
@@ -486,12 +520,29 @@ __device__ __forceinline__ void analyze_body(const Cfg &c, const Seg &g, uint32_
     {
         wave_lds_fence();
 
-        BlockRegs<BS, Rows<BS, BYTES>::HALF> regs;
+        BlockRegs<BS, Rows<BS, BYTES>::HALF && BS != 0 ? false : Rows<BS, BYTES>::HALF> regs;
+        constexpr bool PK = Rows<BS, BYTES>::HALF && BS != 0;   // uint16 rows: analysed two samples at a time
         const bool valid = lane < g.nv;
         // every lane loads a row (idle lanes re-read the last valid one) so that the block lives in
         // registers instead of behind a conditionally assigned pointer
-        const uint32_t *d = regs.load(rows + (valid ? lane : g.nv - 1) * stride);
-        const bool zero = valid && block_is_zero<BS>(d, bs);
+        const uint32_t *row = rows + (valid ? lane : g.nv - 1) * stride;
+        uint32_t w[PK ? BS / 2 : 1];                            // the block as sample pairs
+        const uint32_t *d = nullptr;
+        bool zero;
+        if (PK) {
+#pragma unroll
+            for (int q = 0; q < (PK ? BS / 8 : 0); q++) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(row + 4 * q);
+                w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+            }
+            uint32_t any = 0;
+#pragma unroll
+            for (int j = 0; j < (PK ? BS / 2 : 0); j++) any |= w[j];
+            zero = valid && any == 0;
+        } else {
+            d = regs.load(row);
+            zero = valid && block_is_zero<BS>(d, bs);
+        }
         const uint64_t zmask = __ballot(zero);
 
         uint32_t m = meta_pack(0, OPT_ZCONT, 0, 0);
@@ -504,7 +555,9 @@ __device__ __forceinline__ void analyze_body(const Cfg &c, const Seg &g, uint32_
                 if (run) m = meta_pack(c.id_len + 1 + ref * c.bps + fs + 1, OPT_ZERO, fs, 0);
             } else {
                 BlockChoice ch;
-                if (BS == 0)
+                if (PK)
+                    ch = choose_option_pk<(PK ? BS : 8)>(w, c, ref);
+                else if (BS == 0)
                     ch = (c.bps > 16) ? choose_option<BS, true>(d, c, ref) : choose_option<BS, false>(d, c, ref);
                 else
                     ch = choose_option<BS, WIDE_T>(d, c, ref);

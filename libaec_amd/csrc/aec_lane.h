@@ -166,18 +166,20 @@ AEC_HD uint64_t fs_sum(const uint32_t *d, uint32_t bs_rt, uint32_t k)
 // length (reference encode.c:329-410; see the note at the top of this file).
 //   n = number of coded samples (bs - ref); the sum runs over the whole block because the
 //   reference sample slot holds d = 0 (encode.c:254, 323-324).
-template <int BS, bool WIDE>
-AEC_HD void assess_split(const uint32_t *d, uint32_t bs_rt, uint32_t n, uint32_t kmax,
-                         uint32_t &klo, uint32_t &khi, uint32_t &len_min)
+// Plateau search of the split option over any evaluator fs(k) = sum of (sample >> k): the
+// kernels' packed 16-bit evaluator and the plain one below share this control flow.
+template <class FS>
+AEC_HD void assess_split_with(FS fs, uint32_t n, uint32_t kmax, uint32_t &klo, uint32_t &khi,
+                              uint32_t &len_min)
 {
-    const uint64_t s0 = fs_sum<BS, WIDE>(d, bs_rt, 0);
+    const uint64_t s0 = fs(0u);
     // smallest k that can possibly satisfy g(k) <= n needs n * 2^(k+2) >= s0
     int ks = bit_length64(s0) - bit_length64(n) - 2;
     if (ks < 0) ks = 0;
     if ((uint32_t)ks > kmax) ks = (int)kmax;
 
     uint32_t k = (uint32_t)ks;
-    uint64_t f_cur = k ? fs_sum<BS, WIDE>(d, bs_rt, k) : s0;
+    uint64_t f_cur = k ? fs(k) : s0;
     bool have_lo = false;
     klo = khi = kmax;
     len_min = 0;
@@ -190,7 +192,7 @@ AEC_HD void assess_split(const uint32_t *d, uint32_t bs_rt, uint32_t n, uint32_t
             khi = kmax;
             break;
         }
-        const uint64_t f_next = fs_sum<BS, WIDE>(d, bs_rt, k + 1);
+        const uint64_t f_next = fs(k + 1u);
         const uint64_t g = f_cur - f_next;
         if (!have_lo && g <= n) {
             have_lo = true;
@@ -204,6 +206,14 @@ AEC_HD void assess_split(const uint32_t *d, uint32_t bs_rt, uint32_t n, uint32_t
         k++;
         f_cur = f_next;
     }
+}
+
+template <int BS, bool WIDE>
+AEC_HD void assess_split(const uint32_t *d, uint32_t bs_rt, uint32_t n, uint32_t kmax,
+                         uint32_t &klo, uint32_t &khi, uint32_t &len_min)
+{
+    assess_split_with([&](uint32_t k) { return (uint64_t)fs_sum<BS, WIDE>(d, bs_rt, k); }, n, kmax, klo, khi,
+                      len_min);
 }
 
 // Second-extension option length, exact replica of the uint64_t arithmetic and the in-order
@@ -242,20 +252,16 @@ struct BlockChoice {
 };
 
 // reference encode.c:585-612 m_select_code_option (plus the CDS framing of 520-563)
-template <int BS, bool WIDE>
-AEC_HD BlockChoice choose_option(const uint32_t *d, const Cfg &c, uint32_t ref)
+// the choice between the assessed options (reference encode.c:585-612, note the tie rules)
+AEC_HD BlockChoice choose_from(const Cfg &c, uint32_t bs, uint32_t ref, uint32_t split_len, uint32_t se_len,
+                               uint32_t klo, uint32_t khi)
 {
-    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const uint32_t n = bs - ref;
     const uint32_t uncomp_len = n * c.bps;         // encode.c:270, 746: (bs - ref) * bps
-    BlockChoice r;
-    uint32_t split_len = 0xFFFFFFFFu;
-    r.klo = 0;
-    r.khi = 31;
-    if (c.id_len > 1)
-        assess_split<BS, WIDE>(d, bs, n, c.kmax, r.klo, r.khi, split_len);
-    const uint32_t se_len = assess_se<BS>(d, bs, uncomp_len);
     const uint32_t head = c.id_len + ref * c.bps;
+    BlockChoice r;
+    r.klo = klo;
+    r.khi = khi;
     if (split_len < uncomp_len) {
         if (split_len < se_len) { r.opt = OPT_SPLIT; r.bits = head + split_len; }
         else                    { r.opt = OPT_SE;    r.bits = head + se_len; }
@@ -264,6 +270,18 @@ AEC_HD BlockChoice choose_option(const uint32_t *d, const Cfg &c, uint32_t ref)
         else                      { r.opt = OPT_SE;     r.bits = head + se_len; }
     }
     return r;
+}
+
+template <int BS, bool WIDE>
+AEC_HD BlockChoice choose_option(const uint32_t *d, const Cfg &c, uint32_t ref)
+{
+    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
+    const uint32_t n = bs - ref;
+    uint32_t split_len = 0xFFFFFFFFu, klo = 0, khi = 31;
+    if (c.id_len > 1)
+        assess_split<BS, WIDE>(d, bs, n, c.kmax, klo, khi, split_len);
+    const uint32_t se_len = assess_se<BS>(d, bs, n * c.bps);
+    return choose_from(c, bs, ref, split_len, se_len, klo, khi);
 }
 
 // Zero-block run bookkeeping inside one segment (reference encode.c:614-659, 565-583).
