@@ -442,7 +442,7 @@ __device__ __forceinline__ BlockChoice choose_option_pk(const uint32_t *w, const
 {
     const uint32_t n = (uint32_t)BS - ref;
     const u16x2 ones = {1, 1};
-    auto fs = [&](uint32_t k) -> uint64_t {
+    auto fs = [&](uint32_t k) -> uint32_t {       // at most 64 * 65535 < 2^22
         const u16x2 kk = {(unsigned short)k, (unsigned short)k};
         uint32_t s = 0;
 #pragma unroll

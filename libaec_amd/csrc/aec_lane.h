@@ -172,14 +172,15 @@ template <class FS>
 AEC_HD void assess_split_with(FS fs, uint32_t n, uint32_t kmax, uint32_t &klo, uint32_t &khi,
                               uint32_t &len_min)
 {
-    const uint64_t s0 = fs(0u);
+    using T = decltype(fs(0u));        // 32-bit sums where the evaluator guarantees they fit
+    const T s0 = fs(0u);
     // smallest k that can possibly satisfy g(k) <= n needs n * 2^(k+2) >= s0
     int ks = bit_length64(s0) - bit_length64(n) - 2;
     if (ks < 0) ks = 0;
     if ((uint32_t)ks > kmax) ks = (int)kmax;
 
     uint32_t k = (uint32_t)ks;
-    uint64_t f_cur = k ? fs(k) : s0;
+    T f_cur = k ? fs(k) : s0;
     bool have_lo = false;
     klo = khi = kmax;
     len_min = 0;
@@ -192,8 +193,8 @@ AEC_HD void assess_split_with(FS fs, uint32_t n, uint32_t kmax, uint32_t &klo, u
             khi = kmax;
             break;
         }
-        const uint64_t f_next = fs(k + 1u);
-        const uint64_t g = f_cur - f_next;
+        const T f_next = fs(k + 1u);
+        const T g = f_cur - f_next;
         if (!have_lo && g <= n) {
             have_lo = true;
             klo = k;
