@@ -226,9 +226,12 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
         const bool act = ci < nchunks;
         const uint4 v = f.v[it];
         const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
-        if (Rows<BS, BYTES>::HALF && pp && !(c.flags & F_SIGNED)) {
-            // unsigned samples of at most 16 bits: stay packed, two samples per instruction, from the
-            // loaded words to the uint16 rows (pw[] = sample pairs in stream order)
+        if (Rows<BS, BYTES>::HALF && pp) {
+            // samples of at most 16 bits stay packed, two per instruction, from the loaded words to the
+            // uint16 rows (pw[] = sample pairs in stream order).  Signed samples are biased by
+            // 2^(bps-1) first -- flip the sign bit, drop the sign copies above it -- which turns
+            // [xmin, xmax] into [0, 2^bps - 1] and leaves differences and distances to the bounds,
+            // hence the mapped values (reference encode.c:294-309), unchanged.
             constexpr uint32_t NW = SPC / 2;
             uint32_t pw[NW];
             if (BYTES == 2) {
@@ -242,11 +245,20 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
                     pw[2 * j + 1] = __builtin_amdgcn_perm(0u, vw[j], 0x0c030c02u);
                 }
             }
+            const bool sgn = c.flags & F_SIGNED;
+            const uint32_t full = low_mask32(c.bps);
+            if (sgn) {
+                const uint32_t flip = (1u << (c.bps - 1)) * 0x00010001u, keep = full * 0x00010001u;
+#pragma unroll
+                for (uint32_t j = 0; j < NW; j++) pw[j] = (pw[j] ^ flip) & keep;
+            }
             // the word before this chunk: the neighbour lane's last word, or the carried sample
-            const uint32_t before = wave_shr1(pw[NW - 1], carry << 16);
+            const uint32_t cbias = sgn ? (carry ^ (1u << (c.bps - 1))) & full : carry;
+            const uint32_t before = wave_shr1(pw[NW - 1], cbias << 16);
             carry = wave_last(pw[NW - 1]) >> 16;
+            if (sgn) carry ^= 1u << (c.bps - 1);       // back to the raw form the next round expects
             if (act) {
-                const uint32_t xm = c.xmax | (c.xmax << 16);
+                const uint32_t xm = (sgn ? full : c.xmax) * 0x00010001u;
                 uint32_t dw[NW];
 #pragma unroll
                 for (uint32_t j = 0; j < NW; j++)
