@@ -499,8 +499,6 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const uint32_t stride = Rows<BS, BYTES>::stride_words(bs);
     uint32_t *rows = smem + (size_t)wave * 64u * stride;
-    const bool pp = c.flags & F_PREPROCESS;
-    constexpr bool WIDE_T = (BYTES >= 3);
 
     const uint64_t gwave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     uint64_t sg = gwave * segs_per_wave;
