@@ -141,6 +141,10 @@ AEC_GPU_API int aec_gpu_decode_segments_async(aec_gpu_ctx *ctx, const aec_gpu_pa
  * The call may allocate table workspace (up to ~340 MiB for inputs of 8 MiB and more).
  */
 AEC_GPU_API void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits);
+
+/* Release the context's workspaces that are larger than keep_bytes (they are re-allocated on
+ * demand); for callers that keep a context around between jobs of very different size. */
+AEC_GPU_API void aec_gpu_trim(aec_gpu_ctx *ctx, size_t keep_bytes);
 AEC_GPU_API int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
                                     size_t in_bytes, uint64_t start_bit, uint64_t *d_rsi_bit_offsets,
                                     uint64_t max_rsi, aec_gpu_dec_result *d_result, void *stream);

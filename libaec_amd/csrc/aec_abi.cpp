@@ -11,8 +11,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <vector>
 
 #include "../../include/aec_gpu.h"
@@ -22,6 +25,16 @@
 using namespace aec;
 
 namespace {
+
+// AEC_ABI_TRACE=1 in the environment: say on stderr where a device-side failure was detected
+int fail_at(int code, int line)
+{
+    static const bool trace = getenv("AEC_ABI_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "libaec (MI355X): error %d raised at aec_abi.cpp:%d (last HIP error: %s)\n", code, line,
+                       hipGetErrorString(hipPeekAtLastError()));
+    return code;
+}
+#define AEC_FAIL(code) fail_at((code), __LINE__)
 
 struct DevBuf {
     void *p = nullptr;
@@ -52,6 +65,7 @@ struct internal_state {
     bool encoder;
     aec_gpu_params prm;
     Cfg cfg;                       // derived values (sizes are per batch, not used from here)
+    int device;
     aec_gpu_ctx *ctx;
     hipStream_t stream;
     DevBuf d_in, d_out, d_off, d_res;
@@ -84,16 +98,81 @@ struct internal_state {
 
 namespace {
 
+// Device-side belongings of a stream.  Callers like the HDF5 SZIP filter run one
+// aec_buffer_encode / aec_buffer_decode per chunk, i.e. an init / end cycle per megabyte: creating
+// a HIP stream, a pinned result record and four device buffers each time (and freeing them, which
+// synchronises the device) costs more than coding the chunk.  So *_end parks them in a small
+// process-wide pool and *_init takes them from there.  Buffers above kKeepBytes are released
+// first; the pool is never torn down at exit (the driver reclaims it with the process -- calling
+// into HIP from static destructors is not safe).
+struct Kit {
+    int device = -1;
+    aec_gpu_ctx *ctx = nullptr;
+    hipStream_t stream = nullptr;
+    DevBuf d_in, d_out, d_off, d_res;
+    void *h_res = nullptr;
+};
+constexpr size_t kPoolMax = 8, kKeepBytes = (size_t)64 << 20;
+std::mutex g_pool_mu;
+std::vector<Kit> *g_pool = nullptr;      // heap object on purpose: no destructor at exit
+
+void destroy_kit(Kit &k)
+{
+    k.d_in.release();
+    k.d_out.release();
+    k.d_off.release();
+    k.d_res.release();
+    if (k.h_res) (void)hipHostFree(k.h_res);
+    if (k.stream) (void)hipStreamDestroy(k.stream);
+    if (k.ctx) aec_gpu_destroy(k.ctx);
+    k = Kit{};
+}
+
+bool take_kit(int device, Kit *out)
+{
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (!g_pool) return false;
+    for (size_t i = 0; i < g_pool->size(); i++)
+        if ((*g_pool)[i].device == device) {
+            *out = (*g_pool)[i];
+            g_pool->erase(g_pool->begin() + (ptrdiff_t)i);
+            return true;
+        }
+    return false;
+}
+
+void park_kit(Kit &k)
+{
+    for (DevBuf *b : {&k.d_in, &k.d_out, &k.d_off})
+        if (b->cap > kKeepBytes) b->release();
+    aec_gpu_trim(k.ctx, kKeepBytes);
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        if (!g_pool) g_pool = new (std::nothrow) std::vector<Kit>();
+        if (g_pool && g_pool->size() < kPoolMax) {
+            g_pool->push_back(k);
+            k = Kit{};
+            return;
+        }
+    }
+    destroy_kit(k);
+}
+
 void free_state(internal_state *s)
 {
     if (!s) return;
-    s->d_in.release();
-    s->d_out.release();
-    s->d_off.release();
-    s->d_res.release();
-    if (s->h_res) (void)hipHostFree(s->h_res);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
-    if (s->ctx) aec_gpu_destroy(s->ctx);
+    Kit k;
+    k.device = s->device;
+    k.ctx = s->ctx;
+    k.stream = s->stream;
+    k.d_in = s->d_in;
+    k.d_out = s->d_out;
+    k.d_off = s->d_off;
+    k.d_res = s->d_res;
+    k.h_res = s->h_res;
+    // everything enqueued for this stream object has been waited for by the calls that enqueued it
+    if (k.ctx && k.stream && k.h_res && k.d_res.p) park_kit(k);
+    else destroy_kit(k);
     delete s;
 }
 
@@ -102,9 +181,9 @@ int init_common(struct aec_stream *strm, bool enc)
     aec_gpu_params prm{strm->bits_per_sample, strm->block_size, strm->rsi, strm->flags};
     Cfg c;
     const int rc = make_cfg(prm.bits_per_sample, prm.block_size, prm.rsi, prm.flags, 0, enc, &c);
-    if (rc != RC_OK) return rc;
+    if (rc != RC_OK) return AEC_FAIL(rc);
     internal_state *s = new (std::nothrow) internal_state();
-    if (!s) return AEC_MEM_ERROR;
+    if (!s) return AEC_FAIL(AEC_MEM_ERROR);
     s->encoder = enc;
     s->prm = prm;
     s->cfg = c;
@@ -124,10 +203,21 @@ int init_common(struct aec_stream *strm, bool enc)
     s->ctx = nullptr;
     s->stream = nullptr;
     s->h_res = nullptr;
-    if (aec_gpu_create(&s->ctx) != RC_OK || hipStreamCreate(&s->stream) != hipSuccess ||
-        hipHostMalloc(&s->h_res, 256, hipHostMallocDefault) != hipSuccess || !s->d_res.ensure(256)) {
+    s->device = -1;
+    Kit k;
+    if (hipGetDevice(&s->device) == hipSuccess && take_kit(s->device, &k)) {
+        s->ctx = k.ctx;
+        s->stream = k.stream;
+        s->d_in = k.d_in;
+        s->d_out = k.d_out;
+        s->d_off = k.d_off;
+        s->d_res = k.d_res;
+        s->h_res = k.h_res;
+        aec_gpu_set_index_hint(s->ctx, 0);
+    } else if (s->device < 0 || aec_gpu_create(&s->ctx) != RC_OK || hipStreamCreate(&s->stream) != hipSuccess ||
+               hipHostMalloc(&s->h_res, 256, hipHostMallocDefault) != hipSuccess || !s->d_res.ensure(256)) {
         free_state(s);
-        return AEC_MEM_ERROR;   // no usable HIP device: the product has no CPU path
+        return AEC_FAIL(AEC_MEM_ERROR);   // no usable HIP device: the product has no CPU path
     }
     strm->state = s;
     strm->total_in = 0;         // reference encode.c:897-898, decode.c:785-786
@@ -163,31 +253,31 @@ int encode_batch(internal_state *s, const uint8_t *data, size_t nbytes, struct a
     const size_t cap = aec_gpu_encode_bound(&s->prm, nbytes);
     const uint64_t nrsi = aec_gpu_rsi_count(&s->prm, nbytes);
     (void)nrsi;
-    if (!s->d_in.ensure(nbytes + 16) || !s->d_out.ensure(cap)) return AEC_MEM_ERROR;
+    if (!s->d_in.ensure(nbytes + 16) || !s->d_out.ensure(cap)) return AEC_FAIL(AEC_MEM_ERROR);
     if (hipMemcpyAsync(s->d_in.p, data, nbytes, hipMemcpyHostToDevice, s->stream) != hipSuccess)
-        return AEC_MEM_ERROR;
+        return AEC_FAIL(AEC_MEM_ERROR);
     const int rc = aec_gpu_encode_async(s->ctx, &s->prm, s->d_in.p, nbytes, s->d_out.p, cap, s->part_bits,
                                         s->k, nullptr, static_cast<aec_gpu_enc_result *>(s->d_res.p),
                                         s->stream);
-    if (rc != RC_OK) return rc;
+    if (rc != RC_OK) return AEC_FAIL(rc);
     if (hipMemcpyAsync(s->h_res, s->d_res.p, sizeof(aec_gpu_enc_result), hipMemcpyDeviceToHost,
                        s->stream) != hipSuccess ||
         hipStreamSynchronize(s->stream) != hipSuccess)
-        return AEC_MEM_ERROR;
+        return AEC_FAIL(AEC_MEM_ERROR);
     const aec_gpu_enc_result res = *static_cast<aec_gpu_enc_result *>(s->h_res);
-    if (res.overflow) return AEC_MEM_ERROR;   // cannot happen: cap is the worst case
+    if (res.overflow) return AEC_FAIL(AEC_MEM_ERROR);   // cannot happen: cap is the worst case
     const uint64_t bits = (uint64_t)s->part_bits + res.total_bits;
     const size_t whole = (size_t)(bits / 8), nb = (size_t)((bits + 7) / 8);
     size_t direct = 0;
     if (strm && s->outq.empty()) direct = whole < strm->avail_out ? whole : strm->avail_out;
     const uint8_t *d_bytes = static_cast<const uint8_t *>(s->d_out.p);
     if (direct && hipMemcpy(strm->next_out, d_bytes, direct, hipMemcpyDeviceToHost) != hipSuccess)
-        return AEC_MEM_ERROR;
+        return AEC_FAIL(AEC_MEM_ERROR);
     const size_t at = s->outq.size();
     s->outq.resize(at + (nb - direct));
     if (nb > direct &&
         hipMemcpy(s->outq.data() + at, d_bytes + direct, nb - direct, hipMemcpyDeviceToHost) != hipSuccess)
-        return AEC_MEM_ERROR;
+        return AEC_FAIL(AEC_MEM_ERROR);
     if (direct) strm->next_out[0] |= s->part_byte;
     else if (nb) s->outq[at] |= s->part_byte;
     s->part_bits = (uint32_t)(bits % 8);
@@ -216,9 +306,9 @@ int decode_staged(internal_state *s, struct aec_stream *strm)
     // plus the reference sample when the preprocessor is on; that bounds the offset table
     const uint64_t min_rsi_bits = (uint64_t)c.segs_per_rsi * (c.id_len + 2) + ((c.flags & F_PREPROCESS) ? c.bps : 0);
     const uint64_t max_rsi = avail_bits / min_rsi_bits + 2;
-    if (!s->d_in.ensure(nbytes + 16) || !s->d_off.ensure((max_rsi + 1) * 8)) return AEC_MEM_ERROR;
+    if (!s->d_in.ensure(nbytes + 16) || !s->d_off.ensure((max_rsi + 1) * 8)) return AEC_FAIL(AEC_MEM_ERROR);
     if (hipMemcpyAsync(s->d_in.p, s->stage.data(), nbytes, hipMemcpyHostToDevice, s->stream) != hipSuccess)
-        return AEC_MEM_ERROR;
+        return AEC_FAIL(AEC_MEM_ERROR);
     aec_gpu_dec_result *dres = static_cast<aec_gpu_dec_result *>(s->d_res.p);
     aec_gpu_dec_result *hres = static_cast<aec_gpu_dec_result *>(s->h_res);
     // Look-ahead of the speculative index = a small multiple of the average coded RSI: measured on
@@ -232,23 +322,23 @@ int decode_staged(internal_state *s, struct aec_stream *strm)
     aec_gpu_set_index_hint(s->ctx, hint + hint / 2);
     int rc = aec_gpu_index_async(s->ctx, &s->prm, s->d_in.p, nbytes, start_rel,
                                  static_cast<uint64_t *>(s->d_off.p), max_rsi, dres, s->stream);
-    if (rc != RC_OK) return rc;
+    if (rc != RC_OK) return AEC_FAIL(rc);
     if (hipMemcpyAsync(hres, dres, sizeof(*hres), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
         hipStreamSynchronize(s->stream) != hipSuccess)
-        return AEC_MEM_ERROR;
+        return AEC_FAIL(AEC_MEM_ERROR);
     const aec_gpu_dec_result idx = *hres;
     if (idx.n_rsi) s->rsi_bits_seen = (idx.end_bit - start_rel) / idx.n_rsi;
     const uint64_t n_items = idx.n_rsi + (idx.tail_blocks ? 1 : 0);
     const uint64_t blocks = idx.n_rsi * c.rsi + idx.tail_blocks;
     const size_t blk_bytes = (size_t)c.bs * c.bytes;
     if (blocks * c.bs > s->delivered) {
-        if (!s->d_out.ensure(blocks * blk_bytes + 16)) return AEC_MEM_ERROR;
+        if (!s->d_out.ensure(blocks * blk_bytes + 16)) return AEC_FAIL(AEC_MEM_ERROR);
         rc = aec_gpu_decode_async(s->ctx, &s->prm, s->d_in.p, nbytes, static_cast<uint64_t *>(s->d_off.p),
                                   n_items, blocks, s->d_out.p, dres, s->stream);
-        if (rc != RC_OK) return rc;
+        if (rc != RC_OK) return AEC_FAIL(rc);
         if (hipMemcpyAsync(hres, dres, sizeof(*hres), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
             hipStreamSynchronize(s->stream) != hipSuccess)
-            return AEC_MEM_ERROR;
+            return AEC_FAIL(AEC_MEM_ERROR);
         if (hres->status == DEC_DATA_ERROR) return AEC_DATA_ERROR;
         if (hres->status != DEC_OK) return AEC_DATA_ERROR;   // the index pass vouched for completeness
         const size_t skip = (size_t)s->delivered * c.bytes;
@@ -260,7 +350,7 @@ int decode_staged(internal_state *s, struct aec_stream *strm)
             direct -= direct % c.bytes;
         }
         if (direct) {
-            if (hipMemcpy(strm->next_out, d_bytes, direct, hipMemcpyDeviceToHost) != hipSuccess) return AEC_MEM_ERROR;
+            if (hipMemcpy(strm->next_out, d_bytes, direct, hipMemcpyDeviceToHost) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
             strm->next_out += direct;
             strm->avail_out -= direct;
         }
@@ -269,7 +359,7 @@ int decode_staged(internal_state *s, struct aec_stream *strm)
             s->outq.resize(at + (total - skip - direct));
             if (hipMemcpy(s->outq.data() + at, d_bytes + direct, total - skip - direct, hipMemcpyDeviceToHost) !=
                 hipSuccess)
-                return AEC_MEM_ERROR;
+                return AEC_FAIL(AEC_MEM_ERROR);
         }
     }
     // advance the cursor to the start of the (possibly empty) trailing partial RSI
@@ -278,7 +368,7 @@ int decode_staged(internal_state *s, struct aec_stream *strm)
         uint64_t off = 0;
         if (hipMemcpy(&off, static_cast<uint64_t *>(s->d_off.p) + idx.n_rsi, 8, hipMemcpyDeviceToHost) !=
             hipSuccess)
-            return AEC_MEM_ERROR;
+            return AEC_FAIL(AEC_MEM_ERROR);
         new_start_rel = off;
         s->delivered = idx.tail_blocks * c.bs;
     } else {
@@ -413,7 +503,7 @@ int aec_decode(struct aec_stream *strm, int flush)
         if (rc == AEC_DATA_ERROR) s->sticky_error = rc;
     }
     if (rc != AEC_OK) return rc;          // reference decode.c:818-819 (totals left as they are)
-    if (strm->avail_out > 0 && strm->avail_out < bytes) return AEC_MEM_ERROR;   // decode.c:821-823
+    if (strm->avail_out > 0 && strm->avail_out < bytes) return AEC_FAIL(AEC_MEM_ERROR);   // decode.c:821-823
     strm->total_in -= strm->avail_in;     // reference decode.c:827-828
     strm->total_out -= strm->avail_out;
     return AEC_OK;

@@ -7,6 +7,9 @@
 
 #include "../../include/aec_gpu.h"
 #include "aec_cfg.h"
+#include <cstdio>
+#include <cstdlib>
+
 #include "aec_kernels.h"
 
 using namespace aec;
@@ -127,14 +130,6 @@ int aec_gpu_reserve(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes)
     const size_t need = enc_workspace_bytes(c, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5]);
     if (need > ctx->ws_bytes) {
         if (ctx->ws) (void)hipFree(ctx->ws);
-    if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
-    if (ctx->idx_side_ok) {
-        (void)hipStreamDestroy(ctx->idx_side.stream);
-        for (int b = 0; b < 2; b++) {
-            (void)hipEventDestroy(ctx->idx_side.spec_done[b]);
-            (void)hipEventDestroy(ctx->idx_side.walk_done[b]);
-        }
-    }
         ctx->ws = nullptr;
         ctx->ws_bytes = 0;
         if (hipMalloc(&ctx->ws, need) != hipSuccess) return RC_MEM_ERROR;
@@ -286,10 +281,29 @@ int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d
     launch_index(c, static_cast<const uint8_t *>(d_in), in_bytes, start_bit, d_rsi_bit_offsets, max_rsi,
                  reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream), ctx->idx_ws,
                  ctx->idx_ws_bytes, hint, ctx->idx_side_ok ? &ctx->idx_side : nullptr);
-    return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && getenv("AEC_ABI_TRACE"))
+        fprintf(stderr, "aec_gpu_index_async: %s (in_bytes %zu start %llu max_rsi %llu hint %llu ws %zu)\n",
+                hipGetErrorString(e), in_bytes, (unsigned long long)start_bit, (unsigned long long)max_rsi,
+                (unsigned long long)hint, ctx->idx_ws_bytes);
+    return e == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
 void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits) { ctx->idx_hint = rsi_bits; }
+
+void aec_gpu_trim(aec_gpu_ctx *ctx, size_t keep_bytes)
+{
+    if (ctx->ws && ctx->ws_bytes > keep_bytes) {
+        (void)hipFree(ctx->ws);
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    if (ctx->idx_ws && ctx->idx_ws_bytes > keep_bytes) {
+        (void)hipFree(ctx->idx_ws);
+        ctx->idx_ws = nullptr;
+        ctx->idx_ws_bytes = 0;
+    }
+}
 
 int aec_gpu_index_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
                               const uint64_t *d_chunk_offsets, uint64_t n_chunks, uint64_t rsi_per_chunk,
