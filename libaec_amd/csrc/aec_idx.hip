@@ -512,7 +512,12 @@ SpecGeom spec_geom(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint)
     if (look > kSpecWMax - 2048) look = kSpecWMax - 2048;
     if (look < 2048) look = 2048;
     g.look = (uint32_t)((look + 31) & ~31ull);
-    uint64_t core = (total_bits / 2048 + 1023) & ~1023ull;
+    // about one window per CU for small inputs, and windows of at least three RSIs (a hop of the
+    // walker costs a memory round trip: it should cover several RSIs)
+    uint64_t core = (total_bits / 256 + 1023) & ~1023ull;
+    uint64_t three = 3 * rsi_bits_hint;
+    if (three > total_bits / 64) three = total_bits / 64;      // (tiny inputs: keep 64 windows at least)
+    if (core < three) core = (three + 1023) & ~1023ull;
     if (core < 2048) core = 2048;
     if (core > 16384) core = 16384;
     if (core > kSpecWMax - g.look) core = (kSpecWMax - g.look) & ~1023ull;
