@@ -3,6 +3,7 @@
 at full size -- through round trips and hashes."""
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -80,8 +81,9 @@ def test_golden_vectors(api, golden):
 
 
 def test_random_sweep_vs_oracle(api):
-    rng = np.random.default_rng(2025)
-    for it in range(150):
+    # AEC_SWEEP_ITERS / AEC_SWEEP_SEED in the environment turn this into a soak test
+    rng = np.random.default_rng(int(os.environ.get("AEC_SWEEP_SEED", "2025")))
+    for it in range(int(os.environ.get("AEC_SWEEP_ITERS", "150"))):
         bps = int(rng.integers(1, 33))
         flags = 0
         if rng.random() < 0.75:
@@ -100,7 +102,7 @@ def test_random_sweep_vs_oracle(api):
         else:
             bs = int(rng.choice([8, 16, 32, 64]))
         rsi = int(rng.choice([1, 2, 3, 5, 17, 63, 64, 65, 128, 130, 300, 4096]))
-        n = int(rng.integers(1, 20000))
+        n = int(rng.integers(1, 20000)) if rng.random() < 0.9 else int(rng.integers(20000, 400000))
         mode = rng.integers(0, 3)
         if mode == 0:
             vals = random_walk_samples(rng, n, bps, flags, scale=float(rng.choice([0.3, 1, 5, 50, 1000])),
