@@ -414,14 +414,25 @@ AEC_HD void emit_small(BitWriter<Sink> &w, const uint32_t *d, const Cfg &c, uint
     const bool is_zero = live && opt == OPT_ZERO;
     const uint32_t k = is_split ? k_or_fs : 0u;
     const uint32_t km = low_mask32(k);
-    uint64_t ua = is_zero ? 1u : 0u;     // unary region, right aligned
-    uint64_t fa = 0;                     // field region, right aligned
+    // Unary and field regions, right aligned.  The loop carries no per-sample predicate: lanes
+    // that are not split blocks run it on k = 0 and have both registers replaced afterwards; only
+    // sample 0 can be the reference slot (skipped).  Shifts are taken modulo 64: a lane whose
+    // codes do not fit is not `live` here (small_eligible) and goes through emit_block.
+    uint64_t ua = 0, fa = 0;
 #pragma unroll
     for (uint32_t i = 0; i < (uint32_t)BS; i++) {
-        const bool act = is_split && i >= ref;
         const uint32_t t = d[i] >> k;
-        ua = (ua << (act ? (t + 1u) & 63u : 0u)) | (act ? 1u : 0u);
-        fa = (fa << (act ? k : 0u)) | (act ? d[i] & km : 0u);
+        if (i == 0) {
+            ua = ref ? 0u : 1u;                          // (1 << (t + 1)) >> (t + 1) == the lone 1
+            fa = ref ? 0u : (uint64_t)(d[0] & km);
+        } else {
+            ua = (ua << ((t + 1u) & 63u)) | 1u;
+            fa = (fa << k) | (d[i] & km);
+        }
+    }
+    if (!is_split) {
+        ua = is_zero ? 1u : 0u;
+        fa = 0;
     }
     if (AEC_ANY(is_se)) {
 #pragma unroll
@@ -431,12 +442,27 @@ AEC_HD void emit_small(BitWriter<Sink> &w, const uint32_t *d, const Cfg &c, uint
             ua = (ua << (is_se ? (m + 1u) & 63u : 0u)) | (is_se ? 1u : 0u);
         }
     }
+    // header: option id (+ the low-entropy selector bit), then the reference sample; it rides in
+    // front of the unary region when the two fit one 64-bit register -- one put less
+    const uint32_t idv = is_split ? k + 1u : (is_se ? 1u : 0u);
+    const uint32_t idb = c.id_len + (is_split ? 0u : 1u);
+    const uint32_t hb = idb + (ref ? c.bps : 0u);
+    const bool merged = hb + ubits <= 64u;
+    if (AEC_ANY(live && !merged)) {
+        if (live && !merged) {
+            w.put(idv, idb);
+            if (ref) w.put(ref_sample, c.bps);
+        }
+    }
     if (live) {
-        const uint32_t idv = is_split ? k + 1u : (is_se ? 1u : 0u);
-        w.put(idv, c.id_len + (is_split ? 0u : 1u));
-        if (ref) w.put(ref_sample, c.bps);
-        if (ubits > 32) w.put((uint32_t)(ua >> 32), ubits - 32);
-        w.put((uint32_t)ua, ubits > 32 ? 32u : ubits);
+        uint32_t nb = ubits;
+        if (merged) {
+            const uint64_t hdr = ref ? ((uint64_t)idv << c.bps) | ref_sample : (uint64_t)idv;
+            ua |= hdr << (ubits & 63u);                  // merged implies ubits < 64 (hb >= 1)
+            nb = ubits + hb;
+        }
+        if (nb > 32) w.put((uint32_t)(ua >> 32), nb - 32);
+        w.put((uint32_t)ua, nb > 32 ? 32u : nb);
         if (fbits > 32) w.put((uint32_t)(fa >> 32), fbits - 32);
         if (fbits) w.put((uint32_t)fa, fbits > 32 ? 32u : fbits);
         w.finish();
