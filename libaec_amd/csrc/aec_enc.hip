@@ -823,6 +823,13 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
                 emit_small<(BS > 0 && BS <= 16 ? BS : 8)>(bw, d, c, opt, karg, ref, ref_sample, ubits, fbits, small);
                 done = done || small;
             }
+            if (BS == 32) {
+                // blocks of 32: the split option appended in groups (aec_lane.h emit_split_groups;
+                // C3 pack 2.40 -> 2.19 ms.  For blocks of 64 it costs registers and was slower.)
+                const bool grp = !done && opt == OPT_SPLIT;
+                emit_split_groups<32>(bw, d, c, karg, ref, ref_sample, grp);
+                done = done || grp;
+            }
             if (__any(!done)) {
                 if (!done) emit_block<BS>(bw, d, c, opt, karg, ref, ref_sample);
             }

@@ -347,6 +347,65 @@ struct BitWriter {
     }
 };
 
+// Split option for blocks of 32 or 64 samples (reference encode.c:520-534): the unary parts are
+// assembled sixteen at a time and the fields eight at a time in a 64-bit register and appended with
+// two puts per group, instead of one put (and its flush test) per sample.  A group that does not
+// fit -- unary parts of more than 64 bits, k above 8 -- is appended sample by sample.
+template <int BS, class Sink>
+AEC_HD void emit_split_groups(BitWriter<Sink> &w, const uint32_t *d, const Cfg &c, uint32_t k, uint32_t ref,
+                              uint32_t ref_sample, bool live)
+{
+    static_assert(BS % 16 == 0, "whole groups");
+    if (!live) return;
+    w.put(k + 1u, c.id_len);
+    if (ref) w.put(ref_sample, c.bps);
+#pragma unroll
+    for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += 16) {
+        uint64_t ua = 0;
+        uint32_t bits = 0;
+        bool big = false;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) {
+            const uint32_t i = g0 + j;
+            const uint32_t t = d[i] >> k;
+            const bool skip = i == 0 && ref;                // the reference slot carries no code
+            big = big || (!skip && t >= 64u);
+            const uint32_t n1 = skip ? 0u : t + 1u;
+            bits += n1 & 127u;
+            ua = (ua << (n1 & 63u)) | (skip ? 0u : 1u);
+        }
+        if (!big && bits <= 64u) {
+            if (bits > 32u) w.put((uint32_t)(ua >> 32), bits - 32u);
+            if (bits) w.put((uint32_t)ua, bits > 32u ? 32u : bits);
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < 16; j++)
+                if (!(g0 + j == 0 && ref)) w.unary(d[g0 + j] >> k);
+        }
+    }
+    if (k != 0 && k <= 8u) {
+        const uint32_t m = low_mask32(k);
+#pragma unroll
+        for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += 8) {
+            uint64_t fa = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const bool skip = g0 + j == 0 && ref;
+                fa = (fa << (skip ? 0u : k)) | (skip ? 0u : d[g0 + j] & m);
+            }
+            const uint32_t bits = (8u - ((g0 == 0 && ref) ? 1u : 0u)) * k;
+            if (bits > 32u) w.put((uint32_t)(fa >> 32), bits - 32u);
+            w.put((uint32_t)fa, bits > 32u ? 32u : bits);
+        }
+    } else if (k != 0) {
+        const uint32_t m = low_mask32(k);
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)BS; i++)
+            if (i >= ref) w.put(d[i] & m, k);
+    }
+    w.finish();
+}
+
 // Emit one block's CDS (reference encode.c:520-583).  d[0] of a reference block is ignored
 // for SPLIT/SE payloads exactly as the reference does (sample slot 0 holds 0 / is skipped).
 template <int BS, class Sink>

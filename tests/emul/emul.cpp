@@ -103,6 +103,8 @@ static int encode_t(const Cfg &c, const uint8_t *in, uint8_t *out, size_t cap, u
                                small_eligible(c, c.bs, opt, karg, ref, meta_len(meta[l]), ubits, fbits);
             if (small && c.bs == 8) emit_small<8>(w, &d[l * c.bs], c, opt, karg, ref, ref_sample, ubits, fbits, true);
             else if (small) emit_small<16>(w, &d[l * c.bs], c, opt, karg, ref, ref_sample, ubits, fbits, true);
+            else if (opt == OPT_SPLIT && c.bs == 32) emit_split_groups<32>(w, &d[l * c.bs], c, karg, ref, ref_sample, true);
+            else if (opt == OPT_SPLIT && c.bs == 64) emit_split_groups<64>(w, &d[l * c.bs], c, karg, ref, ref_sample, true);
             else emit_block<0>(w, &d[l * c.bs], c, opt, karg, ref, ref_sample);
             off += meta_len(meta[l]);
         }
