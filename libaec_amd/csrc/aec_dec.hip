@@ -1,12 +1,16 @@
 // aec_dec.hip -- gfx950 decoder kernels for the CCSDS 121.0-B-2 adaptive entropy coder.
 //
-//   k_decode  ONE LANE PER RSI.  A coded data set can only be located by parsing its
+//   k_decode  ONE LANE PER RSI (or per 64-block SEGMENT when the encoder's segment table is at
+//             hand: template parameter SEG).  A coded data set can only be located by parsing its
 //             predecessor (the stream has no lengths, reference src/decode.c:402-421), so the
 //             bit-serial dependency is kept inside a lane: the lane walks its RSI block by block
 //             with a 64-bit window (reference decode.c:222-340), runs the inverse predictor
 //             (decode.c:67-141), which is a serial chain as well, and stores whole blocks in the
 //             caller's byte order (decode.c:144-189).  Parallelism comes from the RSIs: 4 GiB of
-//             16-bit / block 16 / rsi 128 data is one million independent lanes.
+//             16-bit / block 16 / rsi 128 data is one million independent lanes.  The compressed
+//             words reach a lane through its column of an LDS ring (16-byte loads issued ahead);
+//             blocks of 16 or 32 bytes leave through LDS rows written out transposed, as whole
+//             64-byte sectors -- per-lane 16-byte stores 2 KiB apart bounded the kernel.
 //   (the index pass for streams that arrive without an offset table lives in aec_idx.hip)
 #include <hip/hip_runtime.h>
 
