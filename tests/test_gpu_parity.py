@@ -117,6 +117,41 @@ def test_random_sweep_vs_oracle(api):
         check_roundtrip(api, f"it{it}-n{bps}-j{bs}-r{rsi}-f{flags}-len{n}", bps, bs, rsi, flags, data)
 
 
+def test_concurrent_streams_share_the_resource_pool(api):
+    """Four host threads run one-shot and streaming calls at the same time (ctypes releases the GIL):
+    streams are independent objects (SURVEY 8(b) threading contract) and the device-side resources
+    they take from / return to the pool of the ABI layer must never be shared by two live streams."""
+    import threading
+    cases = []
+    rng = np.random.default_rng(99)
+    for bps, bs, rsi, flags, n in ((16, 16, 128, PP, 300_000), (8, 8, 128, PP | MSB, 500_000),
+                                   (32, 32, 64, PP | SGN | MSB, 120_000), (12, 64, 17, PP, 90_000)):
+        vals = random_walk_samples(rng, n, bps, flags, scale=3.0, zero_frac=0.2)
+        data = pack_samples(vals, bps, flags)
+        rc, want, *_ = oracle_encode(data, bps, bs, rsi, flags)
+        assert rc == AEC_OK
+        cases.append((bps, bs, rsi, flags, data, want))
+    errors = []
+
+    def work(tid):
+        try:
+            for it in range(12):
+                bps, bs, rsi, flags, data, want = cases[(tid + it) % len(cases)]
+                rc, enc = api.aec_buffer_encode(data, bps, bs, rsi, flags)
+                assert rc == AEC_OK and enc == want, ("encode", tid, it)
+                rc, dec = api.aec_buffer_decode(enc, bps, bs, rsi, flags, len(data))
+                assert rc == AEC_OK and dec == bytes(data), ("decode", tid, it)
+        except Exception as e:          # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+
+
 def test_edge_sizes_and_errors(api):
     # empty input -> single zero byte (reference encode.c:686-695)
     rc, enc = api.aec_buffer_encode(b"", 16, 16, 128, PP)
