@@ -10,6 +10,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The built libraries are not in the repository's history: a fresh checkout builds them first
+    # (hipcc cross-compiles gfx950 without a GPU; the oracle needs gcc only).
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "libaec_amd", "lib", "libaec.so.0")):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(root, "libaec_amd", "csrc")], check=True,
+                       stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(root, "oracle", "_build", "libaec_oracle.so")):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, stdout=subprocess.DEVNULL)
 
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
