@@ -237,6 +237,43 @@ def test_streaming_matches_one_shot(api):
         assert bytes(dec) == dec_o, (bps, bs, rsi, flags)
 
 
+def test_streaming_decode_resumes_inside_rsis(api):
+    """Streaming decode of streams with full-size RSIs, fed in pieces that end anywhere: every call
+    re-indexes from the start of the last incomplete RSI (speculative tables + walker from a bit
+    offset inside the staged bytes) and must deliver exactly the samples not delivered before."""
+    from libaec_amd.api import Decoder
+    rng = np.random.default_rng(int(os.environ.get("AEC_SWEEP_SEED", "17")))
+    for bps, bs, rsi, flags in ((16, 16, 128, PP), (8, 8, 128, PP | MSB), (12, 32, 64, PP | SGN)):
+        nb = bytes_per_sample(bps, flags)
+        n = bs * rsi * 37 + 5 * bs + 3
+        vals = random_walk_samples(rng, n, bps, flags, scale=4.0, zero_frac=0.15)
+        data = pack_samples(vals, bps, flags)
+        rc, whole, *_ = oracle_encode(data, bps, bs, rsi, flags)
+        nblk = (n + bs - 1) // bs
+        rc, want, _ = oracle_decode(whole, bps, bs, rsi, flags, nblk * bs * nb)
+        d = Decoder(bps, bs, rsi, flags)
+        dec = bytearray()
+        pos = 0
+        while pos < len(whole):
+            step = int(rng.choice([1, 700, 3000, 20000, 60000]))
+            chunk = whole[pos:pos + step]
+            off = 0
+            while True:
+                # never more room than the caller expects in all: a rest-of-segment zero run that
+                # closes the short last RSI would otherwise be paid out to the nominal segment end
+                # (the reference does the same -- the stream does not say where the data stop)
+                room = min(int(rng.choice([nb, 1000 * nb, 1 << 20])), len(want) - len(dec))
+                rc, used, got = d.call(chunk[off:], room, AEC_NO_FLUSH)
+                assert rc == AEC_OK
+                dec += got
+                off += used
+                if off >= len(chunk) and not got:
+                    break
+            pos += step
+        d.end()
+        assert bytes(dec) == want, (bps, bs, rsi, flags)
+
+
 def test_device_api_offsets_index_and_carry(gpu):
     import torch
     bps, bs, rsi, flags = 16, 16, 128, PP
