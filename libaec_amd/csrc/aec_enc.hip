@@ -773,6 +773,8 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
     if (sg < sg_end) feeder.prefetch(c, in, gnext, lane);
     uint32_t pending = 0;        // open tail word of the previous segment (stream bit order)
     bool first_seg = true, carried_shared = false;
+    // the image buffer starts out zero and every word is zeroed again when it is copied out
+    for (uint32_t w = lane; w < obuf_words; w += kWave) obuf[w] = 0u;
     for (; sg < sg_end; sg++) {
         const auto cur = feeder.pre;
         const Seg g = gnext;
@@ -804,7 +806,7 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
         const uint32_t nwords = (lead + total + 31u) >> 5;
         // image of the segment; its first word continues the previous segment of this wave, whose
         // open tail word was kept in `pending` instead of being written out
-        for (uint32_t w = lane; w < nwords; w += kWave) obuf[w] = (w == 0) ? pending : 0u;
+        if (lane == 0) obuf[0] = pending;
         wave_lds_fence();
 
         {
@@ -846,8 +848,10 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
         // word 0 also holds bits of another wave only in the wave's first segment, or when a one-word
         // segment carried that word along
         const bool left_shared = first_seg ? lead != 0 : carried_shared;
+        const uint32_t tail_word = carry_tail ? obuf[nwords - 1] : 0u;   // uniform: every lane reads the same word
         for (uint32_t w = lane; w < nwords; w += kWave) {
             const uint32_t v = obuf[w];
+            obuf[w] = 0u;
             const uint64_t idx = gw + w;
             const bool is_tail = w == nwords - 1 && tail != 0;
             if (idx < cap_words && !(is_tail && carry_tail)) {
@@ -859,7 +863,7 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
                     __hip_atomic_fetch_or(&out_words[idx], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        pending = carry_tail ? obuf[nwords - 1] : 0u;     // uniform: every lane reads the same word
+        pending = tail_word;
         carried_shared = carry_tail && nwords == 1 && left_shared;
         first_seg = false;
         wave_lds_fence();
