@@ -90,11 +90,23 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, uint32_t)
 __device__ __forceinline__ uint32_t clamp_pack(KClamp c) { return c.lo | (c.hi << 8); }
 __device__ __forceinline__ KClamp clamp_unpack(uint32_t p) { return KClamp{p & 0xFFu, (p >> 8) & 0xFFu}; }
 
+// Inclusive scan of clamp compositions ("first a, then b": both bounds of a are clamped by b).
+// Inside the scan a clamp is a pair of 16-bit halves (lo, hi), so one step is two byte permutes
+// that replicate b's bounds and a packed max and min -- instead of unpacking, four compares /
+// selects and repacking.  In and out: the lo | hi << 8 form of clamp_pack.
 __device__ __forceinline__ uint32_t wave_incl_clamp(uint32_t v, uint32_t)
 {
-    return wave_scan_dpp(v, clamp_pack(kclamp_identity()), [](uint32_t a, uint32_t b) {
-        return clamp_pack(kclamp_then(clamp_unpack(a), clamp_unpack(b)));
+    typedef unsigned short cl16x2 __attribute__((ext_vector_type(2)));
+    const uint32_t wide = (v & 0xFFu) | ((v & 0xFF00u) << 8);
+    const KClamp id = kclamp_identity();
+    const uint32_t r = wave_scan_dpp(wide, id.lo | (id.hi << 16), [](uint32_t a, uint32_t b) {
+        const uint32_t blo = __builtin_amdgcn_perm(b, b, 0x01000100u), bhi = __builtin_amdgcn_perm(b, b, 0x03020302u);
+        const cl16x2 t = __builtin_elementwise_min(
+            __builtin_elementwise_max(__builtin_bit_cast(cl16x2, a), __builtin_bit_cast(cl16x2, blo)),
+            __builtin_bit_cast(cl16x2, bhi));
+        return __builtin_bit_cast(uint32_t, t);
     });
+    return (r & 0xFFu) | ((r >> 8) & 0xFF00u);
 }
 
 struct Seg {
