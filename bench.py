@@ -69,10 +69,11 @@ def typical_tiled(nbytes):
     return np.tile(one, (nbytes + one.size - 1) // one.size)[:nbytes].copy()
 
 
-def measured_traffic(kernel, size_mib):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary taken on this
-    workload size (profiles/*/traffic_*.json, written by tests/prof_traffic.sh: FETCH_SIZE and
-    WRITE_SIZE in separate passes, gfx950 FETCH correction applied where the access is wide)."""
+def measured_traffic(kernel, size_mib, config):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary taken on THIS
+    configuration and workload size (profiles/*/traffic_*.json, written by tests/prof_traffic.sh:
+    FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 FETCH correction applied where the access is
+    wide).  None when there is no summary for exactly this configuration -- never another one's."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_*.json"))):
@@ -80,7 +81,7 @@ def measured_traffic(kernel, size_mib):
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("size_mib") == size_mib and kernel in d.get("kernels", {}):
+        if d.get("size_mib") == size_mib and d.get("config", "c2") == config and kernel in d.get("kernels", {}):
             best = (d["kernels"][kernel]["traffic"], os.path.relpath(f, ROOT))
     return best
 
@@ -111,7 +112,17 @@ def cpu_baseline(sample):
             "compressed_bytes": len(enc)}, enc
 
 
-def cpu_all_cores(host, seconds=10.0):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_all_cores(host, seconds=3.0):
     """The reference on every host core: the input cut into contiguous RSI-aligned shards, one
     independent stream per core (the reference has no threading),
     driven by the pthread harness oracle/mt_harness.c; passes are repeated to about `seconds`."""
@@ -148,21 +159,24 @@ def cpu_all_cores(host, seconds=10.0):
     if reps > 1:
         run(reps)
     return {"value": round(cores * per * reps / dt.value / 1e9, 3), "unit": "GB/s", "cores": cores,
-            "kind": "reference",
+            "cpu": cpu_model(), "kind": "reference",
             "sample": f"{cores} independent streams of {per >> 20} MiB (contiguous RSI-aligned shards of the "
                       f"rank-0 input), one pthread each, {reps} encode+decode passes in memory"}
 
 
-def abi_end_to_end(host):
+def abi_end_to_end(host_sample):
     """PCIe-inclusive rate of the drop-in ABI: aec_buffer_encode / aec_buffer_decode of the product
-    library on HOST buffers the caller already owns (pageable, pages touched): H2D, kernels, D2H;
-    the decode also finds the RSI starts first, because a bare stream carries no entry points.
-    Reported beside `value`, never as `value`."""
+    library on PINNED host buffers: H2D, kernels, D2H; the decode also finds the RSI starts first,
+    because a bare stream carries no entry points.  Reported beside `value`, never as `value`."""
+    import torch
     from libaec_amd import api
     lib = api.library()
-    n = host.size
-    enc = np.zeros(n // 2 + (1 << 20), dtype=np.uint8)
-    dec = np.zeros(n, dtype=np.uint8)
+    n = host_sample.size
+    t_host = torch.from_numpy(host_sample).pin_memory()
+    host = t_host.numpy()
+    t_enc = torch.zeros(n // 2 + (1 << 20), dtype=torch.uint8).pin_memory()
+    t_dec = torch.zeros(n, dtype=torch.uint8).pin_memory()
+    enc, dec = t_enc.numpy(), t_dec.numpy()
 
     def call(fn, src, src_len, dst):
         st = api.AecStream()
@@ -179,7 +193,7 @@ def abi_end_to_end(host):
     assert rc == 0 and rc2 == 0 and dlen == n and np.array_equal(dec, host)
     return {"sample_MiB": n >> 20, "encode_GBps": round(n / t_enc / 1e9, 3),
             "decode_GBps": round(n / t_dec / 1e9, 3), "compressed_bytes": int(clen),
-            "note": "one aec_buffer_encode / aec_buffer_decode call on pageable host buffers through "
+            "note": "one aec_buffer_encode / aec_buffer_decode call on pinned host buffers through "
                     "libaec.so.0: init, H2D, kernels (decode: + RSI index pass), D2H, end"}
 
 
@@ -189,13 +203,17 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size-mib", type=int, default=4096, help="input bytes per GPU (MiB)")
-    ap.add_argument("--cpu-sample-mib", type=int, default=1024)
+    ap.add_argument("--cpu-sample-mib", type=int, default=0,
+                    help="prefix of the input the one-core CPU reference codes (0 = the whole input, "
+                         "1 GiB for the slow 8-bit configuration); the GPU stream is compared with all of it")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="BASELINE.json configuration (the headline metric is quoted on c2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", action="store_true",
-                    help="also report the reference on all host cores and the PCIe-inclusive ABI rate "
-                         "(about a minute more; not part of the timed region)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras of the line: reference on all host cores, bare-stream "
+                         "decode (index pass + lane-per-RSI decode, no encoder side information), "
+                         "PCIe-inclusive ABI rate")
+    ap.add_argument("--extras", action="store_true", help="(kept for old command lines: extras are on by default)")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: independent shard streams, no exchange and no all-gather")
     ap.add_argument("--overlap", action="store_true",
@@ -255,16 +273,51 @@ def main():
     assert dres["status"] == 0, "decode reported an error"
     assert torch.equal(d_dec[:nbytes], d_in), "round trip differs"
 
-    cpu = None
+    cpu, exact = None, None
     if rank == 0 and not args.no_cpu_baseline:
-        sample = host[: min(nbytes, args.cpu_sample_mib << 20)]
+        # One host core codes the WHOLE input with the reference (about 15-30 s; the 8-bit configuration,
+        # four times slower per byte, a 1 GiB prefix) and EVERY byte of the GPU stream is compared with
+        # what it produced (a prefix of whole RSIs codes to a prefix of the stream).
+        mib = args.cpu_sample_mib or (1024 if args.config == "c5" else args.size_mib)
+        sample = host[: min(nbytes, mib << 20)]
         cpu, enc_cpu = cpu_baseline(sample)
-        # the GPU stream's prefix must be the CPU stream (whole RSIs code to a prefix of the stream)
-        nfull = len(enc_cpu) - 1
-        assert d_out[:nfull].cpu().numpy().tobytes() == enc_cpu[:nfull], "GPU stream != CPU reference stream"
+        whole = sample.size == nbytes
+        ncmp = len(enc_cpu) if whole else len(enc_cpu) - 1
+        assert whole is False or len(enc_cpu) == cbytes, "GPU stream length != CPU reference stream length"
+        ref_np = np.frombuffer(enc_cpu, dtype=np.uint8)
+        for o in range(0, ncmp, 256 << 20):
+            hi = min(ncmp, o + (256 << 20))
+            assert np.array_equal(d_out[o:hi].cpu().numpy(), ref_np[o:hi]), "GPU stream != CPU reference stream"
+        exact = {"compared_bytes": ncmp, "of_stream_bytes": cbytes, "input_MiB": sample.size >> 20}
+        del ref_np, enc_cpu
     extras = {}
-    if rank == 0 and args.extras:
+    if rank == 0 and not args.no_extras:
         extras["cpu_baseline_all_cores"] = cpu_all_cores(host)
+        # ---- bare stream: no offset table, no segment table -- what a stream from another producer
+        # looks like.  Index pass (speculative tables + walk) + lane-per-RSI decode, timed together.
+        d_idx = torch.zeros(n_rsi + 2, dtype=torch.int64, device=dev)
+        d_ires = torch.zeros(40, dtype=torch.uint8, device=dev)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        t_idx, t_dec = [], []
+        for _ in range(3):
+            d_idx.zero_()
+            e0.record()
+            codec.index_async(d_out, cbytes, 0, d_idx, n_rsi + 1, d_ires)
+            e1.record()
+            codec.decode_async(d_out, cbytes, d_idx, n_rsi, n_blk, d_dec, d_dres)
+            e2.record()
+            torch.cuda.synchronize()
+            t_idx.append(e0.elapsed_time(e1))
+            t_dec.append(e1.elapsed_time(e2))
+        ires = d_ires.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]
+        assert int(ires["n_rsi"]) == n_rsi and torch.equal(d_idx[:n_rsi], d_off[:n_rsi]), "index pass != encoder's table"
+        assert torch.equal(d_dec[:nbytes], d_in), "bare-stream round trip differs"
+        ti, td = sorted(t_idx)[1], sorted(t_dec)[1]
+        extras["decode_bare"] = {"GBps": round(nbytes / ((ti + td) * 1e-3) / 1e9, 2), "index_ms": round(ti, 3),
+                                 "decode_ms": round(td, 3),
+                                 "note": "aec_gpu_index_async + aec_gpu_decode_async (one lane per RSI) on the "
+                                         "stream alone, median of 3"}
+        del d_idx
         extras["abi_end_to_end"] = abi_end_to_end(host[: 256 << 20])
     del host
 
@@ -284,22 +337,20 @@ def main():
     from libaec_amd import shard
     sharded = (world > 1 and not args.no_gather) or args.shard_path
     if sharded:
-        def exchange(bits, lo, hi):
-            if world > 1:
-                return shard.exchange_plans(bits, lo, hi, device=dev)
-            return [(bits, lo, hi)]
-
-        def gather(local, slot):
-            if world > 1:
-                return shard.gather_slices(local, slot)
-            return local[:slot].clone()
-
+        # sizes for the all-gather come from one untimed plan (the timed steps never go to the host)
         codec.encode_plan_async(d_in, nbytes, d_eres)
         r0 = d_eres.cpu().numpy().view(gpu.ENC_RESULT_DTYPE)[0]
-        plans0 = exchange(int(r0["total_bits"]), int(r0["k_lo"]), int(r0["k_hi"]))
+        if world > 1:
+            plans0 = shard.exchange_plans(int(r0["total_bits"]), int(r0["k_lo"]), int(r0["k_hi"]), device=dev)
+        else:
+            plans0 = [(int(r0["total_bits"]), int(r0["k_lo"]), int(r0["k_hi"]))]
         slot = shard.slot_bytes(plans0)
         assert slot <= d_out.numel()
+        dsh = shard.DeviceShard(codec, rank, world, slot)
         d_stream = torch.zeros(sum((b + 7) // 8 for b, _, _ in plans0) + 64, dtype=torch.uint8, device=dev)
+        d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+        my_start = sum(b for b, _, _ in plans0[:rank])
+        mine = (my_start % 8 + plans0[rank][0] + 7) // 8
         comm = torch.cuda.Stream(device=dev)
 
     # Two HIP streams: the encode of step i+1 runs beside the decode of step i (double-buffered
@@ -333,17 +384,15 @@ def main():
             codec.encode_async(d_in, nbytes, d_out, d_off, d_eres)
             decode_async(cbytes)
             return
-        codec.encode_plan_async(d_in, nbytes, d_eres)
-        r = d_eres.cpu().numpy().view(gpu.ENC_RESULT_DTYPE)[0]            # 24 bytes, one sync
-        plans = exchange(int(r["total_bits"]), int(r["k_lo"]), int(r["k_hi"]))
-        start, k_in = shard.carry_in(plans, rank)
-        codec.encode_emit_async(d_in, nbytes, d_out, d_off, d_eres, start % 8, k_in)
+        # plan -> 24-byte all-gather of the plan records as they lie in HBM -> emit at the global bit
+        # offset (start bit and carried k derived on the device) -> [side stream: all-gather of the
+        # slices + stitch kernel] beside the decode of the local shard.  No host round trip.
+        dsh.step(d_in, nbytes, d_out, d_off, d_eres)
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(comm):
             comm.wait_event(ready)
-            shard.stitch(gather(d_out, slot), slot, plans, out=d_stream)
-        mine = (start % 8 + plans[rank][0] + 7) // 8
+            dsh.gather_and_stitch(d_out, d_stream, d_total)
         decode_async(mine)
         torch.cuda.current_stream().wait_stream(comm)
 
@@ -395,7 +444,7 @@ def main():
         algo = {"analyze": nbytes, "pack": nbytes + cbytes, "decode": nbytes + cbytes}
         dom = max(algo, key=lambda k: phase[k])
         achieved = algo[dom] / (phase[dom] * 1e-3) / 1e9
-        traffic = measured_traffic(f"k_{dom}", args.size_mib)
+        traffic = measured_traffic(f"k_{dom}", args.size_mib, args.config)
         enc_ms = phase["analyze"] + phase["scan"] + phase["clear"] + phase["pack"]
         out = {
             "metric": "encode+decode GB/s (input bytes)",
@@ -416,7 +465,7 @@ def main():
                                       "offset, RCCL all-gather + stitch overlapped with decode" if sharded else ""),
                        "bits_per_sample": BPS, "block_size": BS, "rsi": RSI, "flags": FLAGS,
                        "input_bytes_per_gpu": nbytes, "compressed_bytes_rank0": cbytes,
-                       "ratio": round(nbytes / cbytes, 3), "bit_exact_vs_cpu": cpu is not None,
+                       "ratio": round(nbytes / cbytes, 3), "bit_exact_vs_cpu": exact,
                        "parallelism": (f"{world} rank(s), one bit-exact stream" if sharded
                                        else f"{world} independent shard stream(s)")},
             "roofline": {"bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -430,6 +479,8 @@ def main():
             "phases_ms": {k: round(v, 4) for k, v in phase.items()},
             "encode_GBps": round(nbytes / (enc_ms * 1e-3) / 1e9, 2),
             "decode_GBps": round(nbytes / (phase["decode"] * 1e-3) / 1e9, 2),
+            "decode_note": "decode_GBps uses the encoder's segment table (side information next to the unchanged "
+                           "stream); decode_bare is the rate from the stream alone",
         }
         out.update({k: v for k, v in extras.items() if v is not None})
         print(json.dumps(out))

@@ -43,7 +43,8 @@ typedef struct aec_gpu_dec_result {
     uint64_t tail_blocks;  /* index pass: complete blocks of the trailing partial RSI */
     uint64_t end_bit;      /* index pass: bit position after the last complete coded data set */
     uint32_t status;       /* 0 ok, 1 input ended inside a coded data set, 2 corrupt stream */
-    uint32_t pad;
+    uint32_t pad;          /* index pass: 1 = stopped because the input ended; aec_gpu_decode_indexed_async:
+                              samples released from the coded data set the input ends in */
     uint64_t bad_rsi;      /* lowest RSI with status != 0 */
 } aec_gpu_dec_result;
 
@@ -105,6 +106,27 @@ AEC_GPU_API int aec_gpu_encode_emit_async(aec_gpu_ctx *ctx, const aec_gpu_params
                                           void *stream);
 
 /*
+ * The same without a host round trip between PLAN and EMIT: d_plans is the array of the plan records
+ * (aec_gpu_enc_result, as written by aec_gpu_encode_plan_async) of ALL shards in stream order -- with
+ * RCCL: ncclAllGather(sendbuff = the local record, recvbuff = d_plans, sendcount = 24, ncclUint8) --
+ * and `rank` this shard's index.  The start bit (sum of the preceding total_bits) and the carried k
+ * (composition of the preceding clamps) are computed on the device; the shard is written at bit
+ * (start % 8) of d_out[0].  aec_gpu_stitch_async reassembles the all-gathered slices
+ * (ncclAllGather of d_out[0 .. slot_bytes) of every rank into d_gathered; slot_bytes a multiple of 16
+ * that holds the largest slice; 16 readable bytes behind the last slot) into ONE stream at d_stream:
+ * slice r lands at byte (start_r / 8), bytes shared by two slices are OR-ed.  *d_total_bytes
+ * (optional) receives the stream length, max(1, ceil(total bits / 8)).  At most 64 shards.
+ */
+AEC_GPU_API int aec_gpu_encode_emit_planned_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                                  size_t in_bytes, void *d_out, size_t out_cap,
+                                                  const aec_gpu_enc_result *d_plans, unsigned int rank,
+                                                  uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result,
+                                                  void *stream);
+AEC_GPU_API int aec_gpu_stitch_async(const void *d_gathered, size_t slot_bytes,
+                                     const aec_gpu_enc_result *d_plans, unsigned int world, void *d_stream,
+                                     size_t stream_cap, uint64_t *d_total_bytes, void *stream);
+
+/*
  * Decode n_rsi RSIs whose start bits are d_rsi_bit_offsets[0..n_rsi) (relative to d_in, which
  * must be 4-byte aligned and readable up to the next multiple of 4) into d_out, producing
  * `total_blocks` whole blocks (the last RSI may be short).  d_out needs
@@ -148,6 +170,27 @@ AEC_GPU_API void aec_gpu_trim(aec_gpu_ctx *ctx, size_t keep_bytes);
 AEC_GPU_API int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
                                     size_t in_bytes, uint64_t start_bit, uint64_t *d_rsi_bit_offsets,
                                     uint64_t max_rsi, aec_gpu_dec_result *d_result, void *stream);
+
+/*
+ * Streaming callers (the libaec ABI layer): continue an index pass INSIDE an RSI.  start_bit is a
+ * coded-data-set boundary, `start_block` blocks of the current RSI (which began at rsi_start_bit) lie
+ * before it; entry 0 of the offset table receives rsi_start_bit, n_rsi / tail_blocks count from that
+ * RSI.  The table needs max_rsi + 1 entries here: entry [max_rsi] receives the start bit of the RSI the
+ * pass ended in (the trailing partial RSI when tail_blocks != 0).  aec_gpu_decode_indexed_async then decodes what such a pass found WITHOUT the host reading its
+ * result first: the kernel takes the counts from d_index_result on the device; max_rsi (the bound given
+ * to the index pass) sizes the launch, d_out must hold max_rsi whole RSIs and one block.  As the reference's
+ * resumable readers do (src/decode.c:423-460), it also releases the samples of the coded data set the input
+ * ends in whose bits have arrived: d_result->pad of them, behind the last complete block.
+ * d_result must be a different record than d_index_result.
+ */
+AEC_GPU_API int aec_gpu_index_resume_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                           size_t in_bytes, uint64_t start_bit, unsigned int start_block,
+                                           uint64_t rsi_start_bit, uint64_t *d_rsi_bit_offsets,
+                                           uint64_t max_rsi, aec_gpu_dec_result *d_result, void *stream);
+AEC_GPU_API int aec_gpu_decode_indexed_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                             size_t in_bytes, const uint64_t *d_rsi_bit_offsets,
+                                             uint64_t max_rsi, const aec_gpu_dec_result *d_index_result,
+                                             void *d_out, aec_gpu_dec_result *d_result, void *stream);
 
 /*
  * Many independent streams in one launch -- the shape of an HDF5 / netCDF dataset stored as SZIP

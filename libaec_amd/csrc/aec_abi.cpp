@@ -4,18 +4,29 @@
 // machines (reference src/encode.c:467-518, 661-754, 909-963 and src/decode.c:342-400,
 // 797-854).  Its contract is kept -- any chunking of input and output, cumulative
 // total_in/total_out, AEC_FLUSH semantics, the same return codes -- but the states are replaced
-// by staging: input is collected until whole RSIs are available, every whole RSI present at a
-// call is coded in ONE batch on the GPU with the bit position and k carried between batches,
-// and produced bytes wait in a queue until the caller offers room.  There is no CPU codec in
-// here: without a working HIP device every call fails with AEC_MEM_ERROR.
+// by staging and batching:
+//
+//   encode  input is collected on the host until it is worth a launch (a batch threshold, AEC_FLUSH,
+//           or a call that brings no new input while whole RSIs wait); every whole RSI staged is then
+//           coded in ONE batch on the GPU with the bit position and k carried between batches.  Cost
+//           is linear in the input for any chunking (a caller feeding one sample per call pays a
+//           vector append per call, not a launch).
+//   decode  the compressed stream is kept RESIDENT ON THE DEVICE: only new bytes are uploaded, the
+//           index walker resumes at the coded data set where it stopped (position + blocks of the
+//           current RSI), the decoder takes its item counts from the walker's record on the device,
+//           and one host synchronisation returns both records and the first output bytes.  A batch
+//           is bounded by the room the caller offers (at least kMinBatchOut), so memory is
+//           O(offered output + undecoded input), never O(decoded size of everything staged).
+//
+// There is no CPU codec in here: without a working HIP device every call fails with AEC_MEM_ERROR.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <new>
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include "../../include/aec_gpu.h"
@@ -39,15 +50,23 @@ int fail_at(int code, int line)
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
-    bool ensure(size_t n)
+    // keep: bytes at the front that must survive a reallocation (copied device to device)
+    bool ensure(size_t n, size_t keep = 0)
     {
         if (n <= cap) return true;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
         size_t want = n + n / 4 + 256;
         want = (want + 255) & ~(size_t)255;
-        if (hipMalloc(&p, want) != hipSuccess) return false;
+        void *q = nullptr;
+        if (hipMalloc(&q, want) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (p && keep && hipMemcpy(q, p, keep, hipMemcpyDeviceToDevice) != hipSuccess) {
+            (void)hipFree(q);
+            return false;
+        }
+        if (p) (void)hipFree(p);
+        p = q;
         cap = want;
         return true;
     }
@@ -59,6 +78,15 @@ struct DevBuf {
     }
 };
 
+// batching thresholds
+constexpr size_t kEncBatchBytes = (size_t)1 << 20;   // staged input that is worth a launch without AEC_FLUSH
+constexpr size_t kEncDirectMin = (size_t)64 << 10;   // whole RSIs offered in one call: coded from the caller's buffer
+constexpr size_t kDecTrickle = 4096;                 // new input below this is collected before a launch ...
+constexpr size_t kDecDirectMin = 4096;               // ... at or above it goes straight to the device
+constexpr size_t kMinBatchOut = (size_t)4 << 20;     // output a decode batch may produce beyond the room offered
+constexpr size_t kBacklogMax = (size_t)64 << 20;     // undecoded input held on the device before more is accepted
+constexpr size_t kBounce = (size_t)256 << 10;        // pinned bounce buffer: first output bytes ride with the records
+
 }  // namespace
 
 struct internal_state {
@@ -69,12 +97,10 @@ struct internal_state {
     aec_gpu_ctx *ctx;
     hipStream_t stream;
     DevBuf d_in, d_out, d_off, d_res;
-    void *h_res;                   // pinned mirror of the device result record
+    uint8_t *h_res;                // pinned: 256 bytes of records, then kBounce bytes of bounce buffer
 
-    size_t out_room;               // decoder: avail_out of the current call (sizes the index look-ahead)
-    uint64_t rsi_bits_seen;        // decoder: average coded RSI of the previous batch (0 = none yet)
-
-    std::vector<uint8_t> stage;    // input not yet coded
+    std::vector<uint8_t> stage;    // encoder: input not yet coded; decoder: input not yet on the device
+    size_t stage_pos;              // encoder: first staged byte still to be coded
     std::vector<uint8_t> outq;     // produced bytes not yet delivered
     size_t outq_pos;
 
@@ -87,12 +113,16 @@ struct internal_state {
     int flush;                     // last flush argument
     bool flushed;                  // reference state->flushed
 
-    // decoder position: the stage holds the stream from byte `stage_base`; the RSI being
-    // decoded starts at absolute bit rsi_start_bit; `delivered` samples of it were queued
-    uint64_t stage_base;
-    uint64_t rsi_start_bit;
-    uint64_t delivered;
-    bool new_input;
+    // decoder: d_in holds stream bytes [base, base + d_len); all *_bit values are absolute stream bits
+    uint64_t base;                 // multiple of 16
+    size_t d_len;
+    uint64_t rsi_start_bit;        // start of the RSI being decoded
+    uint64_t walk_bit;             // coded-data-set boundary where the index walker resumes
+    uint32_t walk_blocks;          // blocks of that RSI in front of walk_bit
+    uint64_t delivered;            // samples of that RSI already handed out
+    size_t walked_len;             // d_len at the last index pass (anything beyond it is new)
+    bool more;                     // the last batch stopped at its RSI bound: decodable input remains
+    bool launched;                 // at least one batch has run
     int sticky_error;
 };
 
@@ -110,7 +140,7 @@ struct Kit {
     aec_gpu_ctx *ctx = nullptr;
     hipStream_t stream = nullptr;
     DevBuf d_in, d_out, d_off, d_res;
-    void *h_res = nullptr;
+    uint8_t *h_res = nullptr;
 };
 constexpr size_t kPoolMax = 8, kKeepBytes = (size_t)64 << 20;
 std::mutex g_pool_mu;
@@ -187,6 +217,7 @@ int init_common(struct aec_stream *strm, bool enc)
     s->encoder = enc;
     s->prm = prm;
     s->cfg = c;
+    s->stage_pos = 0;
     s->outq_pos = 0;
     s->k = 0;
     s->part_bits = 0;
@@ -195,10 +226,15 @@ int init_common(struct aec_stream *strm, bool enc)
     s->finished = false;
     s->flush = AEC_NO_FLUSH;
     s->flushed = false;
-    s->stage_base = 0;
+    s->base = 0;
+    s->d_len = 0;
     s->rsi_start_bit = 0;
+    s->walk_bit = 0;
+    s->walk_blocks = 0;
     s->delivered = 0;
-    s->new_input = false;
+    s->walked_len = 0;
+    s->more = false;
+    s->launched = false;
     s->sticky_error = AEC_OK;
     s->ctx = nullptr;
     s->stream = nullptr;
@@ -215,7 +251,8 @@ int init_common(struct aec_stream *strm, bool enc)
         s->h_res = k.h_res;
         aec_gpu_set_index_hint(s->ctx, 0);
     } else if (s->device < 0 || aec_gpu_create(&s->ctx) != RC_OK || hipStreamCreate(&s->stream) != hipSuccess ||
-               hipHostMalloc(&s->h_res, 256, hipHostMallocDefault) != hipSuccess || !s->d_res.ensure(256)) {
+               hipHostMalloc(reinterpret_cast<void **>(&s->h_res), 256 + kBounce, hipHostMallocDefault) != hipSuccess ||
+               !s->d_res.ensure(256)) {
         free_state(s);
         return AEC_FAIL(AEC_MEM_ERROR);   // no usable HIP device: the product has no CPU path
     }
@@ -225,9 +262,10 @@ int init_common(struct aec_stream *strm, bool enc)
     return AEC_OK;
 }
 
-size_t drain(struct aec_stream *strm, internal_state *s, size_t granule)
+inline size_t drain(struct aec_stream *strm, internal_state *s, size_t granule)
 {
     size_t n = s->outq.size() - s->outq_pos;
+    if (n == 0) return 0;
     if (n > strm->avail_out) n = strm->avail_out;
     n -= n % granule;
     if (n) {
@@ -243,16 +281,14 @@ size_t drain(struct aec_stream *strm, internal_state *s, size_t granule)
     return n;
 }
 
-// Code `nbytes` of staged input (whole samples) as one GPU batch; append produced whole bytes
-// to the queue and keep the open byte / k as carry.
-// With `strm` given and nothing queued, finished bytes go straight into the caller's buffer (no
-// pass through the queue); only what does not fit, and the open byte, are queued.
-int encode_batch(internal_state *s, const uint8_t *data, size_t nbytes, struct aec_stream *strm = nullptr)
+// Code `nbytes` of input (whole samples) as one GPU batch; append produced whole bytes to the queue
+// and keep the open byte / k as carry.  Nothing is queued when this runs, so finished bytes go
+// straight into the caller's buffer as far as it has room: the first kBounce of them ride with the
+// result record (one synchronisation), only what does not fit -- and the open byte -- is queued.
+int encode_batch(internal_state *s, const uint8_t *data, size_t nbytes, struct aec_stream *strm)
 {
     if (nbytes == 0) return AEC_OK;
     const size_t cap = aec_gpu_encode_bound(&s->prm, nbytes);
-    const uint64_t nrsi = aec_gpu_rsi_count(&s->prm, nbytes);
-    (void)nrsi;
     if (!s->d_in.ensure(nbytes + 16) || !s->d_out.ensure(cap)) return AEC_FAIL(AEC_MEM_ERROR);
     if (hipMemcpyAsync(s->d_in.p, data, nbytes, hipMemcpyHostToDevice, s->stream) != hipSuccess)
         return AEC_FAIL(AEC_MEM_ERROR);
@@ -260,25 +296,45 @@ int encode_batch(internal_state *s, const uint8_t *data, size_t nbytes, struct a
                                         s->k, nullptr, static_cast<aec_gpu_enc_result *>(s->d_res.p),
                                         s->stream);
     if (rc != RC_OK) return AEC_FAIL(rc);
-    if (hipMemcpyAsync(s->h_res, s->d_res.p, sizeof(aec_gpu_enc_result), hipMemcpyDeviceToHost,
-                       s->stream) != hipSuccess ||
+    const uint8_t *d_bytes = static_cast<const uint8_t *>(s->d_out.p);
+    uint8_t *bounce = s->h_res + 256;
+    const size_t spec = cap < kBounce ? cap : kBounce;          // speculative: the size is not known yet
+    if (hipMemcpyAsync(s->h_res, s->d_res.p, sizeof(aec_gpu_enc_result), hipMemcpyDeviceToHost, s->stream) !=
+            hipSuccess ||
+        hipMemcpyAsync(bounce, d_bytes, spec, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
         hipStreamSynchronize(s->stream) != hipSuccess)
         return AEC_FAIL(AEC_MEM_ERROR);
-    const aec_gpu_enc_result res = *static_cast<aec_gpu_enc_result *>(s->h_res);
+    const aec_gpu_enc_result res = *reinterpret_cast<aec_gpu_enc_result *>(s->h_res);
     if (res.overflow) return AEC_FAIL(AEC_MEM_ERROR);   // cannot happen: cap is the worst case
     const uint64_t bits = (uint64_t)s->part_bits + res.total_bits;
     const size_t whole = (size_t)(bits / 8), nb = (size_t)((bits + 7) / 8);
-    size_t direct = 0;
-    if (strm && s->outq.empty()) direct = whole < strm->avail_out ? whole : strm->avail_out;
-    const uint8_t *d_bytes = static_cast<const uint8_t *>(s->d_out.p);
-    if (direct && hipMemcpy(strm->next_out, d_bytes, direct, hipMemcpyDeviceToHost) != hipSuccess)
-        return AEC_FAIL(AEC_MEM_ERROR);
+    // bytes [0, whole) are finished, byte `whole` (if nb > whole) is the new open byte
+    size_t direct = whole < strm->avail_out ? whole : strm->avail_out;
+    uint8_t *out0 = strm->next_out;
+    if (direct) {
+        const size_t from_bounce = direct < spec ? direct : spec;
+        memcpy(strm->next_out, bounce, from_bounce);
+        if (direct > from_bounce &&
+            hipMemcpy(strm->next_out + from_bounce, d_bytes + from_bounce, direct - from_bounce,
+                      hipMemcpyDeviceToHost) != hipSuccess)
+            return AEC_FAIL(AEC_MEM_ERROR);
+    }
+    const size_t rest = nb - direct;                     // queued: unfinished bytes + the open byte
     const size_t at = s->outq.size();
-    s->outq.resize(at + (nb - direct));
-    if (nb > direct &&
-        hipMemcpy(s->outq.data() + at, d_bytes + direct, nb - direct, hipMemcpyDeviceToHost) != hipSuccess)
-        return AEC_FAIL(AEC_MEM_ERROR);
-    if (direct) strm->next_out[0] |= s->part_byte;
+    s->outq.resize(at + rest);
+    if (rest) {
+        size_t done = 0;
+        if (direct < spec) {
+            done = spec - direct < rest ? spec - direct : rest;
+            memcpy(s->outq.data() + at, bounce + direct, done);
+        }
+        if (rest > done &&
+            hipMemcpy(s->outq.data() + at + done, d_bytes + direct + done, rest - done, hipMemcpyDeviceToHost) !=
+                hipSuccess)
+            return AEC_FAIL(AEC_MEM_ERROR);
+    }
+    // the byte the batch started in carries the bits of the previous batch
+    if (direct) out0[0] |= s->part_byte;
     else if (nb) s->outq[at] |= s->part_byte;
     s->part_bits = (uint32_t)(bits % 8);
     s->part_byte = s->part_bits ? s->outq[at + whole - direct] : 0;
@@ -292,105 +348,159 @@ int encode_batch(internal_state *s, const uint8_t *data, size_t nbytes, struct a
     return AEC_OK;
 }
 
-// Decode everything decodable in the staged input (see internal_state for the cursor).
-// Samples go straight into the caller's buffer as far as it has room (the queue is empty whenever
-// this runs); the rest is queued.
-int decode_staged(internal_state *s, struct aec_stream *strm)
+// ---- decoder ------------------------------------------------------------------------------------
+
+// bytes one RSI can occupy at most in the stream (every block uncompressed)
+inline uint64_t worst_rsi_bytes(const Cfg &c)
+{
+    return ((uint64_t)c.rsi * (c.id_len + (uint64_t)c.bs * c.bps) + c.bps + 7) / 8 + 1;
+}
+
+// Append `n` bytes at `src` (host) to the device-resident stream.
+int upload(internal_state *s, const uint8_t *src, size_t n)
+{
+    if (n == 0) return AEC_OK;
+    if (!s->d_in.ensure(s->d_len + n + 32, s->d_len)) return AEC_FAIL(AEC_MEM_ERROR);
+    if (hipMemcpyAsync(static_cast<uint8_t *>(s->d_in.p) + s->d_len, src, n, hipMemcpyHostToDevice, s->stream) !=
+        hipSuccess)
+        return AEC_FAIL(AEC_MEM_ERROR);
+    s->d_len += n;
+    return AEC_OK;
+}
+
+// One batch: index from where the walker stopped, decode what it found, hand out / queue the samples.
+int decode_run(internal_state *s, struct aec_stream *strm)
 {
     const Cfg &c = s->cfg;
-    const size_t nbytes = s->stage.size();
-    if (nbytes == 0) return AEC_OK;
-    const uint64_t start_rel = s->rsi_start_bit - s->stage_base * 8;
-    const uint64_t avail_bits = (uint64_t)nbytes * 8 - start_rel;
-    // the shortest possible RSI is all zero blocks: one zero-run CDS (id_len + 2 bits) per segment,
-    // plus the reference sample when the preprocessor is on; that bounds the offset table
-    const uint64_t min_rsi_bits = (uint64_t)c.segs_per_rsi * (c.id_len + 2) + ((c.flags & F_PREPROCESS) ? c.bps : 0);
-    const uint64_t max_rsi = avail_bits / min_rsi_bits + 2;
-    if (!s->d_in.ensure(nbytes + 16) || !s->d_off.ensure((max_rsi + 1) * 8)) return AEC_FAIL(AEC_MEM_ERROR);
-    if (hipMemcpyAsync(s->d_in.p, s->stage.data(), nbytes, hipMemcpyHostToDevice, s->stream) != hipSuccess)
-        return AEC_FAIL(AEC_MEM_ERROR);
-    aec_gpu_dec_result *dres = static_cast<aec_gpu_dec_result *>(s->d_res.p);
-    aec_gpu_dec_result *hres = static_cast<aec_gpu_dec_result *>(s->h_res);
-    // Look-ahead of the speculative index = a small multiple of the average coded RSI: measured on
-    // the previous batch of this stream, else estimated from the room the caller offers for output.
-    uint64_t hint = s->rsi_bits_seen;
-    if (!hint) {
-        const uint64_t rsi_bytes = (uint64_t)c.rsi * c.bs * c.bytes;
-        const uint64_t expect = (s->out_room + rsi_bytes - 1) / rsi_bytes;
-        if (expect) hint = avail_bits / expect;
+    if (!s->stage.empty()) {
+        const int rc = upload(s, s->stage.data(), s->stage.size());
+        if (rc != AEC_OK) return rc;
+        // (the copy out of this pageable vector has been staged by the runtime when the call returns,
+        // and the batch below is waited for in any case)
+        s->stage.clear();
     }
-    aec_gpu_set_index_hint(s->ctx, hint + hint / 2);
-    int rc = aec_gpu_index_async(s->ctx, &s->prm, s->d_in.p, nbytes, start_rel,
-                                 static_cast<uint64_t *>(s->d_off.p), max_rsi, dres, s->stream);
+    s->launched = true;
+    s->more = false;
+    if (s->d_len == 0) return AEC_OK;
+    const size_t blk_bytes = (size_t)c.bs * c.bytes;
+    const size_t rsi_bytes = (size_t)c.rsi * blk_bytes;
+    const uint64_t base_bits = s->base * 8;
+    const uint64_t walk_rel = s->walk_bit - base_bits, rsi_rel = s->rsi_start_bit - base_bits;
+    const size_t skip = (size_t)s->delivered * c.bytes;   // bytes of the current RSI already handed out
+
+    // bound of the batch: the room offered (at least kMinBatchOut), and no more than the input can hold
+    const size_t room = (strm->avail_out > kMinBatchOut ? strm->avail_out : kMinBatchOut) + skip;
+    uint64_t max_rsi = room / rsi_bytes + 2;
+    const uint64_t min_rsi_bits = (uint64_t)c.segs_per_rsi * (c.id_len + 2) + ((c.flags & F_PREPROCESS) ? c.bps : 0);
+    const uint64_t avail_bits = (uint64_t)s->d_len * 8 - rsi_rel;
+    if (max_rsi > avail_bits / min_rsi_bits + 2) max_rsi = avail_bits / min_rsi_bits + 2;
+    // the part of the resident stream this batch can need
+    uint64_t span = walk_rel / 8 + max_rsi * worst_rsi_bytes(c) + 64;
+    const size_t in_bytes = span < s->d_len ? (size_t)span : s->d_len;
+    if (!s->d_off.ensure((max_rsi + 2) * 8) || !s->d_out.ensure(max_rsi * rsi_bytes + blk_bytes + 64))
+        return AEC_FAIL(AEC_MEM_ERROR);
+
+    aec_gpu_dec_result *d_idx = static_cast<aec_gpu_dec_result *>(s->d_res.p), *d_dec = d_idx + 1;
+    uint64_t *d_off = static_cast<uint64_t *>(s->d_off.p);
+    // look-ahead of the speculative index: the average coded RSI seen so far in this stream, if any
+    int rc = aec_gpu_index_resume_async(s->ctx, &s->prm, s->d_in.p, in_bytes, walk_rel, s->walk_blocks, rsi_rel,
+                                        d_off, max_rsi, d_idx, s->stream);
     if (rc != RC_OK) return AEC_FAIL(rc);
-    if (hipMemcpyAsync(hres, dres, sizeof(*hres), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+    rc = aec_gpu_decode_indexed_async(s->ctx, &s->prm, s->d_in.p, in_bytes, d_off, max_rsi, d_idx, s->d_out.p,
+                                      d_dec, s->stream);
+    if (rc != RC_OK) return AEC_FAIL(rc);
+    // records, the start of the trailing partial RSI, and the first output bytes: one synchronisation
+    uint8_t *bounce = s->h_res + 256;
+    const uint8_t *d_bytes = static_cast<const uint8_t *>(s->d_out.p) + skip;
+    size_t spec = max_rsi * rsi_bytes - skip;
+    if (spec > kBounce) spec = kBounce;
+    if (hipMemcpyAsync(s->h_res, d_idx, 2 * sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost, s->stream) !=
+            hipSuccess ||
+        hipMemcpyAsync(s->h_res + 128, d_off + max_rsi, 8, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
+        hipMemcpyAsync(bounce, d_bytes, spec, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
         hipStreamSynchronize(s->stream) != hipSuccess)
         return AEC_FAIL(AEC_MEM_ERROR);
-    const aec_gpu_dec_result idx = *hres;
-    if (idx.n_rsi) s->rsi_bits_seen = (idx.end_bit - start_rel) / idx.n_rsi;
-    const uint64_t n_items = idx.n_rsi + (idx.tail_blocks ? 1 : 0);
-    const uint64_t blocks = idx.n_rsi * c.rsi + idx.tail_blocks;
-    const size_t blk_bytes = (size_t)c.bs * c.bytes;
-    if (blocks * c.bs > s->delivered) {
-        if (!s->d_out.ensure(blocks * blk_bytes + 16)) return AEC_FAIL(AEC_MEM_ERROR);
-        rc = aec_gpu_decode_async(s->ctx, &s->prm, s->d_in.p, nbytes, static_cast<uint64_t *>(s->d_off.p),
-                                  n_items, blocks, s->d_out.p, dres, s->stream);
-        if (rc != RC_OK) return AEC_FAIL(rc);
-        if (hipMemcpyAsync(hres, dres, sizeof(*hres), hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
-            hipStreamSynchronize(s->stream) != hipSuccess)
-            return AEC_FAIL(AEC_MEM_ERROR);
-        if (hres->status == DEC_DATA_ERROR) return AEC_DATA_ERROR;
-        if (hres->status != DEC_OK) return AEC_DATA_ERROR;   // the index pass vouched for completeness
-        const size_t skip = (size_t)s->delivered * c.bytes;
-        const size_t total = (size_t)blocks * blk_bytes;
-        const uint8_t *d_bytes = static_cast<const uint8_t *>(s->d_out.p) + skip;
-        size_t direct = 0;
-        if (s->outq.empty()) {
-            direct = total - skip < strm->avail_out ? total - skip : strm->avail_out;
-            direct -= direct % c.bytes;
+    const aec_gpu_dec_result idx = reinterpret_cast<aec_gpu_dec_result *>(s->h_res)[0];
+    const aec_gpu_dec_result dec = reinterpret_cast<aec_gpu_dec_result *>(s->h_res)[1];
+    uint64_t tail_start = 0;
+    memcpy(&tail_start, s->h_res + 128, 8);
+
+    // What is good: all of it, or -- when the decoder met a corrupt coded data set the walker could
+    // not see (a second-extension code beyond the table, reference decode.c:589-616) -- the RSIs in
+    // front of the first bad one; the reference delivers every sample preceding the error as well.
+    uint64_t good_rsi = idx.n_rsi, tail_blocks = idx.tail_blocks;
+    bool corrupt = idx.status == DEC_DATA_ERROR;
+    if (dec.status != DEC_OK) {
+        corrupt = true;
+        if (dec.bad_rsi <= good_rsi) {
+            good_rsi = dec.bad_rsi;
+            tail_blocks = 0;
         }
+    }
+    // samples released from the coded data set the input ends in (reference decode.c:423-460)
+    const uint32_t part = (!corrupt && idx.pad == 1) ? dec.pad : 0u;
+    const uint64_t blocks = good_rsi * c.rsi + tail_blocks;
+    const size_t total = (size_t)blocks * blk_bytes + (size_t)part * c.bytes;
+    if (total > skip) {
+        const size_t fresh = total - skip;
+        size_t direct = fresh < strm->avail_out ? fresh : strm->avail_out;
+        direct -= direct % c.bytes;
         if (direct) {
-            if (hipMemcpy(strm->next_out, d_bytes, direct, hipMemcpyDeviceToHost) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+            const size_t from_bounce = direct < spec ? direct : spec;
+            memcpy(strm->next_out, bounce, from_bounce);
+            if (direct > from_bounce &&
+                hipMemcpy(strm->next_out + from_bounce, d_bytes + from_bounce, direct - from_bounce,
+                          hipMemcpyDeviceToHost) != hipSuccess)
+                return AEC_FAIL(AEC_MEM_ERROR);
             strm->next_out += direct;
             strm->avail_out -= direct;
         }
-        if (total - skip > direct) {
-            const size_t at = s->outq.size();
-            s->outq.resize(at + (total - skip - direct));
-            if (hipMemcpy(s->outq.data() + at, d_bytes + direct, total - skip - direct, hipMemcpyDeviceToHost) !=
-                hipSuccess)
+        if (fresh > direct) {
+            const size_t rest = fresh - direct, at = s->outq.size();
+            s->outq.resize(at + rest);
+            size_t done = 0;
+            if (direct < spec) {
+                done = spec - direct < rest ? spec - direct : rest;
+                memcpy(s->outq.data() + at, bounce + direct, done);
+            }
+            if (rest > done &&
+                hipMemcpy(s->outq.data() + at + done, d_bytes + direct + done, rest - done, hipMemcpyDeviceToHost) !=
+                    hipSuccess)
                 return AEC_FAIL(AEC_MEM_ERROR);
         }
     }
-    // advance the cursor to the start of the (possibly empty) trailing partial RSI
-    uint64_t new_start_rel = idx.end_bit;
+    if (corrupt) return AEC_DATA_ERROR;
+
+    // advance: the walker resumes behind the last complete coded data set
+    s->walk_bit = base_bits + idx.end_bit;
+    s->walk_blocks = (uint32_t)idx.tail_blocks;
     if (idx.tail_blocks) {
-        uint64_t off = 0;
-        if (hipMemcpy(&off, static_cast<uint64_t *>(s->d_off.p) + idx.n_rsi, 8, hipMemcpyDeviceToHost) !=
-            hipSuccess)
-            return AEC_FAIL(AEC_MEM_ERROR);
-        new_start_rel = off;
-        s->delivered = idx.tail_blocks * c.bs;
+        s->rsi_start_bit = base_bits + tail_start;
+        s->delivered = idx.tail_blocks * c.bs + part;
     } else {
-        s->delivered = 0;
+        s->rsi_start_bit = s->walk_bit;
+        s->delivered = part;
     }
-    s->rsi_start_bit = s->stage_base * 8 + new_start_rel;
-    const uint64_t drop = s->rsi_start_bit / 8 - s->stage_base;
-    if (drop) {
-        s->stage.erase(s->stage.begin(), s->stage.begin() + (ptrdiff_t)drop);
-        s->stage_base += drop;
+    s->walked_len = in_bytes;
+    // stopped at the bound with input left: the caller's next call (or this one, if it still has
+    // room) goes on from here
+    s->more = idx.n_rsi >= max_rsi || in_bytes < s->d_len;
+
+    // drop the consumed front of the resident stream once it is the larger part (the copy must not overlap)
+    const uint64_t keep_from = (s->rsi_start_bit / 8 - s->base) & ~(uint64_t)15;
+    const size_t rem = s->d_len - (size_t)keep_from;
+    if (keep_from >= rem && keep_from >= 4096) {
+        if (rem && hipMemcpyAsync(s->d_in.p, static_cast<uint8_t *>(s->d_in.p) + keep_from, rem,
+                                  hipMemcpyDeviceToDevice, s->stream) != hipSuccess)
+            return AEC_FAIL(AEC_MEM_ERROR);
+        s->base += keep_from;
+        s->d_len = rem;
+        s->walked_len = s->walked_len > keep_from ? s->walked_len - (size_t)keep_from : 0;
     }
-    return idx.status == DEC_DATA_ERROR ? AEC_DATA_ERROR : AEC_OK;
+    return AEC_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int aec_encode_init(struct aec_stream *strm) { return init_common(strm, true); }
-int aec_decode_init(struct aec_stream *strm) { return init_common(strm, false); }
-
-int aec_encode(struct aec_stream *strm, int flush)
+int encode_call(struct aec_stream *strm, int flush)
 {
     internal_state *s = strm->state;
     const size_t bytes = s->cfg.bytes;
@@ -398,6 +508,8 @@ int aec_encode(struct aec_stream *strm, int flush)
     s->flush = flush;
     strm->total_in += strm->avail_in;     // reference encode.c:919-920
     strm->total_out += strm->avail_out;
+    const bool brought = strm->avail_in >= bytes;
+    int rc = AEC_OK;
 
     for (;;) {
         drain(strm, s, 1);
@@ -407,52 +519,137 @@ int aec_encode(struct aec_stream *strm, int flush)
             break;
         }
         // only whole samples are ever consumed (reference encode.c:673-674)
-        size_t take = strm->avail_in - strm->avail_in % bytes;
-        int rc = AEC_OK;
-        if (s->stage.empty() && take >= rsi_bytes) {
+        const size_t take = strm->avail_in - strm->avail_in % bytes;
+        size_t staged = s->stage.size() - s->stage_pos;
+        if (staged == 0 && take >= rsi_bytes && (take >= kEncDirectMin || flush == AEC_FLUSH)) {
             // whole RSIs offered and nothing staged: code them from the caller's buffer
             const size_t direct = take / rsi_bytes * rsi_bytes;
             rc = encode_batch(s, strm->next_in, direct, strm);
             strm->next_in += direct;
             strm->avail_in -= direct;
-            if (rc != AEC_OK) {
-                strm->total_in -= strm->avail_in;
-                strm->total_out -= strm->avail_out;
-                return rc;
-            }
+            if (rc != AEC_OK) break;
             continue;
         }
         if (take) {
+            if (s->stage_pos && s->stage_pos == s->stage.size()) {
+                s->stage.clear();
+                s->stage_pos = 0;
+            }
             s->stage.insert(s->stage.end(), strm->next_in, strm->next_in + take);
             strm->next_in += take;
             strm->avail_in -= take;
+            staged += take;
         }
-        const size_t whole = s->stage.size() / rsi_bytes * rsi_bytes;
-        if (whole) {
-            rc = encode_batch(s, s->stage.data(), whole, strm);
-            s->stage.erase(s->stage.begin(), s->stage.begin() + (ptrdiff_t)whole);
-        } else if (flush == AEC_FLUSH) {
-            // last, short RSI (reference encode.c:676-684), then the final byte (686-695)
-            rc = encode_batch(s, s->stage.data(), s->stage.size(), strm);
-            s->stage.clear();
-            if (rc == AEC_OK) {
-                if (s->part_bits || !s->any_bits) s->outq.push_back(s->part_byte);
-                s->part_bits = 0;
-                s->part_byte = 0;
-                s->finished = true;
+        const size_t whole = staged / rsi_bytes * rsi_bytes;
+        // A launch is worth it for a batch of some size, is due on AEC_FLUSH, and is what a caller asks
+        // for who comes back without new input while whole RSIs wait (the reference would have coded
+        // them by now: tests/check_aec.c encode_decode_small collects its output that way).
+        if (whole && (flush == AEC_FLUSH || whole >= kEncBatchBytes || !brought)) {
+            rc = encode_batch(s, s->stage.data() + s->stage_pos, whole, strm);
+            s->stage_pos += whole;
+            if (s->stage_pos == s->stage.size()) {
+                s->stage.clear();
+                s->stage_pos = 0;
+            } else if (s->stage_pos >= s->stage.size() - s->stage_pos) {
+                s->stage.erase(s->stage.begin(), s->stage.begin() + (ptrdiff_t)s->stage_pos);
+                s->stage_pos = 0;
             }
-        } else {
-            break;                        // need more input
+            if (rc != AEC_OK) break;
+            continue;
         }
-        if (rc != AEC_OK) {
-            strm->total_in -= strm->avail_in;
-            strm->total_out -= strm->avail_out;
-            return rc;
+        if (flush == AEC_FLUSH) {
+            // last, short RSI (reference encode.c:676-684), then the final byte (686-695)
+            rc = encode_batch(s, s->stage.data() + s->stage_pos, staged, strm);
+            s->stage.clear();
+            s->stage_pos = 0;
+            if (rc != AEC_OK) break;
+            if (s->part_bits || !s->any_bits) s->outq.push_back(s->part_byte);
+            s->part_bits = 0;
+            s->part_byte = 0;
+            s->finished = true;
+            continue;
         }
+        break;                            // need more input
     }
     strm->total_in -= strm->avail_in;     // reference encode.c:933-934
     strm->total_out -= strm->avail_out;
+    return rc;
+}
+
+int decode_call(struct aec_stream *strm, int flush)
+{
+    internal_state *s = strm->state;
+    const size_t bytes = s->cfg.bytes;
+    strm->total_in += strm->avail_in;     // reference decode.c:811-812
+    strm->total_out += strm->avail_out;
+    int rc = s->sticky_error;
+    const bool brought = strm->avail_in != 0;
+
+    while (rc == AEC_OK) {
+        drain(strm, s, bytes);
+        if (!s->outq.empty()) break;      // output full (or less than one sample of room)
+        // Accept input while the undecoded backlog on the device is moderate; large pieces go straight
+        // to the device, trickles are collected on the host first.
+        if (strm->avail_in && s->d_len - (size_t)((s->walk_bit / 8) - s->base) < kBacklogMax) {
+            size_t n = strm->avail_in < kBacklogMax ? strm->avail_in : kBacklogMax;
+            if (n >= kDecDirectMin && s->stage.empty()) {
+                rc = upload(s, strm->next_in, n);
+                if (rc != AEC_OK) break;
+            } else {
+                s->stage.insert(s->stage.end(), strm->next_in, strm->next_in + n);
+            }
+            strm->next_in += n;
+            strm->avail_in -= n;
+        }
+        const bool pending = !s->stage.empty() || s->d_len > s->walked_len || s->more;
+        if (!pending) break;
+        // When to run a batch: always, except for a caller that trickles input in (new bytes, fewer
+        // than kDecTrickle waiting, AEC_NO_FLUSH, not the first call): those are collected until a
+        // call brings nothing new -- which is how such callers ask for the rest (reference
+        // src/aec.c:191-221, tests/check_aec.c:138-166) -- so that a byte-at-a-time caller costs a
+        // vector append per call instead of a launch.
+        const bool trickle = brought && flush != AEC_FLUSH && s->launched && !s->more &&
+                             s->d_len <= s->walked_len && s->stage.size() < kDecTrickle;
+        if (trickle) break;
+        const size_t out_before = strm->avail_out, q_before = s->outq.size();
+        const uint64_t walk_before = s->walk_bit;
+        rc = decode_run(s, strm);
+        if (rc == AEC_DATA_ERROR) s->sticky_error = rc;
+        if (rc != AEC_OK) break;
+        const bool progressed = out_before != strm->avail_out || q_before != s->outq.size() ||
+                                walk_before != s->walk_bit;
+        if (!progressed) break;           // what is here needs more input before anything else comes out
+    }
+    if (rc == AEC_DATA_ERROR) drain(strm, s, bytes);   // the samples in front of the error are delivered
+    if (rc != AEC_OK) return rc;          // reference decode.c:818-819 (totals left as they are)
+    if (strm->avail_out > 0 && strm->avail_out < bytes) return AEC_FAIL(AEC_MEM_ERROR);   // decode.c:821-823
+    strm->total_in -= strm->avail_in;     // reference decode.c:827-828
+    strm->total_out -= strm->avail_out;
     return AEC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aec_encode_init(struct aec_stream *strm)
+{
+    try { return init_common(strm, true); } catch (const std::bad_alloc &) { return AEC_MEM_ERROR; }
+}
+int aec_decode_init(struct aec_stream *strm)
+{
+    try { return init_common(strm, false); } catch (const std::bad_alloc &) { return AEC_MEM_ERROR; }
+}
+
+int aec_encode(struct aec_stream *strm, int flush)
+{
+    try {
+        return encode_call(strm, flush);
+    } catch (const std::bad_alloc &) {
+        strm->total_in -= strm->avail_in;      // (added on entry, as on every other way out)
+        strm->total_out -= strm->avail_out;
+        return AEC_MEM_ERROR;
+    }
 }
 
 int aec_encode_end(struct aec_stream *strm)
@@ -480,33 +677,12 @@ int aec_buffer_encode(struct aec_stream *strm)
 
 int aec_decode(struct aec_stream *strm, int flush)
 {
-    (void)flush;                          // ignored by the reference as well (decode.c:797)
-    internal_state *s = strm->state;
-    const size_t bytes = s->cfg.bytes;
-    strm->total_in += strm->avail_in;     // reference decode.c:811-812
-    strm->total_out += strm->avail_out;
-    int rc = s->sticky_error;
-
-    while (rc == AEC_OK) {
-        drain(strm, s, bytes);
-        if (!s->outq.empty()) break;      // output full (or less than one sample of room)
-        if (strm->avail_in) {
-            s->stage.insert(s->stage.end(), strm->next_in, strm->next_in + strm->avail_in);
-            strm->next_in += strm->avail_in;
-            strm->avail_in = 0;
-            s->new_input = true;
-        }
-        if (!s->new_input) break;         // nothing new to look at
-        s->new_input = false;
-        s->out_room = strm->avail_out;
-        rc = decode_staged(s, strm);
-        if (rc == AEC_DATA_ERROR) s->sticky_error = rc;
+    try {
+        return decode_call(strm, flush);   // (flush is ignored by the reference, decode.c:797; here it only
+                                           // says that the caller is not trickling input in)
+    } catch (const std::bad_alloc &) {
+        return AEC_MEM_ERROR;
     }
-    if (rc != AEC_OK) return rc;          // reference decode.c:818-819 (totals left as they are)
-    if (strm->avail_out > 0 && strm->avail_out < bytes) return AEC_FAIL(AEC_MEM_ERROR);   // decode.c:821-823
-    strm->total_in -= strm->avail_in;     // reference decode.c:827-828
-    strm->total_out -= strm->avail_out;
-    return AEC_OK;
 }
 
 int aec_decode_end(struct aec_stream *strm)

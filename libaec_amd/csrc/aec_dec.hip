@@ -207,8 +207,15 @@ __global__ void __launch_bounds__(256)
 k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
          const uint64_t *__restrict__ rsi_off, const SegEntry *__restrict__ seg_table, uint64_t n_rsi,
          uint64_t total_blocks, uint8_t *__restrict__ out, DecResult *res, uint32_t ring_words, uint32_t maxw,
-         uint32_t needw, uint8_t *__restrict__ dump)
+         uint32_t needw, uint8_t *__restrict__ dump, const DecResult *__restrict__ idx)
 {
+    // item counts straight from the record the index pass left on the device (the grid was sized for
+    // the most it could find): no host round trip between the two passes
+    if (idx) {
+        const uint64_t whole = idx->n_rsi, tail = idx->tail_blocks;
+        n_rsi = whole + (tail ? 1u : 0u);
+        total_blocks = whole * c.rsi + tail;
+    }
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t nwords_vec = nwords >= 4 ? ((nwords + 3) & ~3ull) - 4 : 0;   // last 16-byte chunk
@@ -434,6 +441,89 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     if (STG && (b % G) != 0) flush(b / G);             // rows of the last, partial group
 }
 
+// ---- the coded data set the input ends in ------------------------------------------------------------
+// The reference's resumable readers release every sample whose bits have arrived, also from a coded
+// data set that is cut by the end of the input (reference src/decode.c:342-400 bits_ask / fs_ask,
+// :423-460 m_split_output / m_split_fs, :560-587 m_se_decode, :646-657 m_uncomp_copy): the
+// reference sample as soon as its bits are there, second-extension pairs code by code, uncompressed
+// samples one by one, split samples once ALL fundamental sequences of the block are in, one per
+// k-bit field.  The block-parallel kernel above only handles complete coded data sets; this
+// single-lane kernel adds the samples of the ONE incomplete coded data set behind them (the index
+// pass says where it starts: idx->end_bit, block idx->tail_blocks of RSI idx->n_rsi of the batch).
+__global__ void __launch_bounds__(64)
+k_decode_partial(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
+                 const DecResult *__restrict__ idx, uint8_t *__restrict__ out, DecResult *res)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (idx->pad != 1u || idx->status != DEC_OK) return;     // the walk did not stop for lack of input
+    const uint32_t bs = c.bs, bps = c.bps;
+    const bool pp = c.flags & F_PREPROCESS, sgn = c.flags & F_SIGNED, msb = c.flags & F_MSB;
+    const uint32_t b = (uint32_t)idx->tail_blocks;
+    const uint32_t ref = (pp && b == 0) ? 1u : 0u;
+    BitReader r;
+    r.init(words, nwords, end_bit, idx->end_bit);
+    auto has = [&](uint32_t n) { return r.pos + n <= end_bit; };
+    auto unary_ok = [&](uint32_t &z) { return r.unary(z) && r.pos <= end_bit; };
+    uint32_t d[kMaxBlockSize];
+    uint32_t cnt = 0;
+    do {
+        if (!has(c.id_len)) break;
+        const uint32_t id = r.get(c.id_len);
+        if (id == 0) {
+            if (!has(1)) break;
+            const uint32_t sel = r.get(1);
+            if (ref) {
+                if (!has(bps)) break;
+                d[cnt++] = r.get(bps);
+            }
+            if (!sel) break;                                 // a zero-block code is all or nothing
+            uint32_t i = ref;
+            while (i < bs) {
+                uint32_t m = 0, sum = 0, second = 0;
+                if (!unary_ok(m)) break;
+                if (!se_lookup(m, sum, second)) {            // beyond the table: corrupt (decode.c:589-616)
+                    report(res, DEC_DATA_ERROR, idx->n_rsi);
+                    break;
+                }
+                if ((i & 1u) == 0) d[cnt++] = sum - second, i++;
+                d[cnt++] = second;
+                i++;
+            }
+        } else if (id == (1u << c.id_len) - 1u) {
+            while (cnt < bs && has(bps)) d[cnt++] = r.get(bps);
+        } else {
+            const uint32_t k = id - 1u;
+            if (ref) {
+                if (!has(bps)) break;
+                d[cnt++] = r.get(bps);
+            }
+            uint32_t fs[kMaxBlockSize];
+            const uint32_t n = bs - ref;
+            uint32_t got = 0;
+            while (got < n && unary_ok(fs[got])) got++;
+            if (got < n) break;
+            for (uint32_t i = 0; i < n && has(k); i++) d[cnt++] = (fs[i] << k) + (k ? r.get(k) : 0u);
+        }
+    } while (false);
+    if (cnt >= bs) cnt = bs - 1;                             // (a complete block is the index pass's business)
+    // inverse predictor (reference decode.c:67-141) continuing from the sample in front, byte-order store
+    const uint64_t first = (idx->n_rsi * c.rsi + b) * (uint64_t)bs;       // sample index in `out`
+    uint32_t x = 0;
+    if (pp && !ref && cnt) {
+        const uint32_t prev = load_sample_bytes(out + (first - 1) * c.bytes, c.bytes, msb);
+        x = sgn ? sign_extend(prev & low_mask32(bps), bps) : prev & low_mask32(bps);
+    }
+    for (uint32_t i = 0; i < cnt; i++) {
+        uint32_t v;
+        if (!pp) v = d[i];
+        else if (i == 0 && ref) v = x = sgn ? sign_extend(d[0], bps) : d[0];
+        else v = x = sgn ? unpp_signed(x, d[i], c.xmax) : unpp_unsigned(x, d[i], c.xmax);
+        for (uint32_t t = 0; t < c.bytes; t++)
+            out[(first + i) * c.bytes + t] = (uint8_t)(v >> (8 * (msb ? c.bytes - 1 - t : t)));
+    }
+    res->pad = cnt;
+}
+
 __global__ void k_dec_result_init(DecResult *res)
 {
     res->n_rsi = 0;
@@ -454,7 +544,10 @@ uint8_t *dump_buffer()
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
     if (dev < 0 || dev >= 64) dev = 0;
-    if (!buf[dev]) (void)hipMalloc(reinterpret_cast<void **>(&buf[dev]), 64 * kMaxBlockSize * 4);
+    if (!buf[dev] && hipMalloc(reinterpret_cast<void **>(&buf[dev]), 64 * kMaxBlockSize * 4) != hipSuccess) {
+        buf[dev] = nullptr;            // the caller reports the failure (idle lanes would store through it)
+        (void)hipGetLastError();
+    }
     return buf[dev];
 }
 
@@ -506,14 +599,16 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, bool stage
 template <int BS, bool SEG>
 void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          const uint64_t *rsi_off, const SegEntry *seg_table, uint64_t n_rsi,
-                         uint64_t total_blocks, uint8_t *out, DecResult *res, hipStream_t st)
+                         uint64_t total_blocks, uint8_t *out, DecResult *res, hipStream_t st, uint8_t *dump,
+                         const DecResult *idx)
 {
     const uint32_t blk = (uint32_t)BS * c.bytes;
-    const DecGeom g = dec_geom(c, n_rsi, total_blocks ? end_bit / total_blocks : 0, blk == 16 || blk == 32);
+    // (counts taken from the index record: the average coded data set is not known here -- full ring)
+    const DecGeom g = dec_geom(c, n_rsi, (total_blocks && !idx) ? end_bit / total_blocks : 0, blk == 16 || blk == 32);
     const dim3 block(64 * g.waves), grid(g.grid);
 #define AEC_GO(B)                                                                                   \
     hipLaunchKernelGGL((k_decode<BS, B, SEG>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
-                       rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, g.needw, dump_buffer())
+                       rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, g.needw, dump, idx)
     switch (c.bytes) {
     case 1: AEC_GO(1); break;
     case 2: AEC_GO(2); break;
@@ -526,12 +621,15 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
 }  // namespace
 
 template <bool SEG>
-static void launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
+static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
                               const SegEntry *d_seg, uint64_t n_items, uint64_t total_blocks, uint8_t *d_out,
-                              DecResult *d_res, hipStream_t st, const PhaseEvents *prof)
+                              DecResult *d_res, hipStream_t st, const PhaseEvents *prof,
+                              const DecResult *d_idx = nullptr)
 {
+    uint8_t *dump = dump_buffer();
+    if (!dump) return false;
     hipLaunchKernelGGL(k_dec_result_init, dim3(1), dim3(1), 0, st, d_res);
-    if (n_items == 0) return;
+    if (n_items == 0) return true;
     if (prof) (void)hipEventRecord(prof->ev[5], st);
     const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
     const uint64_t nwords = (in_bytes + 3) / 4;
@@ -540,33 +638,43 @@ static void launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
     const bool vec_ok = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
     const uint32_t bs = vec_ok ? c.bs : 0;
     switch (bs) {
-    case 8: launch_decode_bytes<8, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st); break;
-    case 16: launch_decode_bytes<16, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st); break;
-    case 32: launch_decode_bytes<32, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st); break;
-    case 64: launch_decode_bytes<64, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st); break;
+    case 8: launch_decode_bytes<8, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx); break;
+    case 16: launch_decode_bytes<16, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx); break;
+    case 32: launch_decode_bytes<32, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx); break;
+    case 64: launch_decode_bytes<64, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx); break;
     default:
     {
         const DecGeom g = dec_geom(c, n_items, 0, false);   // the sample-by-sample reader has no second attempt: full ring
         hipLaunchKernelGGL((k_decode<0, 0, SEG>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
-                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, g.needw, dump_buffer());
+                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, g.needw, dump, d_idx);
         break;
     }
     }
     if (prof) (void)hipEventRecord(prof->ev[6], st);
+    return true;
 }
 
-void launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
+bool launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
                    uint64_t n_rsi, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res, hipStream_t st,
-                   const PhaseEvents *prof)
+                   const PhaseEvents *prof, const DecResult *d_idx)
 {
-    launch_decode_any<false>(c, d_in, in_bytes, d_rsi_off, nullptr, n_rsi, total_blocks, d_out, d_res, st, prof);
+    return launch_decode_any<false>(c, d_in, in_bytes, d_rsi_off, nullptr, n_rsi, total_blocks, d_out, d_res, st,
+                                    prof, d_idx);
 }
 
-void launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const SegEntry *d_seg_table,
+void launch_decode_partial(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const DecResult *d_idx, uint8_t *d_out,
+                           DecResult *d_res, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_decode_partial, dim3(1), dim3(64), 0, st, c, reinterpret_cast<const uint32_t *>(d_in),
+                       (uint64_t)((in_bytes + 3) / 4), (uint64_t)in_bytes * 8, d_idx, d_out, d_res);
+}
+
+bool launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const SegEntry *d_seg_table,
                             uint64_t n_seg, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res,
                             hipStream_t st, const PhaseEvents *prof)
 {
-    launch_decode_any<true>(c, d_in, in_bytes, nullptr, d_seg_table, n_seg, total_blocks, d_out, d_res, st, prof);
+    return launch_decode_any<true>(c, d_in, in_bytes, nullptr, d_seg_table, n_seg, total_blocks, d_out, d_res, st,
+                                   prof);
 }
 
 }  // namespace aec

@@ -697,9 +697,14 @@ k_scan_apply(const uint32_t *__restrict__ seg_bits, const uint16_t *__restrict__
              uint64_t nseg, const ScanPartial *__restrict__ partials, uint32_t start_bit, uint32_t k_in,
              uint32_t segs_per_rsi, uint64_t rsi_count, uint64_t *__restrict__ seg_start,
              uint8_t *__restrict__ seg_kin, uint64_t *__restrict__ rsi_off, EncResult *res,
-             uint32_t *__restrict__ out_words, uint64_t cap_words, uint32_t segs_per_wave)
+             uint32_t *__restrict__ out_words, uint64_t cap_words, uint32_t segs_per_wave,
+             const ShardCarry *__restrict__ carry)
 {
     __shared__ ScanVal sh[4];
+    if (carry) {                       // one stream over several devices: what precedes this shard
+        start_bit = (uint32_t)(carry->start_bit & 7u);
+        k_in = carry->k_in;
+    }
     const uint64_t base = (uint64_t)blockIdx.x * kScanChunk + (uint64_t)threadIdx.x * kScanItems;
     ScanVal item[kScanItems];
     ScanVal acc = scan_identity();
@@ -991,7 +996,7 @@ size_t enc_workspace_bytes(const Cfg &c, size_t *off_meta, size_t *off_bits, siz
 void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out_cap,
                    uint32_t start_bit, uint32_t k_in, const EncWorkspace &ws, uint64_t *d_rsi_off,
                    EncResult *d_res, hipStream_t st, const PhaseEvents *prof, uint32_t phases,
-                   SegEntry *d_seg_table)
+                   SegEntry *d_seg_table, const ShardCarry *d_carry)
 {
     auto mark = [&](int i) { if (prof) (void)hipEventRecord(prof->ev[i], st); };
     uint32_t *out_words = reinterpret_cast<uint32_t *>(d_out);
@@ -1017,7 +1022,7 @@ void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out
             hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)nchunks), dim3(256), 0, st, ws.seg_bits,
                                ws.seg_clamp, nseg, ws.partials, start_bit, k_in, c.segs_per_rsi, c.rsi_count,
                                ws.seg_start, ws.seg_kin, d_rsi_off, d_res, out_words, cap_words,
-                               make_geom(c, true).segs_per_wave);
+                               make_geom(c, true).segs_per_wave, d_carry);
         else {
             if (d_rsi_off) (void)hipMemsetAsync(d_rsi_off, 0, sizeof(uint64_t), st);   // empty batch: single entry
             if (out_cap >= 16) (void)hipMemsetAsync(d_out, 0, 16, st);

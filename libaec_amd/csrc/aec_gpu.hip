@@ -40,6 +40,7 @@ struct aec_gpu_ctx {
     uint64_t idx_hint;     // caller's estimate of the coded RSI size in bits (0 = derive from max_rsi)
     IdxSide idx_side;      // side stream + events of the index pass (created on first use)
     bool idx_side_ok;
+    ShardCarry *carry;     // device record: what precedes this context's shard (emit_planned)
 };
 static_assert(sizeof(aec_gpu_seg_entry) == sizeof(SegEntry), "segment table layout");
 
@@ -69,6 +70,7 @@ int aec_gpu_create(aec_gpu_ctx **out)
     ctx->idx_hint = 0;
     ctx->idx_side = IdxSide{};
     ctx->idx_side_ok = false;
+    ctx->carry = nullptr;
     ctx->enc_calls = ctx->dec_calls = 0;
     for (auto &set : ctx->ev)
         for (auto &e : set.ev) e = nullptr;
@@ -81,6 +83,7 @@ void aec_gpu_destroy(aec_gpu_ctx *ctx)
     if (!ctx) return;
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
+    if (ctx->carry) (void)hipFree(ctx->carry);
     if (ctx->idx_side_ok) {
         (void)hipStreamDestroy(ctx->idx_side.stream);
         for (int b = 0; b < 2; b++) {
@@ -140,7 +143,8 @@ int aec_gpu_reserve(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes)
 
 static int encode_phases(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
                          void *d_out, size_t out_cap, unsigned int start_bit, unsigned int k_in,
-                         uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result, void *stream, uint32_t phases)
+                         uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result, void *stream, uint32_t phases,
+                         const ShardCarry *d_carry = nullptr)
 {
     Cfg c;
     int rc = cfg_from(p, in_bytes, true, &c);
@@ -163,7 +167,7 @@ static int encode_phases(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *
     ws.partials = reinterpret_cast<ScanPartial *>(base + o[5]);
     launch_encode(c, static_cast<const uint8_t *>(d_in), static_cast<uint8_t *>(d_out), out_cap, start_bit,
                   k_in, ws, d_rsi_bit_offsets, reinterpret_cast<EncResult *>(d_result),
-                  static_cast<hipStream_t>(stream), ctx->enc_events(phases), phases, ctx->seg_table);
+                  static_cast<hipStream_t>(stream), ctx->enc_events(phases), phases, ctx->seg_table, d_carry);
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
@@ -189,6 +193,37 @@ int aec_gpu_encode_emit_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const v
                          stream, ENC_EMIT);
 }
 
+int aec_gpu_encode_emit_planned_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                                      void *d_out, size_t out_cap, const aec_gpu_enc_result *d_plans,
+                                      unsigned int rank, uint64_t *d_rsi_bit_offsets, aec_gpu_enc_result *d_result,
+                                      void *stream)
+{
+    if (!d_plans || rank >= 64) return RC_CONF_ERROR;
+    if (!ctx->carry && hipMalloc(reinterpret_cast<void **>(&ctx->carry), sizeof(ShardCarry)) != hipSuccess) {
+        ctx->carry = nullptr;
+        (void)hipGetLastError();
+        return RC_MEM_ERROR;
+    }
+    launch_shard_carry(reinterpret_cast<const EncResult *>(d_plans), rank, ctx->carry,
+                       static_cast<hipStream_t>(stream));
+    return encode_phases(ctx, p, d_in, in_bytes, d_out, out_cap, 0, 0, d_rsi_bit_offsets, d_result, stream,
+                         ENC_EMIT, ctx->carry);
+}
+
+int aec_gpu_stitch_async(const void *d_gathered, size_t slot_bytes, const aec_gpu_enc_result *d_plans,
+                         unsigned int world, void *d_stream, size_t stream_cap, uint64_t *d_total_bytes,
+                         void *stream)
+{
+    if (!d_gathered || !d_plans || !d_stream || world == 0 || world > 64 || (slot_bytes & 15u) ||
+        (reinterpret_cast<uintptr_t>(d_gathered) & 15u) || (reinterpret_cast<uintptr_t>(d_stream) & 15u))
+        return RC_CONF_ERROR;
+    (void)hipGetLastError();
+    launch_stitch(static_cast<const uint8_t *>(d_gathered), slot_bytes, reinterpret_cast<const EncResult *>(d_plans),
+                  world, static_cast<uint8_t *>(d_stream), stream_cap, d_total_bytes,
+                  static_cast<hipStream_t>(stream));
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
+}
+
 int aec_gpu_decode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
                          const uint64_t *d_rsi_bit_offsets, uint64_t n_rsi, uint64_t total_blocks,
                          void *d_out, aec_gpu_dec_result *d_result, void *stream)
@@ -199,9 +234,10 @@ int aec_gpu_decode_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *
     if (reinterpret_cast<uintptr_t>(d_in) & 3u) return RC_CONF_ERROR;
     if (n_rsi && (total_blocks > n_rsi * c.rsi || total_blocks <= (n_rsi - 1) * c.rsi)) return RC_CONF_ERROR;
     (void)hipGetLastError();
-    launch_decode(c, static_cast<const uint8_t *>(d_in), in_bytes, d_rsi_bit_offsets, n_rsi, total_blocks,
-                  static_cast<uint8_t *>(d_out), reinterpret_cast<DecResult *>(d_result),
-                  static_cast<hipStream_t>(stream), ctx->dec_events());
+    if (!launch_decode(c, static_cast<const uint8_t *>(d_in), in_bytes, d_rsi_bit_offsets, n_rsi, total_blocks,
+                       static_cast<uint8_t *>(d_out), reinterpret_cast<DecResult *>(d_result),
+                       static_cast<hipStream_t>(stream), ctx->dec_events()))
+        return RC_MEM_ERROR;
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
@@ -229,42 +265,36 @@ int aec_gpu_decode_segments_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, con
     const uint64_t full = total_blocks / c.rsi, rem = total_blocks % c.rsi;
     if (n_seg != full * c.segs_per_rsi + (rem + 63) / 64) return RC_CONF_ERROR;
     (void)hipGetLastError();
-    launch_decode_segments(c, static_cast<const uint8_t *>(d_in), in_bytes,
-                           reinterpret_cast<const SegEntry *>(d_seg_table), n_seg, total_blocks,
-                           static_cast<uint8_t *>(d_out), reinterpret_cast<DecResult *>(d_result),
-                           static_cast<hipStream_t>(stream), ctx->dec_events());
+    if (!launch_decode_segments(c, static_cast<const uint8_t *>(d_in), in_bytes,
+                                reinterpret_cast<const SegEntry *>(d_seg_table), n_seg, total_blocks,
+                                static_cast<uint8_t *>(d_out), reinterpret_cast<DecResult *>(d_result),
+                                static_cast<hipStream_t>(stream), ctx->dec_events()))
+        return RC_MEM_ERROR;
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
-int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
-                        uint64_t start_bit, uint64_t *d_rsi_bit_offsets, uint64_t max_rsi,
-                        aec_gpu_dec_result *d_result, void *stream)
+static int index_common(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                        uint64_t start_bit, uint32_t start_block, uint64_t rsi_start_bit,
+                        uint64_t *d_rsi_bit_offsets, uint64_t max_rsi, aec_gpu_dec_result *d_result, void *stream,
+                        uint32_t tail_slot)
 {
     Cfg c;
     const int rc = cfg_from(p, 0, false, &c);
     if (rc != RC_OK) return rc;
     if (reinterpret_cast<uintptr_t>(d_in) & 3u) return RC_CONF_ERROR;
+    if (start_block >= c.rsi || (start_block && rsi_start_bit > start_bit)) return RC_CONF_ERROR;
     (void)hipGetLastError();
-    // table workspace of the speculative index; a failed allocation only means the serial walk
-    // expected RSIs -> average coded RSI size, which sizes the look-ahead of the speculation
+    // Table workspace of the speculative index.  The look-ahead of the speculation is sized from the
+    // average coded RSI: the caller's hint, else input bits / expected RSIs.  A failed allocation
+    // only means the serial walk.
     const uint64_t in_bits = (uint64_t)in_bytes * 8;
     const uint64_t hint = ctx->idx_hint ? ctx->idx_hint
                           : ((max_rsi && in_bits > start_bit) ? (in_bits - start_bit) / max_rsi : 0);
     const size_t need = index_workspace_bytes(c, in_bytes, start_bit, hint);
     if (need > ctx->idx_ws_bytes) {
-        if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
-    if (ctx->idx_side_ok) {
-        (void)hipStreamDestroy(ctx->idx_side.stream);
-        for (int b = 0; b < 2; b++) {
-            (void)hipEventDestroy(ctx->idx_side.spec_done[b]);
-            (void)hipEventDestroy(ctx->idx_side.walk_done[b]);
-        }
-    }
+        if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);     // (synchronises: no walker still reads it)
         ctx->idx_ws = nullptr;
         ctx->idx_ws_bytes = 0;
-    ctx->idx_hint = 0;
-    ctx->idx_side = IdxSide{};
-    ctx->idx_side_ok = false;
         const size_t want = need + need / 4;
         if (hipMalloc(&ctx->idx_ws, want) == hipSuccess) ctx->idx_ws_bytes = want;
         else (void)hipGetLastError();
@@ -280,13 +310,53 @@ int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d
     }
     launch_index(c, static_cast<const uint8_t *>(d_in), in_bytes, start_bit, d_rsi_bit_offsets, max_rsi,
                  reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream), ctx->idx_ws,
-                 ctx->idx_ws_bytes, hint, ctx->idx_side_ok ? &ctx->idx_side : nullptr);
+                 ctx->idx_ws_bytes, hint, ctx->idx_side_ok ? &ctx->idx_side : nullptr, start_block,
+                 rsi_start_bit, tail_slot);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess && getenv("AEC_ABI_TRACE"))
         fprintf(stderr, "aec_gpu_index_async: %s (in_bytes %zu start %llu max_rsi %llu hint %llu ws %zu)\n",
                 hipGetErrorString(e), in_bytes, (unsigned long long)start_bit, (unsigned long long)max_rsi,
                 (unsigned long long)hint, ctx->idx_ws_bytes);
     return e == hipSuccess ? RC_OK : RC_MEM_ERROR;
+}
+
+int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                        uint64_t start_bit, uint64_t *d_rsi_bit_offsets, uint64_t max_rsi,
+                        aec_gpu_dec_result *d_result, void *stream)
+{
+    return index_common(ctx, p, d_in, in_bytes, start_bit, 0u, start_bit, d_rsi_bit_offsets, max_rsi, d_result,
+                        stream, 0u);
+}
+
+int aec_gpu_index_resume_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                               uint64_t start_bit, unsigned int start_block, uint64_t rsi_start_bit,
+                               uint64_t *d_rsi_bit_offsets, uint64_t max_rsi, aec_gpu_dec_result *d_result,
+                               void *stream)
+{
+    return index_common(ctx, p, d_in, in_bytes, start_bit, start_block, rsi_start_bit, d_rsi_bit_offsets, max_rsi,
+                        d_result, stream, 1u);
+}
+
+int aec_gpu_decode_indexed_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                                 const uint64_t *d_rsi_bit_offsets, uint64_t max_rsi,
+                                 const aec_gpu_dec_result *d_index_result, void *d_out,
+                                 aec_gpu_dec_result *d_result, void *stream)
+{
+    Cfg c;
+    const int rc = cfg_from(p, 0, false, &c);
+    if (rc != RC_OK) return rc;
+    if ((reinterpret_cast<uintptr_t>(d_in) & 3u) || !d_index_result || d_index_result == d_result)
+        return RC_CONF_ERROR;
+    (void)hipGetLastError();
+    if (!launch_decode(c, static_cast<const uint8_t *>(d_in), in_bytes, d_rsi_bit_offsets, max_rsi,
+                       max_rsi * c.rsi, static_cast<uint8_t *>(d_out), reinterpret_cast<DecResult *>(d_result),
+                       static_cast<hipStream_t>(stream), ctx->dec_events(),
+                       reinterpret_cast<const DecResult *>(d_index_result)))
+        return RC_MEM_ERROR;
+    launch_decode_partial(c, static_cast<const uint8_t *>(d_in), in_bytes,
+                          reinterpret_cast<const DecResult *>(d_index_result), static_cast<uint8_t *>(d_out),
+                          reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream));
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
 void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits) { ctx->idx_hint = rsi_bits; }

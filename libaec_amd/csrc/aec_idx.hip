@@ -240,7 +240,8 @@ __global__ void __launch_bounds__(64)
 k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
         uint64_t start_bit, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res,
         const uint64_t *__restrict__ chunk_off, const IdxTables tabs, IdxHop *__restrict__ hops,
-        uint32_t hop_cap, IdxCarry *carry, uint32_t first, uint32_t last)
+        uint32_t hop_cap, IdxCarry *carry, uint32_t first, uint32_t last, uint32_t start_block,
+        uint64_t rsi_start, uint32_t tail_slot)
 {
     __shared__ __attribute__((aligned(16))) uint32_t win[kIdxWindowWords];
     uint64_t r = 0;
@@ -251,6 +252,15 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         res += blockIdx.x;
     } else if (blockIdx.x != 0) {
         return;
+    }
+    // the first walk of a call starts the result record (there is no separate init launch)
+    if (!chunk_off && first && threadIdx.x == 0) {
+        res->n_rsi = 0;
+        res->tail_blocks = 0;
+        res->end_bit = start_bit;
+        res->status = DEC_OK;
+        res->pad = 0;
+        res->bad_rsi = ~0ull;
     }
     if (carry && !first) {               // continue where the walk over the previous table chunk stopped
         if (!carry->active) {
@@ -326,6 +336,14 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     br.init(LdsWindowFetch{win, base}, end_bit, start_bit);
     uint64_t good = start_bit;
     uint32_t b = 0, status = DEC_OK, nh = 0;
+    // Resumed walk (streaming callers): start_bit is a CDS boundary inside an RSI that began at
+    // rsi_start and of which start_block blocks lie before start_bit.
+    uint64_t cur_start = start_bit;          // start of the RSI being walked
+    if (first && !chunk_off && start_block) {
+        b = start_block;
+        cur_start = rsi_start;
+        if (lane == 0 && max_rsi) rsi_off[0] = rsi_start;
+    }
     if (coop) load_regs(good >> 5);
     for (;;) {
         bool hopped = false;
@@ -368,6 +386,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                 return;
             }
             if (lane == 0) rsi_off[r] = good;
+            cur_start = good;
         }
         // keep the whole next CDS (and the readers' look-ahead) inside the LDS window
         if ((good >> 5) + (coop ? 66u : maxw + 2u) > base + kIdxWindowWords) {
@@ -448,9 +467,12 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         carry->n_hops = nh;
     }
     if (lane == 0) {
+        // streaming callers: where the trailing partial RSI began, in a slot of its own behind the table
+        if (tail_slot && !chunk_off) rsi_off[max_rsi] = cur_start;
         res->n_rsi = r;
         res->tail_blocks = b;
         res->end_bit = good;
+        if (!chunk_off) res->pad = status == DEC_NEED_INPUT ? 1u : 0u;
         if (chunk_off) {               // per-stream records are written in full (no init kernel)
             res->status = status == DEC_DATA_ERROR ? DEC_DATA_ERROR : DEC_OK;
             res->pad = 0;
@@ -463,15 +485,6 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
 }
 
 
-__global__ void k_idx_result_init(DecResult *res)
-{
-    res->n_rsi = 0;
-    res->tail_blocks = 0;
-    res->end_bit = 0;
-    res->status = DEC_OK;
-    res->pad = 0;
-    res->bad_rsi = ~0ull;
-}
 
 struct SpecGeom {
     bool ok;
@@ -589,16 +602,16 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
 
 void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
                   uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
-                  void *d_ws, size_t ws_bytes, uint64_t rsi_bits_hint, const IdxSide *side)
+                  void *d_ws, size_t ws_bytes, uint64_t rsi_bits_hint, const IdxSide *side,
+                  uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot)
 {
     const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
     const uint64_t nwords = (in_bytes + 3) / 4, end_bit = (uint64_t)in_bytes * 8;
-    hipLaunchKernelGGL(k_idx_result_init, dim3(1), dim3(1), 0, st, d_res);
     const size_t need = index_workspace_bytes(c, in_bytes, start_bit, rsi_bits_hint);
     if (!need || !d_ws || ws_bytes < need) {           // serial walk only
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off,
                            max_rsi, d_res, (const uint64_t *)nullptr, IdxTables{}, (IdxHop *)nullptr, 0u,
-                           (IdxCarry *)nullptr, 1u, 1u);
+                           (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start, tail_slot);
         return;
     }
     allow_big_lds();
@@ -636,7 +649,7 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
         }
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, wst, c, words, nwords, end_bit, start_bit, d_rsi_off,
                            max_rsi, d_res, (const uint64_t *)nullptr, tabs, t.hops, hop_cap, carry,
-                           first ? 1u : 0u, last ? 1u : 0u);
+                           first ? 1u : 0u, last ? 1u : 0u, start_block, rsi_start, tail_slot);
         hipLaunchKernelGGL(k_expand, dim3((hop_cap + 255) / 256), dim3(256), 0, wst, carry, t.hops, tabs,
                            (c.flags & F_PAD_RSI) ? 1u : 0u, d_rsi_off);
         if (piped) (void)hipEventRecord(side->walk_done[b], wst);
@@ -653,7 +666,7 @@ void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, cons
     hipLaunchKernelGGL(k_index, dim3((uint32_t)n_chunks), dim3(64), 0, st, c,
                        reinterpret_cast<const uint32_t *>(d_in), (uint64_t)((in_bytes + 3) / 4),
                        (uint64_t)in_bytes * 8, (uint64_t)0, d_rsi_off, rsi_per_chunk, d_res, d_chunk_off,
-                       IdxTables{}, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u);
+                       IdxTables{}, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, 0u, (uint64_t)0, 0u);
 }
 
 }  // namespace aec

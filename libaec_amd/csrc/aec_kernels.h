@@ -22,12 +22,21 @@ struct EncResult {
     uint32_t k_lo, k_hi;   // the batch's k transfer function: k_out = min(max(k_in, k_lo), k_hi)
 };
 
+// What precedes a shard of a stream that is coded on several devices (computed on the device from
+// the all-gathered plan records of the preceding shards: aec_shard.hip).
+struct ShardCarry {
+    uint64_t start_bit;    // absolute bit position of the shard in the whole stream
+    uint32_t k_in;         // carried k
+    uint32_t pad;
+};
+
 struct DecResult {
     uint64_t n_rsi;        // index pass: complete RSIs found
     uint64_t tail_blocks;  // index pass: blocks of the trailing incomplete RSI
     uint64_t end_bit;      // index pass: bit after the last complete CDS
     uint32_t status;       // DEC_OK / DEC_NEED_INPUT / DEC_DATA_ERROR (worst over all lanes)
-    uint32_t pad;
+    uint32_t pad;          // index pass: 1 = the walk ended because the input did (inside a coded data set);
+                           // indexed decode: samples released from that incomplete coded data set
     uint64_t bad_rsi;      // first RSI that reported a non-OK status
 };
 
@@ -73,17 +82,32 @@ enum : uint32_t { ENC_PLAN = 1, ENC_EMIT = 2, ENC_ALL = 3 };
 void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out_cap,
                    uint32_t start_bit, uint32_t k_in, const EncWorkspace &ws, uint64_t *d_rsi_off,
                    EncResult *d_res, hipStream_t stream, const PhaseEvents *prof = nullptr,
-                   uint32_t phases = ENC_ALL, SegEntry *d_seg_table = nullptr);
+                   uint32_t phases = ENC_ALL, SegEntry *d_seg_table = nullptr,
+                   const ShardCarry *d_carry = nullptr);
+
+// One stream over several devices (aec_shard.hip): carry-in of shard `rank` from the plan records of
+// all shards; reassembly of the gathered slices into one stream.
+void launch_shard_carry(const EncResult *d_plans, uint32_t rank, ShardCarry *d_carry, hipStream_t stream);
+void launch_stitch(const uint8_t *d_gathered, size_t slot, const EncResult *d_plans, uint32_t world,
+                   uint8_t *d_stream, size_t cap, uint64_t *d_total_bytes, hipStream_t stream);
 
 // Enqueues the RSI-parallel decoder: one lane per RSI, offsets in bits from d_in.
 //   total_blocks  blocks to produce (the last RSI may be short); d_out holds whole blocks
-void launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
+// d_idx (optional): the record an index pass left on the device; the kernel then takes the number of
+// RSIs and blocks from it (n_rsi = the most the index pass could find, it sizes the grid).
+// false = the device-side scratch the kernels need could not be allocated.
+bool launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
                    uint64_t n_rsi, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res,
-                   hipStream_t stream, const PhaseEvents *prof = nullptr);
+                   hipStream_t stream, const PhaseEvents *prof = nullptr, const DecResult *d_idx = nullptr);
+
+// Samples of the coded data set the input ends in (single lane; see k_decode_partial): after
+// launch_decode with the same d_idx / d_out / d_res; their number is left in d_res->pad.
+void launch_decode_partial(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const DecResult *d_idx,
+                           uint8_t *d_out, DecResult *d_res, hipStream_t stream);
 
 // Same, one lane per SEGMENT (needs the encoder's segment table): the way to fill the chip when
 // RSIs are large (32-bit, block 32, rsi 4096 = 512 KiB per RSI, only 8192 RSIs in 4 GiB).
-void launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const SegEntry *d_seg_table,
+bool launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const SegEntry *d_seg_table,
                             uint64_t n_seg, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res,
                             hipStream_t stream, const PhaseEvents *prof = nullptr);
 
@@ -101,7 +125,8 @@ struct IdxSide {
 void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
                   uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t stream,
                   void *d_ws = nullptr, size_t ws_bytes = 0, uint64_t rsi_bits_hint = 0,
-                  const IdxSide *side = nullptr);
+                  const IdxSide *side = nullptr, uint32_t start_block = 0, uint64_t rsi_start = 0,
+                  uint32_t tail_slot = 0);
 
 // Index pass over many independent streams stored in one buffer (e.g. the chunks of an HDF5
 // dataset): stream s occupies bytes [chunk_off[s], chunk_off[s+1]) (chunk_off 4-byte aligned values,

@@ -6,6 +6,7 @@
 // aec_buffer_encode / aec_buffer_decode call, which is where the GPU does the work.
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "../../include/szlib.h"
@@ -61,11 +62,7 @@ Geometry geometry(const SZ_com_t *p, unsigned bits_per_sample)
     return g;
 }
 
-}  // namespace
-
-extern "C" {
-
-int SZ_BufftoBuffCompress(void *dest, size_t *destLen, const void *source, size_t sourceLen, SZ_com_t *param)
+int compress(void *dest, size_t *destLen, const void *source, size_t sourceLen, SZ_com_t *param)
 {
     if (param->pixels_per_block <= 0 || param->pixels_per_scanline <= 0) return SZ_PARAM_ERROR;
     struct aec_stream strm;
@@ -78,6 +75,10 @@ int SZ_BufftoBuffCompress(void *dest, size_t *destLen, const void *source, size_
     strm.next_out = static_cast<unsigned char *>(dest);
     strm.avail_out = *destLen;
 
+    // Only whole pixels are coded.  (The reference sizes its padding buffer from the floor of
+    // sourceLen / pixel size but copies sourceLen bytes, sz_compat.c:148-166: a trailing fraction of
+    // a pixel overruns that buffer there.  It is dropped here.)
+    sourceLen -= sourceLen % (planes ? (size_t)param->bits_per_pixel / 8 : g.pixel);
     std::vector<uint8_t> plane_buf;
     const uint8_t *src = static_cast<const uint8_t *>(source);
     if (planes) {
@@ -112,7 +113,7 @@ int SZ_BufftoBuffCompress(void *dest, size_t *destLen, const void *source, size_
     return rc == AEC_STREAM_ERROR ? SZ_OUTBUFF_FULL : rc;                               // sz_compat.c:171-174
 }
 
-int SZ_BufftoBuffDecompress(void *dest, size_t *destLen, const void *source, size_t sourceLen, SZ_com_t *param)
+int decompress(void *dest, size_t *destLen, const void *source, size_t sourceLen, SZ_com_t *param)
 {
     if (param->pixels_per_block <= 0 || param->pixels_per_scanline <= 0) return SZ_PARAM_ERROR;
     struct aec_stream strm;
@@ -159,6 +160,21 @@ int SZ_BufftoBuffDecompress(void *dest, size_t *destLen, const void *source, siz
     if (planes) from_planes(static_cast<uint8_t *>(dest), tmp.data(), *destLen, (size_t)param->bits_per_pixel / 8);
     else if (padded_lines) memcpy(dest, tmp.data(), *destLen);
     return SZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// (allocation failures of the marshalling buffers must not leave through the C entry points)
+int SZ_BufftoBuffCompress(void *dest, size_t *destLen, const void *source, size_t sourceLen, SZ_com_t *param)
+{
+    try { return compress(dest, destLen, source, sourceLen, param); } catch (const std::bad_alloc &) { return SZ_MEM_ERROR; }
+}
+
+int SZ_BufftoBuffDecompress(void *dest, size_t *destLen, const void *source, size_t sourceLen, SZ_com_t *param)
+{
+    try { return decompress(dest, destLen, source, sourceLen, param); } catch (const std::bad_alloc &) { return SZ_MEM_ERROR; }
 }
 
 int SZ_encoder_enabled(void) { return 1; }

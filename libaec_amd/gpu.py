@@ -50,6 +50,14 @@ def _lib():
         lib.aec_gpu_encode_plan_async.argtypes = [vp, pp, vp, sz, vp, vp]
         lib.aec_gpu_encode_emit_async.restype = C.c_int
         lib.aec_gpu_encode_emit_async.argtypes = [vp, pp, vp, sz, vp, sz, C.c_uint, C.c_uint, vp, vp, vp]
+        lib.aec_gpu_encode_emit_planned_async.restype = C.c_int
+        lib.aec_gpu_encode_emit_planned_async.argtypes = [vp, pp, vp, sz, vp, sz, vp, C.c_uint, vp, vp, vp]
+        lib.aec_gpu_stitch_async.restype = C.c_int
+        lib.aec_gpu_stitch_async.argtypes = [vp, sz, vp, C.c_uint, vp, sz, vp, vp]
+        lib.aec_gpu_index_resume_async.restype = C.c_int
+        lib.aec_gpu_index_resume_async.argtypes = [vp, pp, vp, sz, u64, C.c_uint, u64, vp, u64, vp, vp]
+        lib.aec_gpu_decode_indexed_async.restype = C.c_int
+        lib.aec_gpu_decode_indexed_async.argtypes = [vp, pp, vp, sz, vp, u64, vp, vp, vp, vp]
         lib.aec_gpu_decode_async.restype = C.c_int
         lib.aec_gpu_decode_async.argtypes = [vp, pp, vp, sz, vp, u64, u64, vp, vp, vp]
         lib.aec_gpu_segment_count.restype = u64
@@ -64,6 +72,19 @@ def _lib():
         lib.aec_gpu_index_async.argtypes = [vp, pp, vp, sz, u64, vp, u64, vp, vp]
         _bound = True
     return lib
+
+
+def stitch_async(d_gathered, slot, d_plans, world, d_stream, d_total=None, stream=None):
+    """aec_gpu_stitch_async: compact the all-gathered slices (world slots of `slot` bytes in d_gathered,
+    16 readable bytes behind the last) into one stream at d_stream, on the device."""
+    import torch
+    lib = _lib()
+    st = C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+    rc = lib.aec_gpu_stitch_async(C.c_void_p(d_gathered.data_ptr()), slot, C.c_void_p(d_plans.data_ptr()), world,
+                                  C.c_void_p(d_stream.data_ptr()), d_stream.numel(),
+                                  C.c_void_p(d_total.data_ptr()) if d_total is not None else None, st)
+    if rc != 0:
+        raise RuntimeError(f"aec_gpu_stitch_async failed ({rc})")
 
 
 class Codec:
@@ -159,6 +180,36 @@ class Codec:
             C.c_void_p(d_result.data_ptr()), self._stream(stream))
         if rc != 0:
             raise RuntimeError(f"aec_gpu_encode_emit_async failed ({rc})")
+
+    def encode_emit_planned_async(self, d_in, in_bytes, d_out, d_offsets, d_result, d_plans, rank, stream=None):
+        """second half without a host round trip: d_plans = the all-gathered 24-byte plan records of
+        all shards (uint8 tensor, world * 24 bytes), rank = this shard's index; start bit and carried
+        k are computed on the device"""
+        rc = self.lib.aec_gpu_encode_emit_planned_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes, C.c_void_p(d_out.data_ptr()),
+            d_out.numel(), C.c_void_p(d_plans.data_ptr()), rank,
+            C.c_void_p(d_offsets.data_ptr()) if d_offsets is not None else None,
+            C.c_void_p(d_result.data_ptr()), self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_encode_emit_planned_async failed ({rc})")
+
+    def index_resume_async(self, d_in, in_bytes, start_bit, start_block, rsi_start_bit, d_offsets, max_rsi,
+                           d_result, stream=None):
+        """d_offsets needs max_rsi + 1 entries (the last receives the start of the trailing partial RSI)"""
+        rc = self.lib.aec_gpu_index_resume_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes, start_bit, start_block,
+            rsi_start_bit, C.c_void_p(d_offsets.data_ptr()), max_rsi, C.c_void_p(d_result.data_ptr()),
+            self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_index_resume_async failed ({rc})")
+
+    def decode_indexed_async(self, d_in, in_bytes, d_offsets, max_rsi, d_index_result, d_out, d_result, stream=None):
+        rc = self.lib.aec_gpu_decode_indexed_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes, C.c_void_p(d_offsets.data_ptr()),
+            max_rsi, C.c_void_p(d_index_result.data_ptr()), C.c_void_p(d_out.data_ptr()),
+            C.c_void_p(d_result.data_ptr()), self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_decode_indexed_async failed ({rc})")
 
     def decode_async(self, d_in, in_bytes, d_offsets, n_rsi, total_blocks, d_out, d_result, stream=None):
         rc = self.lib.aec_gpu_decode_async(

@@ -9,8 +9,12 @@ rank by ONE all-gather (RCCL over xGMI when the group's backend is "nccl") follo
 stitch that ORs the shared boundary bytes.  The result is byte-identical to coding the whole input
 on one device (and to the CPU reference).
 
-Everything here is backend-agnostic torch / torch.distributed code: the CPU tests drive it with
-gloo and a test encoder, bench.py with RCCL and the HIP kernels.
+The host-side helpers below (exchange_plans / carry_in / stitch) are backend-agnostic torch code:
+the CPU tests drive them with gloo and a test encoder.  On the device the same step runs WITHOUT a
+host round trip (DeviceShard): the 24-byte plan records are all-gathered as they lie in HBM,
+aec_gpu_encode_emit_planned_async derives start bit and carried k from them in a kernel, and
+aec_gpu_stitch_async compacts the gathered slices (libaec_amd/csrc/aec_shard.hip); a C caller does
+the same with two ncclAllGather calls.
 """
 from typing import List, Sequence, Tuple
 
@@ -93,3 +97,38 @@ def stitch(gathered: torch.Tensor, slot: int, plans: Sequence[Tuple[int, int, in
             out[dst] |= first          # boundary byte shared with the previous slice
         start += bits
     return out, nbytes
+
+
+class DeviceShard:
+    """One rank's part of a stream coded on `world` devices, all on the device (no host sync per step).
+
+        sh = DeviceShard(codec, rank, world, slot, group)
+        sh.step(d_in, nbytes, d_out, d_off, d_eres)     # plan -> all-gather 24 B -> emit at the global offset
+        sh.gather_and_stitch(d_out, d_stream, d_total)  # all-gather of the slices -> one stream (device kernel)
+
+    `slot` (bytes, a multiple of 4096) must hold the largest slice; it has to be known on the host to
+    size the all-gather, e.g. from a first run (slot_bytes(plans)) or from a bound on the ratio.
+    world == 1 works without a process group (the gathers are copies)."""
+
+    def __init__(self, codec, rank, world, slot, group=None):
+        from . import gpu
+        self.gpu, self.codec, self.rank, self.world, self.slot, self.group = gpu, codec, rank, world, slot, group
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.d_plans = torch.zeros(world * 24, dtype=torch.uint8, device=dev)
+        self.d_gathered = torch.zeros(world * slot + 16, dtype=torch.uint8, device=dev)
+
+    def step(self, d_in, nbytes, d_out, d_off, d_eres):
+        self.codec.encode_plan_async(d_in, nbytes, d_eres)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.d_plans, d_eres[:24], group=self.group)
+        else:
+            self.d_plans.copy_(d_eres[:24])
+        self.codec.encode_emit_planned_async(d_in, nbytes, d_out, d_off, d_eres, self.d_plans, self.rank)
+
+    def gather_and_stitch(self, d_out, d_stream, d_total=None):
+        view = self.d_gathered[: self.world * self.slot]
+        if self.world > 1:
+            dist.all_gather_into_tensor(view, d_out[: self.slot], group=self.group)
+        else:
+            view.copy_(d_out[: self.slot])
+        self.gpu.stitch_async(self.d_gathered, self.slot, self.d_plans, self.world, d_stream, d_total)

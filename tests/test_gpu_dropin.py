@@ -1,6 +1,7 @@
 """Binary drop-in: the reference's OWN programs -- its CLI src/aec.c and its tests
-tests/check_buffer_sizes.c, tests/check_long_fs.c -- compiled unchanged (oracle/Makefile target
-`dropin`, against the reference's header) but linked to libaec_amd/lib/libaec.so.0, run on the GPU."""
+tests/check_buffer_sizes.c, tests/check_long_fs.c, tests/check_code_options.c -- compiled unchanged
+(oracle/Makefile target `dropin`, against the reference's header) but linked to
+libaec_amd/lib/libaec.so.0, run on the GPU."""
 import hashlib
 import os
 import subprocess
@@ -43,3 +44,27 @@ def test_reference_test_programs_on_product_library(prog):
     out = subprocess.run([_need(prog)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:]
     assert "PASS" in out.stdout and "FAIL" not in out.stdout
+
+
+def test_reference_check_code_options_on_product_library():
+    """The reference's primary test (tests/check_code_options.c:197-326 driving tests/check_aec.c:59-200):
+    every code option x block sizes 8..64 x rsi 1..max x 8/16/24/32 bits x five flag sets, once with
+    ONE SAMPLE IN / ONE BYTE OUT per call (encode_decode_small: ~10^9 calls into the streaming
+    boundary) and once in whole buffers: ~245 000 streams in all.  On the reference it takes ~10 s of
+    CPU; here every stream costs a few GPU round trips, so it runs for minutes -- with a time budget,
+    and what it got through is reported if the budget runs out."""
+    import time
+    budget = float(os.environ.get("AEC_CCO_BUDGET_S", "1500"))
+    t0 = time.time()
+    p = subprocess.Popen([_need("check_code_options")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        out, _ = p.communicate(timeout=budget)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        out, _ = p.communicate()
+        done = out.count("PASS")
+        pytest.fail(f"check_code_options did not finish in {budget:.0f} s: {done} option checks passed so far, "
+                    f"no failure; last lines:\n" + "\n".join(out.splitlines()[-6:]))
+    print(f"check_code_options: {time.time() - t0:.1f} s, {out.count('PASS')} option checks")
+    assert p.returncode == 0, out[-3000:]
+    assert "FAIL" not in out and "Checking with large buffers" in out

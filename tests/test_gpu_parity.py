@@ -476,17 +476,71 @@ def test_pad_rsi_and_restricted_through_abi(api):
         check_roundtrip(api, f"restricted-{bps}", bps, 16, 10, fl, pack_samples(vals, bps, fl))
 
 
+def _check_truncated(dec, dec_o, plain, bs, nb, what):
+    """What a stream cut inside a coded data set must give: every sample whose bits arrived, exactly as
+    the reference's resumable readers release them (see aec_abi.cpp decode_run / k_decode PARTIAL)."""
+    assert dec_o == plain[: len(dec_o)]
+    assert dec == dec_o, (what, len(dec), len(dec_o))
+
+
 def test_corrupt_and_truncated_streams(api):
-    """A stream cut inside a coded data set yields the complete CDSes before the cut and AEC_OK;
-    a zero-run that overruns its RSI is AEC_DATA_ERROR (reference decode.c:543-544)."""
+    """A stream cut inside a coded data set: compared with the oracle's decode of the same truncated
+    input (reference decode.c:342-400, 423-460).  A zero-run that overruns its RSI is AEC_DATA_ERROR
+    (reference decode.c:543-544)."""
     data = pack_samples(np.arange(4096) * 3 % 4096, 16, PP)
     rc, enc = api.aec_buffer_encode(data, 16, 16, 16, PP)
-    rc, dec = api.aec_buffer_decode(enc[: len(enc) // 2], 16, 16, 16, PP, data.size)
-    assert rc == AEC_OK and 0 < len(dec) < data.size and len(dec) % 32 == 0
-    assert dec == data.tobytes()[: len(dec)]
+    rng = np.random.default_rng(11)
+    for cut in [len(enc) // 2] + [int(v) for v in rng.integers(1, len(enc), 12)]:
+        rc, dec = api.aec_buffer_decode(enc[:cut], 16, 16, 16, PP, data.size)
+        rc_o, dec_o, _ = oracle_decode(enc[:cut], 16, 16, 16, PP, data.size)
+        assert rc == rc_o == AEC_OK
+        _check_truncated(dec, dec_o, data.tobytes(), 16, 2, cut)
     # all-zero blocks in an RSI of 3: ID 0000 + 0 (zero run) + ref 16 bits + fs code "0000001"
     # (fs = 6 -> 6 blocks) overruns the 3-block RSI
     bad = bytes([0b00000000, 0x00, 0x00, 0b00000001, 0x00])
     rc, _ = api.aec_buffer_decode(bad, 16, 16, 3, PP, 4096)
     rc_o, _, _ = oracle_decode(bad, 16, 16, 3, PP, 4096)
     assert rc == rc_o == api.AEC_DATA_ERROR
+
+
+def test_truncated_streams_release_what_arrived(api):
+    """Streams of all code options cut at random bytes, one-shot and fed in two pieces: the samples
+    delivered are exactly those the reference's resumable readers release (oracle pinned against the
+    reference on this in tests/test_oracle.py::test_truncated_streams_vs_reference)."""
+    from libaec_amd.api import Decoder
+    rng = np.random.default_rng(2718)
+    for it in range(40):
+        bps = int(rng.choice([8, 12, 16, 24, 32]))
+        flags = PP if rng.random() < 0.8 else 0
+        if rng.random() < 0.5:
+            flags |= MSB
+        if rng.random() < 0.4:
+            flags |= SGN
+        bs = int(rng.choice([8, 16, 32, 64]))
+        rsi = int(rng.choice([1, 3, 16, 64, 130]))
+        nb = bytes_per_sample(bps, flags)
+        n = int(rng.integers(bs, 6000))
+        vals = random_walk_samples(rng, n, bps, flags, scale=float(rng.choice([0.3, 3, 50, 5000])),
+                                   zero_frac=float(rng.choice([0.05, 0.5])))
+        data = pack_samples(vals, bps, flags)
+        rc, enc, *_ = oracle_encode(data, bps, bs, rsi, flags)
+        cap = ((n + bs - 1) // bs) * bs * nb
+        for cut in [int(v) for v in rng.integers(0, len(enc) + 1, 4)]:
+            rc_o, dec_o, _ = oracle_decode(enc[:cut], bps, bs, rsi, flags, cap)
+            rc, dec = api.aec_buffer_decode(enc[:cut], bps, bs, rsi, flags, cap)
+            assert rc == rc_o == AEC_OK and dec == dec_o, (it, bps, bs, rsi, flags, n, cut, len(dec), len(dec_o))
+            # the same bytes in two calls: what the first call released early must not come again
+            first = int(rng.integers(0, cut + 1))
+            d = Decoder(bps, bs, rsi, flags)
+            got = bytearray()
+            for piece in (enc[:first], enc[first:cut], b""):
+                off = 0
+                while True:
+                    rc, used, out = d.call(piece[off:], cap, AEC_NO_FLUSH if piece else AEC_FLUSH)
+                    assert rc == AEC_OK
+                    got += out
+                    off += used
+                    if off >= len(piece) and not out:
+                        break
+            d.end()
+            assert bytes(got) == dec_o, (it, bps, bs, rsi, flags, n, cut, first, len(got), len(dec_o))

@@ -156,6 +156,34 @@ def test_differential_vs_reference():
             assert rc_r == rc_o and (rc_r != AEC_OK or dec_r == dec_o), (it, bps, bs, rsi, flags, n, c)
 
 
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (reference tree absent)")
+def test_truncated_streams_vs_reference():
+    """A stream cut anywhere (also inside a coded data set): the reference's resumable readers release
+    every sample whose bits arrived (decode.c:342-400, 423-460, 560-587, 646-657); the oracle must
+    release exactly the same ones.  This pins the behaviour the GPU tests hold the product to."""
+    rng = np.random.default_rng(78)
+    for it in range(150):
+        bps = int(rng.choice([8, 12, 16, 24, 32]))
+        flags = AEC_DATA_PREPROCESS if rng.random() < 0.8 else 0
+        if rng.random() < 0.5:
+            flags |= AEC_DATA_MSB
+        if rng.random() < 0.4:
+            flags |= AEC_DATA_SIGNED
+        bs = int(rng.choice([8, 16, 32, 64]))
+        rsi = int(rng.choice([1, 3, 16, 64, 130]))
+        n = int(rng.integers(bs, 4000))
+        vals = random_walk_samples(rng, n, bps, flags, scale=float(rng.choice([0.3, 3, 50, 5000])),
+                                   zero_frac=float(rng.choice([0.05, 0.5])))
+        data = pack_samples(vals, bps, flags)
+        rc, enc = ref_encode(data, bps, bs, rsi, flags)
+        assert rc == AEC_OK
+        cap = ((n + bs - 1) // bs) * bs * bytes_per_sample(bps, flags)
+        for cut in [int(v) for v in rng.integers(0, len(enc) + 1, 6)]:
+            rc_r, dec_r = ref_decode(enc[:cut], bps, bs, rsi, flags, cap)
+            rc_o, dec_o, _ = oracle_decode(enc[:cut], bps, bs, rsi, flags, cap)
+            assert rc_r == rc_o and dec_r == dec_o, (it, bps, bs, rsi, flags, n, cut, len(dec_r), len(dec_o))
+
+
 def test_pad_rsi_decode():
     """AEC_PAD_RSI (decoder side, reference decode.c:407-408): every RSI starts on a byte boundary.
     The reference encoder never pads (ENABLE_RSI_PADDING is dead code, encode.c:499-505), so such a
