@@ -81,8 +81,9 @@ struct DevBuf {
 // batching thresholds
 constexpr size_t kEncBatchBytes = (size_t)1 << 20;   // staged input that is worth a launch without AEC_FLUSH
 constexpr size_t kEncDirectMin = (size_t)64 << 10;   // whole RSIs offered in one call: coded from the caller's buffer
-constexpr size_t kDecTrickle = 4096;                 // new input below this is collected before a launch ...
-constexpr size_t kDecDirectMin = 4096;               // ... at or above it goes straight to the device
+constexpr size_t kDecTinyCall = 8;                   // a call that brings at most this many bytes is a trickle ...
+constexpr size_t kDecTrickle = 4096;                 // ... collected on the host up to this many before a launch
+constexpr size_t kDecDirectMin = 4096;               // input of at least this size goes straight to the device
 constexpr size_t kMinBatchOut = (size_t)4 << 20;     // output a decode batch may produce beyond the room offered
 constexpr size_t kBacklogMax = (size_t)64 << 20;     // undecoded input held on the device before more is accepted
 constexpr size_t kBounce = (size_t)256 << 10;        // pinned bounce buffer: first output bytes ride with the records
@@ -117,6 +118,7 @@ struct internal_state {
     uint64_t base;                 // multiple of 16
     size_t d_len;
     uint64_t rsi_start_bit;        // start of the RSI being decoded
+    uint64_t rsi_bits_seen;        // average coded RSI of the previous batch (0 = none yet)
     uint64_t walk_bit;             // coded-data-set boundary where the index walker resumes
     uint32_t walk_blocks;          // blocks of that RSI in front of walk_bit
     uint64_t delivered;            // samples of that RSI already handed out
@@ -229,6 +231,7 @@ int init_common(struct aec_stream *strm, bool enc)
     s->base = 0;
     s->d_len = 0;
     s->rsi_start_bit = 0;
+    s->rsi_bits_seen = 0;
     s->walk_bit = 0;
     s->walk_blocks = 0;
     s->delivered = 0;
@@ -402,7 +405,15 @@ int decode_run(internal_state *s, struct aec_stream *strm)
 
     aec_gpu_dec_result *d_idx = static_cast<aec_gpu_dec_result *>(s->d_res.p), *d_dec = d_idx + 1;
     uint64_t *d_off = static_cast<uint64_t *>(s->d_off.p);
-    // look-ahead of the speculative index: the average coded RSI seen so far in this stream, if any
+    // Look-ahead of the speculative index = a small multiple of the average coded RSI: measured on
+    // the previous batch of this stream, else estimated from the room the caller offers for output
+    // (whole-buffer callers offer the decoded size).
+    uint64_t hint = s->rsi_bits_seen;
+    if (!hint && strm->avail_out >= rsi_bytes) {
+        const uint64_t expect = (strm->avail_out + skip + rsi_bytes - 1) / rsi_bytes;
+        hint = ((uint64_t)s->d_len * 8 - rsi_rel) / expect;
+    }
+    aec_gpu_set_index_hint(s->ctx, hint + hint / 2);
     int rc = aec_gpu_index_resume_async(s->ctx, &s->prm, s->d_in.p, in_bytes, walk_rel, s->walk_blocks, rsi_rel,
                                         d_off, max_rsi, d_idx, s->stream);
     if (rc != RC_OK) return AEC_FAIL(rc);
@@ -470,6 +481,7 @@ int decode_run(internal_state *s, struct aec_stream *strm)
         }
     }
     if (corrupt) return AEC_DATA_ERROR;
+    if (idx.n_rsi) s->rsi_bits_seen = (idx.end_bit - rsi_rel) / (idx.n_rsi + (idx.tail_blocks ? 1 : 0));
 
     // advance: the walker resumes behind the last complete coded data set
     s->walk_bit = base_bits + idx.end_bit;
@@ -583,7 +595,7 @@ int decode_call(struct aec_stream *strm, int flush)
     strm->total_in += strm->avail_in;     // reference decode.c:811-812
     strm->total_out += strm->avail_out;
     int rc = s->sticky_error;
-    const bool brought = strm->avail_in != 0;
+    const size_t brought = strm->avail_in;
 
     while (rc == AEC_OK) {
         drain(strm, s, bytes);
@@ -603,12 +615,13 @@ int decode_call(struct aec_stream *strm, int flush)
         }
         const bool pending = !s->stage.empty() || s->d_len > s->walked_len || s->more;
         if (!pending) break;
-        // When to run a batch: always, except for a caller that trickles input in (new bytes, fewer
-        // than kDecTrickle waiting, AEC_NO_FLUSH, not the first call): those are collected until a
-        // call brings nothing new -- which is how such callers ask for the rest (reference
-        // src/aec.c:191-221, tests/check_aec.c:138-166) -- so that a byte-at-a-time caller costs a
-        // vector append per call instead of a launch.
-        const bool trickle = brought && flush != AEC_FLUSH && s->launched && !s->more &&
+        // When to run a batch: always -- a caller may take "output not full" to mean that everything
+        // the input allows has come out -- except for a caller that trickles input in a few bytes per
+        // call (at most kDecTinyCall new bytes, fewer than kDecTrickle waiting, AEC_NO_FLUSH, not the
+        // first call): those bytes are collected until a call brings nothing new, which is how such
+        // callers ask for the rest (reference src/aec.c:191-221, tests/check_aec.c:138-166), so that a
+        // byte-at-a-time caller costs a vector append per call instead of a launch.
+        const bool trickle = brought && brought <= kDecTinyCall && flush != AEC_FLUSH && s->launched && !s->more &&
                              s->d_len <= s->walked_len && s->stage.size() < kDecTrickle;
         if (trickle) break;
         const size_t out_before = strm->avail_out, q_before = s->outq.size();
