@@ -64,9 +64,13 @@ AEC_HD uint32_t spec_rank(const SpecWin &s, uint32_t q)
 // position just behind the j-th 1-bit of the window (j >= 1), kSpecInvalid if there are fewer
 AEC_HD uint32_t spec_select(const SpecWin &s, uint32_t j)
 {
-    const bool have = j <= s.rank[s.nwords];
-    const uint32_t jj = have ? j : 1u;
+    // (a window without enough 1-bits -- none at all in a stretch of zero padding -- has no sel[]
+    // entry to start from: the search below must not run in that case)
+    const bool have = j >= 1u && j <= s.rank[s.nwords];
+    if (!have) return kSpecInvalid;
+    const uint32_t jj = j;
     uint32_t w = s.sel[(jj - 1u) >> 5];
+    if (w >= s.nwords) return kSpecInvalid;          // cannot happen for a consistent table
     // the word is at most 31 one-bits further on: probe four words at once (independent loads),
     // walk on only in sparse regions
     {
@@ -82,7 +86,7 @@ AEC_HD uint32_t spec_select(const SpecWin &s, uint32_t j)
             w += 3;
         } else {
             w += 4;
-            while (s.rank[w + 1] < jj) w++;
+            while (w + 1u < s.nwords && s.rank[w + 1] < jj) w++;
         }
     }
     uint32_t r = jj - s.rank[w];            // 1-based rank inside the word, from the MSB
