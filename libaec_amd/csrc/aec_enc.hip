@@ -531,71 +531,79 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
     }
 }
 
+// Phase B of one segment (rows already in LDS): this lane's block summary (meta_pack), the segment's
+// bit length and its k clamp (lo | hi << 8), both wave-uniform.
+template <int BS, int BYTES>
+__device__ __forceinline__ uint32_t analyze_segment(const Cfg &c, const Seg &g, const uint32_t *rows, uint32_t stride,
+                                                    uint32_t lane, uint32_t &tot, uint32_t &cl)
+{
+    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
+    const bool pp = c.flags & F_PREPROCESS;
+    constexpr bool WIDE_T = (BYTES >= 3);
+    BlockRegs<BS, Rows<BS, BYTES>::HALF && BS != 0 ? false : Rows<BS, BYTES>::HALF> regs;
+    constexpr bool PK = Rows<BS, BYTES>::HALF && BS != 0;   // uint16 rows: analysed two samples at a time
+    const bool valid = lane < g.nv;
+    // every lane loads a row (idle lanes re-read the last valid one) so that the block lives in
+    // registers instead of behind a conditionally assigned pointer
+    const uint32_t *row = rows + (valid ? lane : g.nv - 1) * stride;
+    uint32_t w[PK ? BS / 2 : 1];                            // the block as sample pairs
+    const uint32_t *d = nullptr;
+    bool zero;
+    if (PK) {
+#pragma unroll
+        for (int q = 0; q < (PK ? BS / 8 : 0); q++) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(row + 4 * q);
+            w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+        }
+        uint32_t any = 0;
+#pragma unroll
+        for (int j = 0; j < (PK ? BS / 2 : 0); j++) any |= w[j];
+        zero = valid && any == 0;
+    } else {
+        d = regs.load(row);
+        zero = valid && block_is_zero<BS>(d, bs);
+    }
+    const uint64_t zmask = __ballot(zero);
+
+    uint32_t m = meta_pack(0, OPT_ZCONT, 0, 0);
+    KClamp kc = kclamp_identity();
+    if (valid) {
+        const uint32_t ref = (pp && g.b0 == 0 && lane == 0) ? 1u : 0u;
+        if (zero) {
+            uint32_t fs = 0;
+            const uint32_t run = zero_run_at(zmask, lane, g.nv, fs);
+            if (run) m = meta_pack(c.id_len + 1 + ref * c.bps + fs + 1, OPT_ZERO, fs, 0);
+        } else {
+            BlockChoice ch;
+            if (PK)
+                ch = choose_option_pk<(PK ? BS : 8)>(w, c, ref);
+            else if (BS == 0)
+                ch = (c.bps > 16) ? choose_option<BS, true>(d, c, ref) : choose_option<BS, false>(d, c, ref);
+            else
+                ch = choose_option<BS, WIDE_T>(d, c, ref);
+            m = meta_pack(ch.bits, ch.opt, ch.klo, ch.khi);
+            if (c.id_len > 1) kc = KClamp{ch.klo, ch.khi};
+        }
+    }
+    tot = wave_last(wave_incl_sum(meta_len(m), lane));
+    cl = wave_last(wave_incl_clamp(clamp_pack(kc), lane));
+    return m;
+}
+
 template <int BS, int BYTES>
 __device__ __forceinline__ void analyze_body(const Cfg &c, const Seg &g, uint32_t *rows, uint32_t stride,
                                              uint32_t lane, uint64_t sg, uint32_t *__restrict__ meta,
                                              uint32_t *__restrict__ seg_bits, uint16_t *__restrict__ seg_clamp)
 {
-    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
-    const bool pp = c.flags & F_PREPROCESS;
-    constexpr bool WIDE_T = (BYTES >= 3);
-    {
-        wave_lds_fence();
-
-        BlockRegs<BS, Rows<BS, BYTES>::HALF && BS != 0 ? false : Rows<BS, BYTES>::HALF> regs;
-        constexpr bool PK = Rows<BS, BYTES>::HALF && BS != 0;   // uint16 rows: analysed two samples at a time
-        const bool valid = lane < g.nv;
-        // every lane loads a row (idle lanes re-read the last valid one) so that the block lives in
-        // registers instead of behind a conditionally assigned pointer
-        const uint32_t *row = rows + (valid ? lane : g.nv - 1) * stride;
-        uint32_t w[PK ? BS / 2 : 1];                            // the block as sample pairs
-        const uint32_t *d = nullptr;
-        bool zero;
-        if (PK) {
-#pragma unroll
-            for (int q = 0; q < (PK ? BS / 8 : 0); q++) {
-                const uint4 t = *reinterpret_cast<const uint4 *>(row + 4 * q);
-                w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
-            }
-            uint32_t any = 0;
-#pragma unroll
-            for (int j = 0; j < (PK ? BS / 2 : 0); j++) any |= w[j];
-            zero = valid && any == 0;
-        } else {
-            d = regs.load(row);
-            zero = valid && block_is_zero<BS>(d, bs);
-        }
-        const uint64_t zmask = __ballot(zero);
-
-        uint32_t m = meta_pack(0, OPT_ZCONT, 0, 0);
-        KClamp kc = kclamp_identity();
-        if (valid) {
-            const uint32_t ref = (pp && g.b0 == 0 && lane == 0) ? 1u : 0u;
-            if (zero) {
-                uint32_t fs = 0;
-                const uint32_t run = zero_run_at(zmask, lane, g.nv, fs);
-                if (run) m = meta_pack(c.id_len + 1 + ref * c.bps + fs + 1, OPT_ZERO, fs, 0);
-            } else {
-                BlockChoice ch;
-                if (PK)
-                    ch = choose_option_pk<(PK ? BS : 8)>(w, c, ref);
-                else if (BS == 0)
-                    ch = (c.bps > 16) ? choose_option<BS, true>(d, c, ref) : choose_option<BS, false>(d, c, ref);
-                else
-                    ch = choose_option<BS, WIDE_T>(d, c, ref);
-                m = meta_pack(ch.bits, ch.opt, ch.klo, ch.khi);
-                if (c.id_len > 1) kc = KClamp{ch.klo, ch.khi};
-            }
-            meta[g.blk0 + lane] = m;
-        }
-        const uint32_t tot = wave_last(wave_incl_sum(meta_len(m), lane));
-        const uint32_t cl = wave_last(wave_incl_clamp(clamp_pack(kc), lane));
-        if (lane == 0) {
-            seg_bits[sg] = tot;
-            seg_clamp[sg] = (uint16_t)cl;
-        }
-        wave_lds_fence();
+    wave_lds_fence();
+    uint32_t tot, cl;
+    const uint32_t m = analyze_segment<BS, BYTES>(c, g, rows, stride, lane, tot, cl);
+    if (lane < g.nv) meta[g.blk0 + lane] = m;
+    if (lane == 0) {
+        seg_bits[sg] = tot;
+        seg_clamp[sg] = (uint16_t)cl;
     }
+    wave_lds_fence();
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -760,6 +768,64 @@ k_seg_table(const Cfg c, const uint8_t *__restrict__ in, const uint64_t *__restr
     table[sg] = SegEntry{seg_start[sg], prev, 0u};
 }
 
+// Emission of one segment into its LDS image (rows in LDS, block summaries in registers): offsets
+// inside the segment by a DPP prefix sum of the lengths, k by the DPP clamp scan from the k carried
+// into the segment.  Word 0 of the image continues `pending`, the open tail word of the wave's
+// previous segment.  Returns the segment's bit length and clamp (wave-uniform).
+template <int BS, int BYTES>
+__device__ __forceinline__ void emit_segment(const Cfg &c, const Seg &g, const uint32_t *rows, uint32_t stride,
+                                             uint32_t *obuf, uint32_t lane, uint32_t m, uint32_t kin, uint32_t lead,
+                                             uint32_t ref_sample, uint32_t pending, uint32_t &total, uint32_t &seg_cl)
+{
+    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
+    const bool pp = c.flags & F_PREPROCESS;
+    const bool valid = lane < g.nv;
+    const uint32_t len = meta_len(m), opt = meta_opt(m);
+    const uint32_t incl = wave_incl_sum(len, lane);
+    total = wave_last(incl);
+    const uint32_t excl = incl - len;
+
+    const bool updates_k = valid && opt != OPT_ZERO && opt != OPT_ZCONT && c.id_len > 1;
+    const KClamp kc = updates_k ? KClamp{meta_a(m), meta_b(m)} : kclamp_identity();
+    const uint32_t incl_c = wave_incl_clamp(clamp_pack(kc), lane);
+    seg_cl = wave_last(incl_c);
+    const uint32_t excl_c = wave_shr1(incl_c, clamp_pack(kclamp_identity()));
+    const uint32_t k = kclamp_apply(kc, kclamp_apply(clamp_unpack(excl_c), kin));
+
+    // image of the segment; its first word continues the previous segment of this wave, whose
+    // open tail word was kept in `pending` instead of being written out
+    if (lane == 0) obuf[0] = pending;
+    wave_lds_fence();
+    {
+        const bool emits = valid && opt != OPT_ZCONT;
+        const uint32_t ref = (pp && g.b0 == 0 && lane == 0) ? 1u : 0u;
+        const uint32_t karg = opt == OPT_ZERO ? meta_a(m) : k;
+        BlockRegs<BS, Rows<BS, BYTES>::HALF> regs;
+        const uint32_t *d = regs.load(rows + (valid ? lane : 0u) * stride);
+        LdsSink sink{obuf};
+        BitWriter<LdsSink> bw(sink, lead + excl);
+        bool done = !emits;
+        if (BS > 0 && BS <= 16) {
+            // small blocks: unary and field regions assembled in registers (aec_lane.h emit_small)
+            uint32_t ubits = 0, fbits = 0;
+            const bool small = emits && small_eligible(c, bs, opt, karg, ref, len, ubits, fbits);
+            emit_small<(BS > 0 && BS <= 16 ? BS : 8)>(bw, d, c, opt, karg, ref, ref_sample, ubits, fbits, small);
+            done = done || small;
+        }
+        if (BS == 32) {
+            // blocks of 32: the split option appended in groups (aec_lane.h emit_split_groups;
+            // C3 pack 2.40 -> 2.19 ms.  For blocks of 64 it costs registers and was slower.)
+            const bool grp = !done && opt == OPT_SPLIT;
+            emit_split_groups<32>(bw, d, c, karg, ref, ref_sample, grp);
+            done = done || grp;
+        }
+        if (__any(!done)) {
+            if (!done) emit_block<BS>(bw, d, c, opt, karg, ref, ref_sample);
+        }
+    }
+    wave_lds_fence();
+}
+
 // ----------------------------------------------------------------------------------------------
 // K3: pack
 // ----------------------------------------------------------------------------------------------
@@ -808,52 +874,10 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
         feeder.prefetch(c, in, gnext, lane);      // next segment's loads fly during this one
         feeder.feed(c, in, g, cur, rows, stride, lane);
 
-        const uint32_t len = meta_len(m), opt = meta_opt(m);
-        const uint32_t incl = wave_incl_sum(len, lane);
-        const uint32_t total = wave_last(incl);
-        const uint32_t excl = incl - len;
-
-        const bool updates_k = valid && opt != OPT_ZERO && opt != OPT_ZCONT && c.id_len > 1;
-        const KClamp kc = updates_k ? KClamp{meta_a(m), meta_b(m)} : kclamp_identity();
-        const uint32_t incl_c = wave_incl_clamp(clamp_pack(kc), lane);
-        const uint32_t excl_c = wave_shr1(incl_c, clamp_pack(kclamp_identity()));
-        const uint32_t k = kclamp_apply(kc, kclamp_apply(clamp_unpack(excl_c), kin));
-
         const uint32_t lead = (uint32_t)(start & 31u);
+        uint32_t total, seg_cl;
+        emit_segment<BS, BYTES>(c, g, rows, stride, obuf, lane, m, kin, lead, ref_sample, pending, total, seg_cl);
         const uint32_t nwords = (lead + total + 31u) >> 5;
-        // image of the segment; its first word continues the previous segment of this wave, whose
-        // open tail word was kept in `pending` instead of being written out
-        if (lane == 0) obuf[0] = pending;
-        wave_lds_fence();
-
-        {
-            const bool emits = valid && opt != OPT_ZCONT;
-            const uint32_t ref = (pp && g.b0 == 0 && lane == 0) ? 1u : 0u;
-            const uint32_t karg = opt == OPT_ZERO ? meta_a(m) : k;
-            BlockRegs<BS, Rows<BS, BYTES>::HALF> regs;
-            const uint32_t *d = regs.load(rows + (valid ? lane : 0u) * stride);
-            LdsSink sink{obuf};
-            BitWriter<LdsSink> bw(sink, lead + excl);
-            bool done = !emits;
-            if (BS > 0 && BS <= 16) {
-                // small blocks: unary and field regions assembled in registers (aec_lane.h emit_small)
-                uint32_t ubits = 0, fbits = 0;
-                const bool small = emits && small_eligible(c, bs, opt, karg, ref, len, ubits, fbits);
-                emit_small<(BS > 0 && BS <= 16 ? BS : 8)>(bw, d, c, opt, karg, ref, ref_sample, ubits, fbits, small);
-                done = done || small;
-            }
-            if (BS == 32) {
-                // blocks of 32: the split option appended in groups (aec_lane.h emit_split_groups;
-                // C3 pack 2.40 -> 2.19 ms.  For blocks of 64 it costs registers and was slower.)
-                const bool grp = !done && opt == OPT_SPLIT;
-                emit_split_groups<32>(bw, d, c, karg, ref, ref_sample, grp);
-                done = done || grp;
-            }
-            if (__any(!done)) {
-                if (!done) emit_block<BS>(bw, d, c, opt, karg, ref, ref_sample);
-            }
-        }
-        wave_lds_fence();
 
         // Copy the image out.  Only a word this wave does not own alone needs an atomic: the first
         // word of the wave's first segment (shared with the previous wave) and the open tail word of
@@ -885,6 +909,342 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
         first_seg = false;
         wave_lds_fence();
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K1+K2+K3 in ONE pass: analysis, scan and emission without a second read of the input
+// ----------------------------------------------------------------------------------------------
+// A workgroup takes a ticket (its partition = the next waves x SEGS segments, so every partition it
+// will ever wait for has started before it), analyses its segments ONCE -- the preprocessed rows of
+// all of them stay in LDS, the block summaries in registers -- and publishes the partition's
+// (bit length, k clamp).  Start bit and carried k come from a decoupled look-back over those
+// aggregates (Merrill & Garland's single-pass scan: the nearest predecessor that already knows its
+// inclusive prefix, plus the aggregates after it), then every wave emits from the rows in LDS.
+// Nothing but the input is read from HBM and nothing but the stream is written: no per-block
+// summaries, no scan kernels, no second pass over the input (reference src/encode.c:235-311,
+// 313-434, 520-583 stay bit-exact: same arithmetic, other order).
+//
+// Hand-offs between workgroups follow /opt/skills/guides/cdna_hip_programming.md Guideline 16, form
+// R2: every shared word is ONE naturally aligned 8-byte granule {status, value} written by a relaxed
+// agent-scope atomic store and polled by relaxed agent-scope atomic loads (the per-XCD L2s are not
+// coherent); all of them are zeroed by a hipMemsetAsync in front of the launch.  Every spin is
+// bounded: a timeout sets *fail (the host reports AEC_MEM_ERROR) instead of hanging the device.
+//   desc[p]   [0:2) status (1 = the partition's own aggregate, 2 = inclusive prefix), [2:7) clamp lo,
+//             [7:12) clamp hi, [12:64) bits
+//   tails[p]  bit 63 valid, bit 62 "the partition ends inside a word", [0:32) that open word (the
+//             stream words two partitions share are written by the later one)
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+__device__ __forceinline__ uint64_t granule_load(const uint64_t *p)
+{
+    return __hip_atomic_load(reinterpret_cast<gu64 *>(reinterpret_cast<uintptr_t>(p)), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void granule_store(uint64_t *p, uint64_t v)
+{
+    __hip_atomic_store(reinterpret_cast<gu64 *>(reinterpret_cast<uintptr_t>(p)), v, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint64_t desc_pack(uint32_t status, ScanVal v)
+{
+    return (uint64_t)status | ((uint64_t)(v.cl & 0x1Fu) << 2) | ((uint64_t)((v.cl >> 8) & 0x1Fu) << 7) | (v.bits << 12);
+}
+__device__ __forceinline__ ScanVal desc_unpack(uint64_t x)
+{
+    return ScanVal{x >> 12, (uint32_t)((x >> 2) & 0x1Fu) | ((uint32_t)((x >> 7) & 0x1Fu) << 8)};
+}
+
+// ordered reduction over the 64 lanes (lane 0 first); result valid in every lane
+__device__ __forceinline__ ScanVal wave_fold(ScanVal v, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t o = 1; o < kWave; o <<= 1) {
+        ScanVal t;
+        t.bits = __shfl_up((unsigned long long)v.bits, o);
+        t.cl = __shfl_up(v.cl, o);
+        if (lane >= o) v = scan_then(t, v);
+    }
+    ScanVal r;
+    r.bits = __shfl((unsigned long long)v.bits, 63);
+    r.cl = __shfl(v.cl, 63);
+    return r;
+}
+
+constexpr uint32_t kSpinLimit = 1u << 22;      // x (s_sleep + an L2 round trip): seconds, never reached in a healthy run
+
+// exclusive prefix of partition p (whole wave; every lane returns it)
+__device__ __forceinline__ ScanVal lookback(const uint64_t *desc, uint32_t p, uint32_t lane, uint32_t *fail)
+{
+    ScanVal acc = scan_identity();               // composition of the partitions after `idx`, up to p - 1
+    int64_t idx = (int64_t)p - 1;
+    for (;;) {
+        // ascending lane = ascending partition: lane j looks at partition idx - (63 - j); in front of the
+        // stream stands a virtual partition that "knows" the empty prefix
+        const int64_t q = idx - (int64_t)(63u - lane);
+        uint64_t x = 2u | ((uint64_t)31u << 7);
+        for (uint32_t spins = 0;; spins++) {
+            if (q >= 0) x = granule_load(desc + q);
+            if (__all((x & 3u) != 0u)) break;
+            if (spins > kSpinLimit) {
+                if (lane == 0) atomicOr(fail, 1u);
+                return acc;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const uint64_t incl = __ballot((x & 3u) == 2u);
+        ScanVal v = desc_unpack(x);
+        if (incl) {
+            const uint32_t jl = 63u - (uint32_t)__builtin_clzll(incl);   // nearest one with an inclusive prefix
+            if (lane < jl) v = scan_identity();
+            return scan_then(wave_fold(v, lane), acc);
+        }
+        acc = scan_then(wave_fold(v, lane), acc);
+        idx -= 64;
+    }
+}
+
+struct WaveEdge {          // the words a wave does not store itself
+    uint64_t head_idx, tail_idx;
+    uint32_t head_val, tail_val;
+    uint32_t shared_head, tail_open;
+};
+
+template <int BS, int BYTES, int SEGS>
+__global__ void __launch_bounds__(256)
+k_encode_fused(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ out_words, uint64_t cap_words,
+               uint64_t *desc, uint64_t *tails, uint32_t *ticket, uint32_t *fail, uint32_t nparts,
+               uint32_t parts_per_wg, uint32_t start_bit, uint32_t k_in, uint64_t *__restrict__ rsi_off,
+               SegEntry *__restrict__ seg_table, EncResult *res, uint32_t obuf_words, uint32_t fast_ok)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    __shared__ uint32_t sh_part;
+    __shared__ ScanVal sh_agg[4], sh_excl;
+    __shared__ WaveEdge sh_edge[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t bs = BS ? (uint32_t)BS : c.bs;
+    const uint32_t stride = Rows<BS, BYTES>::stride_words(bs);
+    const uint32_t seg_words = 64u * stride;
+    uint32_t *rows0 = smem + (size_t)wave * (SEGS * seg_words + obuf_words);
+    uint32_t *obuf = rows0 + SEGS * seg_words;
+    const bool pp = c.flags & F_PREPROCESS, msb = c.flags & F_MSB;
+
+    // One ticket buys parts_per_wg consecutive partitions (a single counter word takes ~88 atomics per
+    // microsecond: tickets must be much rarer than that).  Whatever a partition waits for belongs to a
+    // lower ticket -- a workgroup that is resident and only ever waits for still lower ones -- or to this
+    // workgroup's own earlier rounds.
+    if (threadIdx.x == 0) sh_part = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t p_first = sh_part * parts_per_wg;
+    for (uint32_t w = lane; w < obuf_words; w += kWave) obuf[w] = 0u;   // the image buffer starts out zero
+    for (uint32_t p = p_first; p < p_first + parts_per_wg && p < nparts; p++) {
+    const uint64_t sg0 = ((uint64_t)p * nwaves + wave) * SEGS;
+    const uint32_t nseg = sg0 >= c.total_segs ? 0u : (c.total_segs - sg0 < (uint64_t)SEGS ? (uint32_t)(c.total_segs - sg0) : (uint32_t)SEGS);
+
+    // ---- phase 1: every segment of the wave analysed once; rows stay in LDS, summaries in registers
+    Feeder<BS, BYTES> feeder;
+    feeder.init(c, fast_ok);
+    uint32_t m[SEGS];
+    ScanVal wagg = scan_identity();
+    const Seg g0 = seg_geom(c, nseg ? sg0 : 0);
+    {
+        Seg g = g0;
+        if (nseg) feeder.prefetch(c, in, g, lane);
+#pragma unroll
+        for (int s = 0; s < SEGS; s++) {
+            m[s] = meta_pack(0, OPT_ZCONT, 0, 0);
+            if ((uint32_t)s < nseg) {
+                const auto cur = feeder.pre;
+                const Seg gcur = g;
+                if ((uint32_t)s + 1 < nseg) {
+                    g = seg_next(c, g);
+                    feeder.prefetch(c, in, g, lane);      // next segment's loads fly during this one
+                }
+                uint32_t *rows = rows0 + s * seg_words;
+                feeder.feed(c, in, gcur, cur, rows, stride, lane);
+                wave_lds_fence();
+                uint32_t tot, cl;
+                m[s] = analyze_segment<BS, BYTES>(c, gcur, rows, stride, lane, tot, cl);
+                wagg = scan_then(wagg, ScanVal{tot, cl});
+            }
+        }
+    }
+    if (lane == 0) sh_agg[wave] = wagg;
+    __syncthreads();
+
+    // ---- the partition's place in the stream
+    if (wave == 0) {
+        ScanVal agg = scan_identity();
+        for (uint32_t w = 0; w < nwaves; w++) agg = scan_then(agg, sh_agg[w]);
+        if (lane == 0) granule_store(desc + p, desc_pack(1u, agg));
+        const ScanVal excl = lookback(desc, p, lane, fail);
+        const ScanVal inc = scan_then(excl, agg);
+        if (lane == 0) {
+            granule_store(desc + p, desc_pack(2u, inc));
+            sh_excl = excl;
+            if (p == nparts - 1u) {                      // the stream's totals
+                const KClamp t = clamp_unpack(inc.cl);
+                const uint64_t end = (uint64_t)start_bit + inc.bits;
+                res->total_bits = inc.bits;
+                res->k_out = kclamp_apply(t, k_in);
+                res->overflow = (end + 7) / 8 > cap_words * 4 ? 1u : 0u;
+                res->k_lo = t.lo;
+                res->k_hi = t.hi;
+                if (rsi_off) rsi_off[c.rsi_count] = end;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: emission from the rows in LDS
+    ScanVal run = sh_excl;
+    for (uint32_t w = 0; w < wave; w++) run = scan_then(run, sh_agg[w]);
+    const uint64_t wave_start = (uint64_t)start_bit + run.bits;
+    const uint64_t head_idx = wave_start >> 5;
+    const bool shared_head = (wave_start & 31u) != 0;
+    uint32_t head_val = 0, pending = 0;
+    uint64_t pos = wave_start;
+    {
+        Seg g = g0;
+#pragma unroll
+        for (int s = 0; s < SEGS; s++) {
+            if ((uint32_t)s < nseg) {
+                const Seg gcur = g;
+                if ((uint32_t)s + 1 < nseg) g = seg_next(c, g);
+                const uint32_t kin = kclamp_apply(clamp_unpack(run.cl), k_in);
+                const uint64_t start = pos;
+                uint32_t ref_sample = 0;
+                if (lane == 0) {
+                    if (pp && gcur.b0 == 0)
+                        ref_sample = load_sample_bytes(in + gcur.samp0 * c.bytes, c.bytes, msb) & low_mask32(c.bps);
+                    if (rsi_off && gcur.b0 == 0) rsi_off[gcur.rsi_idx] = start;
+                    if (seg_table) {
+                        uint32_t prev = 0;
+                        if (gcur.b0 != 0) {
+                            uint64_t i = gcur.samp0 - 1;
+                            if (i >= c.total_samples) i = c.total_samples - 1;
+                            prev = load_sample_bytes(in + i * c.bytes, c.bytes, msb);
+                        }
+                        seg_table[sg0 + s] = SegEntry{start, prev, 0u};
+                    }
+                }
+                const uint32_t lead = (uint32_t)(start & 31u);
+                uint32_t total, seg_cl;
+                emit_segment<BS, BYTES>(c, gcur, rows0 + s * seg_words, stride, obuf, lane, m[s], kin, lead, ref_sample,
+                                        pending, total, seg_cl);
+                const uint32_t nwords = (lead + total + 31u) >> 5;
+                const uint64_t gw = start >> 5;
+                const bool open_tail = ((lead + total) & 31u) != 0;
+                // The open tail word goes on into the wave's next segment (or, after the last one, to
+                // whoever writes the word the wave ends in); the word the wave STARTS in, when it also
+                // holds bits of the previous wave, is left to the boundary pass below.
+                const uint32_t tail_word = open_tail ? obuf[nwords - 1] : 0u;
+                if (gw == head_idx) head_val = obuf[0];
+                for (uint32_t w = lane; w < nwords; w += kWave) {
+                    const uint32_t v = obuf[w];
+                    obuf[w] = 0u;
+                    const uint64_t idx = gw + w;
+                    const bool is_tail = w == nwords - 1 && open_tail;
+                    const bool is_head = idx == head_idx && shared_head;
+                    if (idx < cap_words && !is_tail && !is_head) out_words[idx] = bswap32(v);
+                }
+                pending = tail_word;
+                pos += total;
+                run = scan_then(run, ScanVal{total, seg_cl});
+                wave_lds_fence();
+            }
+        }
+    }
+    if (lane == 0) {
+        WaveEdge e;
+        e.head_idx = head_idx;
+        e.head_val = head_val;
+        e.shared_head = shared_head ? 1u : 0u;
+        e.tail_idx = pos >> 5;
+        e.tail_open = (pos & 31u) != 0 ? 1u : 0u;
+        e.tail_val = pending;
+        sh_edge[wave] = e;
+    }
+    __syncthreads();
+
+    // ---- the words waves / partitions share: one lane walks the (at most four) wave edges in order
+    if (threadIdx.x == 0) {
+        uint32_t nact = 0;
+        for (uint32_t w = 0; w < nwaves; w++)
+            if (((uint64_t)p * nwaves + w) * SEGS < c.total_segs) nact = w + 1;
+        const uint64_t part_start = (uint64_t)start_bit + sh_excl.bits;
+        const bool lead_open = (part_start & 31u) != 0;
+        bool all_pass = true;                               // every wave begins and ends inside ONE word
+        for (uint32_t w = 0; w < nact; w++) {
+            const WaveEdge &e = sh_edge[w];
+            all_pass = all_pass && e.shared_head && e.tail_open && e.tail_idx == e.head_idx;
+        }
+        uint32_t c_open = 0, c_val = 0;
+        uint64_t c_idx = 0;
+        auto resolve = [&](uint32_t incoming, bool store) {
+            c_open = lead_open ? 1u : 0u;
+            c_val = incoming;
+            c_idx = part_start >> 5;
+            for (uint32_t w = 0; w < nact; w++) {
+                const WaveEdge &e = sh_edge[w];
+                if (e.shared_head) {
+                    const uint32_t val = e.head_val | (c_open ? c_val : 0u);
+                    if (e.tail_open && e.tail_idx == e.head_idx) {      // still the same word: pass it on
+                        c_open = 1u;
+                        c_val = val;
+                        c_idx = e.head_idx;
+                        continue;
+                    }
+                    if (store && e.head_idx < cap_words) out_words[e.head_idx] = bswap32(val);
+                }
+                c_open = e.tail_open;
+                c_val = e.tail_val;
+                c_idx = e.tail_idx;
+            }
+        };
+        auto publish = [&]() {
+            granule_store(tails + p, (1ull << 63) | ((uint64_t)c_open << 62) | c_val);
+        };
+        // what leaves this partition does not depend on what enters it unless every wave passes the
+        // word on: publish first, so that the chain of partitions never waits on more than one hop
+        if (!all_pass) {
+            resolve(0u, false);
+            publish();
+        }
+        uint32_t incoming = 0;
+        if (lead_open && p > 0) {
+            uint64_t x = 0;
+            for (uint32_t spins = 0;; spins++) {
+                x = granule_load(tails + (p - 1));
+                if (x >> 63) break;
+                if (spins > kSpinLimit) {
+                    atomicOr(fail, 2u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            incoming = (uint32_t)x;
+        }
+        resolve(incoming, true);
+        if (all_pass) publish();
+        if (p == nparts - 1u) {                              // the stream's last word, zero padded, and one more
+            uint64_t z = c_idx;
+            if (c_open) {
+                if (c_idx < cap_words) out_words[c_idx] = bswap32(c_val);
+                z = c_idx + 1;
+            }
+            for (uint64_t w = z; w <= c_idx + 1; w++)
+                if (w < cap_words) out_words[w] = 0u;
+        }
+    }
+    __syncthreads();       // the shared records are reused by the next partition
+    }
+}
+
+// a look-back that timed out (never in a healthy run) must not pass for a result
+__global__ void k_fused_finish(const uint32_t *fail, EncResult *res)
+{
+    if (*fail) res->overflow = 2u;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -974,7 +1334,102 @@ void dispatch(bool pack, const Cfg &c, const uint8_t *in, const EncWorkspace &ws
     }
 }
 
+struct FusedGeom {
+    uint32_t waves, segs, nparts, parts_per_wg, grid, obuf_words;
+    size_t lds_bytes;
+};
+
+// waves per workgroup and segments per wave of the fused kernel: as many segments per wave as keep
+// three or more workgroups on a CU (the look-back costs per partition), at least one
+FusedGeom fused_geom(const Cfg &c)
+{
+    FusedGeom g;
+    const uint32_t stride = (c.bytes <= 2) ? c.bs / 2 + 4 : c.bs + 4;          // Rows<>::stride_words
+    const uint32_t maxlen = c.id_len + c.bs * c.bps + 2 + c.bps;
+    g.obuf_words = ((64u * maxlen + 62u) / 32u + 4u) & ~3u;
+    const size_t seg_bytes = (size_t)64 * stride * 4, obuf_bytes = (size_t)g.obuf_words * 4;
+    static const char *force = getenv("AEC_FUSED_SEGS");
+    g.waves = 4;
+    g.segs = 1;
+    for (uint32_t s : {4u, 2u, 1u}) {
+        if ((seg_bytes * s + obuf_bytes) * 4 <= 53 * 1024 || s == 1) {
+            g.segs = s;
+            break;
+        }
+    }
+    if (force && (atoi(force) == 1 || atoi(force) == 2 || atoi(force) == 4)) g.segs = (uint32_t)atoi(force);
+    while (g.waves > 1 && (seg_bytes * g.segs + obuf_bytes) * g.waves > 160 * 1024) g.waves >>= 1;
+    g.lds_bytes = (seg_bytes * g.segs + obuf_bytes) * g.waves;
+    const uint64_t per = (uint64_t)g.waves * g.segs;
+    g.nparts = (uint32_t)((c.total_segs + per - 1) / per);
+    // partitions per ticket: 1 while the input is small (fill the chip), 4 for large ones
+    g.parts_per_wg = g.nparts >= 16384 ? 4u : 1u;
+    static const char *ppw = getenv("AEC_FUSED_PARTS");
+    if (ppw && atoi(ppw) >= 1 && atoi(ppw) <= 64) g.parts_per_wg = (uint32_t)atoi(ppw);
+    g.grid = (g.nparts + g.parts_per_wg - 1) / g.parts_per_wg;
+    return g;
+}
+
+template <int BS, int BYTES, int SEGS>
+void launch_fused_t(const Cfg &c, const uint8_t *in, uint32_t *out_words, uint64_t cap_words, const FusedGeom &g,
+                    void *ctl, uint32_t start_bit, uint32_t k_in, uint64_t *rsi_off, SegEntry *seg_table,
+                    EncResult *res, uint32_t fast_ok, hipStream_t st)
+{
+    static bool big_lds = false;          // (per instantiation; benign if two threads set it twice)
+    if (!big_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<BS, BYTES, SEGS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big_lds = true;
+    }
+    uint8_t *b = static_cast<uint8_t *>(ctl);
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(b);
+    uint32_t *fail = ticket + 1;
+    uint64_t *desc = reinterpret_cast<uint64_t *>(b + 16);
+    uint64_t *tails = desc + g.nparts;
+    hipLaunchKernelGGL((k_encode_fused<BS, BYTES, SEGS>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, in,
+                       out_words, cap_words, desc, tails, ticket, fail, g.nparts, g.parts_per_wg, start_bit, k_in,
+                       rsi_off, seg_table, res, g.obuf_words, fast_ok);
+    hipLaunchKernelGGL(k_fused_finish, dim3(1), dim3(1), 0, st, fail, res);
+}
+
+template <int BS, int BYTES>
+void launch_fused_segs(const Cfg &c, const uint8_t *in, uint32_t *out_words, uint64_t cap_words, const FusedGeom &g,
+                       void *ctl, uint32_t start_bit, uint32_t k_in, uint64_t *rsi_off, SegEntry *seg_table,
+                       EncResult *res, uint32_t fast_ok, hipStream_t st)
+{
+    switch (g.segs) {
+    case 4: launch_fused_t<BS, BYTES, 4>(c, in, out_words, cap_words, g, ctl, start_bit, k_in, rsi_off, seg_table, res, fast_ok, st); break;
+    case 2: launch_fused_t<BS, BYTES, 2>(c, in, out_words, cap_words, g, ctl, start_bit, k_in, rsi_off, seg_table, res, fast_ok, st); break;
+    default: launch_fused_t<BS, BYTES, 1>(c, in, out_words, cap_words, g, ctl, start_bit, k_in, rsi_off, seg_table, res, fast_ok, st); break;
+    }
+}
+
+template <int BS>
+void launch_fused_bytes(const Cfg &c, const uint8_t *in, uint32_t *out_words, uint64_t cap_words, const FusedGeom &g,
+                        void *ctl, uint32_t start_bit, uint32_t k_in, uint64_t *rsi_off, SegEntry *seg_table,
+                        EncResult *res, uint32_t fast_ok, hipStream_t st)
+{
+    switch (c.bytes) {
+    case 1: launch_fused_segs<BS, 1>(c, in, out_words, cap_words, g, ctl, start_bit, k_in, rsi_off, seg_table, res, fast_ok, st); break;
+    case 2: launch_fused_segs<BS, 2>(c, in, out_words, cap_words, g, ctl, start_bit, k_in, rsi_off, seg_table, res, fast_ok, st); break;
+    case 3: launch_fused_segs<BS, 3>(c, in, out_words, cap_words, g, ctl, start_bit, k_in, rsi_off, seg_table, res, fast_ok, st); break;
+    default: launch_fused_segs<BS, 4>(c, in, out_words, cap_words, g, ctl, start_bit, k_in, rsi_off, seg_table, res, fast_ok, st); break;
+    }
+}
+
 }  // namespace
+
+bool fused_supported(const Cfg &c)
+{
+    static const bool off = getenv("AEC_ENC_TWO_PASS") != nullptr;      // A/B switch for measurements
+    return !off && (c.bs == 8 || c.bs == 16 || c.bs == 32 || c.bs == 64) && c.total_segs != 0;
+}
+
+size_t fused_ctl_bytes(const Cfg &c)
+{
+    const FusedGeom g = fused_geom(c);
+    return ((size_t)16 + (size_t)g.nparts * 16 + 15) & ~(size_t)15;
+}
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -1007,6 +1462,23 @@ void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out
     const uint32_t fast_ok = ((reinterpret_cast<uintptr_t>(d_in) & 15u) == 0 &&
                               ((uint64_t)c.rsi * c.bs * c.bytes) % 16 == 0) ? 1u : 0u;
 
+    if (phases == ENC_ALL && ws.fused_ctl && !d_carry && fused_supported(c)) {
+        // single pass: ticket, fail flag and the look-back granules are zeroed, then ONE kernel
+        const FusedGeom g = fused_geom(c);
+        mark(0);
+        mark(1);
+        (void)hipMemsetAsync(ws.fused_ctl, 0, fused_ctl_bytes(c), st);
+        mark(2);
+        mark(3);
+        switch (c.bs) {
+        case 8: launch_fused_bytes<8>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
+        case 16: launch_fused_bytes<16>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
+        case 32: launch_fused_bytes<32>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
+        default: launch_fused_bytes<64>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
+        }
+        mark(4);
+        return;
+    }
     if (phases & ENC_PLAN) {
         mark(0);
         if (nseg) dispatch(false, c, d_in, ws, nullptr, 0, fast_ok, st);

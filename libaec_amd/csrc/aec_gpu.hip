@@ -41,6 +41,8 @@ struct aec_gpu_ctx {
     IdxSide idx_side;      // side stream + events of the index pass (created on first use)
     bool idx_side_ok;
     ShardCarry *carry;     // device record: what precedes this context's shard (emit_planned)
+    void *fused;           // control block of the single-pass encoder (ticket, fail flag, look-back granules)
+    size_t fused_bytes;
 };
 static_assert(sizeof(aec_gpu_seg_entry) == sizeof(SegEntry), "segment table layout");
 
@@ -71,6 +73,8 @@ int aec_gpu_create(aec_gpu_ctx **out)
     ctx->idx_side = IdxSide{};
     ctx->idx_side_ok = false;
     ctx->carry = nullptr;
+    ctx->fused = nullptr;
+    ctx->fused_bytes = 0;
     ctx->enc_calls = ctx->dec_calls = 0;
     for (auto &set : ctx->ev)
         for (auto &e : set.ev) e = nullptr;
@@ -84,6 +88,7 @@ void aec_gpu_destroy(aec_gpu_ctx *ctx)
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
     if (ctx->carry) (void)hipFree(ctx->carry);
+    if (ctx->fused) (void)hipFree(ctx->fused);
     if (ctx->idx_side_ok) {
         (void)hipStreamDestroy(ctx->idx_side.stream);
         for (int b = 0; b < 2; b++) {
@@ -124,11 +129,9 @@ uint64_t aec_gpu_block_count(const aec_gpu_params *p, size_t in_bytes)
     return c.total_blocks;
 }
 
-int aec_gpu_reserve(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes)
+// workspace of the two-pass encoder (plan / emit: per-block summaries, segment scan)
+static int reserve_two_pass(aec_gpu_ctx *ctx, const Cfg &c)
 {
-    Cfg c;
-    const int rc = cfg_from(p, in_bytes, true, &c);
-    if (rc != RC_OK) return rc;
     size_t o[6];
     const size_t need = enc_workspace_bytes(c, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5]);
     if (need > ctx->ws_bytes) {
@@ -139,6 +142,31 @@ int aec_gpu_reserve(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes)
         ctx->ws_bytes = need;
     }
     return RC_OK;
+}
+
+// control block of the single-pass encoder (16 bytes per 4..16 segments)
+static int reserve_fused(aec_gpu_ctx *ctx, const Cfg &c)
+{
+    const size_t need = fused_ctl_bytes(c);
+    if (need > ctx->fused_bytes) {
+        if (ctx->fused) (void)hipFree(ctx->fused);
+        ctx->fused = nullptr;
+        ctx->fused_bytes = 0;
+        const size_t want = need + need / 4;
+        if (hipMalloc(&ctx->fused, want) != hipSuccess) return RC_MEM_ERROR;
+        ctx->fused_bytes = want;
+    }
+    return RC_OK;
+}
+
+int aec_gpu_reserve(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes)
+{
+    Cfg c;
+    const int rc = cfg_from(p, in_bytes, true, &c);
+    if (rc != RC_OK) return rc;
+    // what aec_gpu_encode_async needs; the (much larger) workspace of the plan / emit pair is
+    // allocated by the first plan call
+    return fused_supported(c) ? reserve_fused(ctx, c) : reserve_two_pass(ctx, c);
 }
 
 static int encode_phases(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
@@ -152,19 +180,25 @@ static int encode_phases(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *
     if (start_bit > 7 || k_in > 31) return RC_CONF_ERROR;
     if ((phases & ENC_EMIT) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) || (out_cap & 15u) || out_cap < 16))
         return RC_CONF_ERROR;
-    rc = aec_gpu_reserve(ctx, p, in_bytes);
+    const bool fused = phases == ENC_ALL && !d_carry && fused_supported(c);
+    rc = fused ? reserve_fused(ctx, c) : reserve_two_pass(ctx, c);
     if (rc != RC_OK) return rc;
     (void)hipGetLastError();   // only launch errors of THIS call are reported below
-    size_t o[6];
-    enc_workspace_bytes(c, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5]);
-    uint8_t *base = static_cast<uint8_t *>(ctx->ws);
-    EncWorkspace ws;
-    ws.meta = reinterpret_cast<uint32_t *>(base + o[0]);
-    ws.seg_bits = reinterpret_cast<uint32_t *>(base + o[1]);
-    ws.seg_clamp = reinterpret_cast<uint16_t *>(base + o[2]);
-    ws.seg_start = reinterpret_cast<uint64_t *>(base + o[3]);
-    ws.seg_kin = base + o[4];
-    ws.partials = reinterpret_cast<ScanPartial *>(base + o[5]);
+    EncWorkspace ws{};
+    if (fused) {
+        ws.fused_ctl = ctx->fused;
+    } else {
+        size_t o[6];
+        enc_workspace_bytes(c, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5]);
+        uint8_t *base = static_cast<uint8_t *>(ctx->ws);
+        ws.meta = reinterpret_cast<uint32_t *>(base + o[0]);
+        ws.seg_bits = reinterpret_cast<uint32_t *>(base + o[1]);
+        ws.seg_clamp = reinterpret_cast<uint16_t *>(base + o[2]);
+        ws.seg_start = reinterpret_cast<uint64_t *>(base + o[3]);
+        ws.seg_kin = base + o[4];
+        ws.partials = reinterpret_cast<ScanPartial *>(base + o[5]);
+        ws.fused_ctl = nullptr;
+    }
     launch_encode(c, static_cast<const uint8_t *>(d_in), static_cast<uint8_t *>(d_out), out_cap, start_bit,
                   k_in, ws, d_rsi_bit_offsets, reinterpret_cast<EncResult *>(d_result),
                   static_cast<hipStream_t>(stream), ctx->enc_events(phases), phases, ctx->seg_table, d_carry);
@@ -367,6 +401,11 @@ void aec_gpu_trim(aec_gpu_ctx *ctx, size_t keep_bytes)
         (void)hipFree(ctx->ws);
         ctx->ws = nullptr;
         ctx->ws_bytes = 0;
+    }
+    if (ctx->fused && ctx->fused_bytes > keep_bytes) {
+        (void)hipFree(ctx->fused);
+        ctx->fused = nullptr;
+        ctx->fused_bytes = 0;
     }
     if (ctx->idx_ws && ctx->idx_ws_bytes > keep_bytes) {
         (void)hipFree(ctx->idx_ws);

@@ -56,7 +56,12 @@ struct EncWorkspace {
     uint64_t *seg_start;     // [total_segs]     absolute start bit per segment
     uint8_t *seg_kin;        // [total_segs]     k carried into the segment
     ScanPartial *partials;   // [ceil(total_segs / 2048) + 1]
+    void *fused_ctl;         // single-pass encoder: ticket, fail flag, look-back granules (fused_ctl_bytes)
 };
+
+// Single-pass encoder (aec_enc.hip k_encode_fused): available for the templated block sizes.
+bool fused_supported(const Cfg &c);
+size_t fused_ctl_bytes(const Cfg &c);
 
 // Optional per-phase timing: when non-null the launchers record these events around the phases.
 //   encode: ev[0] | analyze | ev[1] | scan x3 | ev[2] | clear | ev[3] | pack | ev[4]

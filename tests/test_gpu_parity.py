@@ -544,3 +544,18 @@ def test_truncated_streams_release_what_arrived(api):
                         break
             d.end()
             assert bytes(got) == dec_o, (it, bps, bs, rsi, flags, n, cut, first, len(got), len(dec_o))
+
+
+@pytest.mark.parametrize("env", [{}, {"AEC_FUSED_SEGS": "1"}, {"AEC_FUSED_SEGS": "2", "AEC_FUSED_PARTS": "3"},
+                                 {"AEC_FUSED_SEGS": "4", "AEC_FUSED_PARTS": "1"}, {"AEC_ENC_TWO_PASS": "1"}])
+def test_fused_encoder_edges(env):
+    """tests/fused_edges.py (streams of zero-block runs whose waves / partitions begin and end inside
+    one word, every partition fill, ragged ends) under several geometries of the single-pass encoder
+    and once through the two-pass kernels."""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fused_edges.py")], env=e, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "fused edges ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
