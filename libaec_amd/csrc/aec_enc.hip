@@ -1029,10 +1029,12 @@ k_encode_fused(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict
     uint32_t *obuf = rows0 + SEGS * seg_words;
     const bool pp = c.flags & F_PREPROCESS, msb = c.flags & F_MSB;
 
-    // One ticket buys parts_per_wg consecutive partitions (a single counter word takes ~88 atomics per
-    // microsecond: tickets must be much rarer than that).  Whatever a partition waits for belongs to a
+    // One ticket buys parts_per_wg consecutive partitions.  Whatever a partition waits for belongs to a
     // lower ticket -- a workgroup that is resident and only ever waits for still lower ones -- or to this
-    // workgroup's own earlier rounds.
+    // workgroup's own earlier rounds.  (More than one partition per ticket SERIALISES the grid: the first
+    // partition of ticket T needs the aggregate of the last partition of ticket T-1, which that workgroup
+    // only reaches after emitting its earlier ones -- measured 2.5 s instead of 3 ms at 4 GiB.  Kept as a
+    // knob for experiments; the default is 1.)
     if (threadIdx.x == 0) sh_part = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const uint32_t p_first = sh_part * parts_per_wg;
@@ -1358,12 +1360,11 @@ FusedGeom fused_geom(const Cfg &c)
         }
     }
     if (force && (atoi(force) == 1 || atoi(force) == 2 || atoi(force) == 4)) g.segs = (uint32_t)atoi(force);
-    while (g.waves > 1 && (seg_bytes * g.segs + obuf_bytes) * g.waves > 160 * 1024) g.waves >>= 1;
+    while (g.waves > 1 && (seg_bytes * g.segs + obuf_bytes) * g.waves > 156 * 1024) g.waves >>= 1;
     g.lds_bytes = (seg_bytes * g.segs + obuf_bytes) * g.waves;
     const uint64_t per = (uint64_t)g.waves * g.segs;
     g.nparts = (uint32_t)((c.total_segs + per - 1) / per);
-    // partitions per ticket: 1 while the input is small (fill the chip), 4 for large ones
-    g.parts_per_wg = g.nparts >= 16384 ? 4u : 1u;
+    g.parts_per_wg = 1u;
     static const char *ppw = getenv("AEC_FUSED_PARTS");
     if (ppw && atoi(ppw) >= 1 && atoi(ppw) <= 64) g.parts_per_wg = (uint32_t)atoi(ppw);
     g.grid = (g.nparts + g.parts_per_wg - 1) / g.parts_per_wg;
@@ -1377,8 +1378,10 @@ void launch_fused_t(const Cfg &c, const uint8_t *in, uint32_t *out_words, uint64
 {
     static bool big_lds = false;          // (per instantiation; benign if two threads set it twice)
     if (!big_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<BS, BYTES, SEGS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // (the kernel also has a few hundred bytes of static LDS: ask for less than the CU's 160 KiB)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_encode_fused<BS, BYTES, SEGS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+            (void)hipGetLastError();
         big_lds = true;
     }
     uint8_t *b = static_cast<uint8_t *>(ctl);
@@ -1419,10 +1422,17 @@ void launch_fused_bytes(const Cfg &c, const uint8_t *in, uint32_t *out_words, ui
 
 }  // namespace
 
+// The single-pass kernel is bit-exact (tests/fused_edges.py, and the whole 4 GiB stream of the bench
+// against the CPU reference) but SLOWER than the analyze / scan / pack trio on MI355X: 5.5 ms against
+// 3.74 ms at C2 (4 GiB; 6.9 ms with 4 segments per wave, 7.4 ms with 1).  Keeping the rows of a wave's
+// segments in LDS allows 2-4 workgroups per CU, and the serial sections of a partition -- the ticket,
+// the look-back done by one wave while the others wait at the barrier, the boundary words -- take
+// about 7 of the ~15 microseconds a partition lives; nothing is there to hide them behind.  So the
+// two-pass kernels stay the default and AEC_ENC_FUSED=1 selects this one (kept under test).
 bool fused_supported(const Cfg &c)
 {
-    static const bool off = getenv("AEC_ENC_TWO_PASS") != nullptr;      // A/B switch for measurements
-    return !off && (c.bs == 8 || c.bs == 16 || c.bs == 32 || c.bs == 64) && c.total_segs != 0;
+    static const bool on = getenv("AEC_ENC_FUSED") != nullptr;
+    return on && (c.bs == 8 || c.bs == 16 || c.bs == 32 || c.bs == 64) && c.total_segs != 0;
 }
 
 size_t fused_ctl_bytes(const Cfg &c)

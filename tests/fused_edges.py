@@ -1,6 +1,6 @@
 """Edge cases of the single-pass encoder (k_encode_fused), run on the GPU box by
 tests/test_gpu_parity.py::test_fused_encoder_edges under several AEC_FUSED_SEGS / AEC_FUSED_PARTS
-settings (and once with AEC_ENC_TWO_PASS=1): streams whose waves / partitions begin and end inside
+settings with AEC_ENC_FUSED=1 (and once without): streams whose waves / partitions begin and end inside
 one 32-bit word (long stretches of zero blocks), partitions of every fill, ragged ends, every
 container size -- against the oracle."""
 import os
@@ -57,8 +57,8 @@ def main():
                     m = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), None)
                     raise AssertionError((bps, bs, rsi, flags, kind, n, len(got), len(want), m))
                 n_cases += 1
-    print("fused edges ok:", n_cases, "cases; AEC_FUSED_SEGS=%s AEC_FUSED_PARTS=%s AEC_ENC_TWO_PASS=%s" % (
-        os.environ.get("AEC_FUSED_SEGS"), os.environ.get("AEC_FUSED_PARTS"), os.environ.get("AEC_ENC_TWO_PASS")))
+    print("fused edges ok:", n_cases, "cases; AEC_ENC_FUSED=%s AEC_FUSED_SEGS=%s AEC_FUSED_PARTS=%s" % (
+        os.environ.get("AEC_ENC_FUSED"), os.environ.get("AEC_FUSED_SEGS"), os.environ.get("AEC_FUSED_PARTS")))
 
 
 if __name__ == "__main__":

@@ -546,12 +546,13 @@ def test_truncated_streams_release_what_arrived(api):
             assert bytes(got) == dec_o, (it, bps, bs, rsi, flags, n, cut, first, len(got), len(dec_o))
 
 
-@pytest.mark.parametrize("env", [{}, {"AEC_FUSED_SEGS": "1"}, {"AEC_FUSED_SEGS": "2", "AEC_FUSED_PARTS": "3"},
-                                 {"AEC_FUSED_SEGS": "4", "AEC_FUSED_PARTS": "1"}, {"AEC_ENC_TWO_PASS": "1"}])
+@pytest.mark.parametrize("env", [{"AEC_ENC_FUSED": "1"}, {"AEC_ENC_FUSED": "1", "AEC_FUSED_SEGS": "1"},
+                                 {"AEC_ENC_FUSED": "1", "AEC_FUSED_SEGS": "2", "AEC_FUSED_PARTS": "3"},
+                                 {"AEC_ENC_FUSED": "1", "AEC_FUSED_SEGS": "4", "AEC_FUSED_PARTS": "1"}, {}])
 def test_fused_encoder_edges(env):
     """tests/fused_edges.py (streams of zero-block runs whose waves / partitions begin and end inside
     one word, every partition fill, ragged ends) under several geometries of the single-pass encoder
-    and once through the two-pass kernels."""
+    (opt-in: AEC_ENC_FUSED=1) and once through the default two-pass kernels."""
     import subprocess
     import sys
     e = dict(os.environ)
