@@ -25,6 +25,7 @@
 #include "aec_kernels.h"
 #include "aec_lane.h"
 #include "aec_spec.h"
+#include "aec_spec2.h"
 
 namespace aec {
 
@@ -48,6 +49,41 @@ struct IdxTables {
     const uint16_t *Xb;    // chained hop out of the window core: bits ...
     const uint8_t *Xc;     // ... and RSIs covered (0 = none)
     uint64_t lo, hi;
+};
+
+// Sparse tables of the second-generation speculation (k_spec2): candidates = coded-data-set boundaries
+// found by self-synchronising chains.  Per core window k (core bits each, the first one at bit lo):
+// a bitmap over its bit positions, per bitmap word the number of candidates in front of it (inside the
+// window), and up to cap records {RSI length if an RSI starts here, chained hop out of the window}.
+struct SparseTables {
+    const uint32_t *bitmap;    // bit (31 - i % 32) of word i / 32 <=> position lo + i is a candidate
+    const uint16_t *pre;       // per bitmap word: candidates of ITS window in front of the word
+    const uint2 *rec;          // [window * cap + index]: x = RSI length (0 = unresolved), y = chain (cnt << 24 | bits)
+    const uint16_t *cpos;      // [window * cap + index]: position inside the window core
+    const uint32_t *ccnt;      // [window]: candidates
+    uint64_t lo, hi;           // tabulated bit range
+    uint32_t core, cap;        // bits per window (multiple of 32), record capacity per window
+    // wide walker: per chunk of wpc windows, what every candidate of the chunk's first window leads to
+    const uint4 *wide;         // [chunk * cap + index]: {exit lo, exit hi, RSIs, 1 = resolved}
+    uint32_t wpc;
+};
+
+// record of the candidate at absolute bit p (false: p is not a candidate)
+__device__ __forceinline__ bool sparse_lookup(const SparseTables &t, uint64_t p, uint2 &rec, uint32_t &window,
+                                              uint32_t &index)
+{
+    const uint64_t i = p - t.lo;
+    const uint32_t word = t.bitmap[i >> 5], sh = (uint32_t)(i & 31u);
+    if (!((word >> (31u - sh)) & 1u)) return false;
+    window = (uint32_t)(i / t.core);
+    index = (uint32_t)t.pre[i >> 5] + (sh ? (uint32_t)__popc(word >> (32u - sh)) : 0u);
+    rec = t.rec[(uint64_t)window * t.cap + index];
+    return true;
+}
+
+struct ChunkEntry {        // where the true chain enters a chunk the walker skipped over the wide table
+    uint64_t pos, r;
+    uint32_t valid, pad;
 };
 
 struct IdxHop {            // a chained hop the walker took: k_expand writes its RSI starts
@@ -200,6 +236,245 @@ k_spec(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_
     }
 }
 
+// ---- sparse speculation (aec_spec2.h) ----------------------------------------------------------------
+// One workgroup of 1024 lanes per window = [lead-in | core | look-ahead].  LDS:
+//   win[nw + 2] u32 | marks[nw] u32 | rank[nw + 2] u16 | sel[nw + 2] u16 | mpre[nw + 2] u16 |
+//   cpos[cap] u16 | cnxt[cap] u16 | chop4[cap] u16 | chop16[cap] u16 | ua[cap] u16
+// Output for the candidates inside the core: the window's part of the global bitmap / prefix table
+// and its records (SparseTables above).
+struct Spec2Geom {
+    uint32_t lead, core, look, stride, burn, cap_lds, cap_core;
+};
+
+__global__ void __launch_bounds__(1024)
+k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
+        uint64_t start_bit, const Spec2Geom g, uint32_t *__restrict__ gbitmap, uint16_t *__restrict__ gpre,
+        uint2 *__restrict__ grec, uint16_t *__restrict__ gcpos, uint32_t *__restrict__ gccnt)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
+    __shared__ uint32_t sh_total;
+    const uint32_t W = g.lead + g.core + g.look, nw = W / 32u, cap = g.cap_lds;
+    uint32_t *win = spec_lds;
+    uint32_t *marks = win + nw + 2;
+    uint16_t *rank = reinterpret_cast<uint16_t *>(marks + nw);
+    uint16_t *sel = rank + nw + 2;
+    uint16_t *mpre = sel + nw + 2;
+    uint16_t *cpos = mpre + nw + 2;
+    uint16_t *cnxt = cpos + cap;
+    uint16_t *chop4 = cnxt + cap;
+    uint16_t *chop16 = chop4 + cap;
+    uint16_t *ua = chop16 + cap;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint64_t core_abs = tab_lo + (uint64_t)blockIdx.x * g.core;
+    const uint64_t gw0 = ((uint64_t)blockIdx.x * g.core) >> 5;              // first bitmap word of this window
+    const uint32_t cw = g.core / 32u;
+    auto give_up = [&]() {                                                  // nothing tabulated: the serial walk
+        for (uint32_t i = tid; i < cw; i += nt) {
+            gbitmap[gw0 + i] = 0u;
+            gpre[gw0 + i] = 0;
+        }
+        if (tid == 0) gccnt[blockIdx.x] = 0u;
+    };
+    if (core_abs >= end_bit) {
+        give_up();
+        return;
+    }
+    const uint64_t wstart = core_abs >= g.lead ? core_abs - g.lead : 0;     // multiple of 32
+    const uint32_t c0 = (uint32_t)(core_abs - wstart), c1 = c0 + g.core;
+    const uint64_t w0 = wstart >> 5;
+    for (uint32_t i = tid; i < nw + 2; i += nt) {
+        const uint64_t idx = w0 + i;
+        win[i] = idx < nwords ? bswap32(words[idx]) : 0u;
+        if (i < nw) marks[i] = 0u;
+    }
+    __syncthreads();
+    // prefix counts of 1-bits (and, further down, of marks) per word: one wave, 64 words per round
+    auto prefix16 = [&](const uint32_t *src, uint16_t *dst) {
+        if (tid < 64) {
+            uint32_t carry = 0;
+            for (uint32_t base = 0; base < nw; base += 64) {
+                const uint32_t i = base + tid;
+                const uint32_t pc = i < nw ? (uint32_t)__popc(src[i]) : 0u;
+                const uint32_t incl = wave_incl_sum_dpp(pc);
+                if (i < nw) dst[i + 1] = (uint16_t)(carry + incl);
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+            if (tid == 0) {
+                dst[0] = 0;
+                sh_total = carry;
+            }
+        }
+    };
+    prefix16(win, rank);
+    __syncthreads();
+    for (uint32_t i = tid; i < nw; i += nt) {         // sampled select: word of every 32nd 1-bit
+        const uint32_t lo = rank[i], hi = rank[i + 1], m = (lo + 31u) >> 5;
+        if (32u * m + 1u > lo && 32u * m + 1u <= hi) sel[m] = (uint16_t)i;
+    }
+    __syncthreads();
+    const uint64_t left = end_bit - wstart;
+    const SpecWin s{win, rank, sel, nw, left < W ? (uint32_t)left : W};
+
+    // ---- 1. sync chains: burn in, then mark until a marked boundary is met
+    if (tid == 0 && start_bit >= wstart && start_bit - wstart < s.limit) {
+        const uint32_t q = (uint32_t)(start_bit - wstart);
+        atomicOr(&marks[q >> 5], 1u << (31u - (q & 31u)));                  // the one boundary that is known
+    }
+    for (uint32_t q0 = tid * g.stride; q0 < s.limit; q0 += nt * g.stride) {
+        uint32_t q = q0;
+        bool ok = true;
+        for (uint32_t k = 0; k < g.burn && ok; k++) {
+            const uint32_t len = s2_chain_step(s, c, q);
+            ok = len != 0;
+            q += len;
+        }
+        while (ok && q < s.limit) {
+            const uint32_t bit = 1u << (31u - (q & 31u));
+            if (atomicOr(&marks[q >> 5], bit) & bit) break;
+            const uint32_t len = s2_chain_step(s, c, q);
+            ok = len != 0;
+            q += len;
+        }
+    }
+    __syncthreads();
+    prefix16(marks, mpre);
+    __syncthreads();
+    const uint32_t ncand = sh_total;
+    if (ncand > cap) {                       // (a stream of minimal coded data sets: one candidate per few bits)
+        give_up();
+        return;
+    }
+    // ---- 2. tables on the candidates
+    for (uint32_t i = tid; i < nw; i += nt) {
+        uint32_t m = marks[i], idx = mpre[i];
+        while (m) {
+            const uint32_t b = (uint32_t)__builtin_clz(m);
+            m &= ~(0x80000000u >> b);
+            const uint32_t q = i * 32u + b;
+            cpos[idx] = (uint16_t)q;
+            cnxt[idx] = q < s.limit ? spec_nxt_entry(s, c, q) : (uint16_t)0;
+            idx++;
+        }
+    }
+    __syncthreads();
+    S2Win w{s, marks, mpre, cnxt, chop4, chop16, ncand};
+    for (uint32_t i = tid; i < ncand; i += nt) chop4[i] = s2_hop4(w, c, cpos, i);
+    __syncthreads();
+    for (uint32_t i = tid; i < ncand; i += nt) chop16[i] = s2_hop16(w, cpos, i);
+    __syncthreads();
+    // ---- 3. the RSI hypothesis at every candidate of the core
+    const uint32_t i0 = mpre[c0 >> 5], i1 = mpre[c1 >> 5 < nw ? c1 >> 5 : nw];   // (c0, c1 are multiples of 32)
+    const uint32_t ncore = i1 - i0;
+    for (uint32_t i = i0 + tid; i < i1; i += nt) {
+        const uint32_t q = cpos[i];
+        uint32_t a = q < s.limit ? s2_unit(w, c, q, 0u, c.rsi) : 0u;
+        if (a > 0xFFFFu) a = 0;
+        ua[i] = (uint16_t)a;
+    }
+    __syncthreads();
+    if (ncore > g.cap_core) {
+        give_up();
+        return;
+    }
+    // ---- 4. chains out of the core, records, this window's part of the bitmap
+    for (uint32_t i = i0 + tid; i < i1; i += nt) {
+        uint32_t pos = cpos[i], cnt = 0;
+        while (pos < c1 && pos < s.limit && cnt < 255u) {
+            const uint32_t j = s2_index(w, pos);
+            if (j == kS2NoIndex || !ua[j]) break;
+            pos += ua[j];
+            cnt++;
+        }
+        const uint64_t at = (uint64_t)blockIdx.x * g.cap_core + (i - i0);
+        grec[at] = make_uint2(ua[i], cnt ? ((cnt << 24) | (pos - cpos[i])) : 0u);
+        gcpos[at] = (uint16_t)(cpos[i] - c0);
+    }
+    for (uint32_t i = tid; i < cw; i += nt) {
+        gbitmap[gw0 + i] = marks[(c0 >> 5) + i];
+        gpre[gw0 + i] = (uint16_t)(mpre[(c0 >> 5) + i] - i0);
+    }
+    if (tid == 0) gccnt[blockIdx.x] = ncore;
+}
+
+// ---- wide walker: every candidate of a chunk's first window chases the window chain through the chunk
+__global__ void __launch_bounds__(256)
+k_wide(const SparseTables t, uint32_t nwin, uint64_t end_bit, uint4 *__restrict__ wide)
+{
+    const uint32_t chunk = blockIdx.y;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t first = chunk * t.wpc;
+    if (first >= nwin || i >= t.ccnt[first]) return;
+    const uint32_t last = first + t.wpc < nwin ? first + t.wpc : nwin;      // one past the chunk's windows
+    const uint64_t stop = t.lo + (uint64_t)last * t.core;
+    uint64_t pos = t.lo + (uint64_t)first * t.core + t.cpos[(uint64_t)first * t.cap + i];
+    uint32_t cnt = 0, ok = 1;
+    while (pos < stop && pos < end_bit) {
+        uint2 rec;
+        uint32_t wv, ix;
+        if (!sparse_lookup(t, pos, rec, wv, ix) || !(rec.y >> 24)) {
+            ok = 0;
+            break;
+        }
+        pos += rec.y & 0xFFFFFFu;
+        cnt += rec.y >> 24;
+    }
+    // (a chain that ends at the end of the input inside the last chunk is resolved as far as it goes:
+    // the walker takes over from its exit)
+    wide[(uint64_t)chunk * t.cap + i] = make_uint4((uint32_t)pos, (uint32_t)(pos >> 32), cnt, ok && cnt ? 1u : 0u);
+}
+
+// the true chain through the chunks the walker skipped: one lane per chunk records the window hops
+__global__ void __launch_bounds__(64)
+k_rewalk(const SparseTables t, uint32_t nwin, uint32_t nchunks, uint64_t end_bit,
+         const ChunkEntry *__restrict__ entry, IdxHop *__restrict__ hops, uint32_t *__restrict__ nhops)
+{
+    const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= nchunks) return;
+    uint32_t n = 0;
+    if (entry[chunk].valid) {
+        const uint32_t first = chunk * t.wpc;
+        const uint32_t last = first + t.wpc < nwin ? first + t.wpc : nwin;
+        const uint64_t stop = t.lo + (uint64_t)last * t.core;
+        uint64_t pos = entry[chunk].pos, r = entry[chunk].r;
+        IdxHop *out = hops + (uint64_t)chunk * t.wpc * 2u;
+        while (pos < stop && pos < end_bit && n < t.wpc * 2u) {
+            uint2 rec;
+            uint32_t wv, ix;
+            if (!sparse_lookup(t, pos, rec, wv, ix) || !(rec.y >> 24)) break;   // (cannot happen: k_wide went through)
+            out[n++] = IdxHop{pos, r, rec.y >> 24, 0u};
+            pos += rec.y & 0xFFFFFFu;
+            r += rec.y >> 24;
+        }
+    }
+    nhops[chunk] = n;
+}
+
+// RSI starts inside hops, from the sparse records.  lists == 0: the walker's own hop list (count in
+// carry->n_hops); lists > 0: the per-chunk lists of k_rewalk (`stride` entries apart, counts in nhops).
+__global__ void k_expand2(const SparseTables t, const IdxCarry *__restrict__ carry, const IdxHop *__restrict__ hops,
+                          const uint32_t *__restrict__ nhops, uint32_t lists, uint32_t stride,
+                          uint64_t *__restrict__ rsi_off)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    IdxHop h;
+    if (lists == 0) {
+        if (i >= carry->n_hops) return;
+        h = hops[i];
+    } else {
+        const uint32_t list = i / stride, j = i % stride;
+        if (list >= lists || j >= nhops[list]) return;
+        h = hops[(uint64_t)list * stride + j];
+    }
+    uint64_t p = h.pos;
+    for (uint32_t j = 0; j < h.cnt; j++) {
+        rsi_off[h.r + j] = p;
+        uint2 rec;
+        uint32_t wv, ix;
+        if (!sparse_lookup(t, p, rec, wv, ix)) return;      // (cannot happen inside a chained hop)
+        p += rec.x;
+    }
+}
+
 // RSI starts inside the chained hops of the walker
 __global__ void k_expand(const IdxCarry *__restrict__ carry, const IdxHop *__restrict__ hops,
                          const IdxTables tabs, uint32_t pad_rsi, uint64_t *__restrict__ rsi_off)
@@ -241,7 +516,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         uint64_t start_bit, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res,
         const uint64_t *__restrict__ chunk_off, const IdxTables tabs, IdxHop *__restrict__ hops,
         uint32_t hop_cap, IdxCarry *carry, uint32_t first, uint32_t last, uint32_t start_block,
-        uint64_t rsi_start, uint32_t tail_slot)
+        uint64_t rsi_start, uint32_t tail_slot, const SparseTables sp, ChunkEntry *__restrict__ centry)
 {
     __shared__ __attribute__((aligned(16))) uint32_t win[kIdxWindowWords];
     uint64_t r = 0;
@@ -357,6 +632,38 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             // end of a chain of whole RSIs leaving the window (Xb/Xc; the RSI starts inside the hop
             // are filled in by k_expand), or of this RSI alone (T).  An entry of 0 = not resolved
             // by the tables: that RSI is walked CDS by CDS below.
+            // Sparse tables (k_spec2): at a chunk's first window ONE lookup in the wide walker's table
+            // takes the walk across the whole chunk (k_rewalk / k_expand2 fill in what lies inside);
+            // else the window's chained hop, else this RSI alone.
+            while (sp.bitmap && r < max_rsi && good >= sp.lo && good < sp.hi && good < end_bit) {
+                uint2 rec;
+                uint32_t wv, ix;
+                if (!sparse_lookup(sp, good, rec, wv, ix)) break;
+                if (sp.wide && (wv % sp.wpc) == 0u) {
+                    const uint4 wd = sp.wide[(uint64_t)(wv / sp.wpc) * sp.cap + ix];
+                    if (wd.w && r + wd.z <= max_rsi) {
+                        if (lane == 0) centry[wv / sp.wpc] = ChunkEntry{good, r, 1u, 0u};
+                        good = (uint64_t)wd.x | ((uint64_t)wd.y << 32);
+                        r += wd.z;
+                        hopped = true;
+                        continue;
+                    }
+                }
+                const uint32_t xc = rec.y >> 24, xb = rec.y & 0xFFFFFFu, t = rec.x;
+                if (xc && r + xc <= max_rsi && nh < hop_cap) {
+                    if (lane == 0) hops[nh] = IdxHop{good, r, xc, 0u};
+                    nh++;
+                    good += xb;
+                    r += xc;
+                } else if (t) {
+                    if (lane == 0) rsi_off[r] = good;
+                    good += t;
+                    r++;
+                } else {
+                    break;
+                }
+                hopped = true;
+            }
             while (tabs.T && r < max_rsi && good >= tabs.lo && good < tabs.hi && good < end_bit) {
                 const uint64_t i = good - tabs.lo;
                 const uint32_t xc = tabs.Xc[i], xb = tabs.Xb[i], t = tabs.T[i];
@@ -376,7 +683,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                 hopped = true;
             }
             if (r >= max_rsi) break;
-            if (carry && !last && good >= tabs.hi) {         // the next table chunk continues from here
+            if (carry && !last && good >= (sp.bitmap ? sp.hi : tabs.hi)) {   // the next table chunk continues from here
                 if (lane == 0) {
                     carry->good = good;
                     carry->r = r;
@@ -586,10 +893,151 @@ TableSet table_set_at(uint8_t *p, uint64_t entries)
 
 }  // namespace
 
+namespace {
+
+// ---- sparse path: geometry and workspace ------------------------------------------------------------
+struct Sparse2Plan {
+    bool ok;
+    Spec2Geom g;
+    size_t lds;
+    uint32_t nwin_max;        // windows per super-chunk (one k_spec2 launch)
+    uint32_t wpc;             // windows per chunk of the wide walker
+    uint32_t nchunk_max;
+    // byte offsets inside the workspace (behind the 64-byte carry record)
+    size_t o_bitmap, o_pre, o_rec, o_cpos, o_ccnt, o_wide, o_centry, o_hops, o_rhops, o_nhops, bytes;
+};
+
+constexpr uint32_t kS2WindowBits = 65536;      // lead-in + core + look-ahead (16-bit positions in LDS)
+constexpr uint32_t kS2Lead = 4096;
+constexpr uint32_t kS2SuperWindows = 4096;     // windows per launch: bounds the table workspace (~60 KB each)
+
+// The sparse speculation pays off where the coded data sets are short and unary-dominated, so that
+// the sync chains (aec_spec2.h) fall onto the true chain within a few codes: low-entropy data, a few
+// bits per sample (measured in tests/emul: BASELINE configs 2 and 5 -- no RSI start missed with a
+// 4-kbit lead-in; 32-bit data with 8-bit fields -- chains take tens of kbit to merge, not used there).
+// It needs an estimate of the coded RSI size (look-ahead) and whole RSIs inside a window.
+Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint)
+{
+    Sparse2Plan p{};
+    static const bool off = getenv("AEC_IDX_DENSE") != nullptr;          // A/B switch for measurements
+    if (off || (c.flags & F_PAD_RSI) || !rsi_bits_hint || total_bits < 16384) return p;
+    const uint64_t samples = (uint64_t)c.rsi * c.bs;
+    if (rsi_bits_hint * 2 > samples * 9) return p;                       // more than 4.5 bits per sample
+    uint64_t look = (2 * rsi_bits_hint + 1024 + 31) & ~31ull;
+    if (look < 4096) look = 4096;
+    if (look > kS2WindowBits - kS2Lead - 16384) return p;
+    uint64_t core = (kS2WindowBits - kS2Lead - look) & ~1023ull;
+    // small inputs: about one window per CU
+    const uint64_t want = ((total_bits / 256 + 1023) & ~1023ull);
+    if (core > want) core = want < 8192 ? 8192 : want;
+    p.g.lead = kS2Lead;
+    p.g.core = (uint32_t)core;
+    p.g.look = (uint32_t)look;
+    static const char *e_stride = getenv("AEC_S2_STRIDE"), *e_burn = getenv("AEC_S2_BURN");
+    p.g.stride = e_stride ? (uint32_t)atoi(e_stride) : 64u;
+    p.g.burn = e_burn ? (uint32_t)atoi(e_burn) : 8u;
+    const uint32_t W = p.g.lead + p.g.core + p.g.look, nw = W / 32;
+    p.g.cap_lds = (W / 8 + 63) & ~63u;
+    p.g.cap_core = (p.g.core / 8 + 63) & ~63u;
+    p.lds = (size_t)(nw + 2) * 4 + (size_t)nw * 4 + (size_t)(nw + 2) * 2 * 3 + (size_t)p.g.cap_lds * 2 * 5 + 64;
+    if (p.lds > 156 * 1024) return p;
+    const uint64_t nwin_total = (total_bits + core + core - 1) / core;    // (+ one: the range starts on a core boundary)
+    p.nwin_max = (uint32_t)(nwin_total < kS2SuperWindows ? nwin_total : kS2SuperWindows);
+    p.wpc = p.nwin_max >= 2048 ? 256u : (p.nwin_max >= 64 ? p.nwin_max / 8 : p.nwin_max);
+    if (p.wpc == 0) p.wpc = 1;
+    p.nchunk_max = (p.nwin_max + p.wpc - 1) / p.wpc;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t words = (size_t)p.nwin_max * (p.g.core / 32);
+    size_t o = 64;
+    p.o_bitmap = o; o = up(o + words * 4);
+    p.o_pre = o;    o = up(o + words * 2);
+    p.o_rec = o;    o = up(o + (size_t)p.nwin_max * p.g.cap_core * sizeof(uint2));
+    p.o_cpos = o;   o = up(o + (size_t)p.nwin_max * p.g.cap_core * 2);
+    p.o_ccnt = o;   o = up(o + (size_t)p.nwin_max * 4);
+    p.o_wide = o;   o = up(o + (size_t)p.nchunk_max * p.g.cap_core * sizeof(uint4));
+    p.o_centry = o; o = up(o + (size_t)p.nchunk_max * sizeof(ChunkEntry));
+    p.o_hops = o;   o = up(o + ((size_t)p.nwin_max * 2 + 16) * sizeof(IdxHop));
+    p.o_rhops = o;  o = up(o + (size_t)p.nchunk_max * p.wpc * 2 * sizeof(IdxHop));
+    p.o_nhops = o;  o = up(o + (size_t)p.nchunk_max * 4);
+    p.bytes = o;
+    p.ok = true;
+    return p;
+}
+
+void allow_big_lds2()
+{
+    static std::once_flag once[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    std::call_once(once[dev], [] {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_spec2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                156 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+    });
+}
+
+// Index pass over the sparse tables, super-chunk by super-chunk: speculation (all CUs), wide walker
+// (every candidate of every chunk's first window), the walk (one wavefront: one lookup per chunk where
+// the wide table resolves it, per window or per coded data set where not), then the true chain through
+// the skipped chunks and the RSI starts inside all hops.
+void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
+                         uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
+                         uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot)
+{
+    allow_big_lds2();
+    IdxCarry *carry = reinterpret_cast<IdxCarry *>(base);
+    const uint64_t lo0 = start_bit / p.g.core * p.g.core;
+    const uint64_t span = (uint64_t)p.nwin_max * p.g.core;
+    for (uint64_t lo = lo0; lo < end_bit; lo += span) {
+        const uint64_t bits = end_bit - lo < span ? end_bit - lo : span;
+        const uint32_t nwin = (uint32_t)((bits + p.g.core - 1) / p.g.core);
+        const uint32_t nchunks = (nwin + p.wpc - 1) / p.wpc;
+        const bool first = lo == lo0, last = lo + span >= end_bit;
+        SparseTables t;
+        t.bitmap = reinterpret_cast<const uint32_t *>(base + p.o_bitmap);
+        t.pre = reinterpret_cast<const uint16_t *>(base + p.o_pre);
+        t.rec = reinterpret_cast<const uint2 *>(base + p.o_rec);
+        t.cpos = reinterpret_cast<const uint16_t *>(base + p.o_cpos);
+        t.ccnt = reinterpret_cast<const uint32_t *>(base + p.o_ccnt);
+        t.lo = lo;
+        t.hi = lo + (uint64_t)nwin * p.g.core;
+        t.core = p.g.core;
+        t.cap = p.g.cap_core;
+        t.wide = reinterpret_cast<const uint4 *>(base + p.o_wide);
+        t.wpc = p.wpc;
+        ChunkEntry *centry = reinterpret_cast<ChunkEntry *>(base + p.o_centry);
+        IdxHop *hops = reinterpret_cast<IdxHop *>(base + p.o_hops);
+        IdxHop *rhops = reinterpret_cast<IdxHop *>(base + p.o_rhops);
+        uint32_t *nhops = reinterpret_cast<uint32_t *>(base + p.o_nhops);
+        const uint32_t hop_cap = 2 * nwin + 8;
+        (void)hipMemsetAsync(base + p.o_wide, 0, (size_t)nchunks * p.g.cap_core * sizeof(uint4), st);
+        (void)hipMemsetAsync(centry, 0, (size_t)nchunks * sizeof(ChunkEntry), st);
+        hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, st, c, words, nwords, end_bit, lo, start_bit, p.g,
+                           const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
+                           const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt));
+        hipLaunchKernelGGL(k_wide, dim3((p.g.cap_core + 255) / 256, nchunks), dim3(256), 0, st, t, nwin, end_bit,
+                           const_cast<uint4 *>(t.wide));
+        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
+                           d_res, (const uint64_t *)nullptr, IdxTables{}, hops, hop_cap, carry, first ? 1u : 0u,
+                           last ? 1u : 0u, start_block, rsi_start, tail_slot, t, centry);
+        hipLaunchKernelGGL(k_rewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, t, nwin, nchunks, end_bit, centry, rhops,
+                           nhops);
+        hipLaunchKernelGGL(k_expand2, dim3((hop_cap + 255) / 256), dim3(256), 0, st, t, carry, hops,
+                           (const uint32_t *)nullptr, 0u, 0u, d_rsi_off);
+        hipLaunchKernelGGL(k_expand2, dim3((nchunks * p.wpc * 2 + 255) / 256), dim3(256), 0, st, t, carry, rhops, nhops,
+                           nchunks, p.wpc * 2, d_rsi_off);
+    }
+}
+
+}  // namespace
+
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
 {
     const uint64_t end_bit = (uint64_t)in_bytes * 8;
     if (start_bit >= end_bit) return 0;
+    const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
+    if (sp.ok) return sp.bytes;
     const SpecGeom g = spec_geom(c, end_bit - start_bit, rsi_bits_hint);
     if (!g.ok) return 0;
     const uint64_t lo = start_bit / g.core * g.core;
@@ -611,7 +1059,13 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
     if (!need || !d_ws || ws_bytes < need) {           // serial walk only
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off,
                            max_rsi, d_res, (const uint64_t *)nullptr, IdxTables{}, (IdxHop *)nullptr, 0u,
-                           (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start, tail_slot);
+                           (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start, tail_slot, SparseTables{}, (ChunkEntry *)nullptr);
+        return;
+    }
+    const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
+    if (sp.ok) {
+        launch_index_sparse(c, sp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
+                            static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot);
         return;
     }
     allow_big_lds();
@@ -649,7 +1103,8 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
         }
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, wst, c, words, nwords, end_bit, start_bit, d_rsi_off,
                            max_rsi, d_res, (const uint64_t *)nullptr, tabs, t.hops, hop_cap, carry,
-                           first ? 1u : 0u, last ? 1u : 0u, start_block, rsi_start, tail_slot);
+                           first ? 1u : 0u, last ? 1u : 0u, start_block, rsi_start, tail_slot, SparseTables{},
+                           (ChunkEntry *)nullptr);
         hipLaunchKernelGGL(k_expand, dim3((hop_cap + 255) / 256), dim3(256), 0, wst, carry, t.hops, tabs,
                            (c.flags & F_PAD_RSI) ? 1u : 0u, d_rsi_off);
         if (piped) (void)hipEventRecord(side->walk_done[b], wst);
@@ -666,7 +1121,8 @@ void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, cons
     hipLaunchKernelGGL(k_index, dim3((uint32_t)n_chunks), dim3(64), 0, st, c,
                        reinterpret_cast<const uint32_t *>(d_in), (uint64_t)((in_bytes + 3) / 4),
                        (uint64_t)in_bytes * 8, (uint64_t)0, d_rsi_off, rsi_per_chunk, d_res, d_chunk_off,
-                       IdxTables{}, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, 0u, (uint64_t)0, 0u);
+                       IdxTables{}, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, 0u, (uint64_t)0, 0u, SparseTables{},
+                       (ChunkEntry *)nullptr);
 }
 
 }  // namespace aec

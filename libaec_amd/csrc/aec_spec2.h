@@ -1,0 +1,161 @@
+// aec_spec2.h -- SPARSE speculative RSI index: per-window arithmetic (aec_idx.hip: k_spec2).
+//
+// aec_spec.h gives, with rank/select over a window's 1-bits, "a coded data set (CDS) starts at bit q:
+// where does it end?" in O(1).  The first index pass tabulated that -- and the RSI hypothesis on top
+// of it -- for EVERY bit position of every window and threw nearly all of it away.  This version only
+// works where a CDS can actually start:
+//
+//   1. SYNC CHAINS.  The CDS parse self-synchronises like any prefix code: a walk that starts at an
+//      arbitrary bit falls onto the true chain of CDS boundaries after a few codes.  A lane every
+//      `stride` bits burns in `burn` codes and then MARKS the boundaries it visits in a bitmap until
+//      it reaches one that is marked already (from there on another lane covers the chain).  The
+//      marked positions -- candidates -- are the true boundaries plus a few bogus ones.
+//   2. TABLES ON CANDIDATES ONLY: CDS length, 4- and 16-CDS hops (through marked positions), then the
+//      unit hypothesis "an RSI (short RSIs) / a first or an inner segment of 64 blocks (long RSIs)
+//      starts here" as a walk over those hops; a walk that leaves the marked chain (the reference
+//      sample of a hypothetical RSI start shifts it) computes the CDS ends on demand until it is back.
+//   3. CHAINS of units inside the window core: exit position + units covered, per candidate.
+//
+// Exactness: every table entry is the exact function value at its position (marking only selects
+// WHERE entries exist); the walkers read entries at true unit starts only and fall back to the serial
+// CDS walk where an entry is missing, so results never depend on the speculation.  Everything is
+// __host__ __device__: tests/emul runs it window by window on the CPU against the oracle.
+#pragma once
+
+#include "aec_spec.h"
+
+namespace aec {
+
+constexpr uint32_t kS2NoIndex = 0xFFFFFFFFu;
+
+// Window-relative views (LDS on the device, host arrays in the emulator).  Bit q of the window is bit
+// (31 - q % 32) of word q / 32, for the stream words and for the mark bitmap alike.
+struct S2Win {
+    SpecWin s;               // stream words, rank/select over them, valid bits
+    const uint32_t *marks;   // candidate bitmap, s.nwords words
+    const uint16_t *mpre;    // mpre[w] = candidates in words [0, w)
+    const uint16_t *cnxt;    // per candidate: CDS entry as in aec_spec.h nxt[] (len | kind), 0 = none
+    const uint16_t *chop4;   // per candidate: 4 CDSes on (aec_spec.h hop entry), 0 = none
+    const uint16_t *chop16;  // per candidate: 16 CDSes on
+    uint32_t ncand;
+};
+
+AEC_HD bool s2_marked(const uint32_t *marks, uint32_t q) { return (marks[q >> 5] >> (31u - (q & 31u))) & 1u; }
+
+// index of the candidate at bit q, kS2NoIndex if q is not marked
+AEC_HD uint32_t s2_index(const S2Win &w, uint32_t q)
+{
+    const uint32_t word = w.marks[q >> 5], sh = q & 31u;
+    if (!((word >> (31u - sh)) & 1u)) return kS2NoIndex;
+    return (uint32_t)w.mpre[q >> 5] + (sh ? spec_popc(word >> (32u - sh)) : 0u);
+}
+
+// One step of a sync chain: the CDS at q parsed WITHOUT a reference sample; 0 = no CDS ends inside
+// the window from here.
+AEC_HD uint32_t s2_chain_step(const SpecWin &s, const Cfg &c, uint32_t q)
+{
+    if (q >= s.limit) return 0;
+    uint32_t run;
+    return spec_cds(s, c, q, 0, run);
+}
+
+// hop over 4 CDSes from candidate `idx` through MARKED positions (0 = leaves the marked chain, a
+// rest-of-segment run inside, or too long for the entry format)
+AEC_HD uint16_t s2_hop4(const S2Win &w, const Cfg &c, const uint16_t *cpos, uint32_t idx)
+{
+    uint32_t pos = cpos[idx], extra = 0, i = idx;
+    const uint32_t q = pos;
+    for (int k = 0; k < 4; k++) {
+        if (i == kS2NoIndex) return 0;
+        const uint32_t e = w.cnxt[i];
+        const uint32_t len = e & 0xFFFu, code = len - c.id_len - 1u;
+        const bool zero = e & kNxtZero;
+        if (!e || (zero && code == 5u)) return 0;
+        extra += zero ? (code < 5u ? code : code - 1u) - 1u : 0u;
+        pos += len;
+        if (k < 3) {
+            if (pos >= w.s.limit) return 0;
+            i = s2_index(w, pos);
+        }
+    }
+    return spec_hop_pack(pos - q, extra);
+}
+
+AEC_HD uint16_t s2_hop16(const S2Win &w, const uint16_t *cpos, uint32_t idx)
+{
+    uint32_t pos = cpos[idx], extra = 0, i = idx;
+    const uint32_t q = pos;
+    for (int k = 0; k < 4; k++) {
+        if (i == kS2NoIndex) return 0;
+        const uint32_t e = w.chop4[i];
+        if (!e) return 0;
+        pos += e & kHopBitsMask;
+        extra += e >> 13;
+        if (k < 3) {
+            if (pos >= w.s.limit) return 0;
+            i = s2_index(w, pos);
+        }
+    }
+    return spec_hop_pack(pos - q, extra);
+}
+
+// One step of a unit walk at `pos` with `b` blocks of the RSI done, never beyond `bend` blocks: the
+// widest table entry that fits if pos is a candidate, else the CDS end computed on demand.
+// false = unresolved (leaves the window, malformed, a zero run overrunning the unit).
+AEC_HD bool s2_step(const S2Win &w, const Cfg &c, uint32_t &pos, uint32_t &b, uint32_t bend)
+{
+    if (pos >= w.s.limit) return false;
+    const uint32_t left = bend - b;
+    const uint32_t idx = s2_index(w, pos);
+    uint32_t e1;
+    if (idx != kS2NoIndex) {
+        const uint32_t e16 = w.chop16[idx], e4 = w.chop4[idx];
+        if (e16 && 16u + (e16 >> 13) <= left) {
+            pos += e16 & kHopBitsMask;
+            b += 16u + (e16 >> 13);
+            return true;
+        }
+        if (e4 && 4u + (e4 >> 13) <= left) {
+            pos += e4 & kHopBitsMask;
+            b += 4u + (e4 >> 13);
+            return true;
+        }
+        e1 = w.cnxt[idx];
+    } else {
+        e1 = spec_nxt_entry(w.s, c, pos);
+    }
+    if (!e1) return false;
+    const uint32_t len = e1 & 0xFFFu;
+    uint32_t n = 1;
+    if (e1 & kNxtZero) {
+        n = spec_run_blocks(c, len - c.id_len - 1u, b);
+        if (!n || n > left) return false;
+    }
+    pos += len;
+    b += n;
+    return true;
+}
+
+// Length in bits of the blocks [b0, bend) of an RSI coded from p on (the first CDS carries the
+// reference sample when b0 == 0 and the preprocessor is on); 0 = unresolved inside the window.
+AEC_HD uint32_t s2_unit(const S2Win &w, const Cfg &c, uint32_t p, uint32_t b0, uint32_t bend)
+{
+    uint32_t pos = p, b = b0;
+    if (b0 == 0) {
+        if (!spec_walk_init(c, spec_first_entry(w.s, c, p), p, pos, b)) return 0;
+        if (b > bend) return 0;
+    }
+    while (b < bend)
+        if (!s2_step(w, c, pos, b, bend)) return 0;
+    return pos - p;
+}
+
+// Global record of a candidate (what the walkers read).  Units: short RSIs -- a = the whole RSI;
+// long RSIs -- a = the first segment (with the reference sample), m = an inner segment of 64 blocks.
+// x / mx: chain of a- / m-units from here until it leaves the window core: bits [0,24) = distance,
+// bits [24,32) = units covered (0 = no chain).
+struct S2Rec {
+    uint32_t a, x, m, mx;
+};
+
+}  // namespace aec

@@ -314,3 +314,105 @@ extern "C" int emul_spec(const uint32_t *p, const uint8_t *in, size_t in_len, ui
     }
     return 0;
 }
+
+// ---- sparse speculative index (aec_spec2.h), window by window as k_spec2 does it ------------------
+#include "../../libaec_amd/csrc/aec_spec2.h"
+
+// prm: core, lead, look, stride, burn, mode (0 = unit is the RSI, 1 = units are segments of 64 blocks).
+// Output, DENSE for checking (the kernel writes the same values sparsely): marked[p] = 1 where bit p of
+// the stream is a candidate inside its window's core; recs[p] = its record.
+extern "C" int emul_spec2(const uint32_t *p, const uint8_t *in, size_t in_len, const uint32_t *prm,
+                          uint64_t start_bit, uint8_t *marked, S2Rec *recs)
+{
+    Cfg c;
+    int rc = make_cfg(p[0], p[1], p[2], p[3], 0, false, &c);
+    if (rc) return rc;
+    const uint32_t core = prm[0], lead = prm[1], look = prm[2], stride = prm[3], burn = prm[4], mode = prm[5];
+    const uint64_t end_bit = (uint64_t)in_len * 8;
+    const uint32_t W = lead + core + look, nw = W / 32;
+    std::vector<uint32_t> words((in_len + 3) / 4 + 1, 0);
+    memcpy(words.data(), in, in_len);
+    std::vector<uint32_t> win(nw + 2), marks(nw);
+    std::vector<uint16_t> rank(nw + 1), sel(nw + 2), mpre(nw + 1);
+    const uint64_t tab_lo = start_bit / core * core;
+    for (uint64_t core_abs = tab_lo; core_abs < end_bit; core_abs += core) {
+        const uint64_t wstart = core_abs >= lead ? core_abs - lead : 0;      // (multiple of 32)
+        const uint32_t c0 = (uint32_t)(core_abs - wstart), c1 = c0 + core;
+        for (uint32_t i = 0; i < nw + 2; i++) {
+            const uint64_t idx = wstart / 32 + i;
+            win[i] = idx < words.size() ? bswap32(words[idx]) : 0u;
+        }
+        rank[0] = 0;
+        for (uint32_t i = 0; i < nw; i++) rank[i + 1] = (uint16_t)(rank[i] + __builtin_popcount(win[i]));
+        for (uint32_t i = 0; i < nw; i++) {
+            const uint32_t lo = rank[i], hi = rank[i + 1], m = (lo + 31u) >> 5;
+            if (32u * m + 1u <= hi && 32u * m + 1u > lo) sel[m] = (uint16_t)i;
+        }
+        SpecWin s{win.data(), rank.data(), sel.data(), nw, (uint32_t)std::min<uint64_t>(W, end_bit - wstart)};
+        // 1. sync chains
+        std::fill(marks.begin(), marks.end(), 0u);
+        auto mark = [&](uint32_t q) {
+            const uint32_t bit = 1u << (31u - (q & 31u));
+            const bool was = marks[q >> 5] & bit;
+            marks[q >> 5] |= bit;
+            return was;
+        };
+        if (start_bit >= wstart && start_bit - wstart < s.limit) mark((uint32_t)(start_bit - wstart));
+        for (uint32_t q0 = 0; q0 < s.limit; q0 += stride) {
+            uint32_t q = q0;
+            bool ok = true;
+            for (uint32_t k = 0; k < burn && ok; k++) {
+                const uint32_t len = s2_chain_step(s, c, q);
+                ok = len != 0;
+                q += len;
+            }
+            while (ok && q < s.limit) {
+                if (mark(q)) break;
+                const uint32_t len = s2_chain_step(s, c, q);
+                ok = len != 0;
+                q += len;
+            }
+        }
+        // 2. candidate tables
+        mpre[0] = 0;
+        for (uint32_t i = 0; i < nw; i++) mpre[i + 1] = (uint16_t)(mpre[i] + __builtin_popcount(marks[i]));
+        const uint32_t ncand = mpre[nw];
+        std::vector<uint16_t> cpos(ncand + 1), cnxt(ncand + 1), chop4(ncand + 1), chop16(ncand + 1);
+        for (uint32_t q = 0, i = 0; q < W; q++)
+            if (s2_marked(marks.data(), q)) cpos[i++] = (uint16_t)q;
+        S2Win w{s, marks.data(), mpre.data(), cnxt.data(), chop4.data(), chop16.data(), ncand};
+        for (uint32_t i = 0; i < ncand; i++) cnxt[i] = cpos[i] < s.limit ? spec_nxt_entry(s, c, cpos[i]) : 0;
+        for (uint32_t i = 0; i < ncand; i++) chop4[i] = s2_hop4(w, c, cpos.data(), i);
+        for (uint32_t i = 0; i < ncand; i++) chop16[i] = s2_hop16(w, cpos.data(), i);
+        // 3. units and chains for the candidates of the core
+        std::vector<uint32_t> ua(ncand + 1, 0), um(ncand + 1, 0);
+        for (uint32_t i = 0; i < ncand; i++) {
+            const uint32_t q = cpos[i];
+            if (q < c0 || q >= c1 || q >= s.limit) continue;
+            if (mode == 0) {
+                ua[i] = s2_unit(w, c, q, 0, c.rsi);
+            } else {
+                ua[i] = s2_unit(w, c, q, 0, 64);
+                um[i] = s2_unit(w, c, q, 64, 128);
+            }
+        }
+        auto chain = [&](const std::vector<uint32_t> &u, uint32_t i) -> uint32_t {
+            uint32_t pos = cpos[i], cnt = 0;
+            while (pos < c1 && pos < s.limit && cnt < 255u) {
+                const uint32_t j = s2_index(w, pos);
+                if (j == kS2NoIndex || !u[j]) break;
+                pos += u[j];
+                cnt++;
+            }
+            return cnt ? ((cnt << 24) | (pos - cpos[i])) : 0u;
+        };
+        for (uint32_t i = 0; i < ncand; i++) {
+            const uint32_t q = cpos[i];
+            if (q < c0 || q >= c1 || q >= s.limit) continue;
+            const uint64_t abs = wstart + q;
+            marked[abs] = 1;
+            recs[abs] = S2Rec{ua[i], chain(ua, i), um[i], mode ? chain(um, i) : 0u};
+        }
+    }
+    return 0;
+}

@@ -23,7 +23,8 @@ def emul():
     srcs = [os.path.join(EMUL_DIR, "emul.cpp"),
             os.path.join(ROOT, "libaec_amd", "csrc", "aec_lane.h"),
             os.path.join(ROOT, "libaec_amd", "csrc", "aec_cfg.h"),
-            os.path.join(ROOT, "libaec_amd", "csrc", "aec_spec.h")]
+            os.path.join(ROOT, "libaec_amd", "csrc", "aec_spec.h"),
+            os.path.join(ROOT, "libaec_amd", "csrc", "aec_spec2.h")]
     if not os.path.exists(EMUL_SO) or any(os.path.getmtime(s) > os.path.getmtime(EMUL_SO) for s in srcs):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
                         "-o", EMUL_SO, srcs[0]], check=True)
@@ -193,3 +194,51 @@ def test_carry_in_matches_split_stream(emul):
         tail[0] |= int(o1[nb1])
     merged += tail
     assert bytes(merged) == whole
+
+
+S2_REC = np.dtype([("a", "<u4"), ("x", "<u4"), ("m", "<u4"), ("mx", "<u4")])
+
+
+@pytest.mark.parametrize("bps,bs,rsi,flags,scale,core,look", [
+    (16, 16, 128, AEC_DATA_PREPROCESS, 1.5, 24576, 16384),       # BASELINE config 2 shape
+    (8, 8, 128, AEC_DATA_PREPROCESS, 1.5, 24576, 8192),          # config 5 shape
+    (12, 16, 40, AEC_DATA_PREPROCESS | AEC_DATA_MSB, 2.0, 16384, 8192),
+])
+def test_sparse_speculation_vs_oracle(emul, bps, bs, rsi, flags, scale, core, look):
+    """Sparse speculative index (aec_spec2.h, what k_spec2 runs per window): on low-entropy streams the
+    sync chains must mark (nearly) every true RSI start, and every table value at a true RSI start --
+    the RSI length, the chained hop out of the window -- must be exact.  Values at other candidates are
+    hypotheses nobody reads."""
+    rng = np.random.default_rng(bps + rsi)
+    n = bs * rsi * 150 + 7
+    vals = random_walk_samples(rng, n, bps, flags, scale=scale, zero_frac=0.1, jump_frac=0.0005)
+    data = pack_samples(vals, bps, flags)
+    rc, enc, _, offs, bits = oracle_encode(data, bps, bs, rsi, flags)
+    enc_a = np.frombuffer(enc, dtype=np.uint8)
+    nbits = enc_a.size * 8
+    marked = np.zeros(nbits + 64, np.uint8)
+    recs = np.zeros(nbits + 64, S2_REC)
+    p = (C.c_uint32 * 4)(bps, bs, rsi, flags)
+    prm = (C.c_uint32 * 6)(core, 4096, look, 64, 8, 0)
+    emul.emul_spec2.restype = C.c_int
+    rc = emul.emul_spec2(p, C.c_void_p(enc_a.ctypes.data), C.c_size_t(enc_a.size), prm, C.c_uint64(0),
+                         C.c_void_p(marked.ctypes.data), C.c_void_p(recs.ctypes.data))
+    assert rc == 0
+    o = [int(v) for v in offs] + [bits]
+    full = ((n + bs - 1) // bs) // rsi
+    miss = 0
+    for i in range(full):
+        s, true_len = o[i], o[i + 1] - o[i]
+        if not marked[s]:
+            miss += 1
+            continue
+        a = int(recs["a"][s])
+        assert a in (0, true_len), (i, s, a, true_len)
+        if 2 * true_len < look:
+            assert a == true_len, (i, s, a, true_len)
+        x = int(recs["x"][s])
+        cnt, d = x >> 24, x & 0xFFFFFF
+        if cnt:
+            assert i + cnt <= len(o) - 1 and s + d == o[i + cnt], (i, cnt, d)
+    assert marked[0], "the known start of the stream is always a candidate"
+    assert miss <= full // 20, (miss, full)       # (a missed start only costs speed: that RSI is walked serially)
