@@ -20,7 +20,10 @@
 // runs one serial walker per independent chunk.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
+#include <vector>
 
 #include "aec_kernels.h"
 #include "aec_lane.h"
@@ -249,10 +252,16 @@ struct Spec2Geom {
 __global__ void __launch_bounds__(1024)
 k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
         uint64_t start_bit, const Spec2Geom g, uint32_t *__restrict__ gbitmap, uint16_t *__restrict__ gpre,
-        uint2 *__restrict__ grec, uint16_t *__restrict__ gcpos, uint32_t *__restrict__ gccnt)
+        uint2 *__restrict__ grec, uint16_t *__restrict__ gcpos, uint32_t *__restrict__ gccnt,
+        unsigned long long *__restrict__ prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
     __shared__ uint32_t sh_total;
+    // (diagnostic builds of the host pass `prof`: shader-clock stamps at the phase boundaries)
+    auto stamp = [&](int k) {
+        if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     const uint32_t W = g.lead + g.core + g.look, nw = W / 32u, cap = g.cap_lds;
     uint32_t *win = spec_lds;
     uint32_t *marks = win + nw + 2;
@@ -314,6 +323,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     __syncthreads();
     const uint64_t left = end_bit - wstart;
     const SpecWin s{win, rank, sel, nw, left < W ? (uint32_t)left : W};
+    stamp(1);
 
     // ---- 1. sync chains: burn in, then mark until a marked boundary is met
     if (tid == 0 && start_bit >= wstart && start_bit - wstart < s.limit) {
@@ -337,6 +347,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         }
     }
     __syncthreads();
+    stamp(2);
     prefix16(marks, mpre);
     __syncthreads();
     const uint32_t ncand = sh_total;
@@ -344,34 +355,43 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         give_up();
         return;
     }
-    // ---- 2. tables on the candidates
+    // ---- 2. tables on the candidates (positions first, so that the CDS parse below runs one
+    // candidate per lane instead of one bitmap word per lane)
     for (uint32_t i = tid; i < nw; i += nt) {
         uint32_t m = marks[i], idx = mpre[i];
         while (m) {
             const uint32_t b = (uint32_t)__builtin_clz(m);
             m &= ~(0x80000000u >> b);
-            const uint32_t q = i * 32u + b;
-            cpos[idx] = (uint16_t)q;
-            cnxt[idx] = q < s.limit ? spec_nxt_entry(s, c, q) : (uint16_t)0;
-            idx++;
+            cpos[idx++] = (uint16_t)(i * 32u + b);
         }
     }
     __syncthreads();
+    for (uint32_t i = tid; i < ncand; i += nt) {
+        const uint32_t q = cpos[i];
+        cnxt[i] = q < s.limit ? spec_nxt_entry(s, c, q) : (uint16_t)0;
+    }
+    __syncthreads();
+    stamp(3);
     S2Win w{s, marks, mpre, cnxt, chop4, chop16, ncand};
     for (uint32_t i = tid; i < ncand; i += nt) chop4[i] = s2_hop4(w, c, cpos, i);
     __syncthreads();
     for (uint32_t i = tid; i < ncand; i += nt) chop16[i] = s2_hop16(w, cpos, i);
     __syncthreads();
+    stamp(4);
     // ---- 3. the RSI hypothesis at every candidate of the core
     const uint32_t i0 = mpre[c0 >> 5], i1 = mpre[c1 >> 5 < nw ? c1 >> 5 : nw];   // (c0, c1 are multiples of 32)
     const uint32_t ncore = i1 - i0;
+    // (Flattening this loop -- one step per lane and iteration, a finished lane taking its next candidate
+    // at once -- was measured and is SLOWER here, 521k against 430k cycles per window: the iterations of
+    // the merged loop pay for every path, the on-demand parse included.)
     for (uint32_t i = i0 + tid; i < i1; i += nt) {
         const uint32_t q = cpos[i];
-        uint32_t a = q < s.limit ? s2_unit(w, c, q, 0u, c.rsi) : 0u;
+        uint32_t a = q < s.limit ? s2_unit(w, c, q, 0u, c.rsi, 0xFFFFFFFFu) : 0u;
         if (a > 0xFFFFu) a = 0;
         ua[i] = (uint16_t)a;
     }
     __syncthreads();
+    stamp(5);
     if (ncore > g.cap_core) {
         give_up();
         return;
@@ -394,6 +414,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         gpre[gw0 + i] = (uint16_t)(mpre[(c0 >> 5) + i] - i0);
     }
     if (tid == 0) gccnt[blockIdx.x] = ncore;
+    stamp(6);
 }
 
 // ---- wide walker: every candidate of a chunk's first window chases the window chain through the chunk
@@ -964,6 +985,38 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     return p;
 }
 
+// AEC_S2_PROF=1: phase stamps of k_spec2 (diagnostics; printed by the host at exit of the first launch)
+unsigned long long *spec2_prof_buffer(uint32_t nwin)
+{
+    static const bool on = getenv("AEC_S2_PROF") != nullptr;
+    static unsigned long long *buf = nullptr;
+    if (!on) return nullptr;
+    if (!buf) (void)hipMalloc(reinterpret_cast<void **>(&buf), (size_t)kS2SuperWindows * 8 * sizeof(unsigned long long));
+    (void)nwin;
+    return buf;
+}
+
+void spec2_prof_report(uint32_t nwin, hipStream_t st)
+{
+    unsigned long long *buf = spec2_prof_buffer(nwin);
+    if (!buf) return;
+    static int reports = 0;
+    if (reports++ >= 2) return;
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> h((size_t)nwin * 8);
+    (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
+    double d[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t n = 0;
+    for (uint32_t w = 0; w + 1 < nwin; w++) {
+        if (!h[(size_t)w * 8 + 6]) continue;
+        for (int k = 0; k < 6; k++) d[k] += (double)(h[(size_t)w * 8 + k + 1] - h[(size_t)w * 8 + k]);
+        n++;
+    }
+    fprintf(stderr, "k_spec2 phases (shader-clock ticks per window, %u windows): load+rank %.0f | chains %.0f | "
+            "prefix+cand nxt %.0f | hop4+hop16 %.0f | units %.0f | chain+write %.0f\n", n, d[0] / n, d[1] / n,
+            d[2] / n, d[3] / n, d[4] / n, d[5] / n);
+}
+
 void allow_big_lds2()
 {
     static std::once_flag once[64];
@@ -1015,7 +1068,8 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
         (void)hipMemsetAsync(centry, 0, (size_t)nchunks * sizeof(ChunkEntry), st);
         hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, st, c, words, nwords, end_bit, lo, start_bit, p.g,
                            const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
-                           const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt));
+                           const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin));
+        spec2_prof_report(nwin, st);
         hipLaunchKernelGGL(k_wide, dim3((p.g.cap_core + 255) / 256, nchunks), dim3(256), 0, st, t, nwin, end_bit,
                            const_cast<uint4 *>(t.wide));
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,

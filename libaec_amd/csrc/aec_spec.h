@@ -112,6 +112,35 @@ AEC_HD uint32_t spec_select(const SpecWin &s, uint32_t j)
 //     low entropy  (decode.c:618-644)  header + 1 bit (+ ref); second extension: bs/2 codes,
 //                                      zero blocks: 1 code whose length is the run code
 //     split k      (decode.c:462-502)  header (+ ref); bs - ref codes, then (bs - ref) * k bits
+// 64 window bits from bit q (three words; the caller keeps q + 64 inside the readable words)
+AEC_HD uint64_t spec_peek64(const uint32_t *win, uint32_t q)
+{
+    const uint32_t w = q >> 5, sh = q & 31u;
+    const uint64_t a = ((uint64_t)win[w] << 32) | win[w + 1];
+    const uint64_t hi = a << sh, lo = sh ? ((uint64_t)win[w + 2] >> (32u - sh)) : 0u;
+    return hi | lo;
+}
+
+// offset (from the MSB, 0-based) of the n-th 1-bit of x, 1 <= n <= popcount(x)
+AEC_HD uint32_t spec_select64(uint64_t x, uint32_t n)
+{
+    uint32_t pos = 0, cnt;
+    uint32_t v = (uint32_t)(x >> 32);
+    cnt = spec_popc(v);
+    if (n > cnt) { n -= cnt; pos = 32; v = (uint32_t)x; }
+    cnt = spec_popc(v >> 16);
+    if (n > cnt) { n -= cnt; pos += 16; v &= 0xFFFFu; } else { v >>= 16; }
+    cnt = spec_popc(v >> 8);
+    if (n > cnt) { n -= cnt; pos += 8; v &= 0xFFu; } else { v >>= 8; }
+    cnt = spec_popc(v >> 4);
+    if (n > cnt) { n -= cnt; pos += 4; v &= 0xFu; } else { v >>= 4; }
+    cnt = spec_popc(v >> 2);
+    if (n > cnt) { n -= cnt; pos += 2; v &= 0x3u; } else { v >>= 2; }
+    cnt = v >> 1;
+    if (n > cnt) pos += 1;
+    return pos;
+}
+
 AEC_HD uint32_t spec_cds(const SpecWin &s, const Cfg &c, uint32_t q, uint32_t ref, uint32_t &run)
 {
     run = 0;
@@ -126,7 +155,22 @@ AEC_HD uint32_t spec_cds(const SpecWin &s, const Cfg &c, uint32_t q, uint32_t re
     const uint32_t add = low ? 0u : n * (id - 1u);
     bool ok = in && (unc || q1 < s.limit);
     const uint32_t q1s = (ok && !unc) ? q1 : 0u;
-    const uint32_t e = spec_select(s, spec_rank(s, q1s) + n);
+    // The n-th 1-bit from q1 on ends the unary part.  Short unary regions -- the rule at the optimal
+    // k, where the whole region of a block is at most 3n bits -- are resolved inside ONE 64-bit peek
+    // (two dependent reads of the window in all); only longer ones take the rank/select tables.
+    uint32_t e;
+    const bool can_peek = q1s + 64u <= 32u * s.nwords;
+    const uint64_t U = can_peek ? spec_peek64(s.win, q1s) : 0u;
+    if (can_peek && (uint32_t)
+#if defined(__HIP_DEVICE_COMPILE__)
+            __popcll(U)
+#else
+            __builtin_popcountll(U)
+#endif
+            >= n && n >= 1u)
+        e = q1s + spec_select64(U, n) + 1u;
+    else
+        e = spec_select(s, spec_rank(s, q1s) + n);
     const uint32_t end = unc ? qs + c.id_len + c.bs * c.bps : e + add;
     ok = ok && (unc || e != kSpecInvalid) && end <= s.limit;
     if (!ok) return 0;

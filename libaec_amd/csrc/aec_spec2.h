@@ -102,7 +102,17 @@ AEC_HD uint16_t s2_hop16(const S2Win &w, const uint16_t *cpos, uint32_t idx)
 // One step of a unit walk at `pos` with `b` blocks of the RSI done, never beyond `bend` blocks: the
 // widest table entry that fits if pos is a candidate, else the CDS end computed on demand.
 // false = unresolved (leaves the window, malformed, a zero run overrunning the unit).
-AEC_HD bool s2_step(const S2Win &w, const Cfg &c, uint32_t &pos, uint32_t &b, uint32_t bend)
+#if !defined(__HIPCC__) && defined(AEC_S2_COUNT)
+#define S2_COUNT(i) (s2_counters[i]++)
+static unsigned long long s2_counters[8];
+#else
+#define S2_COUNT(i) ((void)0)
+#endif
+
+// `budget`: on-demand parses this walk may still spend (a bogus hypothesis wanders off the marked chain
+// for dozens of codes; a true one is back on it after the few codes behind an RSI start that no sync
+// chain has covered yet).
+AEC_HD bool s2_step(const S2Win &w, const Cfg &c, uint32_t &pos, uint32_t &b, uint32_t bend, uint32_t &budget)
 {
     if (pos >= w.s.limit) return false;
     const uint32_t left = bend - b;
@@ -111,17 +121,23 @@ AEC_HD bool s2_step(const S2Win &w, const Cfg &c, uint32_t &pos, uint32_t &b, ui
     if (idx != kS2NoIndex) {
         const uint32_t e16 = w.chop16[idx], e4 = w.chop4[idx];
         if (e16 && 16u + (e16 >> 13) <= left) {
+            S2_COUNT(0);
             pos += e16 & kHopBitsMask;
             b += 16u + (e16 >> 13);
             return true;
         }
         if (e4 && 4u + (e4 >> 13) <= left) {
+            S2_COUNT(1);
             pos += e4 & kHopBitsMask;
             b += 4u + (e4 >> 13);
             return true;
         }
+        S2_COUNT(2);
         e1 = w.cnxt[idx];
     } else {
+        S2_COUNT(3);
+        if (budget == 0) return false;
+        budget--;
         e1 = spec_nxt_entry(w.s, c, pos);
     }
     if (!e1) return false;
@@ -138,15 +154,16 @@ AEC_HD bool s2_step(const S2Win &w, const Cfg &c, uint32_t &pos, uint32_t &b, ui
 
 // Length in bits of the blocks [b0, bend) of an RSI coded from p on (the first CDS carries the
 // reference sample when b0 == 0 and the preprocessor is on); 0 = unresolved inside the window.
-AEC_HD uint32_t s2_unit(const S2Win &w, const Cfg &c, uint32_t p, uint32_t b0, uint32_t bend)
+AEC_HD uint32_t s2_unit(const S2Win &w, const Cfg &c, uint32_t p, uint32_t b0, uint32_t bend, uint32_t budget)
 {
     uint32_t pos = p, b = b0;
+    S2_COUNT(4);
     if (b0 == 0) {
         if (!spec_walk_init(c, spec_first_entry(w.s, c, p), p, pos, b)) return 0;
         if (b > bend) return 0;
     }
     while (b < bend)
-        if (!s2_step(w, c, pos, b, bend)) return 0;
+        if (!s2_step(w, c, pos, b, bend, budget)) return 0;
     return pos - p;
 }
 

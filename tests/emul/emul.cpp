@@ -316,9 +316,19 @@ extern "C" int emul_spec(const uint32_t *p, const uint8_t *in, size_t in_len, ui
 }
 
 // ---- sparse speculative index (aec_spec2.h), window by window as k_spec2 does it ------------------
+#define AEC_S2_COUNT 1
 #include "../../libaec_amd/csrc/aec_spec2.h"
+// step statistics of the unit walks (hop16, hop4, table single, on-demand single, units)
+extern "C" void emul_s2_counters(unsigned long long *out, int reset)
+{
+    for (int i = 0; i < 8; i++) {
+        out[i] = aec::s2_counters[i];
+        if (reset) aec::s2_counters[i] = 0;
+    }
+}
 
-// prm: core, lead, look, stride, burn, mode (0 = unit is the RSI, 1 = units are segments of 64 blocks).
+// prm: core, lead, look, stride, burn, mode (0 = unit is the RSI, 1 = units are segments of 64 blocks),
+// marking steps per chain (0 = unbounded), on-demand parses per unit walk (0 = unbounded).
 // Output, DENSE for checking (the kernel writes the same values sparsely): marked[p] = 1 where bit p of
 // the stream is a candidate inside its window's core; recs[p] = its record.
 extern "C" int emul_spec2(const uint32_t *p, const uint8_t *in, size_t in_len, const uint32_t *prm,
@@ -328,6 +338,8 @@ extern "C" int emul_spec2(const uint32_t *p, const uint8_t *in, size_t in_len, c
     int rc = make_cfg(p[0], p[1], p[2], p[3], 0, false, &c);
     if (rc) return rc;
     const uint32_t core = prm[0], lead = prm[1], look = prm[2], stride = prm[3], burn = prm[4], mode = prm[5];
+    const uint32_t max_mark = prm[6] ? prm[6] : 0xFFFFFFFFu;   // marking steps per chain (0 = unbounded)
+    const uint32_t budget = prm[7] ? prm[7] : 0xFFFFFFFFu;     // on-demand parses per unit walk (0 = unbounded)
     const uint64_t end_bit = (uint64_t)in_len * 8;
     const uint32_t W = lead + core + look, nw = W / 32;
     std::vector<uint32_t> words((in_len + 3) / 4 + 1, 0);
@@ -366,7 +378,7 @@ extern "C" int emul_spec2(const uint32_t *p, const uint8_t *in, size_t in_len, c
                 ok = len != 0;
                 q += len;
             }
-            while (ok && q < s.limit) {
+            for (uint32_t steps = 0; ok && q < s.limit && steps < max_mark; steps++) {
                 if (mark(q)) break;
                 const uint32_t len = s2_chain_step(s, c, q);
                 ok = len != 0;
@@ -390,10 +402,10 @@ extern "C" int emul_spec2(const uint32_t *p, const uint8_t *in, size_t in_len, c
             const uint32_t q = cpos[i];
             if (q < c0 || q >= c1 || q >= s.limit) continue;
             if (mode == 0) {
-                ua[i] = s2_unit(w, c, q, 0, c.rsi);
+                ua[i] = s2_unit(w, c, q, 0, c.rsi, budget);
             } else {
-                ua[i] = s2_unit(w, c, q, 0, 64);
-                um[i] = s2_unit(w, c, q, 64, 128);
+                ua[i] = s2_unit(w, c, q, 0, 64, budget);
+                um[i] = s2_unit(w, c, q, 64, 128, budget);
             }
         }
         auto chain = [&](const std::vector<uint32_t> &u, uint32_t i) -> uint32_t {
@@ -412,6 +424,48 @@ extern "C" int emul_spec2(const uint32_t *p, const uint8_t *in, size_t in_len, c
             const uint64_t abs = wstart + q;
             marked[abs] = 1;
             recs[abs] = S2Rec{ua[i], chain(ua, i), um[i], mode ? chain(um, i) : 0u};
+        }
+    }
+    return 0;
+}
+
+// statistics helper for tests: for start positions q0 = first, first + step, ... the number of CDS
+// parses (chain steps, no reference sample) until the chain from q0 lands on a TRUE boundary
+// (truth[] = 1 at true coded-data-set boundaries), capped at max_steps; out[i] = steps or 0xFFFF.
+extern "C" int emul_sync_steps(const uint32_t *p, const uint8_t *in, size_t in_len, const uint8_t *truth,
+                               uint64_t first, uint64_t step, uint32_t n, uint32_t max_steps, uint16_t *out)
+{
+    Cfg c;
+    int rc = make_cfg(p[0], p[1], p[2], p[3], 0, false, &c);
+    if (rc) return rc;
+    const uint32_t W = 65536, nw = W / 32;
+    std::vector<uint32_t> words((in_len + 3) / 4 + 1, 0);
+    memcpy(words.data(), in, in_len);
+    std::vector<uint32_t> win(nw + 2);
+    std::vector<uint16_t> rank(nw + 1), sel(nw + 2);
+    const uint64_t end_bit = (uint64_t)in_len * 8;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t q0 = first + (uint64_t)i * step;
+        const uint64_t wstart = q0 & ~31ull;
+        for (uint32_t k = 0; k < nw + 2; k++) {
+            const uint64_t idx = wstart / 32 + k;
+            win[k] = idx < words.size() ? bswap32(words[idx]) : 0u;
+        }
+        rank[0] = 0;
+        for (uint32_t k = 0; k < nw; k++) rank[k + 1] = (uint16_t)(rank[k] + __builtin_popcount(win[k]));
+        for (uint32_t k = 0; k < nw; k++) {
+            const uint32_t lo = rank[k], hi = rank[k + 1], m = (lo + 31u) >> 5;
+            if (32u * m + 1u <= hi && 32u * m + 1u > lo) sel[m] = (uint16_t)k;
+        }
+        SpecWin s{win.data(), rank.data(), sel.data(), nw, (uint32_t)std::min<uint64_t>(W, end_bit - wstart)};
+        uint32_t q = (uint32_t)(q0 - wstart), steps = 0;
+        out[i] = 0xFFFF;
+        while (steps < max_steps && q < s.limit) {
+            if (truth[wstart + q]) { out[i] = (uint16_t)steps; break; }
+            const uint32_t len = s2_chain_step(s, c, q);
+            if (!len) break;
+            q += len;
+            steps++;
         }
     }
     return 0;

@@ -219,7 +219,7 @@ def test_sparse_speculation_vs_oracle(emul, bps, bs, rsi, flags, scale, core, lo
     marked = np.zeros(nbits + 64, np.uint8)
     recs = np.zeros(nbits + 64, S2_REC)
     p = (C.c_uint32 * 4)(bps, bs, rsi, flags)
-    prm = (C.c_uint32 * 6)(core, 4096, look, 64, 8, 0)
+    prm = (C.c_uint32 * 8)(core, 4096, look, 64, 8, 0, 0, 0)
     emul.emul_spec2.restype = C.c_int
     rc = emul.emul_spec2(p, C.c_void_p(enc_a.ctypes.data), C.c_size_t(enc_a.size), prm, C.c_uint64(0),
                          C.c_void_p(marked.ctypes.data), C.c_void_p(recs.ctypes.data))
