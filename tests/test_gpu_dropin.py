@@ -68,3 +68,31 @@ def test_reference_check_code_options_on_product_library():
     print(f"check_code_options: {time.time() - t0:.1f} s, {out.count('PASS')} option checks")
     assert p.returncode == 0, out[-3000:]
     assert "FAIL" not in out and "Checking with large buffers" in out
+
+
+def test_own_cli_matches_reference_cli(tmp_path, typical_rz):
+    """The product's own `aec` front-end (libaec_amd/csrc/aec_cli.cpp; reference src/aec.c:72-239 is the
+    command line it mirrors): BASELINE config 1 -- decode data/typical.rz, re-encode byte-identically at
+    j64/r256 and at j16/r128 -- with several buffer sizes, option spellings (-n16 / -n 16) and an odd
+    trailing byte in the input."""
+    aec = os.path.join(os.path.dirname(ORACLE_DIR), "libaec_amd", "lib", "aec")
+    if not os.path.exists(aec):
+        pytest.skip("libaec_amd/lib/aec not built")
+    rz, dat, rz2, rz3, dat2 = (str(tmp_path / n) for n in ("t.rz", "t.dat", "t2.rz", "t3.rz", "t2.dat"))
+    open(rz, "wb").write(typical_rz)
+    subprocess.run([aec, "-d", "-n16", "-j64", "-r256", "-m", rz, dat], check=True, timeout=120)
+    dec = open(dat, "rb").read()
+    assert len(dec) == 1 << 20 and hashlib.sha256(dec).hexdigest().startswith("e6e1bf684916")
+    for extra in ([], ["-b", "4096"], ["-b1000003"]):
+        subprocess.run([aec, "-n", "16", "-j", "64", "-r", "256", "-m"] + extra + [dat, rz2], check=True, timeout=300)
+        assert open(rz2, "rb").read() == typical_rz, extra
+        subprocess.run([aec, "-d", "-n16", "-j64", "-r256", "-m"] + extra + [rz2, dat2], check=True, timeout=300)
+        assert open(dat2, "rb").read() == dec, extra
+    subprocess.run([aec, "-n16", "-j16", "-r128", "-m", dat, rz3], check=True, timeout=120)
+    enc = open(rz3, "rb").read()
+    assert len(enc) == 740174 and hashlib.sha256(enc).hexdigest().startswith("60f1f251f7e6")
+    # a trailing byte that does not fill a sample is ignored (reference encode.c:673-698)
+    open(dat, "ab").write(b"\x55")
+    subprocess.run([aec, "-n16", "-j16", "-r128", "-m", dat, rz2], check=True, timeout=120)
+    assert open(rz2, "rb").read() == enc
+    assert subprocess.run([aec, "-x", dat, rz2], capture_output=True).returncode == 1      # usage
