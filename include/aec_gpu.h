@@ -209,6 +209,32 @@ AEC_GPU_API int aec_gpu_index_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params
                                           void *stream);
 
 /*
+ * The two steps above in one enqueue, also for streams whose last RSI is short: index pass (one wavefront
+ * per stream) + ONE decode launch that takes every stream's RSI / block counts from its record in
+ * d_results.  Stream s decodes to d_out + s * rsi_per_chunk * (rsi * block_size * bytes per sample); the
+ * blocks it produced: d_results[s].n_rsi * rsi + d_results[s].tail_blocks.  d_result: overall decode
+ * status (worst over all lanes).  This is the shape of reading an HDF5 / netCDF dataset of SZIP chunks
+ * (the call site it serves: one aec_buffer_decode per chunk, reference src/sz_compat.c:239).
+ */
+AEC_GPU_API int aec_gpu_decode_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                           size_t in_bytes, const uint64_t *d_chunk_offsets, uint64_t n_chunks,
+                                           uint64_t rsi_per_chunk, uint64_t *d_rsi_bit_offsets, void *d_out,
+                                           aec_gpu_dec_result *d_results, aec_gpu_dec_result *d_result,
+                                           void *stream);
+
+/*
+ * n independent streams coded from one device buffer: chunk i = bytes [chunk_offsets[i],
+ * chunk_offsets[i+1]) of d_in (HOST array of n_chunks + 1 offsets, each a multiple of 16) is coded as a
+ * stream of its own (k = 0, bit 0) into d_out + i * slot_bytes (slot_bytes a multiple of 16, at least
+ * aec_gpu_encode_bound of the largest chunk); d_results[i] receives its total_bits.  Everything is
+ * enqueued on `stream`, nothing returns to the host (reference call site: one aec_buffer_encode per
+ * chunk, src/sz_compat.c:170).
+ */
+AEC_GPU_API int aec_gpu_encode_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                           const uint64_t *chunk_offsets, uint64_t n_chunks, void *d_out,
+                                           size_t slot_bytes, aec_gpu_enc_result *d_results, void *stream);
+
+/*
  * Measurement hooks (bench.py): with profiling enabled the context records HIP events on the
  * caller's stream around its kernels, one event set per call (a ring of 32), so a timed loop
  * needs no synchronisation inside it; aec_gpu_phase_ms waits for them and returns the device

@@ -69,6 +69,21 @@ LIBAEC_API int aec_decode_end(struct aec_stream *strm);
 LIBAEC_API int aec_buffer_encode(struct aec_stream *strm);
 LIBAEC_API int aec_buffer_decode(struct aec_stream *strm);
 
+/*
+ * Extension (no reference counterpart): n independent streams with the same parameters in ONE call --
+ * the chunks of an HDF5 / netCDF dataset, where the reference's callers run one aec_buffer_* call per
+ * chunk (reference src/sz_compat.c:170, 239).  Only bits_per_sample, block_size, rsi and flags of
+ * `params` are read.  src[i] / src_len[i]: the i-th input; dst[i]: its output buffer, dst_len[i] its
+ * capacity on entry and the bytes produced on return; status[i] (optional): AEC_OK, AEC_DATA_ERROR
+ * (corrupt stream), AEC_STREAM_ERROR (encode: output did not fit, a prefix was written).  One upload,
+ * one index + one decode launch (decode) or the encoder kernels per chunk (encode), one download.
+ * Returns AEC_OK or the last non-OK status.
+ */
+LIBAEC_API int aec_buffer_encode_batch(const struct aec_stream *params, size_t n, const void *const *src,
+                                       const size_t *src_len, void *const *dst, size_t *dst_len, int *status);
+LIBAEC_API int aec_buffer_decode_batch(const struct aec_stream *params, size_t n, const void *const *src,
+                                       const size_t *src_len, void *const *dst, size_t *dst_len, int *status);
+
 #ifdef __cplusplus
 }
 #endif

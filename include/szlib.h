@@ -53,6 +53,17 @@ SZLIB_API int SZ_BufftoBuffCompress(void *dest, size_t *destLen, const void *sou
 /* reference src/sz_compat.c:185-268: *destLen in = expected bytes, out = bytes produced */
 SZLIB_API int SZ_BufftoBuffDecompress(void *dest, size_t *destLen, const void *source, size_t sourceLen,
                                       SZ_com_t *param);
+/*
+ * Extension (no reference counterpart): n chunks of one dataset -- same SZ_com_t -- in ONE call, which is
+ * how an HDF5 filter pipeline that has several chunks in hand should drive a GPU: one upload, one index +
+ * one decode launch for all chunks (or the encoder kernels chunk after chunk without returning to the
+ * host), one download.  Arguments as in the BufftoBuff calls, per chunk; status[i] (optional) receives
+ * the per-chunk return code.  Output is byte-identical to n BufftoBuff calls.
+ */
+SZLIB_API int SZ_BatchCompress(void *const *dest, size_t *destLen, const void *const *source,
+                               const size_t *sourceLen, size_t n, SZ_com_t *param, int *status);
+SZLIB_API int SZ_BatchDecompress(void *const *dest, size_t *destLen, const void *const *source,
+                                 const size_t *sourceLen, size_t n, SZ_com_t *param, int *status);
 /* reference src/sz_compat.c:270-273 */
 SZLIB_API int SZ_encoder_enabled(void);
 /* netCDF's configure looks for this symbol (reference src/sz_compat.c:275-276) */

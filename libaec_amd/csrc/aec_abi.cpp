@@ -641,9 +641,169 @@ int decode_call(struct aec_stream *strm, int flush)
     return AEC_OK;
 }
 
+// ---- many independent streams per call (include/libaec.h: aec_buffer_*_batch) -------------------------
+struct BatchKit {
+    Kit k;
+    bool ok = false;
+    explicit BatchKit(int device)
+    {
+        if (take_kit(device, &k)) { ok = true; return; }
+        k.device = device;
+        ok = aec_gpu_create(&k.ctx) == RC_OK && hipStreamCreate(&k.stream) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void **>(&k.h_res), 256 + kBounce, hipHostMallocDefault) == hipSuccess &&
+             k.d_res.ensure(256);
+    }
+    ~BatchKit()
+    {
+        if (ok && k.ctx && k.stream && k.h_res && k.d_res.p) park_kit(k);
+        else destroy_kit(k);
+    }
+};
+
+inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src, const size_t *src_len,
+                 void *const *dst, size_t *dst_len, int *status)
+{
+    aec_gpu_params gp{prm->bits_per_sample, prm->block_size, prm->rsi, prm->flags};
+    Cfg c;
+    int rc = make_cfg(gp.bits_per_sample, gp.block_size, gp.rsi, gp.flags, 0, false, &c);
+    if (rc != RC_OK) return AEC_FAIL(rc);
+    if (n == 0) return AEC_OK;
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+    BatchKit bk(device);
+    if (!bk.ok) return AEC_FAIL(AEC_MEM_ERROR);
+    Kit &k = bk.k;
+    const size_t blk_bytes = (size_t)c.bs * c.bytes, rsi_bytes = (size_t)c.rsi * blk_bytes;
+    // geometry: every stream gets room for the RSIs of the largest one
+    uint64_t rpc = 1;
+    std::vector<uint64_t> off(n + 1);
+    size_t total_in = 0;
+    for (size_t i = 0; i < n; i++) {
+        off[i] = total_in;
+        total_in += up16(src_len[i]) + 16;
+        const uint64_t r = (dst_len[i] + rsi_bytes - 1) / rsi_bytes;
+        if (r > rpc) rpc = r;
+    }
+    off[n] = total_in;
+    std::vector<uint8_t> packed(total_in, 0);
+    for (size_t i = 0; i < n; i++) memcpy(packed.data() + off[i], src[i], src_len[i]);
+    // a stream's end must be its own: the index walker takes [off[i], off[i+1]) as the stream, so the real
+    // lengths go into a second table used for the bit limits (padding bytes are zero: never a complete code)
+    const size_t o_choff = up16((size_t)n * rpc * 8), o_res = o_choff + up16((n + 1) * 8), o_one = o_res + up16(n * 40);
+    if (!k.d_in.ensure(total_in + 32) || !k.d_out.ensure((size_t)n * rpc * rsi_bytes + 64) ||
+        !k.d_off.ensure(o_one + 64))
+        return AEC_FAIL(AEC_MEM_ERROR);
+    uint8_t *meta = static_cast<uint8_t *>(k.d_off.p);
+    if (hipMemcpyAsync(k.d_in.p, packed.data(), total_in, hipMemcpyHostToDevice, k.stream) != hipSuccess ||
+        hipMemcpyAsync(meta + o_choff, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, k.stream) != hipSuccess)
+        return AEC_FAIL(AEC_MEM_ERROR);
+    rc = aec_gpu_decode_batch_async(k.ctx, &gp, k.d_in.p, total_in, reinterpret_cast<uint64_t *>(meta + o_choff), n, rpc,
+                                    reinterpret_cast<uint64_t *>(meta), k.d_out.p,
+                                    reinterpret_cast<aec_gpu_dec_result *>(meta + o_res),
+                                    reinterpret_cast<aec_gpu_dec_result *>(meta + o_one), k.stream);
+    if (rc != RC_OK) return AEC_FAIL(rc);
+    std::vector<aec_gpu_dec_result> res(n + 1);
+    if (hipMemcpyAsync(res.data(), meta + o_res, n * sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
+        hipMemcpyAsync(&res[n], meta + o_one, sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
+        hipStreamSynchronize(k.stream) != hipSuccess)
+        return AEC_FAIL(AEC_MEM_ERROR);
+    int worst = AEC_OK;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t blocks = res[i].n_rsi * c.rsi + res[i].tail_blocks;
+        size_t produced = (size_t)blocks * blk_bytes;
+        if (produced > dst_len[i]) produced = dst_len[i] - dst_len[i] % c.bytes;
+        int st = res[i].status == DEC_DATA_ERROR ? AEC_DATA_ERROR : AEC_OK;
+        if (res[n].status != DEC_OK && res[n].bad_rsi / rpc == i) st = AEC_DATA_ERROR;
+        if (produced && hipMemcpyAsync(dst[i], static_cast<uint8_t *>(k.d_out.p) + i * rpc * rsi_bytes, produced,
+                                       hipMemcpyDeviceToHost, k.stream) != hipSuccess)
+            return AEC_FAIL(AEC_MEM_ERROR);
+        dst_len[i] = produced;
+        if (status) status[i] = st;
+        if (st != AEC_OK) worst = st;
+    }
+    if (hipStreamSynchronize(k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+    return worst;
+}
+
+int encode_batch_host(const struct aec_stream *prm, size_t n, const void *const *src, const size_t *src_len,
+                      void *const *dst, size_t *dst_len, int *status)
+{
+    aec_gpu_params gp{prm->bits_per_sample, prm->block_size, prm->rsi, prm->flags};
+    Cfg c;
+    int rc = make_cfg(gp.bits_per_sample, gp.block_size, gp.rsi, gp.flags, 0, true, &c);
+    if (rc != RC_OK) return AEC_FAIL(rc);
+    if (n == 0) return AEC_OK;
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+    BatchKit bk(device);
+    if (!bk.ok) return AEC_FAIL(AEC_MEM_ERROR);
+    Kit &k = bk.k;
+    std::vector<uint64_t> off(n + 1);
+    size_t total_in = 0, largest = 0;
+    for (size_t i = 0; i < n; i++) {
+        off[i] = total_in;
+        const size_t whole = src_len[i] - src_len[i] % c.bytes;          // only whole samples are coded
+        total_in += up16(whole) + 16;
+        if (whole > largest) largest = whole;
+    }
+    off[n] = total_in;
+    std::vector<uint8_t> packed(total_in, 0);
+    std::vector<uint64_t> ends(n + 1);
+    for (size_t i = 0; i < n; i++) memcpy(packed.data() + off[i], src[i], src_len[i] - src_len[i] % c.bytes);
+    const size_t slot = aec_gpu_encode_bound(&gp, largest);
+    if (!k.d_in.ensure(total_in + 32) || !k.d_out.ensure(n * slot) || !k.d_off.ensure(n * sizeof(aec_gpu_enc_result) + 64))
+        return AEC_FAIL(AEC_MEM_ERROR);
+    if (hipMemcpyAsync(k.d_in.p, packed.data(), total_in, hipMemcpyHostToDevice, k.stream) != hipSuccess)
+        return AEC_FAIL(AEC_MEM_ERROR);
+    // chunk i = [off[i], off[i] + whole samples): the padding between chunks is not input
+    aec_gpu_enc_result *d_res = static_cast<aec_gpu_enc_result *>(k.d_off.p);
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t pair[2] = {off[i], off[i] + (src_len[i] - src_len[i] % c.bytes)};
+        rc = aec_gpu_encode_batch_async(k.ctx, &gp, k.d_in.p, pair, 1, static_cast<uint8_t *>(k.d_out.p) + i * slot, slot,
+                                        d_res + i, k.stream);
+        if (rc != RC_OK) return AEC_FAIL(rc);
+    }
+    std::vector<aec_gpu_enc_result> res(n);
+    if (hipMemcpyAsync(res.data(), d_res, n * sizeof(aec_gpu_enc_result), hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
+        hipStreamSynchronize(k.stream) != hipSuccess)
+        return AEC_FAIL(AEC_MEM_ERROR);
+    int worst = AEC_OK;
+    for (size_t i = 0; i < n; i++) {
+        size_t bytes = (size_t)((res[i].total_bits + 7) / 8);
+        if (bytes == 0) bytes = 1;                                           // an empty stream is one zero byte
+        int st = AEC_OK;
+        if (res[i].overflow) st = AEC_MEM_ERROR;
+        else if (bytes > dst_len[i]) { st = AEC_STREAM_ERROR; bytes = dst_len[i]; }   // as aec_buffer_encode: a prefix
+        if (bytes && hipMemcpyAsync(dst[i], static_cast<uint8_t *>(k.d_out.p) + i * slot, bytes, hipMemcpyDeviceToHost,
+                                    k.stream) != hipSuccess)
+            return AEC_FAIL(AEC_MEM_ERROR);
+        dst_len[i] = bytes;
+        if (status) status[i] = st;
+        if (st != AEC_OK) worst = st;
+    }
+    if (hipStreamSynchronize(k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+    return worst;
+}
+
 }  // namespace
 
 extern "C" {
+
+int aec_buffer_decode_batch(const struct aec_stream *params, size_t n, const void *const *src, const size_t *src_len,
+                            void *const *dst, size_t *dst_len, int *status)
+{
+    try { return decode_batch(params, n, src, src_len, dst, dst_len, status); }
+    catch (const std::bad_alloc &) { return AEC_MEM_ERROR; }
+}
+
+int aec_buffer_encode_batch(const struct aec_stream *params, size_t n, const void *const *src, const size_t *src_len,
+                            void *const *dst, size_t *dst_len, int *status)
+{
+    try { return encode_batch_host(params, n, src, src_len, dst, dst_len, status); }
+    catch (const std::bad_alloc &) { return AEC_MEM_ERROR; }
+}
 
 int aec_encode_init(struct aec_stream *strm)
 {

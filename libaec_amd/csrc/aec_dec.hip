@@ -207,7 +207,8 @@ __global__ void __launch_bounds__(256)
 k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
          const uint64_t *__restrict__ rsi_off, const SegEntry *__restrict__ seg_table, uint64_t n_rsi,
          uint64_t total_blocks, uint8_t *__restrict__ out, DecResult *res, uint32_t ring_words, uint32_t maxw,
-         uint32_t needw, uint8_t *__restrict__ dump, const DecResult *__restrict__ idx)
+         uint32_t needw, uint8_t *__restrict__ dump, const DecResult *__restrict__ idx,
+         const DecResult *__restrict__ batch, uint32_t rsi_per_chunk)
 {
     // item counts straight from the record the index pass left on the device (the grid was sized for
     // the most it could find): no host round trip between the two passes
@@ -257,6 +258,15 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             start = e.bit;
             x = (c.flags & F_SIGNED) ? sign_extend(e.prev, c.bps) : e.prev;
             first_blk = rsi_idx * c.rsi + b0;
+        } else if (batch) {
+            // batch of independent streams: stream s owns RSIs [s * rsi_per_chunk, (s + 1) * rsi_per_chunk) of
+            // the table and of the output; what its index pass found says how many of them hold blocks
+            const uint64_t sidx = r / rsi_per_chunk;
+            const uint32_t rin = (uint32_t)(r - sidx * rsi_per_chunk);
+            const uint64_t whole = batch[sidx].n_rsi, tail = batch[sidx].tail_blocks;
+            nb = rin < whole ? c.rsi : (rin == whole ? (uint32_t)tail : 0u);
+            start = nb ? rsi_off[r] : 0;
+            first_blk = r * c.rsi;
         } else {
             uint64_t left = total_blocks - r * c.rsi;
             nb = left > c.rsi ? c.rsi : (uint32_t)left;
@@ -600,15 +610,15 @@ template <int BS, bool SEG>
 void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          const uint64_t *rsi_off, const SegEntry *seg_table, uint64_t n_rsi,
                          uint64_t total_blocks, uint8_t *out, DecResult *res, hipStream_t st, uint8_t *dump,
-                         const DecResult *idx)
+                         const DecResult *idx, const DecResult *batch, uint32_t rpc)
 {
     const uint32_t blk = (uint32_t)BS * c.bytes;
     // (counts taken from the index record: the average coded data set is not known here -- full ring)
-    const DecGeom g = dec_geom(c, n_rsi, (total_blocks && !idx) ? end_bit / total_blocks : 0, blk == 16 || blk == 32);
+    const DecGeom g = dec_geom(c, n_rsi, (total_blocks && !idx && !batch) ? end_bit / total_blocks : 0, blk == 16 || blk == 32);
     const dim3 block(64 * g.waves), grid(g.grid);
 #define AEC_GO(B)                                                                                   \
     hipLaunchKernelGGL((k_decode<BS, B, SEG>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
-                       rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, g.needw, dump, idx)
+                       rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, g.needw, dump, idx, batch, rpc)
     switch (c.bytes) {
     case 1: AEC_GO(1); break;
     case 2: AEC_GO(2); break;
@@ -624,7 +634,7 @@ template <bool SEG>
 static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
                               const SegEntry *d_seg, uint64_t n_items, uint64_t total_blocks, uint8_t *d_out,
                               DecResult *d_res, hipStream_t st, const PhaseEvents *prof,
-                              const DecResult *d_idx = nullptr)
+                              const DecResult *d_idx = nullptr, const DecResult *d_batch = nullptr, uint32_t rpc = 0)
 {
     uint8_t *dump = dump_buffer();
     if (!dump) return false;
@@ -638,15 +648,15 @@ static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
     const bool vec_ok = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
     const uint32_t bs = vec_ok ? c.bs : 0;
     switch (bs) {
-    case 8: launch_decode_bytes<8, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx); break;
-    case 16: launch_decode_bytes<16, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx); break;
-    case 32: launch_decode_bytes<32, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx); break;
-    case 64: launch_decode_bytes<64, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx); break;
+    case 8: launch_decode_bytes<8, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc); break;
+    case 16: launch_decode_bytes<16, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc); break;
+    case 32: launch_decode_bytes<32, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc); break;
+    case 64: launch_decode_bytes<64, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc); break;
     default:
     {
         const DecGeom g = dec_geom(c, n_items, 0, false);   // the sample-by-sample reader has no second attempt: full ring
         hipLaunchKernelGGL((k_decode<0, 0, SEG>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
-                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, g.needw, dump, d_idx);
+                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, g.needw, dump, d_idx, d_batch, rpc);
         break;
     }
     }
@@ -656,10 +666,10 @@ static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
 
 bool launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
                    uint64_t n_rsi, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res, hipStream_t st,
-                   const PhaseEvents *prof, const DecResult *d_idx)
+                   const PhaseEvents *prof, const DecResult *d_idx, const DecResult *d_batch, uint32_t rsi_per_chunk)
 {
     return launch_decode_any<false>(c, d_in, in_bytes, d_rsi_off, nullptr, n_rsi, total_blocks, d_out, d_res, st,
-                                    prof, d_idx);
+                                    prof, d_idx, d_batch, rsi_per_chunk);
 }
 
 void launch_decode_partial(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const DecResult *d_idx, uint8_t *d_out,

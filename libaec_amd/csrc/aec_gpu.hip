@@ -430,6 +430,46 @@ int aec_gpu_index_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const v
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
+int aec_gpu_decode_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                               const uint64_t *d_chunk_offsets, uint64_t n_chunks, uint64_t rsi_per_chunk,
+                               uint64_t *d_rsi_bit_offsets, void *d_out, aec_gpu_dec_result *d_results,
+                               aec_gpu_dec_result *d_result, void *stream)
+{
+    Cfg c;
+    const int rc = cfg_from(p, 0, false, &c);
+    if (rc != RC_OK) return rc;
+    if ((reinterpret_cast<uintptr_t>(d_in) & 15u) || rsi_per_chunk == 0 || rsi_per_chunk > 0xFFFFFFFFull)
+        return RC_CONF_ERROR;
+    if (n_chunks == 0) return RC_OK;
+    (void)hipGetLastError();
+    launch_index_batch(c, static_cast<const uint8_t *>(d_in), in_bytes, d_chunk_offsets, n_chunks, rsi_per_chunk,
+                       d_rsi_bit_offsets, reinterpret_cast<DecResult *>(d_results), static_cast<hipStream_t>(stream));
+    if (!launch_decode(c, static_cast<const uint8_t *>(d_in), in_bytes, d_rsi_bit_offsets, n_chunks * rsi_per_chunk,
+                       n_chunks * rsi_per_chunk * c.rsi, static_cast<uint8_t *>(d_out),
+                       reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream), ctx->dec_events(),
+                       nullptr, reinterpret_cast<const DecResult *>(d_results), (uint32_t)rsi_per_chunk))
+        return RC_MEM_ERROR;
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
+}
+
+int aec_gpu_encode_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                               const uint64_t *chunk_offsets_host, uint64_t n_chunks, void *d_out, size_t slot_bytes,
+                               aec_gpu_enc_result *d_results, void *stream)
+{
+    if (!chunk_offsets_host || (slot_bytes & 15u) || (reinterpret_cast<uintptr_t>(d_out) & 15u)) return RC_CONF_ERROR;
+    // every chunk is a stream of its own (k = 0, bit 0 of its slot): the chunks go through the encoder
+    // kernels one after the other on `stream`, sharing the context's workspace; nothing comes back to the host
+    for (uint64_t i = 0; i < n_chunks; i++) {
+        const uint64_t lo = chunk_offsets_host[i], hi = chunk_offsets_host[i + 1];
+        if (hi < lo || (lo & 15u)) return RC_CONF_ERROR;
+        const int rc = encode_phases(ctx, p, static_cast<const uint8_t *>(d_in) + lo, (size_t)(hi - lo),
+                                     static_cast<uint8_t *>(d_out) + i * slot_bytes, slot_bytes, 0, 0, nullptr,
+                                     d_results + i, stream, ENC_ALL);
+        if (rc != RC_OK) return rc;
+    }
+    return RC_OK;
+}
+
 int aec_gpu_profile(aec_gpu_ctx *ctx, int enable)
 {
     if (enable) {

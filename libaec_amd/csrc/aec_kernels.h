@@ -98,12 +98,15 @@ void launch_stitch(const uint8_t *d_gathered, size_t slot, const EncResult *d_pl
 
 // Enqueues the RSI-parallel decoder: one lane per RSI, offsets in bits from d_in.
 //   total_blocks  blocks to produce (the last RSI may be short); d_out holds whole blocks
+// d_batch (optional, with rsi_per_chunk): records of launch_index_batch, one per independent stream; stream
+// s owns RSIs [s * rsi_per_chunk, ...) of the table and of the output, and its record says how many hold blocks.
 // d_idx (optional): the record an index pass left on the device; the kernel then takes the number of
 // RSIs and blocks from it (n_rsi = the most the index pass could find, it sizes the grid).
 // false = the device-side scratch the kernels need could not be allocated.
 bool launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
                    uint64_t n_rsi, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res,
-                   hipStream_t stream, const PhaseEvents *prof = nullptr, const DecResult *d_idx = nullptr);
+                   hipStream_t stream, const PhaseEvents *prof = nullptr, const DecResult *d_idx = nullptr,
+                   const DecResult *d_batch = nullptr, uint32_t rsi_per_chunk = 0);
 
 // Samples of the coded data set the input ends in (single lane; see k_decode_partial): after
 // launch_decode with the same d_idx / d_out / d_res; their number is left in d_res->pad.

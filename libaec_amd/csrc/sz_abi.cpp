@@ -62,104 +62,180 @@ Geometry geometry(const SZ_com_t *p, unsigned bits_per_sample)
     return g;
 }
 
-int compress(void *dest, size_t *destLen, const void *source, size_t sourceLen, SZ_com_t *param)
+// ---- one chunk, in two steps, so that the batch entry points can put ONE coder call between them ----
+// compress: marshal `source` (byte planes, scan-line padding) into `buf`, fill the stream parameters
+struct Job {
+    struct aec_stream strm;
+    Geometry g;
+    bool planes, padded_lines;
+    size_t lines;
+    std::vector<uint8_t> buf;      // compress: the coder's input; decompress: the coder's output when it needs fixing up
+};
+
+int prepare_compress(Job &j, const void *source, size_t sourceLen, const SZ_com_t *param)
 {
     if (param->pixels_per_block <= 0 || param->pixels_per_scanline <= 0) return SZ_PARAM_ERROR;
-    struct aec_stream strm;
-    const bool planes = param->bits_per_pixel == 32 || param->bits_per_pixel == 64;   // sz_compat.c:134
-    strm.bits_per_sample = planes ? 8u : (unsigned)param->bits_per_pixel;
-    const Geometry g = geometry(param, strm.bits_per_sample);
-    strm.block_size = g.block;
-    strm.rsi = g.rsi;
-    strm.flags = AEC_NOT_ENFORCE | coder_flags(param->options_mask);                   // sz_compat.c:128
-    strm.next_out = static_cast<unsigned char *>(dest);
-    strm.avail_out = *destLen;
-
+    j.planes = param->bits_per_pixel == 32 || param->bits_per_pixel == 64;   // sz_compat.c:134
+    j.strm.bits_per_sample = j.planes ? 8u : (unsigned)param->bits_per_pixel;
+    j.g = geometry(param, j.strm.bits_per_sample);
+    const Geometry &g = j.g;
+    j.strm.block_size = g.block;
+    j.strm.rsi = g.rsi;
+    j.strm.flags = AEC_NOT_ENFORCE | coder_flags(param->options_mask);                   // sz_compat.c:128
     // Only whole pixels are coded.  (The reference sizes its padding buffer from the floor of
     // sourceLen / pixel size but copies sourceLen bytes, sz_compat.c:148-166: a trailing fraction of
     // a pixel overruns that buffer there.  It is dropped here.)
-    sourceLen -= sourceLen % (planes ? (size_t)param->bits_per_pixel / 8 : g.pixel);
+    sourceLen -= sourceLen % (j.planes ? (size_t)param->bits_per_pixel / 8 : g.pixel);
     std::vector<uint8_t> plane_buf;
     const uint8_t *src = static_cast<const uint8_t *>(source);
-    if (planes) {
+    if (j.planes) {
         plane_buf.resize(sourceLen);
         to_planes(plane_buf.data(), src, sourceLen, (size_t)param->bits_per_pixel / 8);
         src = plane_buf.data();
     }
-
     // every scan line becomes one RSI: pad it to whole blocks, repeating the last pixel when the
     // preprocessor is on and with zero pixels otherwise (sz_compat.c:71-94, 148-166)
     const size_t lines = (sourceLen / g.pixel + (size_t)param->pixels_per_scanline - 1) /
                          (size_t)param->pixels_per_scanline;
-    std::vector<uint8_t> padded(g.padded_line * lines);
-    const bool repeat = (strm.flags & AEC_DATA_PREPROCESS) != 0;
+    j.buf.assign(g.padded_line * lines, 0);
+    const bool repeat = (j.strm.flags & AEC_DATA_PREPROCESS) != 0;
     size_t in = 0, out = 0;
     while (in < sourceLen) {
         const size_t take = sourceLen - in < g.line ? sourceLen - in : g.line;
-        memcpy(padded.data() + out, src + in, take);
+        memcpy(j.buf.data() + out, src + in, take);
         in += take;
         const uint8_t *fill = src + in - g.pixel;
         for (size_t k = take; k < g.padded_line; k += g.pixel) {
-            if (repeat) memcpy(padded.data() + out + k, fill, g.pixel);
-            else memset(padded.data() + out + k, 0, g.pixel);
+            if (repeat) memcpy(j.buf.data() + out + k, fill, g.pixel);
+            else memset(j.buf.data() + out + k, 0, g.pixel);
         }
         out += g.padded_line;
     }
-    strm.next_in = padded.data();
-    strm.avail_in = padded.size();
+    return SZ_OK;
+}
 
-    const int rc = aec_buffer_encode(&strm);
-    *destLen = strm.total_out;                                                          // sz_compat.c:175
+int compress(void *dest, size_t *destLen, const void *source, size_t sourceLen, SZ_com_t *param)
+{
+    Job j;
+    const int prc = prepare_compress(j, source, sourceLen, param);
+    if (prc != SZ_OK) return prc;
+    j.strm.next_out = static_cast<unsigned char *>(dest);
+    j.strm.avail_out = *destLen;
+    j.strm.next_in = j.buf.data();
+    j.strm.avail_in = j.buf.size();
+    const int rc = aec_buffer_encode(&j.strm);
+    *destLen = j.strm.total_out;                                                        // sz_compat.c:175
     return rc == AEC_STREAM_ERROR ? SZ_OUTBUFF_FULL : rc;                               // sz_compat.c:171-174
+}
+
+// decompress: where the coder must write (`out` / `cap`), then the fix-up of what it wrote
+int prepare_decompress(Job &j, void *dest, size_t destLen, const SZ_com_t *param, unsigned char *&out, size_t &cap)
+{
+    if (param->pixels_per_block <= 0 || param->pixels_per_scanline <= 0) return SZ_PARAM_ERROR;
+    j.planes = param->bits_per_pixel == 32 || param->bits_per_pixel == 64;
+    j.strm.bits_per_sample = j.planes ? 8u : (unsigned)param->bits_per_pixel;
+    j.g = geometry(param, j.strm.bits_per_sample);
+    j.strm.block_size = j.g.block;
+    j.strm.rsi = j.g.rsi;
+    j.strm.flags = coder_flags(param->options_mask);                                      // sz_compat.c:205
+    j.padded_lines = param->pixels_per_scanline % param->pixels_per_block != 0;
+    j.lines = 0;
+    if (j.padded_lines || j.planes) {                                                     // sz_compat.c:222-236
+        if (j.padded_lines) {
+            j.lines = (destLen / j.g.pixel + (size_t)param->pixels_per_scanline - 1) /
+                      (size_t)param->pixels_per_scanline;
+            j.buf.resize(j.g.padded_line * j.lines);
+        } else {
+            j.buf.resize(destLen);
+        }
+        out = j.buf.data();
+        cap = j.buf.size();
+    } else {
+        out = static_cast<unsigned char *>(dest);
+        cap = destLen;
+    }
+    return SZ_OK;
+}
+
+void finish_decompress(Job &j, void *dest, size_t *destLen, size_t total_out, const SZ_com_t *param)
+{
+    const Geometry &g = j.g;
+    size_t total = total_out;
+    if (j.padded_lines) {                                                                 // sz_compat.c:96-108
+        size_t w = g.line;
+        for (size_t r = g.padded_line; r < total_out; r += g.padded_line) {
+            memmove(j.buf.data() + w, j.buf.data() + r, g.line);
+            w += g.line;
+        }
+        total = j.lines * g.line;
+    }
+    if (total < *destLen) *destLen = total;                                               // sz_compat.c:256-257
+    if (j.planes) from_planes(static_cast<uint8_t *>(dest), j.buf.data(), *destLen, (size_t)param->bits_per_pixel / 8);
+    else if (j.padded_lines) memcpy(dest, j.buf.data(), *destLen);
 }
 
 int decompress(void *dest, size_t *destLen, const void *source, size_t sourceLen, SZ_com_t *param)
 {
-    if (param->pixels_per_block <= 0 || param->pixels_per_scanline <= 0) return SZ_PARAM_ERROR;
-    struct aec_stream strm;
-    const bool planes = param->bits_per_pixel == 32 || param->bits_per_pixel == 64;
-    strm.bits_per_sample = planes ? 8u : (unsigned)param->bits_per_pixel;
-    const Geometry g = geometry(param, strm.bits_per_sample);
-    strm.block_size = g.block;
-    strm.rsi = g.rsi;
-    strm.flags = coder_flags(param->options_mask);                                      // sz_compat.c:205
-    strm.next_in = static_cast<const unsigned char *>(source);
-    strm.avail_in = sourceLen;
-
-    const bool padded_lines = param->pixels_per_scanline % param->pixels_per_block != 0;
-    size_t lines = 0;
-    std::vector<uint8_t> tmp;
-    if (padded_lines || planes) {                                                       // sz_compat.c:222-236
-        if (padded_lines) {
-            lines = (*destLen / g.pixel + (size_t)param->pixels_per_scanline - 1) /
-                    (size_t)param->pixels_per_scanline;
-            tmp.resize(g.padded_line * lines);
-        } else {
-            tmp.resize(*destLen);
-        }
-        strm.next_out = tmp.data();
-        strm.avail_out = tmp.size();
-    } else {
-        strm.next_out = static_cast<unsigned char *>(dest);
-        strm.avail_out = *destLen;
-    }
-
-    const int rc = aec_buffer_decode(&strm);
+    Job j;
+    unsigned char *out = nullptr;
+    size_t cap = 0;
+    const int prc = prepare_decompress(j, dest, *destLen, param, out, cap);
+    if (prc != SZ_OK) return prc;
+    j.strm.next_in = static_cast<const unsigned char *>(source);
+    j.strm.avail_in = sourceLen;
+    j.strm.next_out = out;
+    j.strm.avail_out = cap;
+    const int rc = aec_buffer_decode(&j.strm);
     if (rc != AEC_OK) return rc;
-
-    size_t total = strm.total_out;
-    if (padded_lines) {                                                                 // sz_compat.c:96-108
-        size_t w = g.line;
-        for (size_t r = g.padded_line; r < strm.total_out; r += g.padded_line) {
-            memmove(tmp.data() + w, tmp.data() + r, g.line);
-            w += g.line;
-        }
-        total = lines * g.line;
-    }
-    if (total < *destLen) *destLen = total;                                             // sz_compat.c:256-257
-    if (planes) from_planes(static_cast<uint8_t *>(dest), tmp.data(), *destLen, (size_t)param->bits_per_pixel / 8);
-    else if (padded_lines) memcpy(dest, tmp.data(), *destLen);
+    finish_decompress(j, dest, destLen, j.strm.total_out, param);
     return SZ_OK;
+}
+
+// ---- n chunks with the same parameters: one coder call for all of them ----------------------------------
+int batch_compress(void *const *dest, size_t *destLen, const void *const *source, const size_t *sourceLen, size_t n,
+                   SZ_com_t *param, int *status)
+{
+    std::vector<Job> jobs(n);
+    std::vector<const void *> src(n);
+    std::vector<size_t> src_len(n);
+    for (size_t i = 0; i < n; i++) {
+        const int prc = prepare_compress(jobs[i], source[i], sourceLen[i], param);
+        if (prc != SZ_OK) return prc;
+        src[i] = jobs[i].buf.data();
+        src_len[i] = jobs[i].buf.size();
+    }
+    std::vector<int> st(n, AEC_OK);
+    const int rc = aec_buffer_encode_batch(&jobs[0].strm, n, src.data(), src_len.data(), dest, destLen, st.data());
+    int worst = SZ_OK;
+    for (size_t i = 0; i < n; i++) {
+        const int one = st[i] == AEC_STREAM_ERROR ? SZ_OUTBUFF_FULL : st[i];
+        if (status) status[i] = one;
+        if (one != SZ_OK) worst = one;
+    }
+    return (rc != AEC_OK && worst == SZ_OK) ? rc : worst;
+}
+
+int batch_decompress(void *const *dest, size_t *destLen, const void *const *source, const size_t *sourceLen, size_t n,
+                     SZ_com_t *param, int *status)
+{
+    std::vector<Job> jobs(n);
+    std::vector<void *> out(n);
+    std::vector<size_t> cap(n);
+    for (size_t i = 0; i < n; i++) {
+        unsigned char *o = nullptr;
+        const int prc = prepare_decompress(jobs[i], dest[i], destLen[i], param, o, cap[i]);
+        if (prc != SZ_OK) return prc;
+        out[i] = o;
+    }
+    std::vector<int> st(n, AEC_OK);
+    const int rc = aec_buffer_decode_batch(&jobs[0].strm, n, source, sourceLen, out.data(), cap.data(), st.data());
+    int worst = SZ_OK;
+    for (size_t i = 0; i < n; i++) {
+        if (st[i] == AEC_OK) finish_decompress(jobs[i], dest[i], &destLen[i], cap[i], param);
+        if (status) status[i] = st[i];
+        if (st[i] != AEC_OK) worst = st[i];
+    }
+    return (rc != AEC_OK && worst == SZ_OK) ? rc : worst;
 }
 
 }  // namespace
@@ -175,6 +251,20 @@ int SZ_BufftoBuffCompress(void *dest, size_t *destLen, const void *source, size_
 int SZ_BufftoBuffDecompress(void *dest, size_t *destLen, const void *source, size_t sourceLen, SZ_com_t *param)
 {
     try { return decompress(dest, destLen, source, sourceLen, param); } catch (const std::bad_alloc &) { return SZ_MEM_ERROR; }
+}
+
+int SZ_BatchCompress(void *const *dest, size_t *destLen, const void *const *source, const size_t *sourceLen, size_t n,
+                     SZ_com_t *param, int *status)
+{
+    if (n == 0) return SZ_OK;
+    try { return batch_compress(dest, destLen, source, sourceLen, n, param, status); } catch (const std::bad_alloc &) { return SZ_MEM_ERROR; }
+}
+
+int SZ_BatchDecompress(void *const *dest, size_t *destLen, const void *const *source, const size_t *sourceLen, size_t n,
+                       SZ_com_t *param, int *status)
+{
+    if (n == 0) return SZ_OK;
+    try { return batch_decompress(dest, destLen, source, sourceLen, n, param, status); } catch (const std::bad_alloc &) { return SZ_MEM_ERROR; }
 }
 
 int SZ_encoder_enabled(void) { return 1; }

@@ -71,3 +71,33 @@ def decompress(data, out_size, options_mask, bits_per_pixel, pixels_per_block, p
     """SZ_BufftoBuffDecompress (reference src/sz_compat.c:185-268) -> (rc, bytes)"""
     return _call(lib or library(), "SZ_BufftoBuffDecompress", data, out_size, options_mask, bits_per_pixel,
                  pixels_per_block, pixels_per_scanline)
+
+
+def _batch(name, chunks, out_sizes, options_mask, bits_per_pixel, pixels_per_block, pixels_per_scanline):
+    """SZ_BatchCompress / SZ_BatchDecompress (extension, include/szlib.h): n chunks in one call.
+    Returns (rc, [bytes per chunk], [status per chunk])."""
+    lib = library()
+    fn = getattr(lib, name)
+    fn.restype = C.c_int
+    n = len(chunks)
+    arrs = [np.frombuffer(bytes(c), dtype=np.uint8) if not isinstance(c, np.ndarray)
+            else np.ascontiguousarray(c).view(np.uint8).reshape(-1) for c in chunks]
+    outs = [np.zeros(max(int(s), 1), dtype=np.uint8) for s in out_sizes]
+    src = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    src_len = (C.c_size_t * n)(*[a.size for a in arrs])
+    dst = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    dst_len = (C.c_size_t * n)(*[int(s) for s in out_sizes])
+    status = (C.c_int * n)()
+    p = SZ_com_t(options_mask, bits_per_pixel, pixels_per_block, pixels_per_scanline)
+    rc = fn(dst, dst_len, src, src_len, C.c_size_t(n), C.byref(p), status)
+    return rc, [outs[i][:dst_len[i]].tobytes() for i in range(n)], list(status)
+
+
+def compress_batch(chunks, out_sizes, options_mask, bits_per_pixel, pixels_per_block, pixels_per_scanline):
+    return _batch("SZ_BatchCompress", chunks, out_sizes, options_mask, bits_per_pixel, pixels_per_block,
+                  pixels_per_scanline)
+
+
+def decompress_batch(chunks, out_sizes, options_mask, bits_per_pixel, pixels_per_block, pixels_per_scanline):
+    return _batch("SZ_BatchDecompress", chunks, out_sizes, options_mask, bits_per_pixel, pixels_per_block,
+                  pixels_per_scanline)

@@ -104,3 +104,44 @@ def test_batch_of_foreign_chunks_decodes_in_two_launches(szip):
     assert d_dres.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]["status"] == 0
     assert torch.equal(d_out[:data.size].cpu(), torch.from_numpy(data))
     print(f"batch of {n_chunks} chunks ({data.size >> 20} MiB): {dt * 1e3:.2f} ms -> {data.size / dt / 1e9:.2f} GB/s")
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+def test_sz_batch_calls_vs_reference_shim(szip):
+    """SZ_BatchCompress / SZ_BatchDecompress (n chunks, one call) against the reference shim run chunk by
+    chunk (reference src/sz_compat.c:110-268; tests/check_szcomp.c:6-37 is its own configuration): 1 MiB
+    chunks of 8-bit pixels with NN and NN|MSB, 32-bit pixels coded as byte planes with a scan line that is
+    not a whole number of blocks and a ragged last chunk, and 16-bit pixels."""
+    from test_gpu_parity import gen
+    ref = szip.bind(C.CDLL(REF_SO))
+    NN, MSBO, RAW = szip.SZ_NN_OPTION_MASK, szip.SZ_MSB_OPTION_MASK, szip.SZ_RAW_OPTION_MASK
+    rng = np.random.default_rng(8)
+    d8 = gen(2, 6 << 20)
+    d16 = gen(0, 3 << 20)
+    d32 = np.cumsum(rng.integers(-40, 41, size=300_000)).astype("<i4").view(np.uint8)
+    cases = [
+        ("8-bit NN", NN | RAW, 8, 8, 1024, [d8[i << 20:(i + 1) << 20] for i in range(6)]),
+        ("8-bit NN MSB", NN | MSBO | RAW, 8, 8, 1024, [d8[i << 20:(i + 1) << 20] for i in range(6)]),
+        ("16-bit NN", NN | RAW, 16, 16, 2048, [d16[i << 19:(i + 1) << 19] for i in range(6)]),
+        # 32 bpp: four byte planes, 1000 px per scan line = 62.5 blocks of 16 (padded), ragged last chunk
+        ("32-bit planes", NN | MSBO | RAW, 32, 16, 1000, [d32[:400_000], d32[400_000:800_000], d32[800_000:1_100_004]]),
+        ("8-bit no NN", RAW, 8, 8, 1000, [d8[:250_000], d8[250_000:500_001]]),
+    ]
+    for name, opts, bpp, ppb, pps, chunks in cases:
+        want = [szip.compress(c, c.size * 2 + 4096, opts, bpp, ppb, pps, lib=ref) for c in chunks]
+        assert all(rc == 0 for rc, _ in want), name
+        rc, got, st = szip.compress_batch(chunks, [c.size * 2 + 4096 for c in chunks], opts, bpp, ppb, pps)
+        assert rc == 0 and st == [0] * len(chunks), (name, rc, st)
+        assert got == [w for _, w in want], name
+        # and back, from the reference's streams
+        back = [szip.decompress(w, c.size, opts, bpp, ppb, pps, lib=ref) for (_, w), c in zip(want, chunks)]
+        rc, dec, st = szip.decompress_batch([w for _, w in want], [c.size for c in chunks], opts, bpp, ppb, pps)
+        assert rc == 0 and st == [0] * len(chunks), (name, rc, st)
+        assert dec == [b for _, b in back], name
+    # a chunk whose output does not fit: SZ_OUTBUFF_FULL for that chunk, the others are unaffected
+    name, opts, bpp, ppb, pps, chunks = cases[0]
+    sizes = [c.size * 2 for c in chunks]
+    sizes[2] = 100
+    rc, got, st = szip.compress_batch(chunks, sizes, opts, bpp, ppb, pps)
+    assert st[2] == szip.SZ_OUTBUFF_FULL and [s for i, s in enumerate(st) if i != 2] == [0] * 5
+    assert got[3] == szip.compress(chunks[3], chunks[3].size * 2, opts, bpp, ppb, pps, lib=ref)[1]
