@@ -144,7 +144,7 @@ struct Kit {
     DevBuf d_in, d_out, d_off, d_res;
     uint8_t *h_res = nullptr;
 };
-constexpr size_t kPoolMax = 8, kKeepBytes = (size_t)64 << 20;
+constexpr size_t kPoolMax = 8, kKeepBytes = (size_t)256 << 20;
 std::mutex g_pool_mu;
 std::vector<Kit> *g_pool = nullptr;      // heap object on purpose: no destructor at exit
 
@@ -687,23 +687,65 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
         if (r > rpc) rpc = r;
     }
     off[n] = total_in;
-    std::vector<uint8_t> packed(total_in, 0);
-    for (size_t i = 0; i < n; i++) memcpy(packed.data() + off[i], src[i], src_len[i]);
-    // a stream's end must be its own: the index walker takes [off[i], off[i+1]) as the stream, so the real
-    // lengths go into a second table used for the bit limits (padding bytes are zero: never a complete code)
+    // the index walker takes [off[i], off[i+1]) as stream i: the padding behind a stream is zeroed (zero
+    // bits never complete a coded data set), the streams go up straight from the caller's buffers
     const size_t o_choff = up16((size_t)n * rpc * 8), o_res = o_choff + up16((n + 1) * 8), o_one = o_res + up16(n * 40);
     if (!k.d_in.ensure(total_in + 32) || !k.d_out.ensure((size_t)n * rpc * rsi_bytes + 64) ||
         !k.d_off.ensure(o_one + 64))
         return AEC_FAIL(AEC_MEM_ERROR);
     uint8_t *meta = static_cast<uint8_t *>(k.d_off.p);
-    if (hipMemcpyAsync(k.d_in.p, packed.data(), total_in, hipMemcpyHostToDevice, k.stream) != hipSuccess ||
-        hipMemcpyAsync(meta + o_choff, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, k.stream) != hipSuccess)
+    if (hipMemsetAsync(k.d_in.p, 0, total_in, k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+    for (size_t i = 0; i < n; i++)
+        if (src_len[i] && hipMemcpyAsync(static_cast<uint8_t *>(k.d_in.p) + off[i], src[i], src_len[i],
+                                         hipMemcpyHostToDevice, k.stream) != hipSuccess)
+            return AEC_FAIL(AEC_MEM_ERROR);
+    if (hipMemcpyAsync(meta + o_choff, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, k.stream) != hipSuccess)
         return AEC_FAIL(AEC_MEM_ERROR);
-    rc = aec_gpu_decode_batch_async(k.ctx, &gp, k.d_in.p, total_in, reinterpret_cast<uint64_t *>(meta + o_choff), n, rpc,
-                                    reinterpret_cast<uint64_t *>(meta), k.d_out.p,
-                                    reinterpret_cast<aec_gpu_dec_result *>(meta + o_res),
-                                    reinterpret_cast<aec_gpu_dec_result *>(meta + o_one), k.stream);
-    if (rc != RC_OK) return AEC_FAIL(rc);
+    // Small chunks: one wavefront walks each stream, all streams at once (aec_gpu_decode_batch_async).
+    // Large chunks would each keep ONE wavefront busy for tens of milliseconds that way; they go through
+    // the speculative index one after the other instead (all CUs per chunk), still without returning to
+    // the host in between.
+    aec_gpu_dec_result *d_results = reinterpret_cast<aec_gpu_dec_result *>(meta + o_res);
+    aec_gpu_dec_result *d_one = reinterpret_cast<aec_gpu_dec_result *>(meta + o_one);
+    const bool large = total_in / n >= ((size_t)32 << 10) || n < 64;
+    if (!large) {
+        rc = aec_gpu_decode_batch_async(k.ctx, &gp, k.d_in.p, total_in, reinterpret_cast<uint64_t *>(meta + o_choff), n,
+                                        rpc, reinterpret_cast<uint64_t *>(meta), k.d_out.p, d_results, d_one, k.stream);
+        if (rc != RC_OK) return AEC_FAIL(rc);
+    } else {
+        // (per chunk: its own decode record behind the index records; the overall record is folded on the host)
+        if (!k.d_res.ensure(256)) return AEC_FAIL(AEC_MEM_ERROR);
+        DevBuf dec_recs;
+        if (!dec_recs.ensure(n * sizeof(aec_gpu_dec_result) + 64)) return AEC_FAIL(AEC_MEM_ERROR);
+        aec_gpu_dec_result *d_dec = static_cast<aec_gpu_dec_result *>(dec_recs.p);
+        for (size_t i = 0; i < n && rc == RC_OK; i++) {
+            uint64_t *offs = reinterpret_cast<uint64_t *>(meta) + i * rpc;
+            const uint8_t *in_i = static_cast<const uint8_t *>(k.d_in.p) + off[i];
+            aec_gpu_set_index_hint(k.ctx, rpc ? (uint64_t)src_len[i] * 8 / rpc : 0);
+            rc = aec_gpu_index_async(k.ctx, &gp, in_i, src_len[i], 0, offs, rpc, d_results + i, k.stream);
+            if (rc == RC_OK)
+                rc = aec_gpu_decode_indexed_async(k.ctx, &gp, in_i, src_len[i], offs, rpc, d_results + i,
+                                                  static_cast<uint8_t *>(k.d_out.p) + i * rpc * rsi_bytes, d_dec + i,
+                                                  k.stream);
+        }
+        std::vector<aec_gpu_dec_result> dec(n);
+        if (rc != RC_OK || hipMemcpyAsync(dec.data(), d_dec, n * sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost,
+                                          k.stream) != hipSuccess ||
+            hipMemsetAsync(d_one, 0, sizeof(aec_gpu_dec_result), k.stream) != hipSuccess ||
+            hipStreamSynchronize(k.stream) != hipSuccess) {
+            dec_recs.release();
+            return AEC_FAIL(rc != RC_OK ? rc : AEC_MEM_ERROR);
+        }
+        dec_recs.release();
+        // fold the per-chunk decode status into the per-chunk index records on the host below
+        std::vector<aec_gpu_dec_result> idx(n);
+        if (hipMemcpy(idx.data(), d_results, n * sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost) != hipSuccess)
+            return AEC_FAIL(AEC_MEM_ERROR);
+        for (size_t i = 0; i < n; i++)
+            if (dec[i].status != DEC_OK) idx[i].status = DEC_DATA_ERROR;
+        if (hipMemcpy(d_results, idx.data(), n * sizeof(aec_gpu_dec_result), hipMemcpyHostToDevice) != hipSuccess)
+            return AEC_FAIL(AEC_MEM_ERROR);
+    }
     std::vector<aec_gpu_dec_result> res(n + 1);
     if (hipMemcpyAsync(res.data(), meta + o_res, n * sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
         hipMemcpyAsync(&res[n], meta + o_one, sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
@@ -749,14 +791,15 @@ int encode_batch_host(const struct aec_stream *prm, size_t n, const void *const 
         if (whole > largest) largest = whole;
     }
     off[n] = total_in;
-    std::vector<uint8_t> packed(total_in, 0);
-    std::vector<uint64_t> ends(n + 1);
-    for (size_t i = 0; i < n; i++) memcpy(packed.data() + off[i], src[i], src_len[i] - src_len[i] % c.bytes);
     const size_t slot = aec_gpu_encode_bound(&gp, largest);
     if (!k.d_in.ensure(total_in + 32) || !k.d_out.ensure(n * slot) || !k.d_off.ensure(n * sizeof(aec_gpu_enc_result) + 64))
         return AEC_FAIL(AEC_MEM_ERROR);
-    if (hipMemcpyAsync(k.d_in.p, packed.data(), total_in, hipMemcpyHostToDevice, k.stream) != hipSuccess)
-        return AEC_FAIL(AEC_MEM_ERROR);
+    for (size_t i = 0; i < n; i++) {
+        const size_t whole = src_len[i] - src_len[i] % c.bytes;
+        if (whole && hipMemcpyAsync(static_cast<uint8_t *>(k.d_in.p) + off[i], src[i], whole, hipMemcpyHostToDevice,
+                                    k.stream) != hipSuccess)
+            return AEC_FAIL(AEC_MEM_ERROR);
+    }
     // chunk i = [off[i], off[i] + whole samples): the padding between chunks is not input
     aec_gpu_enc_result *d_res = static_cast<aec_gpu_enc_result *>(k.d_off.p);
     for (size_t i = 0; i < n; i++) {

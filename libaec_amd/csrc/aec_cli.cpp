@@ -120,7 +120,11 @@ int main(int argc, char **argv)
         piece = piece / sample * sample;
         if (piece == 0) piece = sample;
     }
-    std::vector<unsigned char> ibuf(piece), obuf(o.buffer > 4096 ? o.buffer : 4096);
+    // (the decoder reports AEC_MEM_ERROR when it is left with room for a fraction of a sample, reference
+    // decode.c:821-823: the output buffer holds whole samples)
+    size_t room = o.buffer > 4096 ? o.buffer : 4096;
+    room -= room % sample;
+    std::vector<unsigned char> ibuf(piece), obuf(room);
 
     int rc = o.decode ? aec_decode_init(&o.strm) : aec_encode_init(&o.strm);
     if (rc != AEC_OK) {
