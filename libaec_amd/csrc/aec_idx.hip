@@ -246,7 +246,7 @@ k_spec(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_
 // Output for the candidates inside the core: the window's part of the global bitmap / prefix table
 // and its records (SparseTables above).
 struct Spec2Geom {
-    uint32_t lead, core, look, stride, burn, cap_lds, cap_core;
+    uint32_t lead, core, look, stride, burn, cap_lds, cap_core, budget;
 };
 
 __global__ void __launch_bounds__(1024)
@@ -386,7 +386,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     // the merged loop pay for every path, the on-demand parse included.)
     for (uint32_t i = i0 + tid; i < i1; i += nt) {
         const uint32_t q = cpos[i];
-        uint32_t a = q < s.limit ? s2_unit(w, c, q, 0u, c.rsi, 0xFFFFFFFFu) : 0u;
+        uint32_t a = q < s.limit ? s2_unit(w, c, q, 0u, c.rsi, g.budget) : 0u;
         if (a > 0xFFFFu) a = 0;
         ua[i] = (uint16_t)a;
     }
@@ -946,8 +946,12 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     if (rsi_bits_hint * 2 > samples * 9) return p;                       // more than 4.5 bits per sample
     uint64_t look = (2 * rsi_bits_hint + 1024 + 31) & ~31ull;
     if (look < 4096) look = 4096;
+    static const char *e_win = getenv("AEC_S2_WINDOW");
+    uint32_t wbits = e_win ? (uint32_t)atoi(e_win) : kS2WindowBits;
+    if (wbits < 16384 || wbits > kS2WindowBits) wbits = kS2WindowBits;
+    if (look + kS2Lead + 8192 > wbits) wbits = kS2WindowBits;            // long RSIs: the largest window
     if (look > kS2WindowBits - kS2Lead - 16384) return p;
-    uint64_t core = (kS2WindowBits - kS2Lead - look) & ~1023ull;
+    uint64_t core = (wbits - kS2Lead - look) & ~1023ull;
     // small inputs: about one window per CU
     const uint64_t want = ((total_bits / 256 + 1023) & ~1023ull);
     if (core > want) core = want < 8192 ? 8192 : want;
@@ -956,7 +960,9 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     p.g.look = (uint32_t)look;
     static const char *e_stride = getenv("AEC_S2_STRIDE"), *e_burn = getenv("AEC_S2_BURN");
     p.g.stride = e_stride ? (uint32_t)atoi(e_stride) : 64u;
-    p.g.burn = e_burn ? (uint32_t)atoi(e_burn) : 8u;
+    p.g.burn = e_burn ? (uint32_t)atoi(e_burn) : 24u;
+    static const char *e_budget = getenv("AEC_S2_BUDGET");
+    p.g.budget = e_budget ? (uint32_t)atoi(e_budget) : 0xFFFFFFFFu;
     const uint32_t W = p.g.lead + p.g.core + p.g.look, nw = W / 32;
     p.g.cap_lds = (W / 8 + 63) & ~63u;
     p.g.cap_core = (p.g.core / 8 + 63) & ~63u;
@@ -986,19 +992,20 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
 }
 
 // AEC_S2_PROF=1: phase stamps of k_spec2 (diagnostics; printed by the host at exit of the first launch)
-unsigned long long *spec2_prof_buffer(uint32_t nwin)
+unsigned long long *spec2_prof_buffer(uint32_t nwin, bool reset = true)
 {
     static const bool on = getenv("AEC_S2_PROF") != nullptr;
     static unsigned long long *buf = nullptr;
     if (!on) return nullptr;
     if (!buf) (void)hipMalloc(reinterpret_cast<void **>(&buf), (size_t)kS2SuperWindows * 8 * sizeof(unsigned long long));
+    if (reset) (void)hipMemset(buf, 0, (size_t)kS2SuperWindows * 8 * sizeof(unsigned long long));
     (void)nwin;
     return buf;
 }
 
 void spec2_prof_report(uint32_t nwin, hipStream_t st)
 {
-    unsigned long long *buf = spec2_prof_buffer(nwin);
+    unsigned long long *buf = spec2_prof_buffer(nwin, false);
     if (!buf) return;
     static int reports = 0;
     if (reports++ >= 2) return;

@@ -154,6 +154,10 @@ AEC_HD bool s2_step(const S2Win &w, const Cfg &c, uint32_t &pos, uint32_t &b, ui
 
 // Length in bits of the blocks [b0, bend) of an RSI coded from p on (the first CDS carries the
 // reference sample when b0 == 0 and the preprocessor is on); 0 = unresolved inside the window.
+// Two loops, because on a wavefront a loop costs what its most expensive path costs: first the on-demand
+// parses that bring the walk back onto the marked chain (the reference sample of the hypothetical RSI
+// start shifted it off), then table steps only -- the successor of a marked boundary is marked, so the
+// walk never leaves the chain again.
 AEC_HD uint32_t s2_unit(const S2Win &w, const Cfg &c, uint32_t p, uint32_t b0, uint32_t bend, uint32_t budget)
 {
     uint32_t pos = p, b = b0;
@@ -162,8 +166,26 @@ AEC_HD uint32_t s2_unit(const S2Win &w, const Cfg &c, uint32_t p, uint32_t b0, u
         if (!spec_walk_init(c, spec_first_entry(w.s, c, p), p, pos, b)) return 0;
         if (b > bend) return 0;
     }
+    while (b < bend) {                                   // catch-up: on demand until a marked boundary
+        if (pos >= w.s.limit) return 0;
+        if (s2_marked(w.marks, pos)) break;
+        if (budget == 0) return 0;
+        budget--;
+        S2_COUNT(3);
+        const uint32_t e1 = spec_nxt_entry(w.s, c, pos);
+        if (!e1) return 0;
+        const uint32_t len = e1 & 0xFFFu;
+        uint32_t n = 1;
+        if (e1 & kNxtZero) {
+            n = spec_run_blocks(c, len - c.id_len - 1u, b);
+            if (!n || n > bend - b) return 0;
+        }
+        pos += len;
+        b += n;
+    }
+    uint32_t none = 0;                                   // (no on-demand parse from here on)
     while (b < bend)
-        if (!s2_step(w, c, pos, b, bend, budget)) return 0;
+        if (!s2_step(w, c, pos, b, bend, none)) return 0;
     return pos - p;
 }
 
