@@ -84,6 +84,19 @@ __device__ __forceinline__ bool sparse_lookup(const SparseTables &t, uint64_t p,
     return true;
 }
 
+// Dense hop tables for streams whose RSIs are far longer than any window (k_hops / k_hop_compose):
+// "from the coded data set that starts at bit p, where are you 16 / 64 / 256 coded data sets on, and how
+// many blocks beyond that count did zero-block runs cover?"  Independent of the RSI structure -- the
+// walker itself knows its position inside the RSI, parses the coded data set that carries the reference
+// sample and every rest-of-segment run on its own (hops never contain one), and takes the widest hop that
+// stays inside the RSI.  h16: bits [0,13) distance, [13,16) extra blocks; h64 / h256: [0,24) distance,
+// [24,32) extra blocks; 0 = no entry.
+struct HopTables {
+    const uint16_t *h16;
+    const uint32_t *h64, *h256;
+    uint64_t lo, hi;
+};
+
 struct ChunkEntry {        // where the true chain enters a chunk the walker skipped over the wide table
     uint64_t pos, r;
     uint32_t valid, pad;
@@ -97,6 +110,8 @@ struct IdxHop {            // a chained hop the walker took: k_expand writes its
 struct IdxCarry {          // walker state between the table chunks of one stream
     uint64_t good, r;
     uint32_t active, n_hops;
+    uint64_t cur_start;    // hop tables: a chunk may end inside an RSI -- where that RSI began ...
+    uint32_t b, pad;       // ... and the blocks of it in front of `good`
 };
 
 // ---- speculation ------------------------------------------------------------------------------------
@@ -237,6 +252,90 @@ k_spec(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_
         Xb[rel0 + q] = (uint16_t)(pos - q);
         Xc[rel0 + q] = (uint8_t)cnt;
     }
+}
+
+// ---- hop tables (long RSIs) ---------------------------------------------------------------------------
+// LDS: win[nw + 2] u32 | rank[nw + 2] u16 | sel[nw + 2] u16 | nxt[W] u16 | hop4[W] u16
+__global__ void __launch_bounds__(1024)
+k_hops(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
+       uint32_t core, uint32_t look, uint16_t *__restrict__ h16)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
+    const uint32_t W = core + look, nw = W / 32u;
+    uint32_t *win = spec_lds;
+    uint16_t *rank = reinterpret_cast<uint16_t *>(win + nw + 2);
+    uint16_t *sel = rank + nw + 2;
+    uint16_t *nxt = sel + nw + 2;
+    uint16_t *hop4 = nxt + W;
+    const uint64_t rel0 = (uint64_t)blockIdx.x * core;
+    const uint64_t wstart = tab_lo + rel0;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    if (wstart >= end_bit) {
+        for (uint32_t q = tid; q < core; q += nt) h16[rel0 + q] = 0;
+        return;
+    }
+    const uint64_t w0 = wstart >> 5;
+    for (uint32_t i = tid; i < nw + 2; i += nt) {
+        const uint64_t idx = w0 + i;
+        win[i] = idx < nwords ? bswap32(words[idx]) : 0u;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < nw; base += 64) {
+            const uint32_t i = base + tid;
+            const uint32_t pc = i < nw ? (uint32_t)__popc(win[i]) : 0u;
+            const uint32_t incl = wave_incl_sum_dpp(pc);
+            if (i < nw) rank[i + 1] = (uint16_t)(carry + incl);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (tid == 0) rank[0] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nw; i += nt) {
+        const uint32_t lo = rank[i], hi = rank[i + 1], m = (lo + 31u) >> 5;
+        if (32u * m + 1u > lo && 32u * m + 1u <= hi) sel[m] = (uint16_t)i;
+    }
+    __syncthreads();
+    const uint64_t left = end_bit - wstart;
+    const SpecWin s{win, rank, sel, nw, left < W ? (uint32_t)left : W};
+    for (uint32_t q = tid; q < W; q += nt) nxt[q] = q < s.limit ? spec_nxt_entry(s, c, q) : (uint16_t)0;
+    __syncthreads();
+    for (uint32_t q = tid; q < W; q += nt) hop4[q] = spec_hop4(nxt, c, s.limit, q);
+    __syncthreads();
+    for (uint32_t q = tid; q < core; q += nt) h16[rel0 + q] = spec_hop16(hop4, s.limit, q);
+}
+
+// four hops of `src` in a row: dst[p] = where they lead (SRC16: src holds h16 entries, else h64 entries)
+template <bool SRC16>
+__global__ void __launch_bounds__(256)
+k_hop_compose(const void *__restrict__ src, uint32_t *__restrict__ dst, uint64_t n)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint64_t pos = p;
+    uint32_t extra = 0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        ok = ok && pos < n;
+        uint32_t bits, ex;
+        if (SRC16) {
+            const uint32_t e = static_cast<const uint16_t *>(src)[ok ? pos : p];
+            bits = e & kHopBitsMask;
+            ex = e >> 13;
+            ok = ok && e != 0;
+        } else {
+            const uint32_t e = static_cast<const uint32_t *>(src)[ok ? pos : p];
+            bits = e & 0xFFFFFFu;
+            ex = e >> 24;
+            ok = ok && e != 0;
+        }
+        pos += bits;
+        extra += ex;
+    }
+    const uint64_t d = pos - p;
+    dst[p] = (ok && d < (1u << 24) && extra < 256u) ? (uint32_t)d | (extra << 24) : 0u;
 }
 
 // ---- sparse speculation (aec_spec2.h) ----------------------------------------------------------------
@@ -537,7 +636,8 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         uint64_t start_bit, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res,
         const uint64_t *__restrict__ chunk_off, const IdxTables tabs, IdxHop *__restrict__ hops,
         uint32_t hop_cap, IdxCarry *carry, uint32_t first, uint32_t last, uint32_t start_block,
-        uint64_t rsi_start, uint32_t tail_slot, const SparseTables sp, ChunkEntry *__restrict__ centry)
+        uint64_t rsi_start, uint32_t tail_slot, const SparseTables sp, ChunkEntry *__restrict__ centry,
+        const HopTables ht)
 {
     __shared__ __attribute__((aligned(16))) uint32_t win[kIdxWindowWords];
     uint64_t r = 0;
@@ -566,6 +666,8 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         start_bit = carry->good;
         r = carry->r;
     }
+    const uint32_t b_carried = (carry && !first) ? carry->b : 0u;
+    const uint64_t start_carried = (carry && !first) ? carry->cur_start : 0ull;
     const uint32_t lane = threadIdx.x;
     const bool pp = c.flags & F_PREPROCESS;
     const uint32_t maxw = (c.id_len + 1 + c.bps + c.bs * c.bps) / 32 + 4;   // words one CDS can touch
@@ -640,7 +742,12 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         cur_start = rsi_start;
         if (lane == 0 && max_rsi) rsi_off[0] = rsi_start;
     }
+    if (b_carried) {             // the previous table chunk ended inside this RSI
+        b = b_carried;
+        cur_start = start_carried;
+    }
     if (coop) load_regs(good >> 5);
+    bool stale = false;          // the sequential reader lags behind `good` (hops moved it)
     for (;;) {
         bool hopped = false;
         if (b == 0) {
@@ -704,17 +811,63 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                 hopped = true;
             }
             if (r >= max_rsi) break;
-            if (carry && !last && good >= (sp.bitmap ? sp.hi : tabs.hi)) {   // the next table chunk continues from here
+            if (carry && !last && good >= (sp.bitmap ? sp.hi : (ht.h16 ? ht.hi : tabs.hi))) {   // the next table chunk continues from here
                 if (lane == 0) {
                     carry->good = good;
                     carry->r = r;
                     carry->active = 1;
                     carry->n_hops = nh;
+                    carry->b = 0;
+                    carry->cur_start = good;
                 }
                 return;
             }
             if (lane == 0) rsi_off[r] = good;
             cur_start = good;
+        }
+        // Hop tables (long RSIs): 256 / 64 / 16 coded data sets per lookup while that many blocks are left in
+        // the RSI; the coded data set with the reference sample and rest-of-segment runs are parsed below.
+        if (ht.h16 && !(pp && b == 0)) {
+            bool rsi_done = false;
+            while (good >= ht.lo && good < ht.hi && good < end_bit) {
+                const uint64_t i = good - ht.lo;
+                const uint32_t left = c.rsi - b;
+                const uint32_t e256 = (ht.h256 && left >= 256u) ? ht.h256[i] : 0u;
+                const uint32_t e64 = left >= 64u ? ht.h64[i] : 0u;
+                const uint32_t e16 = left >= 16u ? ht.h16[i] : 0u;
+                if (e256 && 256u + (e256 >> 24) <= left) {
+                    good += e256 & 0xFFFFFFu;
+                    b += 256u + (e256 >> 24);
+                } else if (e64 && 64u + (e64 >> 24) <= left) {
+                    good += e64 & 0xFFFFFFu;
+                    b += 64u + (e64 >> 24);
+                } else if (e16 && 16u + (e16 >> 13) <= left) {
+                    good += e16 & kHopBitsMask;
+                    b += 16u + (e16 >> 13);
+                } else {
+                    break;
+                }
+                hopped = true;
+                stale = true;
+                if (b >= c.rsi) {
+                    b = 0;
+                    r++;
+                    rsi_done = true;
+                    break;
+                }
+            }
+            if (rsi_done) continue;              // next RSI: back to the top (offset table, table hops)
+            if (carry && !last && good >= ht.hi) {   // the chunk ends inside this RSI: the next one goes on from here
+                if (lane == 0) {
+                    carry->good = good;
+                    carry->r = r;
+                    carry->active = 1;
+                    carry->n_hops = nh;
+                    carry->b = b;
+                    carry->cur_start = cur_start;
+                }
+                return;
+            }
         }
         // keep the whole next CDS (and the readers' look-ahead) inside the LDS window
         if ((good >> 5) + (coop ? 66u : maxw + 2u) > base + kIdxWindowWords) {
@@ -722,8 +875,10 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             refill(good >> 5);
             br.init(LdsWindowFetch{win, base}, end_bit, good);
             if (coop) load_regs(good >> 5);
-        } else if (hopped) {
+            stale = false;
+        } else if (hopped || stale) {
             br.init(LdsWindowFetch{win, base}, end_bit, good);
+            stale = false;
         }
         const uint32_t ref = (pp && b == 0) ? 1u : 0u;
         uint32_t nblk = 1;
@@ -1081,7 +1236,7 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
                            const_cast<uint4 *>(t.wide));
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
                            d_res, (const uint64_t *)nullptr, IdxTables{}, hops, hop_cap, carry, first ? 1u : 0u,
-                           last ? 1u : 0u, start_block, rsi_start, tail_slot, t, centry);
+                           last ? 1u : 0u, start_block, rsi_start, tail_slot, t, centry, HopTables{});
         hipLaunchKernelGGL(k_rewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, t, nwin, nchunks, end_bit, centry, rhops,
                            nhops);
         hipLaunchKernelGGL(k_expand2, dim3((hop_cap + 255) / 256), dim3(256), 0, st, t, carry, hops,
@@ -1093,6 +1248,104 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
 
 }  // namespace
 
+namespace {
+
+// ---- hop path: geometry and launches ------------------------------------------------------------------
+struct HopPlan {
+    bool ok;
+    uint32_t core, look;
+    size_t lds;
+    uint64_t chunk_bits;      // positions tabulated per launch (multiple of core)
+    size_t set_bytes;         // one table set: h16 + h64 + h256 for chunk_bits positions
+};
+
+constexpr uint32_t kHopWindowBits = 32768;
+constexpr uint64_t kHopChunkBits = 1ull << 25;       // 4 MiB of stream per table chunk (10 bytes per bit)
+
+// Used where neither the sparse nor the RSI tables apply: RSIs longer than any window (BASELINE config 3:
+// a megabit coded per RSI).  The look-ahead must hold 16 coded data sets.
+HopPlan hop_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint)
+{
+    HopPlan p{};
+    static const bool off = getenv("AEC_IDX_NO_HOPS") != nullptr;
+    if (off || (c.flags & F_PAD_RSI) || total_bits < 65536 || c.rsi < 64) return p;
+    // average coded data set from the hint, else half the uncompressed size
+    uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 2;
+    if (cds < 32) cds = 32;
+    uint64_t look = (16 * cds * 3 / 2 + 1023) & ~1023ull;
+    if (look < 4096) look = 4096;
+    if (look > kHopWindowBits - 8192) return p;
+    p.look = (uint32_t)look;
+    p.core = (uint32_t)((kHopWindowBits - look) & ~1023ull);
+    const uint32_t W = p.core + p.look, nw = W / 32;
+    p.lds = (size_t)(nw + 2) * 4 + (size_t)(nw + 2) * 2 * 2 + (size_t)W * 2 * 2;
+    if (p.lds > 156 * 1024) return p;
+    p.chunk_bits = (kHopChunkBits / p.core) * p.core;
+    p.set_bytes = (size_t)((p.chunk_bits * 10 + 255) & ~255ull);
+    p.ok = true;
+    return p;
+}
+
+void allow_big_lds_hops()
+{
+    static std::once_flag once[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    std::call_once(once[dev], [] {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_hops), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                156 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+    });
+}
+
+void launch_index_hops(const Cfg &c, const HopPlan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
+                       uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
+                       uint8_t *base, const IdxSide *side, uint32_t start_block, uint64_t rsi_start,
+                       uint32_t tail_slot)
+{
+    allow_big_lds_hops();
+    IdxCarry *carry = reinterpret_cast<IdxCarry *>(base);
+    const uint64_t lo0 = start_bit / p.core * p.core;
+    const bool multi = end_bit - lo0 > p.chunk_bits;
+    const bool piped = multi && side && side->stream;
+    hipStream_t wst = piped ? side->stream : st;
+    if (piped)
+        for (int b = 0; b < 2; b++) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
+    uint32_t i = 0;
+    for (uint64_t lo = lo0; lo < end_bit; lo += p.chunk_bits, i++) {
+        uint64_t bits = end_bit - lo;
+        if (bits > p.chunk_bits) bits = p.chunk_bits;
+        const uint32_t nwin = (uint32_t)((bits + p.core - 1) / p.core), b = i & 1u;
+        const uint64_t n = (uint64_t)nwin * p.core;
+        const bool first = lo == lo0, last = lo + p.chunk_bits >= end_bit;
+        uint8_t *set = base + 64 + (multi ? (size_t)b * p.set_bytes : 0);
+        uint16_t *h16 = reinterpret_cast<uint16_t *>(set);
+        uint32_t *h64 = reinterpret_cast<uint32_t *>(set + ((p.chunk_bits * 2 + 255) & ~255ull));
+        uint32_t *h256 = h64 + p.chunk_bits;
+        if (piped && i >= 2) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
+        hipLaunchKernelGGL(k_hops, dim3(nwin), dim3(1024), p.lds, st, c, words, nwords, end_bit, lo, p.core, p.look, h16);
+        hipLaunchKernelGGL((k_hop_compose<true>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
+                           (const void *)h16, h64, n);
+        hipLaunchKernelGGL((k_hop_compose<false>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
+                           (const void *)h64, h256, n);
+        if (piped) {
+            (void)hipEventRecord(side->spec_done[b], st);
+            (void)hipStreamWaitEvent(wst, side->spec_done[b], 0);
+        }
+        const HopTables ht{h16, h64, h256, lo, lo + n};
+        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, wst, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
+                           d_res, (const uint64_t *)nullptr, IdxTables{}, (IdxHop *)nullptr, 0u, carry,
+                           first ? 1u : 0u, last ? 1u : 0u, start_block, rsi_start, tail_slot, SparseTables{},
+                           (ChunkEntry *)nullptr, ht);
+        if (piped) (void)hipEventRecord(side->walk_done[b], wst);
+    }
+    if (piped)
+        for (int b = 0; b < 2; b++) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
+}
+
+}  // namespace
+
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
 {
     const uint64_t end_bit = (uint64_t)in_bytes * 8;
@@ -1100,7 +1353,11 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
     const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
     if (sp.ok) return sp.bytes;
     const SpecGeom g = spec_geom(c, end_bit - start_bit, rsi_bits_hint);
-    if (!g.ok) return 0;
+    if (!g.ok) {
+        const HopPlan hp = hop_plan(c, end_bit - start_bit, rsi_bits_hint);
+        if (!hp.ok) return 0;
+        return 64 + hp.set_bytes * (end_bit - start_bit / hp.core * hp.core > hp.chunk_bits ? 2 : 1);
+    }
     const uint64_t lo = start_bit / g.core * g.core;
     uint64_t span = end_bit - lo;
     const bool multi = span > g.chunk_bits;
@@ -1120,7 +1377,8 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
     if (!need || !d_ws || ws_bytes < need) {           // serial walk only
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off,
                            max_rsi, d_res, (const uint64_t *)nullptr, IdxTables{}, (IdxHop *)nullptr, 0u,
-                           (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start, tail_slot, SparseTables{}, (ChunkEntry *)nullptr);
+                           (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start, tail_slot, SparseTables{}, (ChunkEntry *)nullptr,
+                           HopTables{});
         return;
     }
     const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
@@ -1129,8 +1387,14 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
                             static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot);
         return;
     }
-    allow_big_lds();
     const SpecGeom g = spec_geom(c, end_bit - start_bit, rsi_bits_hint);
+    if (!g.ok) {
+        launch_index_hops(c, hop_plan(c, end_bit - start_bit, rsi_bits_hint), words, nwords, end_bit, start_bit,
+                          d_rsi_off, max_rsi, d_res, st, static_cast<uint8_t *>(d_ws), side, start_block, rsi_start,
+                          tail_slot);
+        return;
+    }
+    allow_big_lds();
     const uint64_t lo0 = start_bit / g.core * g.core;
     uint64_t span = end_bit - lo0;
     const bool multi = span > g.chunk_bits;
@@ -1165,7 +1429,7 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, wst, c, words, nwords, end_bit, start_bit, d_rsi_off,
                            max_rsi, d_res, (const uint64_t *)nullptr, tabs, t.hops, hop_cap, carry,
                            first ? 1u : 0u, last ? 1u : 0u, start_block, rsi_start, tail_slot, SparseTables{},
-                           (ChunkEntry *)nullptr);
+                           (ChunkEntry *)nullptr, HopTables{});
         hipLaunchKernelGGL(k_expand, dim3((hop_cap + 255) / 256), dim3(256), 0, wst, carry, t.hops, tabs,
                            (c.flags & F_PAD_RSI) ? 1u : 0u, d_rsi_off);
         if (piped) (void)hipEventRecord(side->walk_done[b], wst);
@@ -1183,7 +1447,7 @@ void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, cons
                        reinterpret_cast<const uint32_t *>(d_in), (uint64_t)((in_bytes + 3) / 4),
                        (uint64_t)in_bytes * 8, (uint64_t)0, d_rsi_off, rsi_per_chunk, d_res, d_chunk_off,
                        IdxTables{}, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, 0u, (uint64_t)0, 0u, SparseTables{},
-                       (ChunkEntry *)nullptr);
+                       (ChunkEntry *)nullptr, HopTables{});
 }
 
 }  // namespace aec

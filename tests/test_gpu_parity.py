@@ -313,6 +313,8 @@ def test_device_api_offsets_index_and_carry(gpu):
     (12, 32, 32, PP | MSB),       # bits not a multiple of 8, short RSIs
     (16, 8, 100, 0),              # no preprocessor (no reference sample), rsi not a multiple of 64
     (4, 16, 64, PP | AEC_RESTRICTED),
+    (32, 32, 4096, PP | MSB | SGN),   # BASELINE config 3 shape: RSIs of a megabit -- hop tables
+    (16, 64, 256, PP | MSB),          # the reference's own sample shape (src/benc.sh:7)
 ])
 def test_speculative_index_mixed_content(gpu, bps, bs, rsi, flags):
     """Index pass over bare streams whose RSIs are wildly different in size: smooth data (RSIs that
