@@ -91,10 +91,14 @@ __device__ __forceinline__ bool sparse_lookup(const SparseTables &t, uint64_t p,
 // sample and every rest-of-segment run on its own (hops never contain one), and takes the widest hop that
 // stays inside the RSI.  h16: bits [0,13) distance, [13,16) extra blocks; h64 / h256: [0,24) distance,
 // [24,32) extra blocks; 0 = no entry.
+// The base level is 16 coded data sets, or 4 where 16 of them do not fit the 13-bit distance of an h16 entry
+// (blocks of 64 16-bit samples: 700 bits per coded data set); n0 says which, the composed levels are 4 n0
+// and 16 n0.
 struct HopTables {
     const uint16_t *h16;
     const uint32_t *h64, *h256;
     uint64_t lo, hi;
+    uint32_t n0;
 };
 
 struct ChunkEntry {        // where the true chain enters a chunk the walker skipped over the wide table
@@ -258,7 +262,7 @@ k_spec(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_
 // LDS: win[nw + 2] u32 | rank[nw + 2] u16 | sel[nw + 2] u16 | nxt[W] u16 | hop4[W] u16
 __global__ void __launch_bounds__(1024)
 k_hops(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
-       uint32_t core, uint32_t look, uint16_t *__restrict__ h16)
+       uint32_t core, uint32_t look, uint16_t *__restrict__ h16, uint32_t n0)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
     const uint32_t W = core + look, nw = W / 32u;
@@ -303,7 +307,7 @@ k_hops(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_
     __syncthreads();
     for (uint32_t q = tid; q < W; q += nt) hop4[q] = spec_hop4(nxt, c, s.limit, q);
     __syncthreads();
-    for (uint32_t q = tid; q < core; q += nt) h16[rel0 + q] = spec_hop16(hop4, s.limit, q);
+    for (uint32_t q = tid; q < core; q += nt) h16[rel0 + q] = n0 == 16u ? spec_hop16(hop4, s.limit, q) : hop4[q];
 }
 
 // four hops of `src` in a row: dst[p] = where they lead (SRC16: src holds h16 entries, else h64 entries)
@@ -832,18 +836,19 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             while (good >= ht.lo && good < ht.hi && good < end_bit) {
                 const uint64_t i = good - ht.lo;
                 const uint32_t left = c.rsi - b;
-                const uint32_t e256 = (ht.h256 && left >= 256u) ? ht.h256[i] : 0u;
-                const uint32_t e64 = left >= 64u ? ht.h64[i] : 0u;
-                const uint32_t e16 = left >= 16u ? ht.h16[i] : 0u;
-                if (e256 && 256u + (e256 >> 24) <= left) {
+                const uint32_t n0 = ht.n0;
+                const uint32_t e256 = (ht.h256 && left >= 16u * n0) ? ht.h256[i] : 0u;
+                const uint32_t e64 = left >= 4u * n0 ? ht.h64[i] : 0u;
+                const uint32_t e16 = left >= n0 ? ht.h16[i] : 0u;
+                if (e256 && 16u * n0 + (e256 >> 24) <= left) {
                     good += e256 & 0xFFFFFFu;
-                    b += 256u + (e256 >> 24);
-                } else if (e64 && 64u + (e64 >> 24) <= left) {
+                    b += 16u * n0 + (e256 >> 24);
+                } else if (e64 && 4u * n0 + (e64 >> 24) <= left) {
                     good += e64 & 0xFFFFFFu;
-                    b += 64u + (e64 >> 24);
-                } else if (e16 && 16u + (e16 >> 13) <= left) {
+                    b += 4u * n0 + (e64 >> 24);
+                } else if (e16 && n0 + (e16 >> 13) <= left) {
                     good += e16 & kHopBitsMask;
-                    b += 16u + (e16 >> 13);
+                    b += n0 + (e16 >> 13);
                 } else {
                     break;
                 }
@@ -1253,7 +1258,7 @@ namespace {
 // ---- hop path: geometry and launches ------------------------------------------------------------------
 struct HopPlan {
     bool ok;
-    uint32_t core, look;
+    uint32_t core, look, n0;
     size_t lds;
     uint64_t chunk_bits;      // positions tabulated per launch (multiple of core)
     size_t set_bytes;         // one table set: h16 + h64 + h256 for chunk_bits positions
@@ -1263,7 +1268,7 @@ constexpr uint32_t kHopWindowBits = 32768;
 constexpr uint64_t kHopChunkBits = 1ull << 25;       // 4 MiB of stream per table chunk (10 bytes per bit)
 
 // Used where neither the sparse nor the RSI tables apply: RSIs longer than any window (BASELINE config 3:
-// a megabit coded per RSI).  The look-ahead must hold 16 coded data sets.
+// a megabit coded per RSI).  The look-ahead must hold the coded data sets of a base entry (16, or 4).
 HopPlan hop_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint)
 {
     HopPlan p{};
@@ -1272,7 +1277,8 @@ HopPlan hop_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint)
     // average coded data set from the hint, else half the uncompressed size
     uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 2;
     if (cds < 32) cds = 32;
-    uint64_t look = (16 * cds * 3 / 2 + 1023) & ~1023ull;
+    p.n0 = cds * 16 * 3 / 2 < kHopBitsMask ? 16u : 4u;         // (distance of a base entry: 13 bits)
+    uint64_t look = (p.n0 * cds * 3 / 2 + 1023) & ~1023ull;
     if (look < 4096) look = 4096;
     if (look > kHopWindowBits - 8192) return p;
     p.look = (uint32_t)look;
@@ -1324,7 +1330,8 @@ void launch_index_hops(const Cfg &c, const HopPlan &p, const uint32_t *words, ui
         uint32_t *h64 = reinterpret_cast<uint32_t *>(set + ((p.chunk_bits * 2 + 255) & ~255ull));
         uint32_t *h256 = h64 + p.chunk_bits;
         if (piped && i >= 2) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
-        hipLaunchKernelGGL(k_hops, dim3(nwin), dim3(1024), p.lds, st, c, words, nwords, end_bit, lo, p.core, p.look, h16);
+        hipLaunchKernelGGL(k_hops, dim3(nwin), dim3(1024), p.lds, st, c, words, nwords, end_bit, lo, p.core, p.look, h16,
+                           p.n0);
         hipLaunchKernelGGL((k_hop_compose<true>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
                            (const void *)h16, h64, n);
         hipLaunchKernelGGL((k_hop_compose<false>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
@@ -1333,7 +1340,7 @@ void launch_index_hops(const Cfg &c, const HopPlan &p, const uint32_t *words, ui
             (void)hipEventRecord(side->spec_done[b], st);
             (void)hipStreamWaitEvent(wst, side->spec_done[b], 0);
         }
-        const HopTables ht{h16, h64, h256, lo, lo + n};
+        const HopTables ht{h16, h64, h256, lo, lo + n, p.n0};
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, wst, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
                            d_res, (const uint64_t *)nullptr, IdxTables{}, (IdxHop *)nullptr, 0u, carry,
                            first ? 1u : 0u, last ? 1u : 0u, start_block, rsi_start, tail_slot, SparseTables{},
