@@ -174,7 +174,7 @@ def abi_end_to_end(host_sample):
     n = host_sample.size
     t_host = torch.from_numpy(host_sample).pin_memory()
     host = t_host.numpy()
-    t_enc = torch.zeros(n // 2 + (1 << 20), dtype=torch.uint8).pin_memory()
+    t_enc = torch.zeros(n + n // 8 + (1 << 20), dtype=torch.uint8).pin_memory()      # (room for incompressible data)
     t_dec = torch.zeros(n, dtype=torch.uint8).pin_memory()
     enc, dec = t_enc.numpy(), t_dec.numpy()
 
