@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collects what profiles/<round>/ holds (run on the GPU box from the repo root):
+#   tests/collect_profiles.sh <outdir-under-gpurun_out>
+# bench lines of every configuration, rocprofv3 kernel statistics of the same command, HBM traffic (PMC,
+# separate passes) per configuration, index / small-call / chunked-SZIP benches, the sharded path on one GPU.
+OUT=$PWD/gpurun_out/$1; R=$PWD
+mkdir -p $OUT
+for c in c2 c3 c5 typical; do
+  python3 bench.py --config $c > $OUT/bench_${c}_4GiB.json 2> $OUT/bench_${c}.err
+done
+python3 bench.py --shard-path --no-extras > $OUT/bench_c2_4GiB_shard_path.json 2>> $OUT/bench_c2.err
+python3 bench.py --overlap --no-extras --no-cpu-baseline > $OUT/bench_c2_4GiB_overlap.json 2>> $OUT/bench_c2.err
+( cd /tmp && export TMPDIR=/tmp
+  for c in c2 c3 c5 typical; do
+    timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$c -- python3 $R/bench.py --config $c --no-cpu-baseline --no-extras > $OUT/bench_${c}_4GiB_under_rocprofv3.json 2> /dev/null
+    f=$(find $OUT/stats_$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats_${c}_4GiB.csv
+  done )
+for c in c2 c3 c5 typical; do
+  bash tests/prof_traffic.sh $1/traffic_$c 4096 $c > /dev/null 2>&1
+  cp $OUT/traffic_$c/traffic.json $OUT/traffic_${c}_4GiB.json 2>/dev/null
+done
+python3 tests/bench_index.py --config c2 --size-mib 1 64 1024 > $OUT/bench_index.txt 2>&1
+python3 tests/bench_index.py --config c5 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
+python3 tests/bench_index.py --config c3 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
+python3 tests/bench_index.py --config typical --size-mib 64 >> $OUT/bench_index.txt 2>&1
+python3 tests/bench_abi_small.py > $OUT/bench_abi_small.txt 2>&1
+python3 tests/bench_sz_chunks.py > $OUT/bench_sz_chunks.txt 2>&1
+python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
+rm -rf $OUT/stats_* $OUT/traffic_c2 $OUT/traffic_c3 $OUT/traffic_c5 $OUT/traffic_typical
