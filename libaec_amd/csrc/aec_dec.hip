@@ -154,22 +154,6 @@ struct RingSrc {
         w1 = q[64];
         w2 = q[128];
     }
-    // the same without bookkeeping (aec_lane.h peek32q / peek64q) ...
-    __device__ __forceinline__ void word2q(uint32_t i, uint32_t &w0, uint32_t &w1)
-    {
-        const uint32_t *q = col + ((slot0 + i) & mask) * 64u;
-        w0 = q[0];
-        w1 = q[64];
-    }
-    __device__ __forceinline__ void word3q(uint32_t i, uint32_t &w0, uint32_t &w1, uint32_t &w2)
-    {
-        const uint32_t *q = col + ((slot0 + i) & mask) * 64u;
-        w0 = q[0];
-        w1 = q[64];
-        w2 = q[128];
-    }
-    // ... and the one check that covers them: reads reached word (p_end >> 5) + 2 at most
-    __device__ __forceinline__ void note_end(uint32_t p_end) { starve |= ((p_end >> 5) + 2u >= limit) ? 1u : 0u; }
     __device__ __forceinline__ bool starved() const { return starve != 0; }
 };
 

@@ -847,35 +847,7 @@ AEC_HD uint64_t peek64(Src &src, uint32_t p)
     return (((uint64_t)hi) << 32) | lo;
 }
 
-// The same peeks without the per-access starvation bookkeeping of the word source: decode_block_noref
-// reads at ascending positions, so ONE check against the position behind the block covers all of them
-// (Src::note_end).
-template <class Src>
-AEC_HD uint32_t peek32q(Src &src, uint32_t p)
-{
-    uint32_t w0, w1;
-    src.word2q(p >> 5, w0, w1);
-    return (uint32_t)((((((uint64_t)w0) << 32) | w1) << (p & 31u)) >> 32);
-}
-template <class Src>
-AEC_HD uint64_t peek64q(Src &src, uint32_t p)
-{
-    uint32_t w0, w1, w2;
-    src.word3q(p >> 5, w0, w1, w2);
-    const uint32_t sh = p & 31u;
-    const uint32_t hi = (uint32_t)((((((uint64_t)w0) << 32) | w1) << sh) >> 32);
-    const uint32_t lo = (uint32_t)((((((uint64_t)w1) << 32) | w2) << sh) >> 32);
-    return (((uint64_t)hi) << 32) | lo;
-}
-
-AEC_HD uint32_t clz32_or32(uint32_t v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__clz((int)v);          // v_ffbh_u32 + v_min_u32: 32 for v == 0, no compare / select
-#else
-    return v ? (uint32_t)__builtin_clz(v) : 32u;
-#endif
-}
+AEC_HD uint32_t clz32_or32(uint32_t v) { return v ? (uint32_t)__builtin_clz(v) : 32u; }
 
 // general unary read at p for codes of any length; stops at end_p (stream end)
 template <class Src>
@@ -1051,7 +1023,7 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
     nzero_blocks = 0;
 
     // ---- 1. header --------------------------------------------------------------------------
-    const uint32_t h = peek32q(src, p);
+    const uint32_t h = peek32(src, p);
     const uint32_t id = h >> (32 - c.id_len);
     const bool lowent = live && id == 0;
     const bool unc = live && id == idmax;
@@ -1069,7 +1041,7 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
     for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += GRP) {
         // (second extension with blocks of 8: its 4 codes are half a group, read in the SE branch)
         const bool gact = split || (se && BS >= 16 && g0 < (uint32_t)BS / 2);
-        uint64_t U = peek64q(src, p);
+        uint64_t U = peek64(src, p);
         if (!gact) U = ~0ull;
         uint32_t used = 0, zmax = 0;
 #pragma unroll
@@ -1104,18 +1076,14 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
             d[i] = (u[i] << k) + f;                      // k == 0 (and u == 0) for uncompressed lanes
         }
     } else {
-        // narrow fields: eight of them per 64-bit peek, taken from the top of the register one after the
-        // other (a 32-bit shift for the field, a 64-bit shift to move on: no per-sample shift amount, no
-        // mask; kk == 0 clears the register so that every field reads 0)
-        const uint32_t rsh = (32u - kk) & 31u;
+        // narrow fields: eight of them per 64-bit peek
+        const uint32_t km = low_mask32(kk);
 #pragma unroll
         for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += GRP) {
-            uint64_t F = peek64q(src, p + g0 * kk);
-            F = kk ? F : 0ull;
+            const uint64_t F = peek64(src, p + g0 * kk);
 #pragma unroll
             for (uint32_t j = 0; j < GRP; j++) {
-                const uint32_t f = (uint32_t)(F >> 32) >> rsh;
-                F <<= kk;
+                const uint32_t f = (uint32_t)(F >> ((64u - (j + 1u) * kk) & 63u)) & km;
                 d[g0 + j] = (u[g0 + j] << k) + f;
             }
         }
@@ -1154,7 +1122,6 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
             for (uint32_t i = 0; i < (uint32_t)BS; i++) d[i] = 0;
         }
     }
-    src.note_end(p);                                     // the quiet peeks above reached at most 2 words beyond p
     if (!live) return DEC_OK;
     if (short_input || p > end_p || src.starved()) return DEC_NEED_INPUT;
     return corrupt ? DEC_DATA_ERROR : DEC_OK;

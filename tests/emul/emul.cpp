@@ -19,9 +19,6 @@ struct MemSrc {
     uint32_t word(uint32_t i) const { const uint64_t idx = base + i; return idx < n ? bswap32(w[idx]) : 0u; }
     void word2(uint32_t i, uint32_t &w0, uint32_t &w1) const { w0 = word(i); w1 = word(i + 1); }
     void word3(uint32_t i, uint32_t &w0, uint32_t &w1, uint32_t &w2) const { w0 = word(i); w1 = word(i + 1); w2 = word(i + 2); }
-    void word2q(uint32_t i, uint32_t &w0, uint32_t &w1) const { word2(i, w0, w1); }
-    void word3q(uint32_t i, uint32_t &w0, uint32_t &w1, uint32_t &w2) const { word3(i, w0, w1, w2); }
-    void note_end(uint32_t) const {}
     bool starved() const { return false; }
 };
 
