@@ -12,14 +12,17 @@ GPU, block 16, rsi 128, AEC_DATA_PREPROCESS (generator: libaec_amd/csrc/datagen.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 With N > 1 the ranks code ONE stream (weak scaling: 4 GiB per rank): every rank plans its shard,
-the ranks exchange three numbers (bits, k clamp), each emits its shard at the global bit offset,
-and ONE RCCL all-gather per step plus a local stitch reassemble the byte-exact stream on every
-rank, on a side stream that overlaps the decode of the local shard (libaec_amd/shard.py).
+the 24-byte plan records are all-gathered as they lie in HBM, each rank derives its start bit and
+carried k on the device and emits its shard at the global bit offset, and ONE RCCL all-gather per step
+plus a stitch kernel reassemble the byte-exact stream on every rank, on a side stream that overlaps
+the decode of the local shard (libaec_amd/shard.py: DeviceShard).  No host round trip inside a step.
 
 Rank 0 prints one JSON line: metric/value (whole-job GB/s of input bytes through encode+decode),
-`roofline` for the dominant kernel (HIP-event time measured in this run) and `cpu_baseline`
-(the reference libaec -- or the oracle port if oracle/_ref is absent -- timed on one host core on
-a bounded prefix of the same input).
+`roofline` for the dominant kernel (HIP-event time measured in this run; traffic from the committed
+PMC summary of exactly this configuration, else null), `cpu_baseline` (the reference libaec -- or
+the oracle port if oracle/_ref is absent -- on one host core over the WHOLE input, whose stream the
+GPU's is compared with byte for byte) and, unless --no-extras: `cpu_baseline_all_cores`, `decode_bare`
+(index pass + decode of the stream alone, no encoder side information), `abi_end_to_end` (pinned).
 """
 import argparse
 import ctypes as C

@@ -29,7 +29,10 @@ struct aec_stream {
     size_t total_out;               /* bytes produced so far */
     unsigned int bits_per_sample;   /* 1..32 */
     unsigned int block_size;        /* samples per block: 8, 16, 32, 64 (any even value <= 64
-                                       with AEC_NOT_ENFORCE) */
+                                       with AEC_NOT_ENFORCE).  LIMIT of this library: the reference accepts
+                                       any even size with AEC_NOT_ENFORCE (src/encode.c:780-783) although
+                                       sizes above 64 overrun its own coded-data-set buffer (encode.h:64-66);
+                                       here they are AEC_CONF_ERROR -- one lane owns one block */
     unsigned int rsi;               /* blocks per reference sample interval, 1..4096 */
     unsigned int flags;             /* AEC_DATA_* | AEC_RESTRICTED | AEC_PAD_RSI | AEC_NOT_ENFORCE */
     struct internal_state *state;   /* owned by the library between *_init and *_end */

@@ -1124,7 +1124,9 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     static const char *e_budget = getenv("AEC_S2_BUDGET");
     p.g.budget = e_budget ? (uint32_t)atoi(e_budget) : 0xFFFFFFFFu;
     const uint32_t W = p.g.lead + p.g.core + p.g.look, nw = W / 32;
-    p.g.cap_lds = (W / 8 + 63) & ~63u;
+    static const char *e_capdiv = getenv("AEC_S2_CAPDIV");
+    const uint32_t capdiv = e_capdiv ? (uint32_t)atoi(e_capdiv) : 8u;
+    p.g.cap_lds = (W / (capdiv ? capdiv : 8u) + 63) & ~63u;
     p.g.cap_core = (p.g.core / 8 + 63) & ~63u;
     p.lds = (size_t)(nw + 2) * 4 + (size_t)nw * 4 + (size_t)(nw + 2) * 2 * 3 + (size_t)p.g.cap_lds * 2 * 5 + 64;
     if (p.lds > 156 * 1024) return p;
