@@ -14,6 +14,7 @@
 //   (the index pass for streams that arrive without an offset table lives in aec_idx.hip)
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "aec_kernels.h"
@@ -587,7 +588,11 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, bool stage
     }
     g.ring_words = rw;
     // (+ the output staging rows of k_decode for small blocks: 64 x 80 bytes, 64 pointers, 64 counts)
-    const size_t per_wave = (size_t)(rw + 2) * 64 * 4 + (staged ? 64 * 80 + 64 * 12 : 0);
+    // (AEC_DEC_LDS_PAD: extra LDS bytes per wave, a diagnostic knob for occupancy experiments; the kernel
+    // never touches them)
+    static const char *e_pad = getenv("AEC_DEC_LDS_PAD");
+    const size_t pad = e_pad ? (size_t)atoi(e_pad) : 0;
+    const size_t per_wave = (size_t)(rw + 2) * 64 * 4 + (staged ? 64 * 80 + 64 * 12 : 0) + pad;
     // waves per workgroup: whatever packs most waves into the 160 KiB of a CU
     uint32_t waves = 1, best = 0;
     for (uint32_t w = 1; w <= 4; w *= 2) {
