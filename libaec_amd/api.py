@@ -32,7 +32,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libaec.so.0")
+    # AEC_AMD_LIB: another build of the same library (A/B runs of kernel variants, tests/ab_build.sh)
+    return os.environ.get("AEC_AMD_LIB") or os.path.join(_HERE, "lib", "libaec.so.0")
 
 
 class AecStream(C.Structure):

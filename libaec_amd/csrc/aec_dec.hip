@@ -201,10 +201,23 @@ __device__ __forceinline__ void ring_put4(uint32_t *col, uint32_t slot0, uint32_
 
 constexpr int kPend = 2;   // 16-byte loads kept in flight per lane across one block iteration
 
+// output staging rows (see k_decode): which block sizes in bytes are staged, and the row length
+#ifndef AEC_STG_ROW
+#define AEC_STG_ROW 64
+#endif
+#ifndef AEC_STG_ROW8
+#define AEC_STG_ROW8 0
+#endif
+#ifndef AEC_DEC_MINW
+#define AEC_DEC_MINW 1
+#endif
+__host__ __device__ constexpr bool stg_on(int blk) { return blk == 16 || blk == 32 || (blk == 8 && AEC_STG_ROW8 != 0); }
+__host__ __device__ constexpr uint32_t stg_row(int blk) { return blk == 8 ? (AEC_STG_ROW8 ? AEC_STG_ROW8 : 64) : AEC_STG_ROW; }
+
 // SEG = false: work item = RSI, start bits from rsi_off.  SEG = true: work item = segment (64
 // blocks), start bit and preceding sample from the encoder's segment table.
 template <int BS, int BYTES, bool SEG>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, AEC_DEC_MINW)
 k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
          const uint64_t *__restrict__ rsi_off, const SegEntry *__restrict__ seg_table, uint64_t n_rsi,
          uint64_t total_blocks, uint8_t *__restrict__ out, DecResult *res, uint32_t ring_words, uint32_t maxw,
@@ -229,8 +242,8 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     // out transposed: 4 lanes per row, whole 64-byte sectors per store instruction.  (Rows of 128
     // bytes -- whole lines -- were slower: 3.26 ms against 2.75 ms at C2, the LDS costs waves.)
     constexpr int BLK = BS * BYTES;
-    constexpr bool STG = BS != 0 && (BLK == 16 || BLK == 32);   // (8-byte blocks: measured slower, LDS cost)
-    constexpr uint32_t kStgRow = 64, kStgStride = 80;            // 16 bytes of padding: conflict-free rows
+    constexpr bool STG = stg_on(BLK);
+    constexpr uint32_t kStgRow = stg_row(BLK), kStgStride = kStgRow + 16u;   // 16 bytes of padding: conflict-free rows
     constexpr uint32_t G = STG ? kStgRow / (uint32_t)(BLK ? BLK : 1) : 1u;
     const uint32_t wave_words = (ring_words + 2u) * 64u + (STG ? (64u * kStgStride + 64u * 12u) / 4u : 0u);
     uint32_t *wbase = smem + (size_t)wave * wave_words;
@@ -282,9 +295,10 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     auto flush = [&](uint32_t group) {
         stg_cnt[lane] = produced * (uint32_t)BLK;
         produced = 0;
+        constexpr uint32_t LPR = kStgRow / 16u, RPI = 64u / LPR;   // lanes per row, rows per store instruction
 #pragma unroll
-        for (uint32_t k = 0; k < kStgRow / 16u; k++) {
-            const uint32_t row = k * 16u + (lane >> 2), chunk = (lane & 3u) * 16u;
+        for (uint32_t k = 0; k < LPR; k++) {
+            const uint32_t row = k * RPI + lane / LPR, chunk = (lane % LPR) * 16u;
             const uint4 v = *reinterpret_cast<const uint4 *>(stage + row * kStgStride + chunk);
             const uint32_t have = stg_cnt[row];
             uint8_t *at = stg_base[row] + (size_t)group * kStgRow + chunk;
@@ -573,7 +587,7 @@ struct DecGeom {
 // stream averages short coded data sets (avg_cds_bits, from the caller's byte and block counts) and
 // one maximal CDS still fits, the ring is HALF that: steady state keeps needw words ahead, a longer
 // CDS is decoded again after a full refill (k_decode).  Incompressible input keeps the full ring.
-DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, bool staged)
+DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, uint32_t stg_row_bytes)
 {
     DecGeom g;
     const uint32_t maxbits = c.id_len + 1 + c.bps + c.bs * c.bps;
@@ -592,7 +606,7 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, bool stage
     // never touches them)
     static const char *e_pad = getenv("AEC_DEC_LDS_PAD");
     const size_t pad = e_pad ? (size_t)atoi(e_pad) : 0;
-    const size_t per_wave = (size_t)(rw + 2) * 64 * 4 + (staged ? 64 * 80 + 64 * 12 : 0) + pad;
+    const size_t per_wave = (size_t)(rw + 2) * 64 * 4 + (stg_row_bytes ? 64 * (stg_row_bytes + 16) + 64 * 12 : 0) + pad;
     // waves per workgroup: whatever packs most waves into the 160 KiB of a CU
     uint32_t waves = 1, best = 0;
     for (uint32_t w = 1; w <= 4; w *= 2) {
@@ -619,7 +633,7 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
 {
     const uint32_t blk = (uint32_t)BS * c.bytes;
     // (counts taken from the index record: the average coded data set is not known here -- full ring)
-    const DecGeom g = dec_geom(c, n_rsi, (total_blocks && !idx && !batch) ? end_bit / total_blocks : 0, blk == 16 || blk == 32);
+    const DecGeom g = dec_geom(c, n_rsi, (total_blocks && !idx && !batch) ? end_bit / total_blocks : 0, stg_on((int)blk) ? stg_row((int)blk) : 0u);
     const dim3 block(64 * g.waves), grid(g.grid);
 #define AEC_GO(B)                                                                                   \
     hipLaunchKernelGGL((k_decode<BS, B, SEG>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
@@ -659,7 +673,7 @@ static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
     case 64: launch_decode_bytes<64, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc); break;
     default:
     {
-        const DecGeom g = dec_geom(c, n_items, 0, false);   // the sample-by-sample reader has no second attempt: full ring
+        const DecGeom g = dec_geom(c, n_items, 0, 0u);   // the sample-by-sample reader has no second attempt: full ring
         hipLaunchKernelGGL((k_decode<0, 0, SEG>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
                            end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, g.needw, dump, d_idx, d_batch, rpc);
         break;

@@ -12,6 +12,7 @@
 // minimal length.  A block is therefore summarised by (len_min, klo, khi); the carried k is
 // a composition of clamps, which is associative and is resolved by a scan (aec_enc.hip).
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -737,12 +738,20 @@ AEC_HD uint32_t unpp_signed(uint32_t xu, uint32_t d, uint32_t xmax)
 // the same mapping as a 91-entry table.  false for m > 90 (outside the table).
 AEC_HD bool se_lookup(uint32_t m, uint32_t &sum, uint32_t &second)
 {
-    if (m > 90) return false;
-    uint32_t s = 0, tri = 0;
-    while (tri + s + 1 <= m) { tri += s + 1; s++; }
+    // s = the largest s with s(s+1)/2 <= m, i.e. floor((sqrt(8m + 1) - 1) / 2).  8m + 1 <= 721 is exact in
+    // float; at a triangular m the root is the integer 2s + 1 exactly, everywhere else it stays at least
+    // 4 / 27 below the next odd integer, so a root good to a few ulp gives the exact floor (checked for
+    // all 91 codes in tests/test_lane_emul.py) -- no loop, no table.
+    const uint32_t mm = m > 90 ? 90u : m;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float root = __builtin_amdgcn_sqrtf((float)(8u * mm + 1u));
+#else
+    const float root = sqrtf((float)(8u * mm + 1u));
+#endif
+    const uint32_t s = (uint32_t)((root - 1.0f) * 0.5f);
     sum = s;
-    second = m - tri;
-    return true;
+    second = mm - ((s * (s + 1u)) >> 1);
+    return m <= 90;
 }
 
 // Decode status codes shared by the kernels and the host
@@ -938,7 +947,7 @@ AEC_HD uint32_t decode_block_any(Src &src, uint32_t &p, uint32_t end_p, uint32_t
     const uint32_t kk = split ? k : (unc ? c.bps : 0u);
     const uint32_t nf = split ? (uint32_t)BS - ref : (unc ? (uint32_t)BS : 0u);
     const uint32_t off = split ? ref : 0u;
-    if (AEC_ANY(kk > 8)) {
+    if (AEC_ANY(kk > 16)) {
         // wide fields (uncompressed blocks, large k): one 32-bit peek per sample
         const uint32_t fsh = (32u - kk) & 31u;
 #pragma unroll
@@ -947,6 +956,23 @@ AEC_HD uint32_t decode_block_any(Src &src, uint32_t &p, uint32_t end_p, uint32_t
             const uint32_t v = peek32(src, act ? p + (i - off) * kk : p);
             const uint32_t f = act ? v >> fsh : 0u;
             d[i] = (u[i] << k) + f;                      // k == 0 for uncompressed lanes
+        }
+    } else if (AEC_ANY(kk > 8)) {
+        // medium fields (16-bit uncompressed blocks among short codes): four of them per 64-bit peek
+        constexpr uint32_t G4 = BS < 4 ? (uint32_t)BS : 4u;
+        const uint32_t km = low_mask32(kk);
+#pragma unroll
+        for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += G4) {
+            const bool gact = kk != 0 && g0 + G4 > off && g0 < nf + off;
+            const uint32_t base = gact ? p + g0 * kk - off * kk : p;
+            const uint64_t F = peek64(src, base);
+#pragma unroll
+            for (uint32_t j = 0; j < G4; j++) {
+                const uint32_t i = g0 + j;
+                const bool act = kk != 0 && i >= off && i - off < nf;
+                const uint32_t f = (uint32_t)(F >> ((64u - (j + 1u) * kk) & 63u)) & km;
+                d[i] = (u[i] << k) + (act ? f : 0u);
+            }
         }
     } else {
         // narrow fields: eight of them per 64-bit peek
@@ -1039,11 +1065,13 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
     constexpr uint32_t GRP = BS < 8 ? (uint32_t)BS : 8u;
 #pragma unroll
     for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += GRP) {
-        // (second extension with blocks of 8: its 4 codes are half a group, read in the SE branch)
-        const bool gact = split || (se && BS >= 16 && g0 < (uint32_t)BS / 2);
+        // (second extension with blocks of 8: its 4 codes are the first half of the one group -- what the
+        // other four slots pick up belongs to the next coded data set and is neither counted nor checked)
+        constexpr bool HALF = BS < 16;
+        const bool gact = split || (se && (HALF || g0 < (uint32_t)BS / 2));
         uint64_t U = peek64(src, p);
         if (!gact) U = ~0ull;
-        uint32_t used = 0, zmax = 0;
+        uint32_t used = 0, zmax = 0, used_h = 0, zmax_h = 0;
 #pragma unroll
         for (uint32_t j = 0; j < GRP; j++) {
             const uint32_t z = clz32_or32((uint32_t)(U >> 32));
@@ -1051,13 +1079,16 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
             U <<= ((z + 1u) & 63u);
             used += z + 1u;
             u[g0 + j] = z;
+            if (HALF && j == GRP / 2 - 1) { used_h = used; zmax_h = zmax; }
         }
+        if (HALF && se) { used = used_h; zmax = zmax_h; }
         const bool bad = zmax >= 32u;                    // a code of 32+ zeros: redo code by code
         if (AEC_ANY(bad)) {
             if (bad) {
                 uint32_t q = p;
 #pragma unroll
-                for (uint32_t j = 0; j < GRP; j++) u[g0 + j] = unary_slow(src, q, end_p, short_input);
+                for (uint32_t j = 0; j < GRP; j++)
+                    if (!(HALF && se) || j < GRP / 2) u[g0 + j] = unary_slow(src, q, end_p, short_input);
                 used = q - p;
             }
         }
@@ -1066,7 +1097,7 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
 
     // ---- 3. field phase ---------------------------------------------------------------------
     const uint32_t kk = split ? k : (unc ? c.bps : 0u);
-    if (AEC_ANY(kk > 8)) {
+    if (AEC_ANY(kk > 16)) {
         // wide fields (uncompressed blocks, large k): one 32-bit peek per sample
         const uint32_t fsh = (32u - kk) & 31u;
 #pragma unroll
@@ -1074,6 +1105,19 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
             const uint32_t v = peek32(src, p + i * kk);
             const uint32_t f = kk != 0 ? v >> fsh : 0u;
             d[i] = (u[i] << k) + f;                      // k == 0 (and u == 0) for uncompressed lanes
+        }
+    } else if (AEC_ANY(kk > 8)) {
+        // medium fields (16-bit uncompressed blocks among short codes): four of them per 64-bit peek
+        constexpr uint32_t G4 = BS < 4 ? (uint32_t)BS : 4u;
+        const uint32_t km = low_mask32(kk);
+#pragma unroll
+        for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += G4) {
+            const uint64_t F = peek64(src, p + g0 * kk);
+#pragma unroll
+            for (uint32_t j = 0; j < G4; j++) {
+                const uint32_t f = (uint32_t)(F >> ((64u - (j + 1u) * kk) & 63u)) & km;
+                d[g0 + j] = (u[g0 + j] << k) + f;
+            }
         }
     } else {
         // narrow fields: eight of them per 64-bit peek
@@ -1093,10 +1137,6 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
     // ---- 4. second extension / zero run (rare, divergent) ------------------------------------
     if (AEC_ANY(se)) {
         if (se) {
-            if (BS < 16) {
-#pragma unroll
-                for (uint32_t j = 0; j < (uint32_t)BS / 2; j++) u[j] = unary_slow(src, p, end_p, short_input);
-            }
 #pragma unroll
             for (uint32_t j = 0; j < (uint32_t)BS / 2; j++) {
                 uint32_t s = 0, second = 0;

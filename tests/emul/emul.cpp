@@ -470,3 +470,9 @@ extern "C" int emul_sync_steps(const uint32_t *p, const uint8_t *in, size_t in_l
     }
     return 0;
 }
+
+// second-extension code -> (sum, second) for every code value (tests the closed form in aec_lane.h)
+extern "C" int emul_se_lookup(uint32_t m, uint32_t *sum, uint32_t *second)
+{
+    return aec::se_lookup(m, *sum, *second) ? 1 : 0;
+}

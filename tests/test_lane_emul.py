@@ -176,6 +176,23 @@ def test_random_sweep_vs_oracle(emul):
         check_case(emul, f"it{it}-n{bps}-j{bs}-r{rsi}-f{flags}-len{n}", bps, bs, rsi, flags, data, expect)
 
 
+def test_second_extension_table(emul):
+    """se_lookup is a closed form; the reference builds the same mapping as a table
+    (reference src/decode.c:679-692: for i in 0..12, for k in 0..i: table[ms] = (i, k))."""
+    emul.emul_se_lookup.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    ms = 0
+    for i in range(13):
+        for k in range(i + 1):
+            s, t = C.c_uint32(0), C.c_uint32(0)
+            assert emul.emul_se_lookup(ms, C.byref(s), C.byref(t)) == 1
+            assert (s.value, t.value) == (i, k), ms
+            ms += 1
+    assert ms == 91
+    for m in (91, 92, 1000, 0xFFFFFFFF):
+        s, t = C.c_uint32(0), C.c_uint32(0)
+        assert emul.emul_se_lookup(m, C.byref(s), C.byref(t)) == 0
+
+
 def test_carry_in_matches_split_stream(emul):
     """Encoding a stream in two batches with (bit offset, k) carried over must give the bytes
     of the one-shot encode -- what the streaming front-end and the multi-GPU split rely on."""
