@@ -206,10 +206,13 @@ constexpr int kPend = 2;   // 16-byte loads kept in flight per lane across one b
 #define AEC_STG_ROW 64
 #endif
 #ifndef AEC_STG_ROW8
-#define AEC_STG_ROW8 0
+#define AEC_STG_ROW8 32
 #endif
 #ifndef AEC_DEC_MINW
 #define AEC_DEC_MINW 1
+#endif
+#ifndef AEC_DEC_UNR8
+#define AEC_DEC_UNR8 2
 #endif
 __host__ __device__ constexpr bool stg_on(int blk) { return blk == 16 || blk == 32 || (blk == 8 && AEC_STG_ROW8 != 0); }
 __host__ __device__ constexpr uint32_t stg_row(int blk) { return blk == 8 ? (AEC_STG_ROW8 ? AEC_STG_ROW8 : 64) : AEC_STG_ROW; }
@@ -309,6 +312,15 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             typedef __attribute__((address_space(1))) u32x4 global_u32x4;
             const u32x4 vv = {v.x, v.y, v.z, v.w};
             *reinterpret_cast<global_u32x4 *>(reinterpret_cast<uintptr_t>(q)) = vv;
+            if (BLK == 8) {                          // an odd number of 8-byte blocks ends in half a chunk
+                const bool half = have == chunk + 8u;
+                if (__any(half)) {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    typedef __attribute__((address_space(1))) u32x2 global_u32x2;
+                    const u32x2 hv = {v.x, v.y};
+                    if (half) *reinterpret_cast<global_u32x2 *>(reinterpret_cast<uintptr_t>(at)) = hv;
+                }
+            }
         }
     };
 
@@ -334,8 +346,11 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     uint32_t zrun = 0;
     bool ok = true;
 
+    // Blocks of 8 samples: UNR = 2 of them per loop iteration -- the ring top-up, the landing of the loads
+    // in flight and the issue of the next ones are paid once per 16 samples like for the larger blocks.
+    constexpr uint32_t UNR = (BS == 8) ? (uint32_t)AEC_DEC_UNR8 : 1u;
     uint32_t b = 0;
-    for (; __any(b < nb && ok); b++) {
+    for (; __any(b < nb && ok); b += UNR) {
         const bool live = b < nb && ok;
         // Order inside one iteration: (rare) synchronous refill -> decode -> land the 16-byte loads
         // issued one iteration ago -> store the block -> issue the next loads.  At the landing
@@ -364,6 +379,11 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
         // ---- one block per lane ----
         const uint32_t ref = (pp && b0 + b == 0) ? 1u : 0u;        // per lane in SEG mode
         if (BS) {
+#pragma unroll
+          for (uint32_t uu = 0; uu < UNR; uu++) {
+            const uint32_t bb = b + uu;
+            const bool live = bb < nb && ok;
+            const uint32_t ref = (pp && b0 + bb == 0) ? 1u : 0u;
             src.limit = landed;
             uint32_t nz = 0;
             const bool parse = live && zrun == 0;
@@ -372,7 +392,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             uint32_t st;
 #pragma nounroll
             for (uint32_t attempt = 0;; attempt++) {
-                st = decode_block<(BS ? BS : 2)>(src, p, end_p, d, c, ref, b0 + b, parse, nz);
+                st = decode_block<(BS ? BS : 2)>(src, p, end_p, d, c, ref, b0 + bb, parse, nz);
                 if (attempt != 0 || needw >= maxw || !__any(parse && src.starved())) break;
                 // Half-size ring (see dec_geom): a CDS longer than the look-ahead kept in steady
                 // state.  Land what is in flight, fill the ring completely from this block's first
@@ -410,26 +430,28 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             // loads, then store the block.  Every lane issues every instruction (idle lanes re-read
             // their base chunk / write to a dump slot), so the instruction count per iteration is
             // fixed and the wait at the landing point can leave the younger stores outstanding.
+            if (uu == 0) {
 #pragma unroll
-            for (int j = 0; j < kPend; j++)
-                if (pv[j]) {
-                    ring_put4(col, slot0, mask, landed, pend[j]);
-                    landed += 4;
+                for (int j = 0; j < kPend; j++)
+                    if (pv[j]) {
+                        ring_put4(col, slot0, mask, landed, pend[j]);
+                        landed += 4;
+                    }
+                const uint32_t next = p >> 5;
+#pragma unroll
+                for (int j = 0; j < kPend; j++) {
+                    pv[j] = live && ok && (landed + 4u * j + 4u - next <= ring_words);
+                    const uint64_t idx = pv[j] ? a0 + landed + 4u * j : 0;   // idle lanes share one line
+                    pend[j] = load_words4_nb(words, idx, nwords_vec);
                 }
-            const uint32_t next = p >> 5;
-#pragma unroll
-            for (int j = 0; j < kPend; j++) {
-                pv[j] = live && ok && (landed + 4u * j + 4u - next <= ring_words);
-                const uint64_t idx = pv[j] ? a0 + landed + 4u * j : 0;   // idle lanes share one line
-                pend[j] = load_words4_nb(words, idx, nwords_vec);
             }
             if (STG) {
                 const bool st_ok = live && ok;
-                store_block<DN, (BYTES ? BYTES : 1)>(stage + lane * kStgStride + (b % G) * (uint32_t)BLK, d, c,
+                store_block<DN, (BYTES ? BYTES : 1)>(stage + lane * kStgStride + (bb % G) * (uint32_t)BLK, d, c,
                                                      ref != 0 && parse, x);
                 produced += st_ok ? 1u : 0u;
                 zrun -= (st_ok && zrun) ? 1u : 0u;
-                if ((b % G) == G - 1u) flush(b / G);
+                if ((bb % G) == G - 1u) flush(bb / G);
             } else {
                 const bool st_ok = live && ok;
                 uint8_t *q = st_ok ? dst : dump + (size_t)lane * blk_bytes;
@@ -437,6 +459,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                 dst += st_ok ? blk_bytes : 0;
                 zrun -= (st_ok && zrun) ? 1u : 0u;
             }
+          }
         } else if (live) {
             br.src.limit = landed;
             bool rf = ref != 0;
@@ -590,7 +613,8 @@ struct DecGeom {
 DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, uint32_t stg_row_bytes)
 {
     DecGeom g;
-    const uint32_t maxbits = c.id_len + 1 + c.bps + c.bs * c.bps;
+    // (blocks of 8 samples are decoded AEC_DEC_UNR8 per top-up of the ring)
+    const uint32_t maxbits = (c.id_len + 1 + c.bps + c.bs * c.bps) * (c.bs == 8 ? (uint32_t)AEC_DEC_UNR8 : 1u);
     g.maxw = maxbits / 32 + 5;   // + look-ahead of the 64-bit peeks
     uint32_t rw = 16;
     while (rw < 2 * g.maxw + 3) rw <<= 1;
