@@ -214,6 +214,10 @@ constexpr int kPend = 2;   // 16-byte loads kept in flight per lane across one b
 #ifndef AEC_DEC_UNR8
 #define AEC_DEC_UNR8 2
 #endif
+#ifndef AEC_DEC_UNR16
+#define AEC_DEC_UNR16 1
+#endif
+__host__ __device__ constexpr uint32_t dec_unroll(int bs) { return bs == 8 ? AEC_DEC_UNR8 : (bs == 16 ? AEC_DEC_UNR16 : 1); }
 __host__ __device__ constexpr bool stg_on(int blk) { return blk == 16 || blk == 32 || (blk == 8 && AEC_STG_ROW8 != 0); }
 __host__ __device__ constexpr uint32_t stg_row(int blk) { return blk == 8 ? (AEC_STG_ROW8 ? AEC_STG_ROW8 : 64) : AEC_STG_ROW; }
 
@@ -338,17 +342,17 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     if (BS == 0) br.init(src, a0 * 32u, end_bit, p);
 
     uint4 pend[kPend];
-    bool pv[kPend];
+    uint32_t pv[kPend];                                   // (0 / 1 in a VGPR: lane masks carried around the loop cost SGPR pairs)
 #pragma unroll
-    for (int j = 0; j < kPend; j++) { pend[j] = make_uint4(0, 0, 0, 0); pv[j] = false; }
+    for (int j = 0; j < kPend; j++) { pend[j] = make_uint4(0, 0, 0, 0); pv[j] = 0u; }
 
     uint32_t d[DN];
     uint32_t zrun = 0;
-    bool ok = true;
+    uint32_t ok = 1u;                                     // (a VGPR, like pv[])
 
     // Blocks of 8 samples: UNR = 2 of them per loop iteration -- the ring top-up, the landing of the loads
     // in flight and the issue of the next ones are paid once per 16 samples like for the larger blocks.
-    constexpr uint32_t UNR = (BS == 8) ? (uint32_t)AEC_DEC_UNR8 : 1u;
+    constexpr uint32_t UNR = dec_unroll(BS);
     uint32_t b = 0;
     for (; __any(b < nb && ok); b += UNR) {
         const bool live = b < nb && ok;
@@ -365,7 +369,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                         ring_put4(col, slot0, mask, landed, pend[j]);
                         landed += 4;
                     }
-                    pv[j] = false;
+                    pv[j] = 0u;
                 }
                 while (__any(live && landed - next < needw)) {
                     if (live && landed - next < needw) {
@@ -405,7 +409,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                         ring_put4(col, slot0, mask, landed, pend[j]);
                         landed += 4;
                     }
-                    pv[j] = false;
+                    pv[j] = 0u;
                 }
                 while (__any(live && landed + 4u - first <= ring_words)) {
                     if (live && landed + 4u - first <= ring_words) {
@@ -421,7 +425,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             if (parse) {
                 if (st != DEC_OK) {
                     report(res, st, r);
-                    ok = false;
+                    ok = 0u;
                 } else if (nz) {
                     zrun = nz;
                 }
@@ -440,7 +444,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                 const uint32_t next = p >> 5;
 #pragma unroll
                 for (int j = 0; j < kPend; j++) {
-                    pv[j] = live && ok && (landed + 4u * j + 4u - next <= ring_words);
+                    pv[j] = (live && ok && (landed + 4u * j + 4u - next <= ring_words)) ? 1u : 0u;
                     const uint64_t idx = pv[j] ? a0 + landed + 4u * j : 0;   // idle lanes share one line
                     pend[j] = load_words4_nb(words, idx, nwords_vec);
                 }
@@ -468,7 +472,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                 const uint32_t st = parse_cds<0>(br, d, c, ref, b0 + b, nz);
                 if (st != DEC_OK) {
                     report(res, st, r);
-                    ok = false;
+                    ok = 0u;
                 } else if (nz) {
                     const uint32_t keep = d[0];
                     for (int i = 0; i < DN; i++) d[i] = 0;
@@ -614,7 +618,7 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, uint32_t s
 {
     DecGeom g;
     // (blocks of 8 samples are decoded AEC_DEC_UNR8 per top-up of the ring)
-    const uint32_t maxbits = (c.id_len + 1 + c.bps + c.bs * c.bps) * (c.bs == 8 ? (uint32_t)AEC_DEC_UNR8 : 1u);
+    const uint32_t maxbits = (c.id_len + 1 + c.bps + c.bs * c.bps) * dec_unroll((int)c.bs);
     g.maxw = maxbits / 32 + 5;   // + look-ahead of the 64-bit peeks
     uint32_t rw = 16;
     while (rw < 2 * g.maxw + 3) rw <<= 1;

@@ -22,6 +22,11 @@
 #define AEC_HD inline
 #endif
 
+// blocks of up to this many samples read all their codes from one 64-bit peek (decode_block_noref)
+#ifndef AEC_DEC_GRP
+#define AEC_DEC_GRP 16
+#endif
+
 // AEC_ANY(x): wave-uniform "some lane needs this" test used to enter rare paths once per
 // wavefront on the device; on the host (one lane at a time) it is just x.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1048,8 +1053,20 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
     bool short_input = false, corrupt = false;
     nzero_blocks = 0;
 
-    // ---- 1. header --------------------------------------------------------------------------
-    const uint32_t h = peek32(src, p);
+    // ---- 1. header, 2. unary phase ------------------------------------------------------------
+    // ONE 64-bit peek serves the header and the first group of up to 16 codes: at the k the reference
+    // picks the unary region of a block is at most 3 bits per sample (see emit_small), so with blocks
+    // of 8 or 16 samples the whole region lies inside it -- two LDS round trips (header, second group)
+    // fewer on the serial path of a lane.  Zeros are shifted in from the right, so a code that runs out
+    // of the window reads as 32+ zeros and takes the code-by-code path like any long code.
+    uint32_t u[BS];
+    // (larger blocks: groups of 8 -- 16 codes of a high-entropy block overrun the window too often)
+    constexpr uint32_t GRP = BS <= AEC_DEC_GRP ? (uint32_t)BS : 8u;
+    // second extension: BS/2 codes; where they end inside group 0, the slots behind them pick up bits
+    // of the next coded data set, neither counted nor checked
+    constexpr uint32_t SEH = ((uint32_t)BS / 2u) % GRP;
+    const uint64_t U0 = peek64(src, p);
+    const uint32_t h = (uint32_t)(U0 >> 32);
     const uint32_t id = h >> (32 - c.id_len);
     const bool lowent = live && id == 0;
     const bool unc = live && id == idmax;
@@ -1058,18 +1075,13 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
     const bool se = lowent && sel;
     const bool zero = lowent && !sel;
     const uint32_t k = split ? id - 1u : 0u;
-    p += live ? c.id_len + (lowent ? 1u : 0u) : 0u;
-
-    // ---- 2. unary phase ---------------------------------------------------------------------
-    uint32_t u[BS];
-    constexpr uint32_t GRP = BS < 8 ? (uint32_t)BS : 8u;
+    const uint32_t hdr = live ? c.id_len + (lowent ? 1u : 0u) : 0u;
+    p += hdr;
 #pragma unroll
     for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += GRP) {
-        // (second extension with blocks of 8: its 4 codes are the first half of the one group -- what the
-        // other four slots pick up belongs to the next coded data set and is neither counted nor checked)
-        constexpr bool HALF = BS < 16;
-        const bool gact = split || (se && (HALF || g0 < (uint32_t)BS / 2));
-        uint64_t U = peek64(src, p);
+        const bool part = SEH != 0 && g0 == 0 && se;
+        const bool gact = split || (se && g0 < (uint32_t)BS / 2);
+        uint64_t U = g0 == 0 ? (U0 << hdr) : peek64(src, p);
         if (!gact) U = ~0ull;
         uint32_t used = 0, zmax = 0, used_h = 0, zmax_h = 0;
 #pragma unroll
@@ -1079,16 +1091,16 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
             U <<= ((z + 1u) & 63u);
             used += z + 1u;
             u[g0 + j] = z;
-            if (HALF && j == GRP / 2 - 1) { used_h = used; zmax_h = zmax; }
+            if (SEH != 0 && g0 == 0 && j == SEH - 1u) { used_h = used; zmax_h = zmax; }
         }
-        if (HALF && se) { used = used_h; zmax = zmax_h; }
+        if (part) { used = used_h; zmax = zmax_h; }
         const bool bad = zmax >= 32u;                    // a code of 32+ zeros: redo code by code
         if (AEC_ANY(bad)) {
             if (bad) {
                 uint32_t q = p;
 #pragma unroll
                 for (uint32_t j = 0; j < GRP; j++)
-                    if (!(HALF && se) || j < GRP / 2) u[g0 + j] = unary_slow(src, q, end_p, short_input);
+                    if (!part || j < SEH) u[g0 + j] = unary_slow(src, q, end_p, short_input);
                 used = q - p;
             }
         }
@@ -1121,12 +1133,13 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
         }
     } else {
         // narrow fields: eight of them per 64-bit peek
+        constexpr uint32_t FG = BS < 8 ? (uint32_t)BS : 8u;
         const uint32_t km = low_mask32(kk);
 #pragma unroll
-        for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += GRP) {
+        for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += FG) {
             const uint64_t F = peek64(src, p + g0 * kk);
 #pragma unroll
-            for (uint32_t j = 0; j < GRP; j++) {
+            for (uint32_t j = 0; j < FG; j++) {
                 const uint32_t f = (uint32_t)(F >> ((64u - (j + 1u) * kk) & 63u)) & km;
                 d[g0 + j] = (u[g0 + j] << k) + f;
             }

@@ -108,6 +108,9 @@ static unsigned long long s2_counters[8];
 #else
 #define S2_COUNT(i) ((void)0)
 #endif
+#ifndef S2_NOTE
+#define S2_NOTE(pos) ((void)0)      // (emulator statistics: positions parsed on demand)
+#endif
 
 // `budget`: on-demand parses this walk may still spend (a bogus hypothesis wanders off the marked chain
 // for dozens of codes; a true one is back on it after the few codes behind an RSI start that no sync
@@ -169,9 +172,10 @@ AEC_HD uint32_t s2_unit(const S2Win &w, const Cfg &c, uint32_t p, uint32_t b0, u
     while (b < bend) {                                   // catch-up: on demand until a marked boundary
         if (pos >= w.s.limit) return 0;
         if (s2_marked(w.marks, pos)) break;
-        if (budget == 0) return 0;
+        if (budget == 0) { S2_COUNT(5); return 0; }
         budget--;
         S2_COUNT(3);
+        S2_NOTE(pos);
         const uint32_t e1 = spec_nxt_entry(w.s, c, pos);
         if (!e1) return 0;
         const uint32_t len = e1 & 0xFFFu;

@@ -317,6 +317,10 @@ extern "C" int emul_spec(const uint32_t *p, const uint8_t *in, size_t in_len, ui
 
 // ---- sparse speculative index (aec_spec2.h), window by window as k_spec2 does it ------------------
 #define AEC_S2_COUNT 1
+#include <unordered_set>
+static std::unordered_set<uint64_t> s2_noted;      // distinct (window, position) pairs parsed on demand
+static uint64_t s2_note_window = 0;
+#define S2_NOTE(pos) (s2_noted.insert((s2_note_window << 24) | (pos)))
 #include "../../libaec_amd/csrc/aec_spec2.h"
 // step statistics of the unit walks (hop16, hop4, table single, on-demand single, units)
 extern "C" void emul_s2_counters(unsigned long long *out, int reset)
@@ -325,6 +329,8 @@ extern "C" void emul_s2_counters(unsigned long long *out, int reset)
         out[i] = aec::s2_counters[i];
         if (reset) aec::s2_counters[i] = 0;
     }
+    out[7] = s2_noted.size();
+    if (reset) s2_noted.clear();
 }
 
 // prm: core, lead, look, stride, burn, mode (0 = unit is the RSI, 1 = units are segments of 64 blocks),
@@ -350,6 +356,7 @@ extern "C" int emul_spec2(const uint32_t *p, const uint8_t *in, size_t in_len, c
     for (uint64_t core_abs = tab_lo; core_abs < end_bit; core_abs += core) {
         const uint64_t wstart = core_abs >= lead ? core_abs - lead : 0;      // (multiple of 32)
         const uint32_t c0 = (uint32_t)(core_abs - wstart), c1 = c0 + core;
+        s2_note_window = core_abs / core;
         for (uint32_t i = 0; i < nw + 2; i++) {
             const uint64_t idx = wstart / 32 + i;
             win[i] = idx < words.size() ? bswap32(words[idx]) : 0u;
