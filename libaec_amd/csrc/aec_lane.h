@@ -1083,18 +1083,23 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
         const bool gact = split || (se && g0 < (uint32_t)BS / 2);
         uint64_t U = g0 == 0 ? (U0 << hdr) : peek64(src, p);
         if (!gact) U = ~0ull;
-        uint32_t used = 0, zmax = 0, used_h = 0, zmax_h = 0;
+        // Per code: or, clz, add, or, 64-bit shift, add.  The or with 1 makes the clz of an empty upper
+        // half read 31, and a code length of 32 (31 zeros -- or more) sets bit 5 of the or of all code
+        // lengths: no min and no max on the way (the plain add / and / or / xor / right shift instructions
+        // issue at twice the rate of everything else, profiles/r02/valu_issue_rate.txt), and a code of
+        // exactly 31 zeros takes the code-by-code path along with the longer ones.
+        uint32_t used = 0, lens = 0, used_h = 0, lens_h = 0;
 #pragma unroll
         for (uint32_t j = 0; j < GRP; j++) {
-            const uint32_t z = clz32_or32((uint32_t)(U >> 32));
-            zmax = z > zmax ? z : zmax;
-            U <<= ((z + 1u) & 63u);
-            used += z + 1u;
-            u[g0 + j] = z;
-            if (SEH != 0 && g0 == 0 && j == SEH - 1u) { used_h = used; zmax_h = zmax; }
+            const uint32_t n1 = (uint32_t)__builtin_clz((uint32_t)(U >> 32) | 1u) + 1u;
+            lens |= n1;
+            U <<= (n1 & 63u);
+            used += n1;
+            u[g0 + j] = n1 - 1u;
+            if (SEH != 0 && g0 == 0 && j == SEH - 1u) { used_h = used; lens_h = lens; }
         }
-        if (part) { used = used_h; zmax = zmax_h; }
-        const bool bad = zmax >= 32u;                    // a code of 32+ zeros: redo code by code
+        if (part) { used = used_h; lens = lens_h; }
+        const bool bad = (lens & 32u) != 0;              // a code of 31+ zeros: redo code by code
         if (AEC_ANY(bad)) {
             if (bad) {
                 uint32_t q = p;
@@ -1132,15 +1137,17 @@ AEC_HD uint32_t decode_block_noref(Src &src, uint32_t &p, uint32_t end_p, uint32
             }
         }
     } else {
-        // narrow fields: eight of them per 64-bit peek
+        // narrow fields: eight of them per 64-bit peek, each taken from the top of the window (a right
+        // shift of the upper half) before the window moves up by one field
         constexpr uint32_t FG = BS < 8 ? (uint32_t)BS : 8u;
-        const uint32_t km = low_mask32(kk);
+        const uint32_t fsh = (32u - kk) & 31u, fm = kk ? 0xFFFFFFFFu : 0u;
 #pragma unroll
         for (uint32_t g0 = 0; g0 < (uint32_t)BS; g0 += FG) {
-            const uint64_t F = peek64(src, p + g0 * kk);
+            uint64_t F = peek64(src, p + g0 * kk);
 #pragma unroll
             for (uint32_t j = 0; j < FG; j++) {
-                const uint32_t f = (uint32_t)(F >> ((64u - (j + 1u) * kk) & 63u)) & km;
+                const uint32_t f = ((uint32_t)(F >> 32) >> fsh) & fm;
+                F <<= kk;
                 d[g0 + j] = (u[g0 + j] << k) + f;
             }
         }

@@ -47,6 +47,31 @@ KERNEL(k_salu, X16(asm volatile("s_and_b64 s[20:21], s[20:21], exec\n s_or_b64 s
 KERNEL(k_mix, X16(asm volatile("v_add_u32 %0, %4, %5\n s_and_b64 s[20:21], s[20:21], exec\n v_and_b32 %1, %4, %5\n s_or_b64 s[22:23], s[22:23], exec" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b) : "s20", "s21", "s22", "s23", "scc");))
 KERNEL(k_dpp, X16(asm volatile("v_add_u32_dpp %0, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %1, %4, %5 row_shr:2 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %2, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %3, %4, %5 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(d), "+v"(e), "+v"(f), "+v"(g) : "v"(a), "v"(b));))
 
+KERNEL(k_sub, X16(asm volatile("v_sub_u32 %0, %4, %5 \n v_sub_u32 %1, %4, %5 \n v_sub_u32 %2, %4, %5 \n v_sub_u32 %3, %4, %5" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b));))
+KERNEL(k_or, X16(asm volatile("v_or_b32 %0, %4, %5 \n v_or_b32 %1, %4, %5 \n v_or_b32 %2, %4, %5 \n v_or_b32 %3, %4, %5" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b));))
+KERNEL(k_xor, X16(asm volatile("v_xor_b32 %0, %4, %5 \n v_xor_b32 %1, %4, %5 \n v_xor_b32 %2, %4, %5 \n v_xor_b32 %3, %4, %5" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b));))
+KERNEL(k_shr32, X16(asm volatile("v_lshrrev_b32 %0, %4, %5 \n v_lshrrev_b32 %1, %4, %5 \n v_lshrrev_b32 %2, %4, %5 \n v_lshrrev_b32 %3, %4, %5" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b));))
+KERNEL(k_max, X16(asm volatile("v_max_u32 %0, %4, %5 \n v_max_u32 %1, %4, %5 \n v_max_u32 %2, %4, %5 \n v_max_u32 %3, %4, %5" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b));))
+KERNEL(k_and_or, X16(asm volatile("v_and_or_b32 %0, %4, %5, %6 \n v_and_or_b32 %1, %4, %5, %6 \n v_and_or_b32 %2, %4, %5, %6 \n v_and_or_b32 %3, %4, %5, %6" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b), "v"(c));))
+KERNEL(k_lshl_or, X16(asm volatile("v_lshl_or_b32 %0, %4, %5, %6 \n v_lshl_or_b32 %1, %4, %5, %6 \n v_lshl_or_b32 %2, %4, %5, %6 \n v_lshl_or_b32 %3, %4, %5, %6" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b), "v"(c));))
+KERNEL(k_max3, X16(asm volatile("v_max3_u32 %0, %4, %5, %6 \n v_max3_u32 %1, %4, %5, %6 \n v_max3_u32 %2, %4, %5, %6 \n v_max3_u32 %3, %4, %5, %6" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b), "v"(c));))
+KERNEL(k_mad24, X16(asm volatile("v_mad_u32_u24 %0, %4, %5, %6 \n v_mad_u32_u24 %1, %4, %5, %6 \n v_mad_u32_u24 %2, %4, %5, %6 \n v_mad_u32_u24 %3, %4, %5, %6" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b), "v"(c));))
+KERNEL(k_bfi, X16(asm volatile("v_bfi_b32 %0, %4, %5, %6 \n v_bfi_b32 %1, %4, %5, %6 \n v_bfi_b32 %2, %4, %5, %6 \n v_bfi_b32 %3, %4, %5, %6" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b), "v"(c));))
+KERNEL(k_xad, X16(asm volatile("v_xad_u32 %0, %4, %5, %6 \n v_xad_u32 %1, %4, %5, %6 \n v_xad_u32 %2, %4, %5, %6 \n v_xad_u32 %3, %4, %5, %6" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b), "v"(c));))
+KERNEL(k_or3, X16(asm volatile("v_or3_b32 %0, %4, %5, %6 \n v_or3_b32 %1, %4, %5, %6 \n v_or3_b32 %2, %4, %5, %6 \n v_or3_b32 %3, %4, %5, %6" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b), "v"(c));))
+KERNEL(k_add_lshl, X16(asm volatile("v_add_lshl_u32 %0, %4, %5, %6 \n v_add_lshl_u32 %1, %4, %5, %6 \n v_add_lshl_u32 %2, %4, %5, %6 \n v_add_lshl_u32 %3, %4, %5, %6" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b), "v"(c));))
+KERNEL(k_pk_lshr, X16(asm volatile("v_pk_lshrrev_b16 %0, %4, %5 \n v_pk_lshrrev_b16 %1, %4, %5 \n v_pk_lshrrev_b16 %2, %4, %5 \n v_pk_lshrrev_b16 %3, %4, %5" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b));))
+KERNEL(k_pk_max, X16(asm volatile("v_pk_max_u16 %0, %4, %5 \n v_pk_max_u16 %1, %4, %5 \n v_pk_max_u16 %2, %4, %5 \n v_pk_max_u16 %3, %4, %5" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b));))
+KERNEL(k_mul24, X16(asm volatile("v_mul_u32_u24 %0, %4, %5 \n v_mul_u32_u24 %1, %4, %5 \n v_mul_u32_u24 %2, %4, %5 \n v_mul_u32_u24 %3, %4, %5" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b));))
+KERNEL(k_ashr, X16(asm volatile("v_ashrrev_i32 %0, %4, %5 \n v_ashrrev_i32 %1, %4, %5 \n v_ashrrev_i32 %2, %4, %5 \n v_ashrrev_i32 %3, %4, %5" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b));))
+KERNEL(k_cnd64, X16(asm volatile("v_cndmask_b32 %0, %4, %5, s[20:21]\n v_cndmask_b32 %1, %4, %5, s[20:21]\n v_cndmask_b32 %2, %4, %5, s[22:23]\n v_cndmask_b32 %3, %4, %5, s[22:23]" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b) : "s20", "s21", "s22", "s23");))
+KERNEL(k_cmpcnd, X16(asm volatile("v_cmp_lt_u32 vcc, %4, %5\n v_cndmask_b32 %0, %4, %5, vcc\n v_cmp_lt_u32 vcc, %5, %4\n v_cndmask_b32 %1, %4, %5, vcc" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b) : "vcc");))
+KERNEL(k_cmp64, X16(asm volatile("v_cmp_lt_u32 s[20:21], %0, %1\n v_cmp_lt_u32 s[22:23], %1, %0\n v_cmp_lt_u32 s[20:21], %0, %1\n v_cmp_lt_u32 s[22:23], %1, %0" : : "v"(a), "v"(b) : "s20", "s21", "s22", "s23");))
+KERNEL(k_not, X16(asm volatile("v_not_b32 %0, %4\n v_not_b32 %1, %5\n v_not_b32 %2, %4\n v_not_b32 %3, %5" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b));))
+KERNEL(k_bfei, X16(asm volatile("v_bfe_i32 %0, %4, 0, 1\n v_bfe_i32 %1, %5, 0, 1\n v_bfe_i32 %2, %4, 0, 1\n v_bfe_i32 %3, %5, 0, 1" : "=v"(d), "=v"(e), "=v"(f), "=v"(g) : "v"(a), "v"(b));))
+KERNEL(k_addchain, X16(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %0, %0, %5\n v_add_u32 %0, %0, %4\n v_add_u32 %0, %0, %5" : "+v"(d) : "v"(e), "v"(f), "v"(a), "v"(b));))
+KERNEL(k_shchain, X16(asm volatile("v_lshlrev_b32 %0, %4, %0\n v_lshrrev_b32 %0, %5, %0\n v_lshlrev_b32 %0, %4, %0\n v_lshrrev_b32 %0, %5, %0" : "+v"(d) : "v"(e), "v"(f), "v"(a), "v"(b));))
+
 struct K { const char *name; void (*fn)(unsigned long long *, unsigned, int); };
 
 int main()
@@ -58,10 +83,10 @@ int main()
               {"v_min_u32", k_min}, {"v_lshl_add_u32", k_lshl_add}, {"v_add3_u32", k_add3}, {"v_mul_lo_u32", k_mul_lo},
               {"v_perm_b32", k_perm}, {"v_alignbit_b32", k_alignbit}, {"v_bfe_u32", k_bfe}, {"v_pk_add_u16", k_pk_add},
               {"v_cmp_lt_u32", k_cmp}, {"v_readlane_b32", k_readlane}, {"s_and/or_b64", k_salu},
-              {"valu+salu 1:1", k_mix}, {"v_add_u32_dpp", k_dpp}};
+              {"valu+salu 1:1", k_mix}, {"v_add_u32_dpp", k_dpp}, {"v_sub_u32", k_sub}, {"v_or_b32", k_or}, {"v_xor_b32", k_xor}, {"v_lshrrev_b32", k_shr32}, {"v_max_u32", k_max}, {"v_and_or_b32", k_and_or}, {"v_lshl_or_b32", k_lshl_or}, {"v_max3_u32", k_max3}, {"v_mad_u32_u24", k_mad24}, {"v_bfi_b32", k_bfi}, {"v_xad_u32", k_xad}, {"v_or3_b32", k_or3}, {"v_add_lshl_u32", k_add_lshl}, {"v_pk_lshrrev_b16", k_pk_lshr}, {"v_pk_max_u16", k_pk_max}, {"v_mul_u32_u24", k_mul24}, {"v_ashrrev_i32", k_ashr}, {"v_cndmask sgpr", k_cnd64}, {"cmp+cndmask vcc", k_cmpcnd}, {"v_cmp -> sgpr", k_cmp64}, {"v_not_b32", k_not}, {"v_bfe_i32", k_bfei}, {"v_add dependent", k_addchain}, {"v_shift dependent", k_shchain}};
     // waves per SIMD: 1, 2, 4 = one workgroup of 256 * w threads per CU; 8 = two workgroups of 1024
     const int wps[] = {1, 2, 4, 8};
-    printf("%-16s", "waves/SIMD:");
+    printf("%-18s", "waves/SIMD:");
     for (int w : wps) printf("%10d", w);
     printf("   (ns per wave-instruction on one SIMD, wall clock; last column: s_memtime ticks per ns)\n");
     hipEvent_t e0, e1;
@@ -69,7 +94,7 @@ int main()
     hipEventCreate(&e1);
     const int reps = 4096;
     for (auto &k : ks) {
-        printf("%-16s", k.name);
+        printf("%-18s", k.name);
         double tick_rate = 0;
         for (int w : wps) {
             const int wg = w == 8 ? 512 : 256, thr = w == 8 ? 1024 : 256 * w;
