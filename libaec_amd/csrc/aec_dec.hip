@@ -199,7 +199,10 @@ __device__ __forceinline__ void ring_put4(uint32_t *col, uint32_t slot0, uint32_
     }
 }
 
-constexpr int kPend = 2;   // 16-byte loads kept in flight per lane across one block iteration
+// 16-byte loads kept in flight per lane across one block iteration: KP = 2 feeds 256 bits per block, enough
+// for the short coded data sets of compressible data; streams that average more per block (large blocks,
+// high-entropy data: typical.dat's 64-sample blocks at 720 bits) would drain the ring and fall into the
+// synchronous refill -- an HBM round trip per 16 bytes -- every iteration, so they run with KP = 4 or 8.
 
 // output staging rows (see k_decode): which block sizes in bytes are staged, and the row length
 #ifndef AEC_STG_ROW
@@ -226,7 +229,7 @@ __host__ __device__ constexpr uint32_t stg_row(int blk) { return blk == 8 ? (AEC
 
 // SEG = false: work item = RSI, start bits from rsi_off.  SEG = true: work item = segment (64
 // blocks), start bit and preceding sample from the encoder's segment table.
-template <int BS, int BYTES, bool SEG>
+template <int BS, int BYTES, bool SEG, int kPend>
 __global__ void __launch_bounds__(256, AEC_DEC_MINW)
 k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
          const uint64_t *__restrict__ rsi_off, const SegEntry *__restrict__ seg_table, uint64_t n_rsi,
@@ -392,10 +395,15 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                     pv[j] = 0u;
                 }
                 while (__any(live && landed - next < needw)) {
-                    if (live && landed - next < needw) {
-                        ring_put4(col, slot0, mask, landed, load_words4(words, a0 + landed, nwords));
-                        landed += 4;
-                    }
+                    uint4 t[kPend];                                // a round of loads per wait, not one
+#pragma unroll
+                    for (int j = 0; j < kPend; j++) t[j] = load_words4(words, a0 + landed + 4u * j, nwords);
+#pragma unroll
+                    for (int j = 0; j < kPend; j++)
+                        if (live && landed - next < needw && landed + 4u - next <= ring_words) {
+                            ring_put4(col, slot0, mask, landed, t[j]);
+                            landed += 4;
+                        }
                 }
             }
         }
@@ -685,9 +693,19 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
     // (counts taken from the index record: the average coded data set is not known here -- full ring)
     const DecGeom g = dec_geom(c, n_rsi, (total_blocks && !idx && !batch) ? end_bit / total_blocks : 0, stg_on((int)blk) ? stg_row((int)blk) : 0u);
     const dim3 block(64 * g.waves), grid(g.grid);
-#define AEC_GO(B)                                                                                   \
-    hipLaunchKernelGGL((k_decode<BS, B, SEG>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
+    // loads in flight per block iteration (see kPend): sized for the average coded data set where the caller
+    // knows it, for the worst case of large blocks where it does not
+    const uint64_t avg = (total_blocks && !idx && !batch) ? end_bit / total_blocks : 0;
+    const int kp = BS >= 32 ? (avg == 0 || avg > 400 ? 8 : (avg > 200 ? 4 : 2)) : (avg > 200 ? 4 : 2);
+#define AEC_GO2(B, KP)                                                                                  \
+    hipLaunchKernelGGL((k_decode<BS, B, SEG, KP>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
                        rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, g.needw, dump, idx, batch, rpc)
+#define AEC_GO(B)                                                                                   \
+    do {                                                                                            \
+        if (kp == 2) AEC_GO2(B, 2);                                                                 \
+        else if (kp == 4) AEC_GO2(B, 4);                                                            \
+        else if (BS >= 32) AEC_GO2(B, (BS >= 32 ? 8 : 4));                                          \
+    } while (0)
     switch (c.bytes) {
     case 1: AEC_GO(1); break;
     case 2: AEC_GO(2); break;
@@ -695,6 +713,7 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
     default: AEC_GO(4); break;
     }
 #undef AEC_GO
+#undef AEC_GO2
 }
 
 }  // namespace
@@ -724,7 +743,7 @@ static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
     default:
     {
         const DecGeom g = dec_geom(c, n_items, 0, 0u);   // the sample-by-sample reader has no second attempt: full ring
-        hipLaunchKernelGGL((k_decode<0, 0, SEG>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
+        hipLaunchKernelGGL((k_decode<0, 0, SEG, 2>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
                            end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, g.needw, dump, d_idx, d_batch, rpc);
         break;
     }
