@@ -2,7 +2,7 @@
 # Collects what profiles/<round>/ holds (run on the GPU box from the repo root):
 #   tests/collect_profiles.sh <outdir-under-gpurun_out>
 # bench lines of every configuration, rocprofv3 kernel statistics of the same command, HBM traffic (PMC,
-# separate passes) per configuration, index / small-call / chunked-SZIP benches, the sharded path on one GPU.
+# separate passes) per configuration, SQ counters of the C2 kernels, the VALU issue-rate microbenchmark, index / small-call / chunked-SZIP benches, the sharded path on one GPU.
 OUT=$PWD/gpurun_out/$1; R=$PWD
 mkdir -p $OUT
 for c in c2 c3 c5 typical; do
@@ -19,6 +19,9 @@ for c in c2 c3 c5 typical; do
   bash tests/prof_traffic.sh $1/traffic_$c 4096 $c > /dev/null 2>&1
   cp $OUT/traffic_$c/traffic.json $OUT/traffic_${c}_4GiB.json 2>/dev/null
 done
+bash tests/prof_pmc2.sh $1/sq_c2 4096 > /dev/null 2>&1
+cp $OUT/sq_c2/summary.txt $OUT/pmc_sq_c2_4GiB.txt 2>/dev/null
+[ -x build/valu_rate ] && timeout 120 build/valu_rate > $OUT/valu_issue_rate.txt 2>&1
 python3 tests/bench_index.py --config c2 --size-mib 1 64 1024 > $OUT/bench_index.txt 2>&1
 python3 tests/bench_index.py --config c5 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
 python3 tests/bench_index.py --config c3 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
@@ -26,4 +29,4 @@ python3 tests/bench_index.py --config typical --size-mib 64 >> $OUT/bench_index.
 python3 tests/bench_abi_small.py > $OUT/bench_abi_small.txt 2>&1
 python3 tests/bench_sz_chunks.py > $OUT/bench_sz_chunks.txt 2>&1
 python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
-rm -rf $OUT/stats_* $OUT/traffic_c2 $OUT/traffic_c3 $OUT/traffic_c5 $OUT/traffic_typical
+rm -rf $OUT/sq_c2 $OUT/stats_* $OUT/traffic_c2 $OUT/traffic_c3 $OUT/traffic_c5 $OUT/traffic_typical
