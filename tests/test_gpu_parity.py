@@ -434,6 +434,19 @@ def test_segment_parallel_decode(gpu):
         blk = np.arange(n) // bs
         v = np.where(blk % every == every - 1, noise, np.clip(v, 0, (1 << bps) - 1).astype(np.uint64))
         cases.append((bps, bs, 128, PP, pack_samples(v, bps, PP)))
+    # high-rate streams (the decoder keeps 4 or 8 loads in flight per block instead of 2): incompressible
+    # samples in every block size; and the staging-row shapes of small blocks (8, 16, 32 bytes per block)
+    # with block counts that end inside a row
+    for bps, bs, rsi in ((16, 16, 128), (16, 32, 64), (16, 64, 70), (32, 64, 33), (8, 32, 65), (24, 16, 50)):
+        n = bs * rsi * 9 + bs * 3
+        noise = rng.integers(0, 1 << bps, n, dtype=np.uint64)
+        cases.append((bps, bs, rsi, PP, pack_samples(noise, bps, PP)))
+    for bps, bs, rsi, nblk_total in ((8, 8, 128, 128 * 7 + 61), (8, 8, 3, 3 * 50 + 1), (16, 8, 65, 65 * 9 + 5), (8, 16, 67, 67 * 6 + 3),
+                                     (8, 32, 64, 64 * 5 + 1), (16, 16, 128, 128 * 4 + 63)):
+        n = bs * nblk_total
+        v = np.clip(np.cumsum(rng.integers(-2, 3, n)) + (1 << (bps - 1)), 0, (1 << bps) - 1).astype(np.uint64)
+        v[rng.random(n) < 0.3] = 0
+        cases.append((bps, bs, rsi, PP, pack_samples(v, bps, PP)))
     for bps, bs, rsi, flags, data in cases:
         data = np.ascontiguousarray(data, dtype=np.uint8)
         codec = gpu.Codec(bps, bs, rsi, flags)
@@ -456,6 +469,8 @@ def test_segment_parallel_decode(gpu):
         res = d_res.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]
         assert res["status"] == 0, (bps, bs, rsi, flags)
         assert torch.equal(d_seg[: nblk * bs * nb], d_ref), (bps, bs, rsi, flags)
+        if not (flags & SGN and bps % 8):         # (signed samples come back sign-extended into their container)
+            assert torch.equal(d_ref[: data.size], d_in), (bps, bs, rsi, flags)
         rc, want, *_ = oracle_encode(data, bps, bs, rsi, flags)
         assert d_out[:nbytes].cpu().numpy().tobytes() == want
 
