@@ -22,6 +22,7 @@ done
 bash tests/prof_pmc2.sh $1/sq_c2 4096 > /dev/null 2>&1
 cp $OUT/sq_c2/summary.txt $OUT/pmc_sq_c2_4GiB.txt 2>/dev/null
 [ -x build/valu_rate ] && timeout 120 build/valu_rate > $OUT/valu_issue_rate.txt 2>&1
+[ -x build/store_pattern ] && timeout 120 build/store_pattern > $OUT/store_pattern.txt 2>&1
 python3 tests/bench_index.py --config c2 --size-mib 1 64 1024 > $OUT/bench_index.txt 2>&1
 python3 tests/bench_index.py --config c5 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
 python3 tests/bench_index.py --config c3 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
