@@ -222,14 +222,17 @@ __device__ __forceinline__ void fast_issue(const Cfg &c, const uint8_t *in, cons
     f.carry = load_sample_raw<BYTES>(in + prev * BYTES);
 }
 
+// `pair`: segments of 512 bytes fill only half the lanes of a round -- lanes 32..63 hold the 32 chunks of the
+// NEXT segment (it follows in memory), which then goes to rows 64..127 in the same pass (ref2: that segment
+// starts an RSI); the caller has checked that both segments are whole.
 template <int BS, int BYTES>
 __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const FastSeg<BS, BYTES> &f,
-                                            uint32_t *rows, uint32_t lane)
+                                            uint32_t *rows, uint32_t lane, bool pair = false, bool ref2 = false)
 {
     constexpr uint32_t SPC = 16 / BYTES;           // samples per chunk
     constexpr uint32_t STRIDE = Rows<BS, BYTES>::stride_words(BS);
     const bool msb = c.flags & F_MSB, pp = c.flags & F_PREPROCESS;
-    const uint32_t nchunks = g.nv * (uint32_t)BS * BYTES / 16u;
+    const uint32_t nchunks = g.nv * (uint32_t)BS * BYTES / 16u * (pair ? 2u : 1u);
     uint32_t carry = sample_byte_order<BYTES>(f.carry, msb);
 
 #pragma unroll
@@ -276,6 +279,7 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
                 for (uint32_t j = 0; j < NW; j++)
                     dw[j] = pp_unsigned_pk(__builtin_amdgcn_alignbit(pw[j], j ? pw[j - 1] : before, 16), pw[j], xm);
                 if (g.b0 == 0 && ci == 0) dw[0] &= 0xFFFF0000u;      // reference sample slot, encode.c:254
+                if (ref2 && ci == FastSeg<BS, BYTES>::CHUNKS) dw[0] &= 0xFFFF0000u;
 #pragma unroll
                 for (uint32_t q = 0; q < NW / 4; q++) {
                     const uint32_t i = ci * SPC + q * 8;
@@ -323,6 +327,7 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
                 for (uint32_t j = 0; j < SPC; j++) dd[j] = pp_unsigned(j ? x[j - 1] : prev, x[j], c.xmax);
             }
             if (pp && g.b0 == 0 && ci == 0) dd[0] = 0;   // reference sample slot, encode.c:254
+            if (pp && ref2 && ci == FastSeg<BS, BYTES>::CHUNKS) dd[0] = 0;
             if (Rows<BS, BYTES>::HALF) {
 #pragma unroll
                 for (uint32_t q = 0; q < SPC / 8; q++) {
@@ -378,6 +383,9 @@ struct Feeder {
     static constexpr int FBS = FAST_T ? BS : 8, FBY = FAST_T ? BYTES : 1;
     // prefetch across segments only while it is cheap in registers (<= 4 x 16 bytes per lane)
     static constexpr bool PIPE = FAST_T && FastSeg<FBS, FBY>::NIT <= 4;
+    // 512-byte segments (8 samples of one byte per block): two of them per feed, see fast_finish
+    static constexpr bool PAIR = PIPE && FastSeg<FBS, FBY>::CHUNKS == 32;
+    static constexpr uint32_t ROWS = PAIR ? 128u : 64u;
     FastSeg<(PIPE ? FBS : 8), (PIPE ? FBY : 1)> pre;
     bool fast;            // run-time half of the decision (alignment, at least one whole chunk)
     uint64_t max_chunk;
@@ -394,14 +402,19 @@ struct Feeder {
             if (fast) fast_issue<(PIPE ? FBS : 8), (PIPE ? FBY : 1)>(c, in, g, lane, max_chunk, pre);
         }
     }
+    // both segments whole, the second right behind the first: one feed serves both
+    __device__ __forceinline__ bool can_pair(const Seg &g, const Seg &g2) const
+    {
+        return PAIR && fast && g.full && g.nv == 64u && g2.full && g2.nv == 64u;
+    }
     // consumes the registers prefetched for g (call prefetch(next) BEFORE this to overlap)
     __device__ __forceinline__ void feed(const Cfg &c, const uint8_t *in, const Seg &g,
                                          const FastSeg<(PIPE ? FBS : 8), (PIPE ? FBY : 1)> &cur, uint32_t *rows,
-                                         uint32_t stride, uint32_t lane)
+                                         uint32_t stride, uint32_t lane, bool pair = false, bool ref2 = false)
     {
         if (PIPE) {
             if (fast && g.full) {
-                fast_finish<(PIPE ? FBS : 8), (PIPE ? FBY : 1)>(c, g, cur, rows, lane);
+                fast_finish<(PIPE ? FBS : 8), (PIPE ? FBY : 1)>(c, g, cur, rows, lane, pair, ref2);
                 return;
             }
         } else if (FAST_T) {
@@ -510,7 +523,7 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const uint32_t stride = Rows<BS, BYTES>::stride_words(bs);
-    uint32_t *rows = smem + (size_t)wave * 64u * stride;
+    uint32_t *rows = smem + (size_t)wave * Feeder<BS, BYTES>::ROWS * stride;
 
     const uint64_t gwave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     uint64_t sg = gwave * segs_per_wave;
@@ -521,13 +534,22 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
     feeder.init(c, fast_ok);
     Seg g = seg_geom(c, sg < sg_end ? sg : 0);
     if (sg < sg_end) feeder.prefetch(c, in, g, lane);
-    for (; sg < sg_end; sg++) {
+    while (sg < sg_end) {
         const auto cur = feeder.pre;
         const Seg gcur = g;
-        if (sg + 1 < sg_end) g = seg_next(c, g);
-        feeder.prefetch(c, in, g, lane);          // next segment's loads fly during this one
-        feeder.feed(c, in, gcur, cur, rows, stride, lane);
+        Seg g2 = gcur;
+        bool pair = false;
+        if (sg + 1 < sg_end) {
+            g2 = seg_next(c, gcur);
+            pair = feeder.can_pair(gcur, g2);
+        }
+        const uint64_t adv = pair ? 2u : 1u;
+        if (sg + adv < sg_end) g = pair ? seg_next(c, g2) : g2;
+        feeder.prefetch(c, in, g, lane);          // the next segment's loads fly during this one
+        feeder.feed(c, in, gcur, cur, rows, stride, lane, pair, pair && g2.b0 == 0);
         analyze_body<BS, BYTES>(c, gcur, rows, stride, lane, sg, meta, seg_bits, seg_clamp);
+        if (pair) analyze_body<BS, BYTES>(c, g2, rows + 64u * stride, stride, lane, sg + 1, meta, seg_bits, seg_clamp);
+        sg += adv;
     }
 }
 
@@ -840,9 +862,9 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const uint32_t stride = Rows<BS, BYTES>::stride_words(bs);
-    const uint32_t per_wave = 64u * stride + obuf_words;
+    const uint32_t per_wave = Feeder<BS, BYTES>::ROWS * stride + obuf_words;
     uint32_t *rows = smem + (size_t)wave * per_wave;
-    uint32_t *obuf = rows + 64u * stride;
+    uint32_t *obuf = rows + Feeder<BS, BYTES>::ROWS * stride;
     const bool pp = c.flags & F_PREPROCESS, msb = c.flags & F_MSB;
 
     const uint64_t gwave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -858,33 +880,35 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
     bool first_seg = true, carried_shared = false;
     // the image buffer starts out zero and every word is zeroed again when it is copied out
     for (uint32_t w = lane; w < obuf_words; w += kWave) obuf[w] = 0u;
-    for (; sg < sg_end; sg++) {
-        const auto cur = feeder.pre;
-        const Seg g = gnext;
-        // everything this segment needs from HBM is requested before the first wait (requesting the
-        // summaries a segment ahead as well was tried: no gain, two registers too many)
-        const bool valid = lane < g.nv;
-        const uint32_t m = valid ? meta[g.blk0 + lane] : meta_pack(0, OPT_ZCONT, 0, 0);
-        const uint32_t kin = seg_kin[sg];
-        const uint64_t start = seg_start[sg];
-        uint32_t ref_sample = 0;
-        if (pp && g.b0 == 0 && lane == 0)
-            ref_sample = load_sample_bytes(in + g.samp0 * c.bytes, c.bytes, msb) & low_mask32(c.bps);
-        if (sg + 1 < sg_end) gnext = seg_next(c, gnext);
-        feeder.prefetch(c, in, gnext, lane);      // next segment's loads fly during this one
-        feeder.feed(c, in, g, cur, rows, stride, lane);
 
-        const uint32_t lead = (uint32_t)(start & 31u);
+    // what a segment needs from HBM besides its samples
+    struct SegIn {
+        uint32_t m, kin, ref_sample;
+        uint64_t start;
+    };
+    auto seg_in = [&](const Seg &g, uint64_t sgi) {
+        SegIn r;
+        r.m = lane < g.nv ? meta[g.blk0 + lane] : meta_pack(0, OPT_ZCONT, 0, 0);
+        r.kin = seg_kin[sgi];
+        r.start = seg_start[sgi];
+        r.ref_sample = 0;
+        if (pp && g.b0 == 0 && lane == 0)
+            r.ref_sample = load_sample_bytes(in + g.samp0 * c.bytes, c.bytes, msb) & low_mask32(c.bps);
+        return r;
+    };
+    // emission of one segment from its rows and copy-out of the image
+    auto do_segment = [&](const Seg &g, const uint32_t *seg_rows, const SegIn &si, uint64_t sgi) {
+        const uint32_t lead = (uint32_t)(si.start & 31u);
         uint32_t total, seg_cl;
-        emit_segment<BS, BYTES>(c, g, rows, stride, obuf, lane, m, kin, lead, ref_sample, pending, total, seg_cl);
+        emit_segment<BS, BYTES>(c, g, seg_rows, stride, obuf, lane, si.m, si.kin, lead, si.ref_sample, pending, total, seg_cl);
         const uint32_t nwords = (lead + total + 31u) >> 5;
 
         // Copy the image out.  Only a word this wave does not own alone needs an atomic: the first
         // word of the wave's first segment (shared with the previous wave) and the open tail word of
         // its last segment.  An open tail in between is carried to the next segment in `pending`.
-        const uint64_t gw = start >> 5;
+        const uint64_t gw = si.start >> 5;
         const uint32_t tail = (lead + total) & 31u;
-        const bool last_seg = sg + 1 == sg_end;
+        const bool last_seg = sgi + 1 == sg_end;
         const bool carry_tail = tail != 0 && !last_seg && nwords > 0;
         // word 0 also holds bits of another wave only in the wave's first segment, or when a one-word
         // segment carried that word along
@@ -908,6 +932,29 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
         carried_shared = carry_tail && nwords == 1 && left_shared;
         first_seg = false;
         wave_lds_fence();
+    };
+
+    while (sg < sg_end) {
+        const auto cur = feeder.pre;
+        const Seg g = gnext;
+        Seg g2 = g;
+        bool pair = false;
+        if (sg + 1 < sg_end) {
+            g2 = seg_next(c, g);
+            pair = feeder.can_pair(g, g2);
+        }
+        const uint64_t adv = pair ? 2u : 1u;
+        // everything this segment needs from HBM is requested before the first wait (requesting the
+        // summaries a segment ahead as well was tried: no gain, two registers too many)
+        const SegIn si = seg_in(g, sg);
+        SegIn si2 = si;
+        if (pair) si2 = seg_in(g2, sg + 1);
+        if (sg + adv < sg_end) gnext = pair ? seg_next(c, g2) : g2;
+        feeder.prefetch(c, in, gnext, lane);      // next segment's loads fly during this one
+        feeder.feed(c, in, g, cur, rows, stride, lane, pair, pair && g2.b0 == 0);
+        do_segment(g, rows, si, sg);
+        if (pair) do_segment(g2, rows + 64u * stride, si2, sg + 1);
+        sg += adv;
     }
 }
 
@@ -1267,7 +1314,9 @@ LaunchGeom make_geom(const Cfg &c, bool with_obuf)
     const uint32_t stride = (templated && c.bytes <= 2) ? c.bs / 2 + 4 : c.bs + 4;   // Rows<>::stride_words
     const uint32_t maxlen = c.id_len + c.bs * c.bps + 2 + c.bps;
     g.obuf_words = with_obuf ? ((64u * maxlen + 62u) / 32u + 4u) & ~3u : 0u;
-    const size_t per_wave = ((size_t)64 * stride + g.obuf_words) * 4;
+    // (512-byte segments are fed two at a time: 128 rows, see Feeder::PAIR)
+    const uint32_t rows = (templated && c.bs * c.bytes == 8) ? 128u : 64u;
+    const size_t per_wave = ((size_t)rows * stride + g.obuf_words) * 4;
     uint32_t wpb = (uint32_t)(65536 / per_wave);
     if (wpb > 4) wpb = 4;
     if (wpb < 1) wpb = 1;

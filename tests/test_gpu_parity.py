@@ -117,6 +117,28 @@ def test_random_sweep_vs_oracle(api):
         check_roundtrip(api, f"it{it}-n{bps}-j{bs}-r{rsi}-f{flags}-len{n}", bps, bs, rsi, flags, data)
 
 
+def test_eight_byte_blocks_fed_in_pairs(api):
+    """Blocks of 8 one-byte samples: a segment is 512 bytes, half a round of 16-byte chunks, and the encoder
+    feeds two segments per round (aec_enc.hip Feeder::PAIR).  Every way two neighbouring segments can relate:
+    same RSI, the second starting an RSI (reference sample slot), a short segment in between (no pairing),
+    odd segment counts per wave, end of data inside a pair; unsigned / signed / MSB / without preprocessing."""
+    rng = np.random.default_rng(88)
+    for bps in (8, 7, 3):
+        for rsi in (64, 128, 65, 130, 192, 1, 4096):
+            for flags in (PP, PP | SGN, 0, PP | MSB | SGN):
+                nblk = int(rng.choice([64 * 9, 64 * 16 + 1, 64 * 33 + 63, 64 * 40 + 7, rsi * 5 + 64 * 3]))
+                n = 8 * nblk - int(rng.integers(0, 8))
+                vals = random_walk_samples(rng, n, bps, flags, scale=float(rng.choice([0.5, 3.0])), zero_frac=0.2)
+                data = pack_samples(vals, bps, flags)
+                check_roundtrip(api, f"pair-n{bps}-r{rsi}-f{flags}-len{n}", bps, 8, rsi, flags, data)
+    # pairs only form where a wave walks several segments, i.e. in inputs of some size
+    for rsi, flags in ((128, PP), (64, PP | SGN), (65, PP), (130, PP | MSB), (4096, 0), (192, PP)):
+        n = (16 << 20) + 8 * 37 + 3
+        vals = random_walk_samples(rng, n, 8, flags, scale=2.0, zero_frac=0.2)
+        data = pack_samples(vals, 8, flags)
+        check_roundtrip(api, f"pair-big-r{rsi}-f{flags}", 8, 8, rsi, flags, data)
+
+
 def test_concurrent_streams_share_the_resource_pool(api):
     """Four host threads run one-shot and streaming calls at the same time (ctypes releases the GIL):
     streams are independent objects (SURVEY 8(b) threading contract) and the device-side resources
