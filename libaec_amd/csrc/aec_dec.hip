@@ -258,12 +258,10 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     constexpr bool STG = stg_on(BLK);
     constexpr uint32_t kStgRow = stg_row(BLK), kStgStride = kStgRow + 16u;   // 16 bytes of padding: conflict-free rows
     constexpr uint32_t G = STG ? kStgRow / (uint32_t)(BLK ? BLK : 1) : 1u;
-    const uint32_t wave_words = (ring_words + 2u) * 64u + (STG ? (64u * kStgStride + 64u * 12u) / 4u : 0u);
+    const uint32_t wave_words = (ring_words + 2u) * 64u + (STG ? (64u * kStgStride) / 4u : 0u);
     uint32_t *wbase = smem + (size_t)wave * wave_words;
     uint32_t *col = wbase + lane;
     uint8_t *stage = reinterpret_cast<uint8_t *>(wbase + (ring_words + 2u) * 64u);
-    uint8_t **stg_base = reinterpret_cast<uint8_t **>(stage + 64u * kStgStride);
-    uint32_t *stg_cnt = reinterpret_cast<uint32_t *>(stage + 64u * kStgStride + 64u * 8u);
     const uint32_t mask = ring_words - 1;
 
     const uint64_t r = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 64u + lane;
@@ -303,18 +301,22 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     }
     const size_t blk_bytes = (size_t)bs * c.bytes;
     uint8_t *dst = out + (size_t)first_blk * blk_bytes;
-    if (STG) stg_base[lane] = dst;
+    // (a row's destination and fill level live in its lane's registers; the lanes that write the row out
+    // fetch them with a lane permute -- as pointer and count arrays they cost 768 bytes of LDS per wave, the
+    // 16th wave of a CU at C2)
+    const uint32_t dst_lo = (uint32_t)reinterpret_cast<uintptr_t>(dst), dst_hi = (uint32_t)(reinterpret_cast<uintptr_t>(dst) >> 32);
     uint32_t produced = 0;                              // blocks this lane parked in the current group
     auto flush = [&](uint32_t group) {
-        stg_cnt[lane] = produced * (uint32_t)BLK;
+        const uint32_t filled = produced * (uint32_t)BLK;
         produced = 0;
         constexpr uint32_t LPR = kStgRow / 16u, RPI = 64u / LPR;   // lanes per row, rows per store instruction
 #pragma unroll
         for (uint32_t k = 0; k < LPR; k++) {
             const uint32_t row = k * RPI + lane / LPR, chunk = (lane % LPR) * 16u;
             const uint4 v = *reinterpret_cast<const uint4 *>(stage + row * kStgStride + chunk);
-            const uint32_t have = stg_cnt[row];
-            uint8_t *at = stg_base[row] + (size_t)group * kStgRow + chunk;
+            const uint32_t have = __shfl(filled, (int)row);
+            const uintptr_t rbase = (uintptr_t)__shfl(dst_lo, (int)row) | ((uintptr_t)__shfl(dst_hi, (int)row) << 32);
+            uint8_t *at = reinterpret_cast<uint8_t *>(rbase) + (size_t)group * kStgRow + chunk;
             uint8_t *q = chunk + 16u <= have ? at : dump + (size_t)lane * 16u;
             // (the row's base pointer comes out of LDS: say that it points to global memory, or
             // the store is emitted as a flat instruction)
@@ -659,12 +661,12 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, uint32_t s
         g.needw = rw / 2;
     }
     g.ring_words = rw;
-    // (+ the output staging rows of k_decode for small blocks: 64 x 80 bytes, 64 pointers, 64 counts)
+    // (+ the output staging rows of k_decode for small blocks: 64 x (row + 16) bytes)
     // (AEC_DEC_LDS_PAD: extra LDS bytes per wave, a diagnostic knob for occupancy experiments; the kernel
     // never touches them)
     static const char *e_pad = getenv("AEC_DEC_LDS_PAD");
     const size_t pad = e_pad ? (size_t)atoi(e_pad) : 0;
-    const size_t per_wave = (size_t)(rw + 2) * 64 * 4 + (stg_row_bytes ? 64 * (stg_row_bytes + 16) + 64 * 12 : 0) + pad;
+    const size_t per_wave = (size_t)(rw + 2) * 64 * 4 + (stg_row_bytes ? 64 * (stg_row_bytes + 16) : 0) + pad;
     // waves per workgroup: whatever packs most waves into the 160 KiB of a CU
     uint32_t waves = 1, best = 0;
     for (uint32_t w = 1; w <= 4; w *= 2) {
