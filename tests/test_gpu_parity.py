@@ -497,6 +497,54 @@ def test_segment_parallel_decode(gpu):
         assert d_out[:nbytes].cpu().numpy().tobytes() == want
 
 
+def test_device_paths_random_sweep(gpu):
+    """Random stream parameters through the DEVICE entry points on inputs large enough for the kernels'
+    multi-segment paths (several segments per wave, paired feeds, staging rows, loads in flight sized for the
+    coded rate): the stream must be the oracle's, and decoding it per RSI and per segment must both give the
+    input back.  AEC_SWEEP_ITERS / AEC_SWEEP_SEED turn it into a soak test."""
+    import torch
+    rng = np.random.default_rng(int(os.environ.get("AEC_SWEEP_SEED", "4711")))
+    for it in range(max(12, int(os.environ.get("AEC_SWEEP_ITERS", "150")) // 6)):
+        bps = int(rng.choice([8, 16, 32, 12, 24, 5]))
+        bs = int(rng.choice([8, 16, 32, 64]))
+        rsi = int(rng.choice([1, 3, 64, 65, 128, 130, 300, 4096]))
+        flags = PP if rng.random() < 0.8 else 0
+        if rng.random() < 0.4:
+            flags |= MSB
+        if rng.random() < 0.3 and bps in (8, 16, 32):    # (signed samples come back sign-extended into their container)
+            flags |= SGN
+        nb = bytes_per_sample(bps, flags)
+        n = int(rng.integers(1 << 18, 1 << 21)) // (bs * nb) * bs + int(rng.integers(0, bs))
+        mode = rng.integers(0, 3)
+        if mode == 0:
+            vals = random_walk_samples(rng, n, bps, flags, scale=float(rng.choice([0.3, 2, 40])), zero_frac=float(rng.choice([0.02, 0.5])))
+        elif mode == 1:
+            lo = -(1 << (bps - 1)) if flags & SGN else 0
+            vals = rng.integers(lo, lo + (1 << bps), size=n)
+        else:
+            vals = np.repeat(rng.integers(0, 1 << min(bps, 6), size=n // 61 + 1), 61)[:n]
+        data = np.ascontiguousarray(pack_samples(vals, bps, flags), dtype=np.uint8)
+        tag = (it, bps, bs, rsi, flags, n)
+        codec = gpu.Codec(bps, bs, rsi, flags)
+        d_in = torch.from_numpy(data).cuda()
+        nseg = codec.segment_count(data.size)
+        d_tab = torch.zeros(nseg * 16, dtype=torch.uint8, device="cuda")
+        codec.set_segment_table(d_tab)
+        d_out, nbytes, tb, k_out, d_off = codec.encode(d_in)
+        codec.set_segment_table(None)
+        rc, want, *_ = oracle_encode(data, bps, bs, rsi, flags)
+        assert rc == AEC_OK and d_out[:nbytes].cpu().numpy().tobytes() == want, tag
+        nrsi, nblk = codec.rsi_count(data.size), codec.block_count(data.size)
+        d_ref, st = codec.decode(d_out, nbytes, d_off, nrsi, nblk)
+        assert st == 0, tag
+        d_seg = torch.empty(nblk * bs * nb + 16, dtype=torch.uint8, device="cuda")
+        d_res = torch.zeros(40, dtype=torch.uint8, device="cuda")
+        codec.decode_segments_async(d_out, nbytes, d_tab, nseg, nblk, d_seg, d_res)
+        assert d_res.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]["status"] == 0, tag
+        assert torch.equal(d_seg[: nblk * bs * nb], d_ref), tag
+        assert torch.equal(d_ref[: data.size], d_in), tag
+
+
 def test_pad_rsi_and_restricted_through_abi(api):
     """Decoder-side AEC_PAD_RSI (reference decode.c:407-408) and the restricted code-option sets
     (id_len 1 and 2, reference encode.c:843-851) through the libaec ABI."""
