@@ -515,6 +515,8 @@ def test_device_paths_random_sweep(gpu):
             flags |= SGN
         nb = bytes_per_sample(bps, flags)
         n = int(rng.integers(1 << 18, 1 << 21)) // (bs * nb) * bs + int(rng.integers(0, bs))
+        if it % 6 == 5:
+            n *= 20                               # enough segments for a wave to walk several of them
         mode = rng.integers(0, 3)
         if mode == 0:
             vals = random_walk_samples(rng, n, bps, flags, scale=float(rng.choice([0.3, 2, 40])), zero_frac=float(rng.choice([0.02, 0.5])))
