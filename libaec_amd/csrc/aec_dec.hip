@@ -199,12 +199,12 @@ __device__ __forceinline__ void ring_put4(uint32_t *col, uint32_t slot0, uint32_
     }
 }
 
-// 16-byte loads kept in flight per lane across one block iteration: KP = 2 feeds 256 bits per block, enough
-// for the short coded data sets of compressible data; streams that average more per block (large blocks,
-// high-entropy data: typical.dat's 64-sample blocks at 720 bits) would drain the ring and fall into the
-// synchronous refill -- an HBM round trip per 16 bytes -- every iteration, so they run with KP = 4 or 8.
-
-// output staging rows (see k_decode): which block sizes in bytes are staged, and the row length
+// Build-time knobs of k_decode for A/B runs (tests/ab_build.sh builds a variant library, AEC_AMD_LIB selects it);
+// the defaults are the measured best:
+//   AEC_STG_ROW / AEC_STG_ROW8   bytes per output staging row for 16- / 32-byte blocks and for 8-byte blocks (0 = none)
+//   AEC_DEC_UNR8 / AEC_DEC_UNR16 blocks of 8 / 16 samples decoded per top-up of the ring
+//   AEC_DEC_OU                   1 = the loop body covers a whole staging row (counted vmcnt past the row stores)
+//   AEC_DEC_MINW                 second __launch_bounds__ argument (waves per SIMD the register allocator must allow)
 #ifndef AEC_STG_ROW
 #define AEC_STG_ROW 64
 #endif
@@ -229,6 +229,10 @@ __host__ __device__ constexpr uint32_t stg_row(int blk) { return blk == 8 ? (AEC
 
 // SEG = false: work item = RSI, start bits from rsi_off.  SEG = true: work item = segment (64
 // blocks), start bit and preceding sample from the encoder's segment table.
+// kPend = 16-byte loads kept in flight per lane across one block iteration: 2 feed 256 bits per block, enough
+// for the short coded data sets of compressible data; streams that average more per block (large blocks,
+// high-entropy data: typical.dat's 64-sample blocks at 720 bits) would drain the ring and fall into the
+// synchronous refill -- an HBM round trip per 16 bytes -- every iteration, so they run with 4 or 8.
 template <int BS, int BYTES, bool SEG, int kPend>
 __global__ void __launch_bounds__(256, AEC_DEC_MINW)
 k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
