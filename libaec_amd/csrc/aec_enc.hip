@@ -520,7 +520,7 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
           uint32_t fast_ok)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: segment geometry and addresses then run on the SALU)
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const uint32_t stride = Rows<BS, BYTES>::stride_words(bs);
     uint32_t *rows = smem + (size_t)wave * Feeder<BS, BYTES>::ROWS * stride;
@@ -645,7 +645,7 @@ __device__ __forceinline__ ScanVal scan_identity() { return ScanVal{0, clamp_pac
 // EXCLUSIVE prefix and the workgroup total
 __device__ __forceinline__ ScanVal block_excl_scan(ScanVal v, ScanVal &total, ScanVal *sh /*[4]*/)
 {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: segment geometry and addresses then run on the SALU)
     ScanVal inc = v;
 #pragma unroll
     for (uint32_t o = 1; o < kWave; o <<= 1) {
@@ -859,7 +859,7 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
        uint32_t fast_ok)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: segment geometry and addresses then run on the SALU)
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const uint32_t stride = Rows<BS, BYTES>::stride_words(bs);
     const uint32_t per_wave = Feeder<BS, BYTES>::ROWS * stride + obuf_words;
@@ -1068,7 +1068,7 @@ k_encode_fused(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict
     __shared__ uint32_t sh_part;
     __shared__ ScanVal sh_agg[4], sh_excl;
     __shared__ WaveEdge sh_edge[4];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const uint32_t stride = Rows<BS, BYTES>::stride_words(bs);
     const uint32_t seg_words = 64u * stride;
