@@ -608,7 +608,14 @@ __device__ __forceinline__ uint32_t analyze_segment(const Cfg &c, const Seg &g, 
         }
     }
     tot = wave_last(wave_incl_sum(meta_len(m), lane));
-    cl = wave_last(wave_incl_clamp(clamp_pack(kc), lane));
+    // The summary of a block that updates k carries the COMPOSITION of the clamps of the segment's blocks up to
+    // and including it (not its own plateau): the pack kernel then gets the block's k as one clamp of the
+    // segment's carried-in k, without scanning the clamps a second time.
+    const uint32_t incl_c = wave_incl_clamp(clamp_pack(kc), lane);
+    cl = wave_last(incl_c);
+    const uint32_t opt = meta_opt(m);
+    // (clamp_pack is lo | hi << 8, the summary keeps them in its two upper bytes: one byte permute)
+    if (valid && opt != OPT_ZERO && opt != OPT_ZCONT && c.id_len > 1) m = __builtin_amdgcn_perm(incl_c, m, 0x05040100u);
     return m;
 }
 
@@ -797,7 +804,7 @@ k_seg_table(const Cfg c, const uint8_t *__restrict__ in, const uint64_t *__restr
 template <int BS, int BYTES>
 __device__ __forceinline__ void emit_segment(const Cfg &c, const Seg &g, const uint32_t *rows, uint32_t stride,
                                              uint32_t *obuf, uint32_t lane, uint32_t m, uint32_t kin, uint32_t lead,
-                                             uint32_t ref_sample, uint32_t pending, uint32_t &total, uint32_t &seg_cl)
+                                             uint32_t ref_sample, uint32_t pending, uint32_t &total)
 {
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const bool pp = c.flags & F_PREPROCESS;
@@ -807,12 +814,10 @@ __device__ __forceinline__ void emit_segment(const Cfg &c, const Seg &g, const u
     total = wave_last(incl);
     const uint32_t excl = incl - len;
 
+    // (the summary holds the composition of the segment's clamps up to and including this block, see
+    // analyze_segment: the block's k is one clamp of the k carried into the segment)
     const bool updates_k = valid && opt != OPT_ZERO && opt != OPT_ZCONT && c.id_len > 1;
-    const KClamp kc = updates_k ? KClamp{meta_a(m), meta_b(m)} : kclamp_identity();
-    const uint32_t incl_c = wave_incl_clamp(clamp_pack(kc), lane);
-    seg_cl = wave_last(incl_c);
-    const uint32_t excl_c = wave_shr1(incl_c, clamp_pack(kclamp_identity()));
-    const uint32_t k = kclamp_apply(kc, kclamp_apply(clamp_unpack(excl_c), kin));
+    const uint32_t k = updates_k ? kclamp_apply(KClamp{meta_a(m), meta_b(m)}, kin) : kin;
 
     // image of the segment; its first word continues the previous segment of this wave, whose
     // open tail word was kept in `pending` instead of being written out
@@ -899,8 +904,8 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
     // emission of one segment from its rows and copy-out of the image
     auto do_segment = [&](const Seg &g, const uint32_t *seg_rows, const SegIn &si, uint64_t sgi) {
         const uint32_t lead = (uint32_t)(si.start & 31u);
-        uint32_t total, seg_cl;
-        emit_segment<BS, BYTES>(c, g, seg_rows, stride, obuf, lane, si.m, si.kin, lead, si.ref_sample, pending, total, seg_cl);
+        uint32_t total;
+        emit_segment<BS, BYTES>(c, g, seg_rows, stride, obuf, lane, si.m, si.kin, lead, si.ref_sample, pending, total);
         const uint32_t nwords = (lead + total + 31u) >> 5;
 
         // Copy the image out.  Only a word this wave does not own alone needs an atomic: the first
@@ -1093,7 +1098,7 @@ k_encode_fused(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict
     // ---- phase 1: every segment of the wave analysed once; rows stay in LDS, summaries in registers
     Feeder<BS, BYTES> feeder;
     feeder.init(c, fast_ok);
-    uint32_t m[SEGS];
+    uint32_t m[SEGS], seg_cl[SEGS];
     ScanVal wagg = scan_identity();
     const Seg g0 = seg_geom(c, nseg ? sg0 : 0);
     {
@@ -1102,6 +1107,7 @@ k_encode_fused(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict
 #pragma unroll
         for (int s = 0; s < SEGS; s++) {
             m[s] = meta_pack(0, OPT_ZCONT, 0, 0);
+            seg_cl[s] = clamp_pack(kclamp_identity());
             if ((uint32_t)s < nseg) {
                 const auto cur = feeder.pre;
                 const Seg gcur = g;
@@ -1114,6 +1120,7 @@ k_encode_fused(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict
                 wave_lds_fence();
                 uint32_t tot, cl;
                 m[s] = analyze_segment<BS, BYTES>(c, gcur, rows, stride, lane, tot, cl);
+                seg_cl[s] = cl;
                 wagg = scan_then(wagg, ScanVal{tot, cl});
             }
         }
@@ -1178,9 +1185,9 @@ k_encode_fused(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict
                     }
                 }
                 const uint32_t lead = (uint32_t)(start & 31u);
-                uint32_t total, seg_cl;
+                uint32_t total;
                 emit_segment<BS, BYTES>(c, gcur, rows0 + s * seg_words, stride, obuf, lane, m[s], kin, lead, ref_sample,
-                                        pending, total, seg_cl);
+                                        pending, total);
                 const uint32_t nwords = (lead + total + 31u) >> 5;
                 const uint64_t gw = start >> 5;
                 const bool open_tail = ((lead + total) & 31u) != 0;
@@ -1199,7 +1206,7 @@ k_encode_fused(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict
                 }
                 pending = tail_word;
                 pos += total;
-                run = scan_then(run, ScanVal{total, seg_cl});
+                run = scan_then(run, ScanVal{total, seg_cl[s]});
                 wave_lds_fence();
             }
         }

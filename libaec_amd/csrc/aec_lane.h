@@ -68,7 +68,8 @@ enum : uint32_t { OPT_ZERO = 0, OPT_SE = 1, OPT_SPLIT = 2, OPT_UNCOMP = 3, OPT_Z
 //   [0:12)  CDS length in bits (<= 5 + 32 + 64*32 = 2085)
 //   [12:15) option
 //   [16:21) klo   (split plateau, or for OPT_ZERO the run's unary value, 7 bits [16:23))
-//   [24:29) khi
+//   [24:29) khi   (in HBM the kernels store, for a block that updates k, the composition of the clamps of its
+//                  segment's blocks up to and including it instead of its own plateau: aec_enc.hip analyze_segment)
 AEC_HD uint32_t meta_pack(uint32_t len, uint32_t opt, uint32_t a, uint32_t b)
 {
     return len | (opt << 12) | (a << 16) | (b << 24);
