@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--size-mib", type=int, default=256)
     ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--pageable", action="store_true", help="ordinary host memory instead of pinned buffers")
     args = ap.parse_args()
     import torch
     from libaec_amd import api
@@ -27,9 +28,10 @@ def main():
     name, kind, bps, bs, rsi, flags = bench.CONFIGS[args.config]
     n = args.size_mib << 20
     host_np = bench.generate(kind, n, 0, 8)
-    t_host = torch.from_numpy(np.asarray(host_np).view(np.uint8)[:n]).pin_memory()
-    t_enc = torch.zeros(n + n // 8 + (1 << 20), dtype=torch.uint8).pin_memory()
-    t_dec = torch.zeros(n, dtype=torch.uint8).pin_memory()
+    pin = (lambda t: t) if args.pageable else (lambda t: t.pin_memory())
+    t_host = pin(torch.from_numpy(np.asarray(host_np).view(np.uint8)[:n].copy()))
+    t_enc = pin(torch.zeros(n + n // 8 + (1 << 20), dtype=torch.uint8))
+    t_dec = pin(torch.zeros(n, dtype=torch.uint8))
     host, enc, dec = t_host.numpy(), t_enc.numpy(), t_dec.numpy()
 
     def call(fn, src, src_len, dst):
@@ -47,7 +49,7 @@ def main():
         clen, te = call("aec_buffer_encode", host, n, enc)
         dlen, td = call("aec_buffer_decode", enc, clen, dec)
         assert dlen == n and np.array_equal(dec, host)
-        print(f"{args.config} {args.size_mib} MiB call {i}: encode {te * 1e3:8.2f} ms ({n / te / 1e9:6.2f} GB/s)   "
+        print(f"{args.config} {args.size_mib} MiB {'pageable' if args.pageable else 'pinned'} call {i}: encode {te * 1e3:8.2f} ms ({n / te / 1e9:6.2f} GB/s)   "
               f"decode {td * 1e3:8.2f} ms ({n / td / 1e9:6.2f} GB/s)   stream {clen} B", flush=True)
 
 
