@@ -702,7 +702,11 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
     // loads in flight per block iteration (see kPend): sized for the average coded data set where the caller
     // knows it, for the worst case of large blocks where it does not
     const uint64_t avg = (total_blocks && !idx && !batch) ? end_bit / total_blocks : 0;
-    const int kp = BS >= 32 ? (avg == 0 || avg > 400 ? 8 : (avg > 200 ? 4 : 2)) : (avg > 200 ? 4 : 2);
+    static const char *e_kp = getenv("AEC_DEC_KP");            // (diagnostic: force 2, 4 or 8)
+    // (measured: 2 up to the 256 bits per block they feed -- C3 at 247: 2.70 ms against 2.74 with 4 --, 8 for the
+    // 720 bits of typical.dat's blocks: 5.8 ms against 7.1 with 4 and 7.8 with 2)
+    int kp = BS >= 32 ? (avg == 0 || avg > 512 ? 8 : (avg > 256 ? 4 : 2)) : (avg > 256 ? 4 : 2);
+    if (e_kp) kp = atoi(e_kp) >= 8 ? (BS >= 32 ? 8 : 4) : (atoi(e_kp) >= 4 ? 4 : 2);
 #define AEC_GO2(B, KP)                                                                                  \
     hipLaunchKernelGGL((k_decode<BS, B, SEG, KP>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
                        rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, g.needw, dump, idx, batch, rpc)
