@@ -222,17 +222,14 @@ __device__ __forceinline__ void fast_issue(const Cfg &c, const uint8_t *in, cons
     f.carry = load_sample_raw<BYTES>(in + prev * BYTES);
 }
 
-// `pair`: segments of 512 bytes fill only half the lanes of a round -- lanes 32..63 hold the 32 chunks of the
-// NEXT segment (it follows in memory), which then goes to rows 64..127 in the same pass (ref2: that segment
-// starts an RSI); the caller has checked that both segments are whole.
 template <int BS, int BYTES>
 __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const FastSeg<BS, BYTES> &f,
-                                            uint32_t *rows, uint32_t lane, bool pair = false, bool ref2 = false)
+                                            uint32_t *rows, uint32_t lane)
 {
     constexpr uint32_t SPC = 16 / BYTES;           // samples per chunk
     constexpr uint32_t STRIDE = Rows<BS, BYTES>::stride_words(BS);
     const bool msb = c.flags & F_MSB, pp = c.flags & F_PREPROCESS;
-    const uint32_t nchunks = g.nv * (uint32_t)BS * BYTES / 16u * (pair ? 2u : 1u);
+    const uint32_t nchunks = g.nv * (uint32_t)BS * BYTES / 16u;
     uint32_t carry = sample_byte_order<BYTES>(f.carry, msb);
 
 #pragma unroll
@@ -279,7 +276,6 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
                 for (uint32_t j = 0; j < NW; j++)
                     dw[j] = pp_unsigned_pk(__builtin_amdgcn_alignbit(pw[j], j ? pw[j - 1] : before, 16), pw[j], xm);
                 if (g.b0 == 0 && ci == 0) dw[0] &= 0xFFFF0000u;      // reference sample slot, encode.c:254
-                if (ref2 && ci == FastSeg<BS, BYTES>::CHUNKS) dw[0] &= 0xFFFF0000u;
 #pragma unroll
                 for (uint32_t q = 0; q < NW / 4; q++) {
                     const uint32_t i = ci * SPC + q * 8;
@@ -327,7 +323,6 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
                 for (uint32_t j = 0; j < SPC; j++) dd[j] = pp_unsigned(j ? x[j - 1] : prev, x[j], c.xmax);
             }
             if (pp && g.b0 == 0 && ci == 0) dd[0] = 0;   // reference sample slot, encode.c:254
-            if (pp && ref2 && ci == FastSeg<BS, BYTES>::CHUNKS) dd[0] = 0;
             if (Rows<BS, BYTES>::HALF) {
 #pragma unroll
                 for (uint32_t q = 0; q < SPC / 8; q++) {
@@ -348,6 +343,78 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
             }
         }
     }
+}
+
+// ---- phase A, direct path: blocks of at most 32 bytes of samples of at most 16 bits ------------------
+// Every lane loads ITS block (lane = block from the start: no chunk -> row transposition through the LDS),
+// maps it with the packed predictor in its own registers -- the sample before the block comes from the
+// neighbour lane -- and hands the sample pairs to the analysis / emission as they are.  The differential
+// profile (profiles/r02/differential_profile_c2.txt) put the LDS feed at 0.69 + 0.78 ms of the 3.6 ms the two
+// encoder kernels take at C2; most of it was not the predictor but the way through the rows.
+template <int BS, int BYTES>
+struct DirectSeg {
+    static constexpr uint32_t NRAW = (uint32_t)BS * BYTES / 4u;      // 2, 4 or 8 words per block
+    uint32_t raw[NRAW];
+    uint32_t carry;   // sample just before the segment, as loaded
+};
+
+// max_blk = index of the last whole block of the input (lanes beyond the segment re-read a valid block)
+template <int BS, int BYTES>
+__device__ __forceinline__ void direct_issue(const Cfg &c, const uint8_t *in, const Seg &g, uint32_t lane,
+                                             uint64_t max_blk, DirectSeg<BS, BYTES> &f)
+{
+    constexpr uint32_t BLK = (uint32_t)BS * BYTES;
+    uint64_t bi = g.blk0 + lane;
+    if (bi > max_blk) bi = max_blk;
+    const uint8_t *p = in + bi * BLK;
+    if (BLK == 8) {
+        const uint2 a = *reinterpret_cast<const uint2 *>(p);
+        f.raw[0] = a.x; f.raw[1] = a.y;
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < BLK / 16u; q++) {
+            const uint4 a = reinterpret_cast<const uint4 *>(p)[q];
+            f.raw[4 * q] = a.x; f.raw[4 * q + 1] = a.y; f.raw[4 * q + 2] = a.z; f.raw[4 * q + 3] = a.w;
+        }
+    }
+    const uint64_t prev = g.samp0 ? g.samp0 - 1 : 0;
+    f.carry = load_sample_raw<BYTES>(in + prev * BYTES);
+}
+
+// the lane's block as BS / 2 words of two mapped 16-bit samples each (what the uint16 rows hold)
+template <int BS, int BYTES>
+__device__ __forceinline__ void direct_finish(const Cfg &c, const Seg &g, const DirectSeg<BS, BYTES> &f,
+                                              uint32_t lane, uint32_t *w)
+{
+    constexpr uint32_t NW = (uint32_t)BS / 2u;
+    const bool msb = c.flags & F_MSB, sgn = c.flags & F_SIGNED;
+    uint32_t pw[NW];
+    if (BYTES == 2) {
+#pragma unroll
+        for (uint32_t j = 0; j < NW; j++)
+            pw[j] = msb ? (((f.raw[j] & 0x00FF00FFu) << 8) | ((f.raw[j] >> 8) & 0x00FF00FFu)) : f.raw[j];
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < NW / 2u; j++) {      // bytes 0,1 and 2,3 widened to 16 bits each
+            pw[2 * j] = __builtin_amdgcn_perm(0u, f.raw[j], 0x0c010c00u);
+            pw[2 * j + 1] = __builtin_amdgcn_perm(0u, f.raw[j], 0x0c030c02u);
+        }
+    }
+    // signed samples biased by 2^(bps-1) as in fast_finish
+    const uint32_t full = low_mask32(c.bps);
+    uint32_t carry = sample_byte_order<BYTES>(f.carry, msb);
+    if (sgn) {
+        const uint32_t flip = (1u << (c.bps - 1)) * 0x00010001u, keep = full * 0x00010001u;
+#pragma unroll
+        for (uint32_t j = 0; j < NW; j++) pw[j] = (pw[j] ^ flip) & keep;
+        carry = (carry ^ (1u << (c.bps - 1))) & full;
+    }
+    const uint32_t before = wave_shr1(pw[NW - 1], carry << 16);
+    const uint32_t xm = (sgn ? full : c.xmax) * 0x00010001u;
+#pragma unroll
+    for (uint32_t j = 0; j < NW; j++)
+        w[j] = pp_unsigned_pk(__builtin_amdgcn_alignbit(pw[j], j ? pw[j - 1] : before, 16), pw[j], xm);
+    if (g.b0 == 0 && lane == 0) w[0] &= 0xFFFF0000u;      // reference sample slot, encode.c:254
 }
 
 // ---- phase A, generic path: lane = sample, byte loads, end-of-data padding -------------------
@@ -383,9 +450,6 @@ struct Feeder {
     static constexpr int FBS = FAST_T ? BS : 8, FBY = FAST_T ? BYTES : 1;
     // prefetch across segments only while it is cheap in registers (<= 4 x 16 bytes per lane)
     static constexpr bool PIPE = FAST_T && FastSeg<FBS, FBY>::NIT <= 4;
-    // 512-byte segments (8 samples of one byte per block): two of them per feed, see fast_finish
-    static constexpr bool PAIR = PIPE && FastSeg<FBS, FBY>::CHUNKS == 32;
-    static constexpr uint32_t ROWS = PAIR ? 128u : 64u;
     FastSeg<(PIPE ? FBS : 8), (PIPE ? FBY : 1)> pre;
     bool fast;            // run-time half of the decision (alignment, at least one whole chunk)
     uint64_t max_chunk;
@@ -395,6 +459,9 @@ struct Feeder {
         const uint64_t total_bytes = c.total_samples * c.bytes;
         fast = FAST_T && fast_ok && total_bytes >= 16;
         max_chunk = total_bytes >= 16 ? total_bytes / 16 - 1 : 0;
+        const uint64_t whole_blocks = c.total_samples / (BS ? (uint32_t)BS : c.bs);
+        max_blk = whole_blocks ? whole_blocks - 1 : 0;
+        if (whole_blocks == 0) fast = false;
     }
     __device__ __forceinline__ void prefetch(const Cfg &c, const uint8_t *in, const Seg &g, uint32_t lane)
     {
@@ -402,19 +469,43 @@ struct Feeder {
             if (fast) fast_issue<(PIPE ? FBS : 8), (PIPE ? FBY : 1)>(c, in, g, lane, max_chunk, pre);
         }
     }
-    // both segments whole, the second right behind the first: one feed serves both
-    __device__ __forceinline__ bool can_pair(const Seg &g, const Seg &g2) const
+    // ---- direct path (see DirectSeg): kernels that take it prefetch with prefetch_direct and fall back to
+    // feed_now for the segments it does not cover (end-of-data padding, no preprocessing)
+    static constexpr bool DIRECT = FAST_T && Rows<BS, BYTES>::HALF && BS * BYTES <= 32;
+    DirectSeg<(DIRECT ? BS : 8), (DIRECT ? BYTES : 1)> pre_direct;
+    uint64_t max_blk;
+    __device__ __forceinline__ bool direct_ok(const Cfg &c, const Seg &g) const
     {
-        return PAIR && fast && g.full && g.nv == 64u && g2.full && g2.nv == 64u;
+        return DIRECT && fast && g.full && (c.flags & F_PREPROCESS);
+    }
+    __device__ __forceinline__ void prefetch_direct(const Cfg &c, const uint8_t *in, const Seg &g, uint32_t lane)
+    {
+        if (DIRECT) {
+            if (fast) direct_issue<(DIRECT ? BS : 8), (DIRECT ? BYTES : 1)>(c, in, g, lane, max_blk, pre_direct);
+        }
+    }
+    // rows of g without a prefetch (fallback of the direct kernels)
+    __device__ __forceinline__ void feed_now(const Cfg &c, const uint8_t *in, const Seg &g, uint32_t *rows,
+                                             uint32_t stride, uint32_t lane)
+    {
+        if (FAST_T) {
+            if (fast && g.full) {
+                FastSeg<FBS, FBY> now;
+                fast_issue<FBS, FBY>(c, in, g, lane, max_chunk, now);
+                fast_finish<FBS, FBY>(c, g, now, rows, lane);
+                return;
+            }
+        }
+        load_segment_generic<BS, BYTES>(c, in, g, rows, stride, lane);
     }
     // consumes the registers prefetched for g (call prefetch(next) BEFORE this to overlap)
     __device__ __forceinline__ void feed(const Cfg &c, const uint8_t *in, const Seg &g,
                                          const FastSeg<(PIPE ? FBS : 8), (PIPE ? FBY : 1)> &cur, uint32_t *rows,
-                                         uint32_t stride, uint32_t lane, bool pair = false, bool ref2 = false)
+                                         uint32_t stride, uint32_t lane)
     {
         if (PIPE) {
             if (fast && g.full) {
-                fast_finish<(PIPE ? FBS : 8), (PIPE ? FBY : 1)>(c, g, cur, rows, lane, pair, ref2);
+                fast_finish<(PIPE ? FBS : 8), (PIPE ? FBY : 1)>(c, g, cur, rows, lane);
                 return;
             }
         } else if (FAST_T) {
@@ -511,7 +602,8 @@ __device__ __forceinline__ BlockChoice choose_option_pk(const uint32_t *w, const
 template <int BS, int BYTES>
 __device__ __forceinline__ void analyze_body(const Cfg &c, const Seg &g, uint32_t *rows, uint32_t stride,
                                              uint32_t lane, uint64_t sg, uint32_t *__restrict__ meta,
-                                             uint32_t *__restrict__ seg_bits, uint16_t *__restrict__ seg_clamp);
+                                             uint32_t *__restrict__ seg_bits, uint16_t *__restrict__ seg_clamp,
+                                             const uint32_t *direct = nullptr);
 
 template <int BS, int BYTES>
 __global__ void __launch_bounds__(256)
@@ -523,7 +615,7 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: segment geometry and addresses then run on the SALU)
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const uint32_t stride = Rows<BS, BYTES>::stride_words(bs);
-    uint32_t *rows = smem + (size_t)wave * Feeder<BS, BYTES>::ROWS * stride;
+    uint32_t *rows = smem + (size_t)wave * 64u * stride;
 
     const uint64_t gwave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     uint64_t sg = gwave * segs_per_wave;
@@ -533,23 +625,33 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
     Feeder<BS, BYTES> feeder;
     feeder.init(c, fast_ok);
     Seg g = seg_geom(c, sg < sg_end ? sg : 0);
+    if (Feeder<BS, BYTES>::DIRECT) {
+        // small blocks: lane = block from the load on, nothing goes through the rows (Feeder::DIRECT)
+        if (sg < sg_end) feeder.prefetch_direct(c, in, g, lane);
+        for (; sg < sg_end; sg++) {
+            const auto cur = feeder.pre_direct;
+            const Seg gcur = g;
+            if (sg + 1 < sg_end) g = seg_next(c, g);
+            feeder.prefetch_direct(c, in, g, lane);       // the next segment's loads fly during this one
+            if (feeder.direct_ok(c, gcur)) {
+                uint32_t w[BS ? BS / 2 : 1];
+                direct_finish<(Feeder<BS, BYTES>::DIRECT ? BS : 8), (Feeder<BS, BYTES>::DIRECT ? BYTES : 1)>(c, gcur, cur, lane, w);
+                analyze_body<BS, BYTES>(c, gcur, rows, stride, lane, sg, meta, seg_bits, seg_clamp, w);
+            } else {
+                feeder.feed_now(c, in, gcur, rows, stride, lane);
+                analyze_body<BS, BYTES>(c, gcur, rows, stride, lane, sg, meta, seg_bits, seg_clamp);
+            }
+        }
+        return;
+    }
     if (sg < sg_end) feeder.prefetch(c, in, g, lane);
-    while (sg < sg_end) {
+    for (; sg < sg_end; sg++) {
         const auto cur = feeder.pre;
         const Seg gcur = g;
-        Seg g2 = gcur;
-        bool pair = false;
-        if (sg + 1 < sg_end) {
-            g2 = seg_next(c, gcur);
-            pair = feeder.can_pair(gcur, g2);
-        }
-        const uint64_t adv = pair ? 2u : 1u;
-        if (sg + adv < sg_end) g = pair ? seg_next(c, g2) : g2;
-        feeder.prefetch(c, in, g, lane);          // the next segment's loads fly during this one
-        feeder.feed(c, in, gcur, cur, rows, stride, lane, pair, pair && g2.b0 == 0);
+        if (sg + 1 < sg_end) g = seg_next(c, g);
+        feeder.prefetch(c, in, g, lane);          // next segment's loads fly during this one
+        feeder.feed(c, in, gcur, cur, rows, stride, lane);
         analyze_body<BS, BYTES>(c, gcur, rows, stride, lane, sg, meta, seg_bits, seg_clamp);
-        if (pair) analyze_body<BS, BYTES>(c, g2, rows + 64u * stride, stride, lane, sg + 1, meta, seg_bits, seg_clamp);
-        sg += adv;
     }
 }
 
@@ -557,7 +659,8 @@ k_analyze(const Cfg c, const uint8_t *__restrict__ in, uint32_t *__restrict__ me
 // bit length and its k clamp (lo | hi << 8), both wave-uniform.
 template <int BS, int BYTES>
 __device__ __forceinline__ uint32_t analyze_segment(const Cfg &c, const Seg &g, const uint32_t *rows, uint32_t stride,
-                                                    uint32_t lane, uint32_t &tot, uint32_t &cl)
+                                                    uint32_t lane, uint32_t &tot, uint32_t &cl,
+                                                    const uint32_t *direct = nullptr)   // the lane's block from direct_finish
 {
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const bool pp = c.flags & F_PREPROCESS;
@@ -572,10 +675,15 @@ __device__ __forceinline__ uint32_t analyze_segment(const Cfg &c, const Seg &g, 
     const uint32_t *d = nullptr;
     bool zero;
     if (PK) {
+        if (direct) {
 #pragma unroll
-        for (int q = 0; q < (PK ? BS / 8 : 0); q++) {
-            const uint4 t = *reinterpret_cast<const uint4 *>(row + 4 * q);
-            w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+            for (int j = 0; j < (PK ? BS / 2 : 0); j++) w[j] = direct[j];
+        } else {
+#pragma unroll
+            for (int q = 0; q < (PK ? BS / 8 : 0); q++) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(row + 4 * q);
+                w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+            }
         }
         uint32_t any = 0;
 #pragma unroll
@@ -622,11 +730,12 @@ __device__ __forceinline__ uint32_t analyze_segment(const Cfg &c, const Seg &g, 
 template <int BS, int BYTES>
 __device__ __forceinline__ void analyze_body(const Cfg &c, const Seg &g, uint32_t *rows, uint32_t stride,
                                              uint32_t lane, uint64_t sg, uint32_t *__restrict__ meta,
-                                             uint32_t *__restrict__ seg_bits, uint16_t *__restrict__ seg_clamp)
+                                             uint32_t *__restrict__ seg_bits, uint16_t *__restrict__ seg_clamp,
+                                             const uint32_t *direct)
 {
     wave_lds_fence();
     uint32_t tot, cl;
-    const uint32_t m = analyze_segment<BS, BYTES>(c, g, rows, stride, lane, tot, cl);
+    const uint32_t m = analyze_segment<BS, BYTES>(c, g, rows, stride, lane, tot, cl, direct);
     if (lane < g.nv) meta[g.blk0 + lane] = m;
     if (lane == 0) {
         seg_bits[sg] = tot;
@@ -804,7 +913,8 @@ k_seg_table(const Cfg c, const uint8_t *__restrict__ in, const uint64_t *__restr
 template <int BS, int BYTES>
 __device__ __forceinline__ void emit_segment(const Cfg &c, const Seg &g, const uint32_t *rows, uint32_t stride,
                                              uint32_t *obuf, uint32_t lane, uint32_t m, uint32_t kin, uint32_t lead,
-                                             uint32_t ref_sample, uint32_t pending, uint32_t &total)
+                                             uint32_t ref_sample, uint32_t pending, uint32_t &total,
+                                             const uint32_t *direct = nullptr)   // the lane's block from direct_finish
 {
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const bool pp = c.flags & F_PREPROCESS;
@@ -828,7 +938,18 @@ __device__ __forceinline__ void emit_segment(const Cfg &c, const Seg &g, const u
         const uint32_t ref = (pp && g.b0 == 0 && lane == 0) ? 1u : 0u;
         const uint32_t karg = opt == OPT_ZERO ? meta_a(m) : k;
         BlockRegs<BS, Rows<BS, BYTES>::HALF> regs;
-        const uint32_t *d = regs.load(rows + (valid ? lane : 0u) * stride);
+        const uint32_t *d;
+        uint32_t dv[BS ? BS : 1];
+        if (direct && BS > 0 && Rows<BS, BYTES>::HALF) {
+#pragma unroll
+            for (int j = 0; j < (BS ? BS / 2 : 0); j++) {
+                dv[2 * j] = direct[j] & 0xFFFFu;
+                dv[2 * j + 1] = direct[j] >> 16;
+            }
+            d = dv;
+        } else {
+            d = regs.load(rows + (valid ? lane : 0u) * stride);
+        }
         LdsSink sink{obuf};
         BitWriter<LdsSink> bw(sink, lead + excl);
         bool done = !emits;
@@ -867,9 +988,9 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: segment geometry and addresses then run on the SALU)
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const uint32_t stride = Rows<BS, BYTES>::stride_words(bs);
-    const uint32_t per_wave = Feeder<BS, BYTES>::ROWS * stride + obuf_words;
+    const uint32_t per_wave = 64u * stride + obuf_words;
     uint32_t *rows = smem + (size_t)wave * per_wave;
-    uint32_t *obuf = rows + Feeder<BS, BYTES>::ROWS * stride;
+    uint32_t *obuf = rows + 64u * stride;
     const bool pp = c.flags & F_PREPROCESS, msb = c.flags & F_MSB;
 
     const uint64_t gwave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -880,7 +1001,10 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
     Feeder<BS, BYTES> feeder;
     feeder.init(c, fast_ok);
     Seg gnext = seg_geom(c, sg < sg_end ? sg : 0);
-    if (sg < sg_end) feeder.prefetch(c, in, gnext, lane);
+    if (sg < sg_end) {
+        if (Feeder<BS, BYTES>::DIRECT) feeder.prefetch_direct(c, in, gnext, lane);
+        else feeder.prefetch(c, in, gnext, lane);
+    }
     uint32_t pending = 0;        // open tail word of the previous segment (stream bit order)
     bool first_seg = true, carried_shared = false;
     // the image buffer starts out zero and every word is zeroed again when it is copied out
@@ -902,10 +1026,10 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
         return r;
     };
     // emission of one segment from its rows and copy-out of the image
-    auto do_segment = [&](const Seg &g, const uint32_t *seg_rows, const SegIn &si, uint64_t sgi) {
+    auto do_segment = [&](const Seg &g, const uint32_t *seg_rows, const SegIn &si, uint64_t sgi, const uint32_t *direct) {
         const uint32_t lead = (uint32_t)(si.start & 31u);
         uint32_t total;
-        emit_segment<BS, BYTES>(c, g, seg_rows, stride, obuf, lane, si.m, si.kin, lead, si.ref_sample, pending, total);
+        emit_segment<BS, BYTES>(c, g, seg_rows, stride, obuf, lane, si.m, si.kin, lead, si.ref_sample, pending, total, direct);
         const uint32_t nwords = (lead + total + 31u) >> 5;
 
         // Copy the image out.  Only a word this wave does not own alone needs an atomic: the first
@@ -939,27 +1063,35 @@ k_pack(const Cfg c, const uint8_t *__restrict__ in, const uint32_t *__restrict__
         wave_lds_fence();
     };
 
-    while (sg < sg_end) {
+    if (Feeder<BS, BYTES>::DIRECT) {
+        // small blocks: lane = block from the load on, nothing goes through the rows (Feeder::DIRECT)
+        for (; sg < sg_end; sg++) {
+            const auto cur = feeder.pre_direct;
+            const Seg g = gnext;
+            const SegIn si = seg_in(g, sg);
+            if (sg + 1 < sg_end) gnext = seg_next(c, gnext);
+            feeder.prefetch_direct(c, in, gnext, lane);   // the next segment's loads fly during this one
+            if (feeder.direct_ok(c, g)) {
+                uint32_t w[BS ? BS / 2 : 1];
+                direct_finish<(Feeder<BS, BYTES>::DIRECT ? BS : 8), (Feeder<BS, BYTES>::DIRECT ? BYTES : 1)>(c, g, cur, lane, w);
+                do_segment(g, rows, si, sg, w);
+            } else {
+                feeder.feed_now(c, in, g, rows, stride, lane);
+                do_segment(g, rows, si, sg, nullptr);
+            }
+        }
+        return;
+    }
+    for (; sg < sg_end; sg++) {
         const auto cur = feeder.pre;
         const Seg g = gnext;
-        Seg g2 = g;
-        bool pair = false;
-        if (sg + 1 < sg_end) {
-            g2 = seg_next(c, g);
-            pair = feeder.can_pair(g, g2);
-        }
-        const uint64_t adv = pair ? 2u : 1u;
         // everything this segment needs from HBM is requested before the first wait (requesting the
         // summaries a segment ahead as well was tried: no gain, two registers too many)
         const SegIn si = seg_in(g, sg);
-        SegIn si2 = si;
-        if (pair) si2 = seg_in(g2, sg + 1);
-        if (sg + adv < sg_end) gnext = pair ? seg_next(c, g2) : g2;
+        if (sg + 1 < sg_end) gnext = seg_next(c, gnext);
         feeder.prefetch(c, in, gnext, lane);      // next segment's loads fly during this one
-        feeder.feed(c, in, g, cur, rows, stride, lane, pair, pair && g2.b0 == 0);
-        do_segment(g, rows, si, sg);
-        if (pair) do_segment(g2, rows + 64u * stride, si2, sg + 1);
-        sg += adv;
+        feeder.feed(c, in, g, cur, rows, stride, lane);
+        do_segment(g, rows, si, sg, nullptr);
     }
 }
 
@@ -1321,9 +1453,7 @@ LaunchGeom make_geom(const Cfg &c, bool with_obuf)
     const uint32_t stride = (templated && c.bytes <= 2) ? c.bs / 2 + 4 : c.bs + 4;   // Rows<>::stride_words
     const uint32_t maxlen = c.id_len + c.bs * c.bps + 2 + c.bps;
     g.obuf_words = with_obuf ? ((64u * maxlen + 62u) / 32u + 4u) & ~3u : 0u;
-    // (512-byte segments are fed two at a time: 128 rows, see Feeder::PAIR)
-    const uint32_t rows = (templated && c.bs * c.bytes == 8) ? 128u : 64u;
-    const size_t per_wave = ((size_t)rows * stride + g.obuf_words) * 4;
+    const size_t per_wave = ((size_t)64 * stride + g.obuf_words) * 4;
     uint32_t wpb = (uint32_t)(65536 / per_wave);
     if (wpb > 4) wpb = 4;
     if (wpb < 1) wpb = 1;

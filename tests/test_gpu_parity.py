@@ -117,11 +117,12 @@ def test_random_sweep_vs_oracle(api):
         check_roundtrip(api, f"it{it}-n{bps}-j{bs}-r{rsi}-f{flags}-len{n}", bps, bs, rsi, flags, data)
 
 
-def test_eight_byte_blocks_fed_in_pairs(api):
-    """Blocks of 8 one-byte samples: a segment is 512 bytes, half a round of 16-byte chunks, and the encoder
-    feeds two segments per round (aec_enc.hip Feeder::PAIR).  Every way two neighbouring segments can relate:
-    same RSI, the second starting an RSI (reference sample slot), a short segment in between (no pairing),
-    odd segment counts per wave, end of data inside a pair; unsigned / signed / MSB / without preprocessing."""
+def test_small_blocks_direct_feed(api):
+    """Blocks of at most 32 bytes take the encoder's direct path (aec_enc.hip Feeder::DIRECT: every lane loads
+    its own block, the sample in front of it comes from the neighbour lane).  Blocks of 8 one-byte samples in
+    every relation two neighbouring segments can have: same RSI, the second starting an RSI (reference sample
+    slot), short segments in between, odd segment counts per wave, end of data inside a segment; unsigned /
+    signed / MSB / without preprocessing (which falls back to the rows in LDS)."""
     rng = np.random.default_rng(88)
     for bps in (8, 7, 3):
         for rsi in (64, 128, 65, 130, 192, 1, 4096):
@@ -131,7 +132,7 @@ def test_eight_byte_blocks_fed_in_pairs(api):
                 vals = random_walk_samples(rng, n, bps, flags, scale=float(rng.choice([0.5, 3.0])), zero_frac=0.2)
                 data = pack_samples(vals, bps, flags)
                 check_roundtrip(api, f"pair-n{bps}-r{rsi}-f{flags}-len{n}", bps, 8, rsi, flags, data)
-    # pairs only form where a wave walks several segments, i.e. in inputs of some size
+    # inputs of some size: a wave walks several segments (prefetch of the next one beside the current)
     for rsi, flags in ((128, PP), (64, PP | SGN), (65, PP), (130, PP | MSB), (4096, 0), (192, PP)):
         n = (16 << 20) + 8 * 37 + 3
         vals = random_walk_samples(rng, n, 8, flags, scale=2.0, zero_frac=0.2)
