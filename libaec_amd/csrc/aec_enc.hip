@@ -25,6 +25,10 @@
 #include "aec_kernels.h"
 #include "aec_lane.h"
 
+// (grouped emission for 64-sample blocks: measured slower -- typical.dat shape 4.53 against 4.36 ms)
+#ifndef AEC_ENC_GRP64
+#define AEC_ENC_GRP64 0
+#endif
 namespace aec {
 
 namespace {
@@ -960,11 +964,11 @@ __device__ __forceinline__ void emit_segment(const Cfg &c, const Seg &g, const u
             emit_small<(BS > 0 && BS <= 16 ? BS : 8)>(bw, d, c, opt, karg, ref, ref_sample, ubits, fbits, small);
             done = done || small;
         }
-        if (BS == 32) {
-            // blocks of 32: the split option appended in groups (aec_lane.h emit_split_groups;
-            // C3 pack 2.40 -> 2.19 ms.  For blocks of 64 it costs registers and was slower.)
+        if (BS == 32 || (BS == 64 && AEC_ENC_GRP64)) {
+            // blocks of 32 (and 64): the split option appended in groups (aec_lane.h emit_split_groups;
+            // C3 pack 2.40 -> 2.19 ms)
             const bool grp = !done && opt == OPT_SPLIT;
-            emit_split_groups<32>(bw, d, c, karg, ref, ref_sample, grp);
+            emit_split_groups<(BS == 32 || BS == 64 ? BS : 32)>(bw, d, c, karg, ref, ref_sample, grp);
             done = done || grp;
         }
         if (__any(!done)) {

@@ -404,6 +404,15 @@ AEC_HD void emit_split_groups(BitWriter<Sink> &w, const uint32_t *d, const Cfg &
             if (bits > 32u) w.put((uint32_t)(fa >> 32), bits - 32u);
             w.put((uint32_t)fa, bits > 32u ? 32u : bits);
         }
+    } else if (k != 0 && k <= 16u) {
+        // fields of 9..16 bits: two per put
+        const uint32_t m = low_mask32(k);
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)BS; i += 2) {
+            const bool skip = i == 0 && ref;
+            const uint32_t a = skip ? 0u : d[i] & m;
+            w.put((a << k) | (d[i + 1] & m), skip ? k : 2u * k);
+        }
     } else if (k != 0) {
         const uint32_t m = low_mask32(k);
 #pragma unroll
@@ -424,10 +433,44 @@ AEC_HD void emit_block(BitWriter<Sink> &w, const uint32_t *d, const Cfg &c, uint
         const uint32_t k = k_or_fs;
         w.put(k + 1u, c.id_len);
         if (ref) w.put(ref_sample, c.bps);
+        if (BS != 0 && BS % 4 == 0) {
+            // fundamental sequences four at a time: one put while the four codes fit 32 bits
 #pragma unroll
-        for (uint32_t i = 0; i < bs; i++)
-            if (i >= ref) w.unary(d[i] >> k);
-        if (k) {
+            for (uint32_t i = 0; i < bs; i += 4) {
+                uint32_t v = 0, bits = 0;
+                bool wide = false;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const bool skip = i + j == 0 && ref;            // the reference slot carries no code
+                    const uint32_t t = d[i + j] >> k;
+                    wide = wide || (!skip && t >= 8u);
+                    const uint32_t n1 = skip ? 0u : (t & 7u) + 1u;
+                    v = (v << n1) | (skip ? 0u : 1u);
+                    bits += n1;
+                }
+                if (!wide) {
+                    if (bits) w.put(v, bits);
+                } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; j++)
+                        if (!(i + j == 0 && ref)) w.unary(d[i + j] >> k);
+                }
+            }
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < bs; i++)
+                if (i >= ref) w.unary(d[i] >> k);
+        }
+        if (k != 0 && k <= 16u && BS != 0) {
+            // fields of up to 16 bits: two per put
+            const uint32_t m = low_mask32(k);
+#pragma unroll
+            for (uint32_t i = 0; i < bs; i += 2) {
+                const bool skip = i == 0 && ref;
+                const uint32_t a = skip ? 0u : d[i] & m;
+                w.put((a << k) | (d[i + 1] & m), skip ? k : 2u * k);
+            }
+        } else if (k) {
             const uint32_t m = low_mask32(k);
 #pragma unroll
             for (uint32_t i = 0; i < bs; i++)
