@@ -487,9 +487,18 @@ AEC_HD void emit_block(BitWriter<Sink> &w, const uint32_t *d, const Cfg &c, uint
     } else if (opt == OPT_UNCOMP) {
         const uint32_t m = low_mask32(c.bps);
         w.put((1u << c.id_len) - 1u, c.id_len);
+        if (BS != 0 && c.bps <= 16u) {
+            // samples of up to 16 bits: two per put
 #pragma unroll
-        for (uint32_t i = 0; i < bs; i++)
-            w.put((i == 0 && ref) ? ref_sample : (d[i] & m), c.bps);
+            for (uint32_t i = 0; i < bs; i += 2) {
+                const uint32_t a = (i == 0 && ref) ? ref_sample : (d[i] & m);
+                w.put((a << c.bps) | (d[i + 1] & m), 2u * c.bps);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < bs; i++)
+                w.put((i == 0 && ref) ? ref_sample : (d[i] & m), c.bps);
+        }
     } else if (opt == OPT_ZERO) {
         w.put(0u, c.id_len + 1u);
         if (ref) w.put(ref_sample, c.bps);
