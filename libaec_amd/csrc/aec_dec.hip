@@ -660,7 +660,12 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, uint32_t s
     while (rw < 2 * g.maxw + 3) rw <<= 1;
     g.needw = g.maxw;
     // half ring: after a full refill at least rw/2 - 3 words lie ahead of any position
-    if (rw >= 32 && g.maxw <= rw / 2 - 3 && avg_cds_bits && avg_cds_bits * 4 <= (uint64_t)rw / 2 * 32) {
+    // (how many average coded data sets half of the half ring -- its steady-state look-ahead -- must hold: 2.  With
+    // 4, typical.dat's 720-bit blocks of 64 samples kept the full ring, 33 KB per wave and 4 waves per CU: 5.8 ms;
+    // on the half ring 3.3 ms, the second attempts included.  AEC_DEC_HALF_FACTOR overrides, for measurements.)
+    static const char *e_hf = getenv("AEC_DEC_HALF_FACTOR");
+    const uint64_t hf = e_hf ? (uint64_t)atoi(e_hf) : 2;
+    if (rw >= 32 && g.maxw <= rw / 2 - 3 && avg_cds_bits && avg_cds_bits * hf <= (uint64_t)rw / 2 * 32) {
         rw /= 2;
         g.needw = rw / 2;
     }
