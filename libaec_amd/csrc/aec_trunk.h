@@ -1,0 +1,596 @@
+// aec_trunk.h -- TRUNK index of a bare stream: per-lane arithmetic (aec_idx.hip: k_trunk, k_trunk_scan,
+// k_hyp_walk, k_hyp_land, k_hyp_chain).
+//
+// A bare CCSDS 121.0-B-2 stream has no entry points: a coded data set (CDS) is found by parsing its
+// predecessor (reference src/decode.c:402-421), and where an RSI starts decides how its first CDS is
+// parsed (reference sample, decode.c:407-411, 462-502) and how long a rest-of-segment zero run is
+// (decode.c:528-530).  The serial walk is replaced by three lane-parallel passes over the stream:
+//
+//   1. TRUNK.  The CDS parse WITHOUT a reference sample ("N-step") self-synchronises like any prefix
+//      code: started at an arbitrary bit it falls onto the true chain of CDS boundaries after a number
+//      of codes of the order of the CDS length in bits.  One lane per window of the stream starts
+//      `lead` bits in front of its window, burns in, and then records every boundary it visits inside
+//      the window: the NODES of the trunk, each with the blocks its CDS covers.  A window whose chain
+//      does not begin where the chain of the window before it ended is a SEAM.  A scan over the
+//      windows numbers the blocks along the trunk (G), so "the node n blocks behind node x" is a
+//      search for G(x) + n -- exact inside a seamless stretch, because there the trunk is ONE path
+//      closed under the N-step.
+//   2. HYPOTHESES.  The trunk is wrong behind every RSI start (it parsed the CDS that carries the
+//      reference sample without one) until it has synchronised again, and it does not know where the
+//      RSIs start.  So every node is tried as an RSI start: parse the first CDS with the reference
+//      sample, parse on (on demand, with the exact block count, rest-of-segment runs included) until
+//      the walk stands on a node of the trunk, then jump the remaining blocks by G.  A walk that
+//      completes its RSI before it meets the trunk goes straight on with the next RSI (up to kTrMaxK),
+//      so that every record ends on a node: the walker never needs a position that is not one, and the
+//      trunk only has to be met once in a while -- it need not be the true chain (where the coded data
+//      sets are long it rarely is).  The RSI starts inside such a record are parsed again, by the lane
+//      that expands it, only for the records the true walk really takes.
+//   3. CHAINS of records inside a window, then the existing wide / serial walkers over windows.
+//
+// Exactness: every record is the exact value of the reference's walk from its node (the trunk only
+// selects WHERE records exist and serves jumps it is closed under); the walkers read records at true
+// RSI starts only and fall back to the serial CDS walk where one is missing.  Everything here is
+// __host__ __device__: tests/emul runs it lane by lane on the CPU against the oracle.
+#pragma once
+
+#include "aec_spec.h"
+
+#ifndef TR_DBG
+#define TR_DBG(...) ((void)0)
+#endif
+
+namespace aec {
+
+constexpr uint32_t kTrMaxK = 63;              // RSIs one record may cover
+constexpr uint32_t kTrMaxScan = 8192;         // longest unary region a table parse follows (bits)
+constexpr uint64_t kTrNone = ~0ull;
+
+// per-node word: bits [0,30) = blocks of the window's nodes in front of this one, [30,32) = kind
+constexpr uint32_t kTrBpMask = 0x3FFFFFFFu;
+constexpr uint32_t kTrRos = 1u;               // rest-of-segment zero run: covers what its RSI position says
+constexpr uint32_t kTrDead = 2u;              // no CDS ends inside the stream from here
+
+struct TrStream {
+    const uint32_t *words;     // big-endian 32-bit words, 4-byte aligned
+    uint64_t nwords;           // readable words (>= 1)
+    uint64_t end_bit;          // bits that belong to the stream
+};
+
+struct TrGeom {
+    uint64_t lo;               // bit position of window 0 (multiple of L)
+    uint64_t start_bit;        // where the stream (or the resumed walk) starts: a true CDS boundary
+    uint32_t L;                // bits per window, multiple of 32, <= 65536
+    uint32_t lead;             // burn-in in front of a region (bits)
+    uint32_t ncap;             // node records in all (the windows' nodes are stored back to back)
+    uint32_t rw;               // windows per region (one trunk lane)
+    uint32_t nwin;             // windows with a trunk (core + look-ahead)
+    uint32_t ncore;            // windows whose nodes get records
+    uint32_t budget;           // coded data sets one hypothesis may parse
+    uint32_t pad;
+};
+
+// Record of a node, the layout the walkers read.
+//   x: bits [0,26) = distance to the node the record ends on, [26,32) = RSIs covered; 0 = none
+//   y: chain of records until it leaves the window: [0,24) distance, [24,32) RSIs; 0 = none
+// Between the walk and the jump a hypothesis is parked in its record: x = distance to the node the walk
+// stands on, y = kTrParked | RSIs completed << 16 | blocks of the current RSI in front of that node.
+struct TrRec {
+    uint32_t x, y;
+};
+constexpr uint32_t kTrParked = 0x80000000u;
+
+struct TrTables {
+    // trunk (k_trunk)
+    uint32_t *bitmap;          // [nwin * L/32]  bit (31 - i % 32) of word i / 32 <=> lo + i is a node
+    uint16_t *pre;             // [nwin * L/32]  nodes of ITS window in front of the word
+    uint32_t *nbase;           // [nwin + 1]     nodes in front of the window (scan); cpos / bp / rec index
+    uint16_t *cpos;            // [ncap]         position inside the window
+    uint32_t *bp;              // [ncap]         block prefix | kind << 30
+    uint32_t *ccnt;            // [nwin]         nodes of the window (0 after the scan if they do not fit ncap)
+    uint32_t *nblk;            // [nwin]         blocks of the window's nodes
+    uint32_t *nros;            // [nwin]         rest-of-segment nodes
+    uint64_t *entry;           // [nwin]         first boundary of the chain at or behind the window start
+    uint64_t *exit;            // [nwin]         first boundary at or behind the window end (kTrNone: the chain died)
+    // scan (k_trunk_scan), nwin + 1 entries each
+    uint64_t *gbase;           // blocks of the trunk in front of the window
+    uint32_t *seampre;         // seams at or in front of the window
+    uint32_t *rospre;          // rest-of-segment nodes in front of the window
+    // hypotheses
+    TrRec *rec;                // [ncap]
+};
+
+AEC_HD uint32_t tr_word(const TrStream &s, uint64_t i)
+{
+    // (words past the end repeat the last one: a CDS that would need them ends behind end_bit and is rejected)
+    return bswap32(s.words[i < s.nwords ? i : s.nwords - 1]);
+}
+
+AEC_HD uint64_t tr_peek64(const TrStream &s, uint64_t q)
+{
+    const uint64_t w = q >> 5;
+    const uint32_t sh = (uint32_t)(q & 31u);
+    const uint64_t a = ((uint64_t)tr_word(s, w) << 32) | tr_word(s, w + 1);
+    const uint64_t lo = sh ? ((uint64_t)tr_word(s, w + 2) >> (32u - sh)) : 0u;
+    return (a << sh) | lo;
+}
+
+AEC_HD uint32_t tr_popc64(uint64_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(x);
+#else
+    return (uint32_t)__builtin_popcountll(x);
+#endif
+}
+
+// Length in bits of the CDS that starts at q (0 = none ends inside the stream, or its unary part is
+// longer than kTrMaxScan).  `nz` = 0 for a CDS of one block, else the zero-block run code fs + 1
+// (reference decode.c:518-536).  Layouts: decode.c:462-502 (split), 589-644 (low entropy), 659-677
+// (uncompressed); restated in SURVEY.md Appendix A.
+AEC_HD uint32_t tr_cds(const TrStream &s, const Cfg &c, uint64_t q, uint32_t ref, uint32_t &nz)
+{
+    nz = 0;
+    if (q + c.id_len >= s.end_bit) return 0;
+    const uint64_t H = tr_peek64(s, q);
+    const uint32_t id = (uint32_t)(H >> (64u - c.id_len));
+    if (id == (1u << c.id_len) - 1u) {
+        const uint32_t len = c.id_len + c.bs * c.bps;
+        return q + len <= s.end_bit ? len : 0u;
+    }
+    const bool low = id == 0u;
+    const uint32_t selbit = (uint32_t)(H >> (63u - c.id_len)) & 1u;
+    const uint32_t hdr = c.id_len + (low ? 1u : 0u) + ref * c.bps;
+    uint32_t need = low ? (selbit ? c.bs / 2u : 1u) : c.bs - ref;
+    const uint32_t add = low ? 0u : need * (id - 1u);
+    const uint64_t q1 = q + hdr;
+    uint64_t p = q1;
+    for (;;) {
+        if (p >= s.end_bit || p - q1 > kTrMaxScan) return 0;
+        const uint64_t U = tr_peek64(s, p);
+        const uint32_t pc = tr_popc64(U);
+        if (pc >= need) {
+            p += spec_select64(U, need) + 1u;
+            break;
+        }
+        need -= pc;
+        p += 64;
+    }
+    if (low && !selbit) nz = (uint32_t)(p - q1);
+    const uint64_t end = p + add;
+    return end <= s.end_bit ? (uint32_t)(end - q) : 0u;
+}
+
+// blocks covered by a CDS with run code nz (0: not a zero-block CDS) at block b of its RSI; 0 = the
+// run overruns the RSI (AEC_DATA_ERROR in the reference, decode.c:543-544)
+AEC_HD uint32_t tr_blocks(const Cfg &c, uint32_t nz, uint32_t b)
+{
+    if (nz == 0u) return 1u;
+    return spec_run_blocks(c, nz, b);
+}
+
+// ---- 1. trunk ----------------------------------------------------------------------------------------
+// The chain through window w, entering at `pos` (its first boundary at or behind the window start; kTrNone:
+// no chain); returns where the chain leaves the window.  The nodes are stored back to back, so a window is
+// walked twice: COUNT writes bitmap, prefix counts and the window's totals (then the scan places the windows'
+// nodes), FILL writes position and block prefix of every node.
+enum : uint32_t { TR_COUNT = 0, TR_FILL = 1 };
+
+AEC_HD uint64_t tr_trunk_window(const TrStream &s, const Cfg &c, const TrGeom &g, const TrTables &t, uint32_t w,
+                                uint64_t pos, uint64_t *exit_out, uint32_t mode)
+{
+    const uint64_t wstart = g.lo + (uint64_t)w * g.L, wend = wstart + g.L;
+    const uint32_t nw = g.L / 32u;
+    uint32_t *bm = t.bitmap + (uint64_t)w * nw;
+    uint16_t *pre = t.pre + (uint64_t)w * nw;
+    if (mode == TR_FILL) {
+        const uint32_t n = t.ccnt[w];
+        if (!n) {                            // nothing to store; a window the scan dropped loses its marks as well
+            if (pos != kTrNone && pos < wend)
+                for (uint32_t i = 0; i < nw; i++) {
+                    bm[i] = 0;
+                    pre[i] = 0;
+                }
+            while (pos != kTrNone && pos < wend) {
+                uint32_t nzc;
+                const uint32_t len = tr_cds(s, c, pos, 0u, nzc);
+                pos = len ? pos + len : kTrNone;
+            }
+            return pos;
+        }
+        uint16_t *cpos = t.cpos + t.nbase[w];
+        uint32_t *bp = t.bp + t.nbase[w];
+        uint32_t cnt = 0, blocks = 0;
+        while (pos != kTrNone && pos < wend) {
+            uint32_t nzc;
+            const uint32_t len = tr_cds(s, c, pos, 0u, nzc);
+            if (cnt < n) {
+                uint32_t nb = 1, kind = 0;
+                if (!len) {
+                    nb = 0;
+                    kind = kTrDead;
+                } else if (nzc == 5u) {
+                    kind = kTrRos;
+                } else if (nzc) {
+                    nb = nzc > 5u ? nzc - 1u : nzc;
+                }
+                cpos[cnt] = (uint16_t)(pos - wstart);
+                bp[cnt] = blocks | (kind << 30);
+                cnt++;
+                blocks += nb;
+            }
+            pos = len ? pos + len : kTrNone;
+        }
+        return pos;
+    }
+    t.entry[w] = pos;
+    uint32_t cnt = 0, blocks = 0, ros = 0, wi = 0, wv = 0, wpre = 0;
+    bool full = false;               // more blocks than a prefix holds: the rest of the window has no trunk
+    while (pos != kTrNone && pos < wend) {
+        uint32_t nzc;
+        const uint32_t len = tr_cds(s, c, pos, 0u, nzc);
+        if (!full && blocks > kTrBpMask - 64u) full = true;
+        if (!full) {
+            const uint32_t rel = (uint32_t)(pos - wstart), word = rel >> 5;
+            while (wi < word) {
+                bm[wi] = wv;
+                pre[wi] = (uint16_t)wpre;
+                wi++;
+                wv = 0;
+                wpre = cnt;
+            }
+            uint32_t nb = 1;
+            if (!len) nb = 0;                                   // (dead end: still a node, covers nothing)
+            else if (nzc == 5u) ros++;                          // (rest of segment: counts one block on the trunk)
+            else if (nzc) nb = nzc > 5u ? nzc - 1u : nzc;
+            wv |= 0x80000000u >> (rel & 31u);
+            cnt++;
+            blocks += nb;
+        }
+        pos = len ? pos + len : kTrNone;
+    }
+    while (wi < nw) {
+        bm[wi] = wv;
+        pre[wi] = (uint16_t)wpre;
+        wi++;
+        wv = 0;
+        wpre = cnt;
+    }
+    exit_out[w] = full ? kTrNone : pos;
+    t.ccnt[w] = cnt;
+    t.nblk[w] = blocks;
+    t.nros[w] = ros;
+    return pos;
+}
+
+// One trunk lane: region r = windows [r * rw, ...).  exit_prev == nullptr: the first pass (burn-in from `lead`
+// bits in front of the region); else a repair pass: a region whose first window does not begin where the
+// window in front of it ended (exit_prev, the result of the pass before) is walked again from there.
+AEC_HD void tr_trunk_region(const TrStream &s, const Cfg &c, const TrGeom &g, const TrTables &t, uint32_t r,
+                            const uint64_t *exit_prev, uint64_t *exit_out, uint32_t mode = TR_COUNT)
+{
+    const uint32_t w0 = r * g.rw, w1 = w0 + g.rw < g.nwin ? w0 + g.rw : g.nwin;
+    const uint64_t rstart = g.lo + (uint64_t)w0 * g.L, rend = g.lo + (uint64_t)w1 * g.L;
+    uint64_t pos;
+    if (mode == TR_FILL) {
+        pos = t.entry[w0];
+    } else if (!exit_prev) {
+        pos = rstart > g.start_bit + g.lead ? rstart - g.lead : g.start_bit;
+        if (rend <= g.start_bit || rstart > s.end_bit) pos = kTrNone;
+        while (pos != kTrNone && pos < rstart) {                         // burn-in
+            uint32_t nzc;
+            const uint32_t len = tr_cds(s, c, pos, 0u, nzc);
+            pos = len ? pos + len : kTrNone;
+        }
+    } else {
+        const uint64_t prev = w0 ? exit_prev[w0 - 1u] : kTrNone;
+        if (prev == kTrNone || prev == t.entry[w0]) {
+            for (uint32_t w = w0; w < w1; w++) exit_out[w] = exit_prev[w];
+            return;
+        }
+        pos = prev;
+    }
+    for (uint32_t w = w0; w < w1; w++) pos = tr_trunk_window(s, c, g, t, w, pos, exit_out, mode);
+}
+
+// scan over the windows (serial form; the kernel does the same with a workgroup scan)
+AEC_HD void tr_scan_serial(const TrGeom &g, const TrTables &t)
+{
+    uint64_t gsum = 0;
+    uint32_t seams = 0, ros = 0, nodes = 0;
+    bool dropped = false;
+    for (uint32_t w = 0; w < g.nwin; w++) {
+        const bool fits = nodes + t.ccnt[w] <= g.ncap;      // (a window whose nodes do not fit has none)
+        if (!fits) {
+            t.ccnt[w] = 0;
+            t.nblk[w] = 0;
+            t.nros[w] = 0;
+        }
+        const bool seam = w == 0 || dropped || t.exit[w - 1] == kTrNone || t.exit[w - 1] != t.entry[w];
+        dropped = !fits;
+        seams += seam ? 1u : 0u;
+        t.nbase[w] = nodes;
+        t.gbase[w] = gsum;
+        t.seampre[w] = seams;
+        t.rospre[w] = ros;
+        nodes += t.ccnt[w];
+        gsum += t.nblk[w];
+        ros += t.nros[w];
+    }
+    t.nbase[g.nwin] = nodes;
+    t.gbase[g.nwin] = gsum;
+    t.seampre[g.nwin] = seams + 1u;
+    t.rospre[g.nwin] = ros;
+}
+
+// node index of absolute bit position p inside the tabulated range (false: not a node)
+AEC_HD bool tr_node_at(const TrGeom &g, const TrTables &t, uint64_t p, uint32_t &w, uint32_t &idx)
+{
+    if (p < g.lo) return false;
+    const uint64_t i = p - g.lo;
+    const uint64_t wi = i / g.L;
+    if (wi >= g.nwin) return false;
+    const uint32_t word = t.bitmap[i >> 5], sh = (uint32_t)(i & 31u);
+    if (!((word >> (31u - sh)) & 1u)) return false;
+    w = (uint32_t)wi;
+    idx = (uint32_t)t.pre[i >> 5] + (sh ? spec_popc(word >> (32u - sh)) : 0u);
+    return true;
+}
+
+AEC_HD bool tr_marked(const TrGeom &g, const TrTables &t, uint64_t p)
+{
+    if (p < g.lo) return false;
+    const uint64_t i = p - g.lo;
+    if (i >= (uint64_t)g.nwin * g.L) return false;
+    return (t.bitmap[i >> 5] >> (31u - (uint32_t)(i & 31u))) & 1u;
+}
+
+// ---- 2. hypotheses ------------------------------------------------------------------------------------
+struct TrHyp {                 // one hypothesis walk in flight
+    uint64_t c;                // the node tried as an RSI start
+    uint64_t pos;              // where the next CDS starts
+    uint32_t b, k, steps;      // blocks of the current RSI done, RSIs completed, coded data sets parsed
+};
+
+enum : uint32_t { TR_RUN = 0, TR_LAND = 1, TR_DONE = 2, TR_FAIL = 3 };
+
+AEC_HD uint64_t tr_rsi_start(const Cfg &c, uint64_t end_of_previous)     // reference decode.c:407-408
+{
+    return (c.flags & F_PAD_RSI) ? (end_of_previous + 7u) & ~7ull : end_of_previous;
+}
+
+// c: the node tried as the place where an RSI starts (with AEC_PAD_RSI: where the RSI in front of it ends)
+AEC_HD void tr_hyp_start(const Cfg &cfg, TrHyp &h, uint64_t c)
+{
+    h.c = c;
+    h.pos = tr_rsi_start(cfg, c);
+    h.b = 0;
+    h.k = 0;
+    h.steps = 0;
+}
+
+// One CDS of the walk.  TR_LAND: the walk stands on a node with blocks of its RSI left (the jump takes
+// over); TR_DONE: h.k whole RSIs, ending on a node at h.pos.
+AEC_HD uint32_t tr_hyp_step(const TrStream &s, const Cfg &c, const TrGeom &g, const TrTables &t, TrHyp &h)
+{
+    if (h.b != 0u && tr_marked(g, t, h.pos)) return TR_LAND;
+    if (h.steps >= g.budget) return TR_FAIL;
+    const uint32_t ref = (h.b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u;
+    uint32_t nz;
+    const uint32_t len = tr_cds(s, c, h.pos, ref, nz);
+    if (!len) return TR_FAIL;
+    const uint32_t nb = tr_blocks(c, nz, h.b);
+    if (!nb || nb > c.rsi - h.b) return TR_FAIL;
+    h.pos += len;
+    h.b += nb;
+    h.steps++;
+    if (h.b == c.rsi) {
+        h.k++;
+        if (tr_marked(g, t, h.pos)) return TR_DONE;
+        if (h.k == kTrMaxK) return TR_FAIL;
+        h.b = 0;
+        h.pos = tr_rsi_start(c, h.pos);
+    }
+    return TR_RUN;
+}
+
+AEC_HD uint32_t tr_rec_pack(uint64_t bits, uint32_t k)
+{
+    return (bits && bits < (1u << 26) && k >= 1u && k <= kTrMaxK) ? (uint32_t)bits | (k << 26) : 0u;
+}
+AEC_HD uint32_t tr_rec_bits(uint32_t x) { return x & 0x03FFFFFFu; }
+AEC_HD uint32_t tr_rec_k(uint32_t x) { return x >> 26; }
+
+// what the walk of node (w, idx) leaves in its record
+AEC_HD void tr_hyp_finish(const TrGeom &g, const TrTables &t, uint32_t w, uint32_t idx, const TrHyp &h, uint32_t state)
+{
+    TrRec r{0u, 0u};
+    const uint64_t d = h.pos - h.c;
+    if (state == TR_DONE) {
+        r.x = tr_rec_pack(d, h.k);
+    } else if (state == TR_LAND && d <= 0xFFFFFFFFull) {
+        r.x = (uint32_t)d;
+        r.y = kTrParked | (h.k << 16) | h.b;            // (b < rsi <= 4096, k < 64)
+    }
+    t.rec[t.nbase[w] + idx] = r;
+}
+
+// window that holds block number G of the trunk, searched from window w on (g.nwin: none)
+AEC_HD uint32_t tr_window_of(const TrGeom &g, const TrTables &t, uint32_t w, uint64_t G)
+{
+    // gallop, then bisect: gbase is non-decreasing, the window is the LAST one with gbase <= G (an empty
+    // window shares its gbase with its successor)
+    uint32_t lo = w, step = 1;
+    uint32_t hi = w + 1;
+    while (hi < g.nwin && t.gbase[hi] <= G) {
+        lo = hi;
+        hi = hi + step < g.nwin ? hi + step : g.nwin;
+        step *= 2;
+    }
+    // invariant: gbase[lo] <= G, (hi == nwin or gbase[hi] > G)
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (t.gbase[mid] <= G) lo = mid;
+        else hi = mid;
+    }
+    return G < t.gbase[lo + 1u] ? lo : g.nwin;
+}
+
+// node of window w whose block prefix is exactly `want` (false: none -- the block lies inside a zero run)
+AEC_HD bool tr_node_of(const TrGeom &g, const TrTables &t, uint32_t w, uint32_t want, uint32_t &idx)
+{
+    const uint32_t *bp = t.bp + t.nbase[w];
+    const uint32_t n = t.ccnt[w];
+    if (!n) return false;
+    uint32_t hi = want < n - 1u ? want : n - 1u;            // bp[i] >= i
+    if ((bp[hi] & kTrBpMask) == want) {
+        idx = hi;
+        return true;
+    }
+    uint32_t lo = 0;
+    while (lo < hi) {                                       // first index with bp >= want, in [lo, hi]
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if ((bp[mid] & kTrBpMask) < want) lo = mid + 1u;
+        else hi = mid;
+    }
+    if ((bp[lo] & kTrBpMask) != want) return false;
+    idx = lo;
+    return true;
+}
+
+// first rest-of-segment node at or behind node (w, i) (false: none inside the tables)
+AEC_HD bool tr_next_ros(const TrGeom &g, const TrTables &t, uint32_t w, uint32_t i, uint32_t &rw, uint32_t &ri)
+{
+    if (t.rospre[g.nwin] == t.rospre[w]) return false;
+    if (t.nros[w]) {
+        const uint32_t *bp = t.bp + t.nbase[w];
+        const uint32_t n = t.ccnt[w];
+        for (uint32_t j = i; j < n; j++)
+            if ((bp[j] >> 30) == kTrRos) {
+                rw = w;
+                ri = j;
+                return true;
+            }
+    }
+    // first later window with one: smallest v > w with rospre[v + 1] > rospre[w + 1]
+    const uint32_t base = t.rospre[w + 1u];
+    if (t.rospre[g.nwin] == base) return false;
+    uint32_t lo = w + 1u, hi = g.nwin - 1u;                 // answer in [lo, hi]
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (t.rospre[mid + 1u] > base) hi = mid;
+        else lo = mid + 1u;
+    }
+    const uint32_t *bp = t.bp + t.nbase[lo];
+    const uint32_t n = t.ccnt[lo];
+    for (uint32_t j = 0; j < n; j++)
+        if ((bp[j] >> 30) == kTrRos) {
+            rw = lo;
+            ri = j;
+            return true;
+        }
+    return false;
+}
+
+AEC_HD uint64_t tr_G(const TrGeom &g, const TrTables &t, uint32_t w, uint32_t i)
+{
+    return t.gbase[w] + (t.bp[t.nbase[w] + i] & kTrBpMask);
+}
+
+// The jump: from node at `pos` with b blocks of the RSI done to the node where the RSI ends.
+// kTrNone = unresolved (seam, end of the tables, zero run across the end, dead node on the way).
+AEC_HD uint64_t tr_jump(const Cfg &c, const TrGeom &g, const TrTables &t, uint64_t pos, uint32_t b)
+{
+    uint32_t w, i;
+    if (!tr_node_at(g, t, pos, w, i)) return kTrNone;
+    const uint32_t seam0 = t.seampre[w];
+    for (uint32_t guard = 0; guard <= c.rsi / 32u + 2u; guard++) {
+        const uint32_t n = c.rsi - b;
+        const uint64_t G = tr_G(g, t, w, i);
+        uint32_t rw = 0, ri = 0;
+        uint64_t dist = ~0ull;                       // blocks between this node and the next rest-of-segment run
+        if (tr_next_ros(g, t, w, i, rw, ri)) dist = tr_G(g, t, rw, ri) - G;
+        TR_DBG("jump: node w%u i%u G %llu b %u n %u nextros w%u i%u dist %lld\n", w, i, (unsigned long long)G, b, n, rw, ri, (long long)dist);
+        if (dist >= n) {                             // the RSI ends in front of (or at) that run
+            const uint32_t tw = tr_window_of(g, t, w, G + n);
+            if (tw >= g.nwin || t.seampre[tw] != seam0) return kTrNone;
+            uint32_t ti;
+            if (!tr_node_of(g, t, tw, (uint32_t)(G + n - t.gbase[tw]), ti)) return kTrNone;
+            return g.lo + (uint64_t)tw * g.L + t.cpos[t.nbase[tw] + ti];
+        }
+        if (t.seampre[rw] != seam0) return kTrNone;
+        b += (uint32_t)dist;
+        const uint32_t left_rsi = c.rsi - b, left_seg = 64u - (b % 64u);
+        b += left_rsi < left_seg ? left_rsi : left_seg;
+        // the node behind the run (it counts one block on the trunk)
+        const uint64_t Gn = tr_G(g, t, rw, ri) + 1u;
+        const uint32_t tw = tr_window_of(g, t, rw, Gn);
+        if (tw >= g.nwin || t.seampre[tw] != seam0) return kTrNone;
+        uint32_t ti;
+        if (!tr_node_of(g, t, tw, (uint32_t)(Gn - t.gbase[tw]), ti)) return kTrNone;
+        w = tw;
+        i = ti;
+        if (b == c.rsi) return g.lo + (uint64_t)w * g.L + t.cpos[t.nbase[w] + i];
+    }
+    return kTrNone;
+}
+
+// jump (k_hyp_land): resolves a parked hypothesis
+AEC_HD void tr_hyp_land(const Cfg &c, const TrGeom &g, const TrTables &t, uint32_t w, uint32_t idx)
+{
+    const uint64_t at = t.nbase[w] + idx;
+    const TrRec r = t.rec[at];
+    if (!(r.y & kTrParked)) return;
+    const uint64_t c0 = g.lo + (uint64_t)w * g.L + t.cpos[at];
+    const uint32_t k = (r.y >> 16) & 0x3Fu, b = r.y & 0xFFFFu;
+    const uint64_t e = tr_jump(c, g, t, c0 + r.x, b);
+    t.rec[at] = TrRec{e == kTrNone ? 0u : tr_rec_pack(e - c0, k + 1u), 0u};
+}
+
+// chain (k_hyp_chain): records from node (w, idx) on until the chain leaves the window
+AEC_HD void tr_hyp_chain(const TrGeom &g, const TrTables &t, uint32_t w, uint32_t idx)
+{
+    const uint64_t wstart = g.lo + (uint64_t)w * g.L, wend = wstart + g.L;
+    const uint64_t at = t.nbase[w] + idx;
+    const uint64_t c0 = wstart + t.cpos[at];
+    uint64_t pos = c0;
+    uint32_t cnt = 0;
+    while (pos < wend) {
+        uint32_t pw, pi;
+        if (!tr_node_at(g, t, pos, pw, pi) || pw != w) break;
+        const uint32_t x = t.rec[t.nbase[w] + pi].x;
+        if (!x || cnt + tr_rec_k(x) > 255u || pos + tr_rec_bits(x) - c0 >= (1u << 24)) break;
+        pos += tr_rec_bits(x);
+        cnt += tr_rec_k(x);
+    }
+    t.rec[at].y = cnt ? (cnt << 24) | (uint32_t)(pos - c0) : 0u;
+}
+
+// The RSI starts inside a record that covers k > 1 RSIs, parsed again from its node (the expansion of the
+// records the true walk took): out[j] = start of RSI j + 1 of the record, j < k - 1.  false = the stream
+// does not parse (cannot happen for a record that was built from it).  With AEC_PAD_RSI p and the values
+// handed to `out` are where the RSIs in front END; tr_rsi_start() of them is where the next ones start.
+template <class Out>
+AEC_HD bool tr_rec_starts(const TrStream &s, const Cfg &c, uint64_t p, uint32_t k, Out out)
+{
+    uint32_t b = 0, done = 0;
+    p = tr_rsi_start(c, p);
+    while (done + 1u < k) {
+        const uint32_t ref = (b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u;
+        uint32_t nz;
+        const uint32_t len = tr_cds(s, c, p, ref, nz);
+        if (!len) return false;
+        const uint32_t nb = tr_blocks(c, nz, b);
+        if (!nb || nb > c.rsi - b) return false;
+        p += len;
+        b += nb;
+        if (b == c.rsi) {
+            out(done, p);
+            done++;
+            b = 0;
+            p = tr_rsi_start(c, p);
+        }
+    }
+    return true;
+}
+
+}  // namespace aec
