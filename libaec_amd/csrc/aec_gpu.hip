@@ -38,8 +38,6 @@ struct aec_gpu_ctx {
     void *idx_ws;          // speculative index tables (aec_idx.hip), grown on demand
     size_t idx_ws_bytes;
     uint64_t idx_hint;     // caller's estimate of the coded RSI size in bits (0 = derive from max_rsi)
-    IdxSide idx_side;      // side stream + events of the index pass (created on first use)
-    bool idx_side_ok;
     ShardCarry *carry;     // device record: what precedes this context's shard (emit_planned)
     void *fused;           // control block of the single-pass encoder (ticket, fail flag, look-back granules)
     size_t fused_bytes;
@@ -70,8 +68,6 @@ int aec_gpu_create(aec_gpu_ctx **out)
     ctx->idx_ws = nullptr;
     ctx->idx_ws_bytes = 0;
     ctx->idx_hint = 0;
-    ctx->idx_side = IdxSide{};
-    ctx->idx_side_ok = false;
     ctx->carry = nullptr;
     ctx->fused = nullptr;
     ctx->fused_bytes = 0;
@@ -89,13 +85,6 @@ void aec_gpu_destroy(aec_gpu_ctx *ctx)
     if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
     if (ctx->carry) (void)hipFree(ctx->carry);
     if (ctx->fused) (void)hipFree(ctx->fused);
-    if (ctx->idx_side_ok) {
-        (void)hipStreamDestroy(ctx->idx_side.stream);
-        for (int b = 0; b < 2; b++) {
-            (void)hipEventDestroy(ctx->idx_side.spec_done[b]);
-            (void)hipEventDestroy(ctx->idx_side.walk_done[b]);
-        }
-    }
     for (auto &set : ctx->ev)
         for (auto &e : set.ev)
             if (e) (void)hipEventDestroy(e);
@@ -152,7 +141,7 @@ static int reserve_fused(aec_gpu_ctx *ctx, const Cfg &c)
         if (ctx->fused) (void)hipFree(ctx->fused);
         ctx->fused = nullptr;
         ctx->fused_bytes = 0;
-        const size_t want = need + need / 4;
+        const size_t want = need + need / 16;
         if (hipMalloc(&ctx->fused, want) != hipSuccess) return RC_MEM_ERROR;
         ctx->fused_bytes = want;
     }
@@ -318,9 +307,8 @@ static int index_common(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d
     if (reinterpret_cast<uintptr_t>(d_in) & 3u) return RC_CONF_ERROR;
     if (start_block >= c.rsi || (start_block && rsi_start_bit > start_bit)) return RC_CONF_ERROR;
     (void)hipGetLastError();
-    // Table workspace of the speculative index.  The look-ahead of the speculation is sized from the
-    // average coded RSI: the caller's hint, else input bits / expected RSIs.  A failed allocation
-    // only means the serial walk.
+    // Table workspace of the trunk index, sized from the average coded RSI: the caller's hint, else input
+    // bits / expected RSIs.  A failed allocation only means the serial walk.
     const uint64_t in_bits = (uint64_t)in_bytes * 8;
     const uint64_t hint = ctx->idx_hint ? ctx->idx_hint
                           : ((max_rsi && in_bits > start_bit) ? (in_bits - start_bit) / max_rsi : 0);
@@ -329,23 +317,13 @@ static int index_common(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d
         if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);     // (synchronises: no walker still reads it)
         ctx->idx_ws = nullptr;
         ctx->idx_ws_bytes = 0;
-        const size_t want = need + need / 4;
+        const size_t want = need + need / 16;
         if (hipMalloc(&ctx->idx_ws, want) == hipSuccess) ctx->idx_ws_bytes = want;
         else (void)hipGetLastError();
     }
-    if (need && !ctx->idx_side_ok) {
-        IdxSide &sd = ctx->idx_side;
-        bool ok = hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) == hipSuccess;
-        for (int b = 0; ok && b < 2; b++)
-            ok = hipEventCreateWithFlags(&sd.spec_done[b], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&sd.walk_done[b], hipEventDisableTiming) == hipSuccess;
-        ctx->idx_side_ok = ok;
-        if (!ok) (void)hipGetLastError();
-    }
     launch_index(c, static_cast<const uint8_t *>(d_in), in_bytes, start_bit, d_rsi_bit_offsets, max_rsi,
                  reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream), ctx->idx_ws,
-                 ctx->idx_ws_bytes, hint, ctx->idx_side_ok ? &ctx->idx_side : nullptr, start_block,
-                 rsi_start_bit, tail_slot);
+                 ctx->idx_ws_bytes, hint, start_block, rsi_start_bit, tail_slot);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess && getenv("AEC_ABI_TRACE"))
         fprintf(stderr, "aec_gpu_index_async: %s (in_bytes %zu start %llu max_rsi %llu hint %llu ws %zu)\n",

@@ -2,22 +2,26 @@
 //
 // A coded data set can only be located by parsing its predecessor (the stream has no lengths,
 // reference src/decode.c:402-421), so finding where the RSIs start is a serial walk in the
-// reference.  Here it is split into
-//   k_spec    SPECULATION, fully parallel: a workgroup takes a window of the stream into LDS,
-//             builds rank/select over its 1-bits, tabulates "a CDS starts at bit q: how long is it"
-//             for every q of the window (aec_spec.h), then tries every bit position of the window's
-//             core as an RSI start (ref CDS + table hops over rsi blocks) and finally chains those
-//             RSI hops until they leave the core.  Output per bit position p: T[p] = length of an
-//             RSI starting at p, Xb/Xc[p] = bits / RSIs of the chained hop out of the window.
-//             Nearly all of that work is thrown away -- only the entries at true RSI starts are
-//             ever read -- but it is what turns the walk into table lookups.
-//   k_index   the WALK, one wavefront: at an RSI start it hops over the tables (one lookup per
-//             window); an RSI the tables did not resolve (longer than the look-ahead, cut by the
-//             end of the stream, malformed) is walked CDS by CDS as before: the stream is served
-//             from an LDS window, unary parts are skipped cooperatively (popcount per lane + DPP scan).
-//   k_expand  fills in the RSI starts inside the chained hops, one lane per hop.
-// Long RSIs (raw RSI bits beyond the LDS look-ahead) take the serial walk alone.  The batch form
-// runs one serial walker per independent chunk.
+// reference.  Here it is split into lane-parallel passes over the stream (aec_trunk.h has the
+// arithmetic and the reasoning) and a walk that only hops over their results:
+//   k_trunk       one lane per region: the self-synchronising parse WITHOUT reference samples, burnt in
+//                 over `lead` bits, records every coded-data-set boundary it visits (the NODES of the trunk)
+//                 window by window; repair passes walk a region again from where its left neighbour ended
+//   k_trunk_scan  numbers nodes and blocks along the trunk, counts seams and rest-of-segment runs
+//   k_hyp_walk    every node is tried as an RSI start: the coded data set with the reference sample, then
+//                 on-demand parses until the walk stands on the trunk again (or has completed up to 63
+//                 RSIs without meeting it)
+//   k_hyp_land    the rest of the RSI as ONE search in the block numbering of the trunk
+//   k_hyp_chain   records chained until they leave their window
+//   k_twide        every node of the first window of every chunk (256 windows) chases the chain through the
+//                 chunk, so that the walk needs one lookup per chunk
+//   k_index       the WALK, one wavefront: hops over those tables; an RSI they did not resolve (cut by the
+//                 end of the stream, malformed, a seam) is walked CDS by CDS: the stream is served from an
+//                 LDS window, unary parts are skipped cooperatively (popcount per lane + DPP scan)
+//   k_trewalk, k_texpand  fill in the RSI starts inside the hops the walk took
+// Every record is the exact result of the reference's walk from its node; the walk reads records at true
+// RSI starts only, so results never depend on the speculation.  The batch form runs one serial walker per
+// independent chunk.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -29,6 +33,7 @@
 #include "aec_lane.h"
 #include "aec_spec.h"
 #include "aec_spec2.h"
+#include "aec_trunk.h"
 
 namespace aec {
 
@@ -46,13 +51,35 @@ __device__ __forceinline__ uint32_t wave_incl_sum_dpp(uint32_t v)
     return v;
 }
 
-// Speculative tables of one chunk of the stream: entries for bit positions [lo, hi).
-struct IdxTables {
-    const uint16_t *T;     // RSI length if an RSI starts here (0 = unresolved)
-    const uint16_t *Xb;    // chained hop out of the window core: bits ...
-    const uint8_t *Xc;     // ... and RSIs covered (0 = none)
-    uint64_t lo, hi;
+// What the walkers read of the trunk tables of one span of the stream (aec_trunk.h: TrTables): per window k
+// (core bits each, the first one at bit lo) a bitmap over its bit positions, per bitmap word the number of
+// nodes in front of it (inside the window), and the nodes' records, stored back to back.
+struct TwTables {
+    const uint32_t *bitmap;    // bit (31 - i % 32) of word i / 32 <=> position lo + i is a node
+    const uint16_t *pre;       // per bitmap word: nodes of ITS window in front of the word
+    const uint32_t *nbase;     // [window]: nodes in front of the window
+    const uint32_t *ccnt;      // [window]: nodes
+    const TrRec *rec;          // [nbase[window] + index]
+    const uint16_t *cpos;      // [nbase[window] + index]: position inside the window
+    uint64_t lo, hi;           // bit range whose nodes have records
+    uint32_t core;             // bits per window (multiple of 32)
+    // wide walker: per chunk of wpc windows, what every node of the chunk's first window leads to
+    const uint4 *wide;         // [chunk * wcap + index]: {exit lo, exit hi, RSIs, 1 = resolved}
+    uint32_t wpc, wcap;
 };
+
+// record of the node at absolute bit p (false: p is not a node)
+__device__ __forceinline__ bool tw_lookup(const TwTables &t, uint64_t p, TrRec &rec, uint32_t &window,
+                                              uint32_t &index)
+{
+    const uint64_t i = p - t.lo;
+    const uint32_t word = t.bitmap[i >> 5], sh = (uint32_t)(i & 31u);
+    if (!((word >> (31u - sh)) & 1u)) return false;
+    window = (uint32_t)(i / t.core);
+    index = (uint32_t)t.pre[i >> 5] + (sh ? (uint32_t)__popc(word >> (32u - sh)) : 0u);
+    rec = t.rec[t.nbase[window] + index];
+    return true;
+}
 
 // Sparse tables of the second-generation speculation (k_spec2): candidates = coded-data-set boundaries
 // found by self-synchronising chains.  Per core window k (core bits each, the first one at bit lo):
@@ -84,264 +111,470 @@ __device__ __forceinline__ bool sparse_lookup(const SparseTables &t, uint64_t p,
     return true;
 }
 
-// Dense hop tables for streams whose RSIs are far longer than any window (k_hops / k_hop_compose):
-// "from the coded data set that starts at bit p, where are you 16 / 64 / 256 coded data sets on, and how
-// many blocks beyond that count did zero-block runs cover?"  Independent of the RSI structure -- the
-// walker itself knows its position inside the RSI, parses the coded data set that carries the reference
-// sample and every rest-of-segment run on its own (hops never contain one), and takes the widest hop that
-// stays inside the RSI.  h16: bits [0,13) distance, [13,16) extra blocks; h64 / h256: [0,24) distance,
-// [24,32) extra blocks; 0 = no entry.
-// The base level is 16 coded data sets, or 4 where 16 of them do not fit the 13-bit distance of an h16 entry
-// (blocks of 64 16-bit samples: 700 bits per coded data set); n0 says which, the composed levels are 4 n0
-// and 16 n0.
-struct HopTables {
-    const uint16_t *h16;
-    const uint32_t *h64, *h256;
-    uint64_t lo, hi;
-    uint32_t n0;
-};
-
 struct ChunkEntry {        // where the true chain enters a chunk the walker skipped over the wide table
     uint64_t pos, r;
     uint32_t valid, pad;
 };
 
-struct IdxHop {            // a chained hop the walker took: k_expand writes its RSI starts
+struct IdxHop {            // a hop the walker took: k_texpand writes the RSI starts inside it
     uint64_t pos, r;
     uint32_t cnt, pad;
 };
 
-struct IdxCarry {          // walker state between the table chunks of one stream
+struct IdxCarry {          // walker state between the spans of one stream
     uint64_t good, r;
     uint32_t active, n_hops;
-    uint64_t cur_start;    // hop tables: a chunk may end inside an RSI -- where that RSI began ...
-    uint32_t b, pad;       // ... and the blocks of it in front of `good`
+    uint32_t n_serial, n_lookups;     // statistics: RSIs walked coded data set by coded data set, table hops taken
 };
 
-// ---- speculation ------------------------------------------------------------------------------------
-// LDS: win[nw + 2] u32 | rank[nw + 2] u16 | sel[nw + 2] u16 | nxt[W] | hop4[W] | hop16[W] | Tl[core] (u16)
-__global__ void __launch_bounds__(1024)
-k_spec(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
-       uint32_t core, uint32_t look, uint16_t *__restrict__ T, uint16_t *__restrict__ Xb,
-       uint8_t *__restrict__ Xc)
+// ---- trunk (aec_trunk.h) -------------------------------------------------------------------------------
+// mode 0: first pass (burn-in + count), 1: repair pass (count), 2: fill (one lane per WINDOW)
+__global__ void __launch_bounds__(64)
+k_trunk(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const uint64_t *exit_prev, uint64_t *exit_out,
+        uint32_t mode)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
-    const uint32_t W = core + look, nw = W / 32u;
-    uint32_t *win = spec_lds;
-    uint16_t *rank = reinterpret_cast<uint16_t *>(win + nw + 2);
-    uint16_t *sel = rank + nw + 2;
-    uint16_t *nxt = sel + nw + 2;
-    uint16_t *hop4 = nxt + W;
-    uint16_t *hop16 = hop4 + W;
-    uint16_t *Tl = hop16 + W;
-    const uint64_t rel0 = (uint64_t)blockIdx.x * core;
-    const uint64_t wstart = tab_lo + rel0;
-    if (wstart >= end_bit) return;
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint64_t w0 = wstart >> 5;
-    for (uint32_t i = tid; i < nw + 2; i += nt) {
-        const uint64_t idx = w0 + i;
-        win[i] = idx < nwords ? bswap32(words[idx]) : 0u;
-    }
-    __syncthreads();
-    if (tid < 64) {                                   // prefix count of 1-bits per word
-        uint32_t carry = 0;
-        for (uint32_t base = 0; base < nw; base += 64) {
-            const uint32_t i = base + tid;
-            const uint32_t pc = i < nw ? (uint32_t)__popc(win[i]) : 0u;
-            const uint32_t incl = wave_incl_sum_dpp(pc);
-            if (i < nw) rank[i + 1] = (uint16_t)(carry + incl);
-            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-        if (tid == 0) rank[0] = 0;
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < nw; i += nt) {         // sampled select: word of every 32nd 1-bit
-        const uint32_t lo = rank[i], hi = rank[i + 1], m = (lo + 31u) >> 5;
-        if (32u * m + 1u > lo && 32u * m + 1u <= hi) sel[m] = (uint16_t)i;
-    }
-    __syncthreads();
-    const uint64_t left = end_bit - wstart;
-    const SpecWin s{win, rank, sel, nw, left < W ? (uint32_t)left : W};
-    // several positions per lane and iteration: the chains of dependent LDS lookups are independent
-    // between positions and the straight-line code lets the scheduler overlap them
-    for (uint32_t q = tid; q < W; q += 2 * nt) {
-        const uint32_t qb = q + nt;
-        const uint16_t ea = q < s.limit ? spec_nxt_entry(s, c, q) : (uint16_t)0;
-        const uint16_t eb = qb < s.limit ? spec_nxt_entry(s, c, qb) : (uint16_t)0;
-        nxt[q] = ea;
-        if (qb < W) nxt[qb] = eb;
-    }
-    __syncthreads();
-    for (uint32_t q = tid; q < W; q += 4 * nt) {
-        uint16_t e[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) e[u] = q + u * nt < W ? spec_hop4(nxt, c, s.limit, q + u * nt) : (uint16_t)0;
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (q + u * nt < W) hop4[q + u * nt] = e[u];
-    }
-    // first CDS of a hypothetical RSI at every core position (carries the reference sample);
-    // parked in Tl until the walk of that position replaces it by the RSI length
-    for (uint32_t q = tid; q < core; q += nt) Tl[q] = q < s.limit ? spec_first_entry(s, c, q) : (uint16_t)0;
-    __syncthreads();
-    for (uint32_t q = tid; q < W; q += 4 * nt) {
-        uint16_t e[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) e[u] = q + u * nt < W ? spec_hop16(hop4, s.limit, q + u * nt) : (uint16_t)0;
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (q + u * nt < W) hop16[q + u * nt] = e[u];
-    }
-    __syncthreads();
-    // RSI walks.  Walk lengths differ wildly between lanes (hypotheses die early or run the full
-    // rsi blocks), so the position loop and the step loop are flattened: every lane keeps kSlots
-    // walks in flight (independent LDS lookups per iteration) and a slot that finishes takes the
-    // lane's next position at once -- a wave is as slow as its lanes' SUMS of steps, not the sum of
-    // per-position maxima.
-    {
-        constexpr int kSlots = 4;
-        const uint32_t per = core / nt;                 // positions per lane: q = tid + k * nt
-        uint32_t wp[kSlots], wpos[kSlots], wb[kSlots], wk[kSlots];
-        bool act[kSlots];
-        auto start = [&](int j) {                       // next position of slot j (k = j, j + kSlots, ...)
-            act[j] = false;
-            while (wk[j] < per) {
-                const uint32_t q = tid + wk[j] * nt;
-                wk[j] += kSlots;
-                if (spec_walk_init(c, Tl[q], q, wpos[j], wb[j])) {
-                    wp[j] = q;
-                    act[j] = true;
-                    return;
-                }
-                Tl[q] = 0;
-            }
-        };
-#pragma unroll
-        for (int j = 0; j < kSlots; j++) {
-            wk[j] = (uint32_t)j;
-            start(j);
-        }
-        for (;;) {
-            bool any = false;
-#pragma unroll
-            for (int j = 0; j < kSlots; j++) {
-                if (!act[j]) continue;
-                any = true;
-                bool done = wb[j] >= c.rsi, ok = true;
-                if (!done) {
-                    ok = spec_walk_step(c, nxt, hop4, hop16, s.limit, wpos[j], wb[j]);
-                    done = !ok || wb[j] >= c.rsi;
-                }
-                if (done) {
-                    uint32_t t = ok ? wpos[j] - wp[j] : 0u;
-                    if (t > 0xFFFFu) t = 0;
-                    Tl[wp[j]] = (uint16_t)t;      // (global T is written from Tl below, coalesced)
-                    start(j);
-                }
-            }
-            if (!any) break;
-        }
-    }
-    __syncthreads();
-    const bool pad = c.flags & F_PAD_RSI;
-    for (uint32_t q = tid; q < core; q += nt) {
-        uint32_t pos = q, cnt = 0;
-        while (pos < core && pos < s.limit && Tl[pos] && cnt < 255u) {
-            pos += Tl[pos];
-            cnt++;
-            if (pad) pos = (pos + 7u) & ~7u;
-        }
-        T[rel0 + q] = Tl[q];
-        Xb[rel0 + q] = (uint16_t)(pos - q);
-        Xc[rel0 + q] = (uint8_t)cnt;
-    }
-}
-
-// ---- hop tables (long RSIs) ---------------------------------------------------------------------------
-// LDS: win[nw + 2] u32 | rank[nw + 2] u16 | sel[nw + 2] u16 | nxt[W] u16 | hop4[W] u16
-__global__ void __launch_bounds__(1024)
-k_hops(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
-       uint32_t core, uint32_t look, uint16_t *__restrict__ h16, uint32_t n0)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
-    const uint32_t W = core + look, nw = W / 32u;
-    uint32_t *win = spec_lds;
-    uint16_t *rank = reinterpret_cast<uint16_t *>(win + nw + 2);
-    uint16_t *sel = rank + nw + 2;
-    uint16_t *nxt = sel + nw + 2;
-    uint16_t *hop4 = nxt + W;
-    const uint64_t rel0 = (uint64_t)blockIdx.x * core;
-    const uint64_t wstart = tab_lo + rel0;
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    if (wstart >= end_bit) {
-        for (uint32_t q = tid; q < core; q += nt) h16[rel0 + q] = 0;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == 2u) {
+        if (i < g.nwin) tr_trunk_window(s, c, g, t, i, t.entry[i], nullptr, TR_FILL);
         return;
     }
-    const uint64_t w0 = wstart >> 5;
-    for (uint32_t i = tid; i < nw + 2; i += nt) {
-        const uint64_t idx = w0 + i;
-        win[i] = idx < nwords ? bswap32(words[idx]) : 0u;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        uint32_t carry = 0;
-        for (uint32_t base = 0; base < nw; base += 64) {
-            const uint32_t i = base + tid;
-            const uint32_t pc = i < nw ? (uint32_t)__popc(win[i]) : 0u;
-            const uint32_t incl = wave_incl_sum_dpp(pc);
-            if (i < nw) rank[i + 1] = (uint16_t)(carry + incl);
-            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-        if (tid == 0) rank[0] = 0;
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < nw; i += nt) {
-        const uint32_t lo = rank[i], hi = rank[i + 1], m = (lo + 31u) >> 5;
-        if (32u * m + 1u > lo && 32u * m + 1u <= hi) sel[m] = (uint16_t)i;
-    }
-    __syncthreads();
-    const uint64_t left = end_bit - wstart;
-    const SpecWin s{win, rank, sel, nw, left < W ? (uint32_t)left : W};
-    for (uint32_t q = tid; q < W; q += nt) nxt[q] = q < s.limit ? spec_nxt_entry(s, c, q) : (uint16_t)0;
-    __syncthreads();
-    for (uint32_t q = tid; q < W; q += nt) hop4[q] = spec_hop4(nxt, c, s.limit, q);
-    __syncthreads();
-    for (uint32_t q = tid; q < core; q += nt) h16[rel0 + q] = n0 == 16u ? spec_hop16(hop4, s.limit, q) : hop4[q];
+    const uint32_t nreg = (g.nwin + g.rw - 1u) / g.rw;
+    if (i < nreg) tr_trunk_region(s, c, g, t, i, mode ? exit_prev : nullptr, exit_out, TR_COUNT);
 }
 
-// four hops of `src` in a row: dst[p] = where they lead (SRC16: src holds h16 entries, else h64 entries)
-template <bool SRC16>
-__global__ void __launch_bounds__(256)
-k_hop_compose(const void *__restrict__ src, uint32_t *__restrict__ dst, uint64_t n)
+// inclusive scan of one 64-bit value per lane over a workgroup of 1024 (16 wavefronts); `total` = sum of all
+__device__ __forceinline__ uint64_t block_incl_scan64(uint64_t v, uint64_t *sh16, uint64_t &total)
 {
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    uint64_t pos = p;
-    uint32_t extra = 0;
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        ok = ok && pos < n;
-        uint32_t bits, ex;
-        if (SRC16) {
-            const uint32_t e = static_cast<const uint16_t *>(src)[ok ? pos : p];
-            bits = e & kHopBitsMask;
-            ex = e >> 13;
-            ok = ok && e != 0;
-        } else {
-            const uint32_t e = static_cast<const uint32_t *>(src)[ok ? pos : p];
-            bits = e & 0xFFFFFFu;
-            ex = e >> 24;
-            ok = ok && e != 0;
-        }
-        pos += bits;
-        extra += ex;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint64_t up = __shfl_up(v, d);
+        if (lane >= d) v += up;
     }
-    const uint64_t d = pos - p;
-    dst[p] = (ok && d < (1u << 24) && extra < 256u) ? (uint32_t)d | (extra << 24) : 0u;
+    __syncthreads();                         // (sh16 may still be read from the previous scan)
+    if (lane == 63u) sh16[wv] = v;
+    __syncthreads();
+    if (tid < 16u) {
+        uint64_t x = sh16[tid];
+        for (uint32_t d = 1; d < 16u; d <<= 1) {
+            const uint64_t up = __shfl_up(x, d);
+            if (tid >= d) x += up;
+        }
+        sh16[tid] = x;
+    }
+    __syncthreads();
+    total = sh16[15];
+    return v + (wv ? sh16[wv - 1u] : 0u);
 }
 
+// One workgroup: exclusive scans over the windows (nodes, blocks, seams, rest-of-segment runs); the same
+// rules as tr_scan_serial.  Four consecutive windows per lane and round.
+__global__ void __launch_bounds__(1024)
+k_trunk_scan(const TrGeom g, const TrTables t)
+{
+    __shared__ uint64_t sh16[16];
+    uint64_t c_nod = 0, c_blk = 0, c_sr = 0;             // carried over the rounds (the same in every lane)
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t base = 0; base < g.nwin; base += 4096u) {
+        const uint32_t w0 = base + tid * 4u;
+        uint32_t nod[4], blk[4], ros[4];
+        uint64_t prev[4], ent[4];
+        uint32_t nsum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t w = w0 + j;
+            const bool in = w < g.nwin;
+            nod[j] = in ? t.ccnt[w] : 0u;
+            blk[j] = in ? t.nblk[w] : 0u;
+            ros[j] = in ? t.nros[w] : 0u;
+            prev[j] = (in && w) ? t.exit[w - 1u] : kTrNone;
+            ent[j] = in ? t.entry[w] : kTrNone;
+            nsum += nod[j];
+        }
+        uint64_t tot;
+        uint64_t P = c_nod + block_incl_scan64(nsum, sh16, tot) - nsum;      // nodes in front, unclipped
+        c_nod += tot;
+        uint64_t Pj[4], bsum = 0, srsum = 0;
+        bool fits[4], seam[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t w = w0 + j;
+            Pj[j] = P;
+            fits[j] = P + nod[j] <= g.ncap;
+            seam[j] = w < g.nwin && (w == 0u || prev[j] == kTrNone || prev[j] != ent[j] || P > g.ncap);
+            P += nod[j];
+            if (!fits[j]) {
+                blk[j] = 0;
+                ros[j] = 0;
+            }
+            bsum += blk[j];
+            srsum += ((uint64_t)(seam[j] ? 1u : 0u) << 32) | ros[j];
+        }
+        uint64_t G = c_blk + block_incl_scan64(bsum, sh16, tot) - bsum;
+        c_blk += tot;
+        uint64_t SR = c_sr + block_incl_scan64(srsum, sh16, tot) - srsum;    // seams / runs in front of w0
+        c_sr += tot;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t w = w0 + j;
+            SR += (uint64_t)(seam[j] ? 1u : 0u) << 32;
+            if (w < g.nwin) {
+                if (!fits[j]) {
+                    t.ccnt[w] = 0;
+                    t.nblk[w] = 0;
+                    t.nros[w] = 0;
+                }
+                t.nbase[w] = (uint32_t)(Pj[j] < g.ncap ? Pj[j] : g.ncap);
+                t.gbase[w] = G;
+                t.seampre[w] = (uint32_t)(SR >> 32);                          // seams at or in front of w
+                t.rospre[w] = (uint32_t)SR;                                   // runs in front of w
+            }
+            G += blk[j];
+            SR += ros[j];
+        }
+    }
+    if (tid == 0) {
+        t.nbase[g.nwin] = (uint32_t)(c_nod < g.ncap ? c_nod : g.ncap);
+        t.gbase[g.nwin] = c_blk;
+        t.seampre[g.nwin] = (uint32_t)(c_sr >> 32) + 1u;
+        t.rospre[g.nwin] = (uint32_t)c_sr;
+    }
+}
+
+// Hypothesis walks.  Every node of the core windows is tried as an RSI start.  One workgroup per group of
+// `wpg` windows (persistent: the groups in turn); the group's stretch of the stream plus a margin behind it is
+// staged in LDS with the trunk marks and, for short coded data sets (NX), the byte table of ordinary coded
+// data sets (aec_trunk.h: TrStaged), so that a step of a walk touches no device memory.  The walks differ
+// wildly in length (a node in the middle of an RSI is back on the trunk after a few coded data sets, one behind
+// a true RSI start after the trunk's resynchronisation distance), so the loop is flat -- one coded data set per
+// lane and round, a lane that finishes takes its next node -- and a round serves ONE kind of step, the kind
+// most lanes wait for:
+//   TABLE   the byte table has the length (an ordinary coded data set inside an RSI)
+//   PARSE   the parse on the staged words (reference sample, zero-block runs, long coded data sets)
+//   REMOTE  device memory: the lane's next node, or a walk that has left the stretch
+// LDS: sw[bits / 32 + 8] u32 | bm[bits / 32] u32 | wnb[wpg + 1] u32 | wnp[wpg + 1] u32 | nx[bits] u8 (NX)
+template <bool NX>
+__global__ void __launch_bounds__(1024)
+k_hyp_walk(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, uint32_t wpg, uint32_t margin,
+           uint32_t ngroups)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hyp_lds[];
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u;
+    const TrGlobal mem{s, g, t};
+    const bool pp = c.flags & F_PREPROCESS;
+    uint32_t pool_cur = 0, pool_end = 0;                     // this wavefront's piece of the pool (same in every lane)
+    for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const uint32_t w0 = grp * wpg;
+        const uint32_t w1 = w0 + wpg < g.ncore ? w0 + wpg : g.ncore;
+        const uint64_t base = g.lo + (uint64_t)w0 * g.L;
+        const uint32_t bits = (w1 - w0) * g.L + margin;
+        const uint32_t nw = bits / 32u;
+        uint32_t *sw = hyp_lds, *bm = sw + nw + 8u, *wnb = bm + nw, *wnp = wnb + wpg + 1u;
+        uint8_t *nx = reinterpret_cast<uint8_t *>(wnp + wpg + 1u);
+        __syncthreads();                                      // (the group before is done with the arrays)
+        {
+            const uint64_t bw0 = base >> 5, gw0 = (base - g.lo) >> 5, gwn = (uint64_t)g.nwin * (g.L / 32u);
+            for (uint32_t i = tid; i < nw + 8u; i += nt) sw[i] = tr_word(s, bw0 + i);
+            for (uint32_t i = tid; i < nw; i += nt) bm[i] = gw0 + i < gwn ? t.bitmap[gw0 + i] : 0u;
+            // nodes of the group's windows: where they are stored, and how many lie in front inside the group
+            if (tid <= w1 - w0) wnb[tid] = t.nbase[w0 + tid];
+        }
+        __syncthreads();
+        if (tid <= w1 - w0) wnp[tid] = wnb[tid] - wnb[0];    // (nbase[w + 1] - nbase[w] = ccnt[w] after the scan)
+        TrStaged st{mem, sw, bm, NX ? nx : nullptr, base, bits};
+        if (NX) {
+            for (uint32_t q = tid; q < bits; q += nt) {
+                TrWin W;
+                st.win(base + q, W);
+                nx[q] = tr_fast_entry(s, c, base + q, W);
+            }
+        }
+        __syncthreads();
+        const uint32_t nnodes = wnp[w1 - w0];
+        // ---- the lane's walks: nodes tid, tid + nt, ... of the group
+        enum : uint32_t { NEW = 0, TABLE = 1, PARSE = 2, REMOTE = 3, IDLE = 4 };
+        uint32_t m = tid, wi = 0, cls = NEW, e8 = 0;          // node number in the group, its window (relative)
+        TrHyp h;
+        auto finish = [&](uint32_t state) {                   // record of the node, on to the next one
+            const uint64_t at = (uint64_t)wnb[wi] + (m - wnp[wi]);
+            TrRec r{0u, 0u};
+            uint32_t park = 0;
+            const uint64_t d = h.pos - h.c;
+            if (state == TR_DONE) {
+                r.x = tr_rec_pack(d, h.k);
+                r.y = r.x ? h.link : 0u;
+            } else if (state == TR_LAND && d <= 0xFFFFFFFFull) {
+                r.x = (uint32_t)d;
+                r.y = h.link;
+                park = kTrParked | (h.k << 16) | h.b;
+            }
+            t.rec[at] = r;
+            t.park[at] = park;
+            m += nt;
+            cls = NEW;
+        };
+        auto classify = [&]() {                               // what the walk's next step needs
+            if (!st.in(h.pos)) {
+                cls = REMOTE;
+            } else if (h.b == 0u && pp) {
+                cls = PARSE;
+            } else {
+                const uint32_t r = (uint32_t)(h.pos - base);
+                if (h.b != 0u && ((bm[r >> 5] >> (31u - (r & 31u))) & 1u)) {
+                    finish(TR_LAND);
+                } else if (h.steps >= g.budget) {
+                    finish(TR_FAIL);
+                } else {
+                    e8 = NX ? nx[r] : 0u;
+                    cls = e8 ? TABLE : PARSE;
+                }
+            }
+        };
+        auto after = [&](uint32_t r) {                        // r = result of tr_hyp_advance / tr_hyp_step
+            if (r != TR_RUN) finish(r);
+            else classify();
+        };
+        for (;;) {
+            const uint32_t nT = (uint32_t)__popcll(__ballot(cls == TABLE));
+            const uint32_t nP = (uint32_t)__popcll(__ballot(cls == PARSE));
+            const uint32_t nR = (uint32_t)__popcll(__ballot(cls == NEW || cls == REMOTE));
+            if (!(nT | nP | nR)) break;
+            if (nR >= 16u || !(nT | nP)) {
+                if (cls == NEW) {
+                    if (m < nnodes) {
+                        while (m >= wnp[wi + 1u]) wi++;
+                        const uint32_t cp = t.cpos[(uint64_t)wnb[wi] + (m - wnp[wi])];
+                        tr_hyp_start(c, h, base + (uint64_t)wi * g.L + cp);
+                        classify();
+                    } else {
+                        cls = IDLE;
+                    }
+                } else if (cls == REMOTE) {
+                    after(tr_hyp_step(s, c, g, mem, h));
+                }
+            } else if (nP >= 16u || !nT) {
+                if (cls == PARSE) {
+                    TrWin W;
+                    st.win(h.pos, W);
+                    uint32_t nb = 1;
+                    const uint32_t len = tr_hyp_parse(s, c, h, W, nb);
+                    if (!len) finish(TR_FAIL);
+                    else after(tr_hyp_advance(c, g, st, h, len, nb));
+                }
+            } else if (cls == TABLE) {
+                after(tr_hyp_advance(c, g, st, h, e8, 1u));
+            }
+            // RSI ends to record: the wavefront's lanes take entries of its piece of the pool together
+            const bool want = cls != NEW && cls != IDLE && h.pend != 0u;
+            const uint64_t wm = __ballot(want);
+            if (wm) {
+                const uint32_t n = (uint32_t)__popcll(wm);
+                if (pool_cur + n > pool_end) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(t.pool_cnt, 256u);
+                    pool_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                    pool_end = pool_cur + 256u;
+                }
+                if (want) {
+                    const uint32_t e = pool_cur + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+                    if (!tr_hyp_commit(g, t, h, e)) finish(TR_FAIL);
+                }
+                pool_cur += n;
+            }
+        }
+    }
+}
+
+// The same walks for long coded data sets, whose walks run over more of the stream than LDS holds: every step
+// reads device memory.  One wavefront per group of `wpg` windows (many nodes per lane, so that the flat loop
+// evens out the walk lengths).  A step is ONE memory round trip -- the 256-bit window at the walk's position
+// and the word of trunk marks leave together -- and everything that needs another one waits in the lane until
+// 16 lanes of the wavefront do (or nothing else is left): a unary part that goes on behind the window, the
+// mark at the end of an RSI, the record of a finished walk and the lane's next node.
+__global__ void __launch_bounds__(64)
+k_hyp_walk_mem(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, uint32_t wpg)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t w0 = blockIdx.x * wpg;
+    if (w0 >= g.ncore) return;
+    const uint32_t w1 = w0 + wpg < g.ncore ? w0 + wpg : g.ncore;
+    const TrGlobal mem{s, g, t};
+    uint32_t pool_cur = 0, pool_end = 0;
+    enum : uint32_t { STEP = 0, LONG = 1, ENDRSI = 2, FIN = 3, IDLE = 4 };
+    uint32_t w = w0, idx = lane, cls = FIN, fin = 0xFFu;      // (fin 0xFF: nothing to record yet, just take a node)
+    TrHyp h;
+    h.pend = 0;
+    for (;;) {
+        const uint32_t nS = (uint32_t)__popcll(__ballot(cls == STEP));
+        const uint32_t nR = (uint32_t)__popcll(__ballot(cls == LONG || cls == ENDRSI || cls == FIN));
+        if (!(nS | nR)) break;
+        if (nR >= 16u || !nS) {
+            if (cls == LONG) {                                // the whole parse, following the unary part through memory
+                TrWin W;
+                tr_win_load(s, h.pos, W);
+                uint32_t nb = 1;
+                const uint32_t len = tr_hyp_parse(s, c, h, W, nb);
+                if (!len) {
+                    cls = FIN;
+                    fin = TR_FAIL;
+                } else {
+                    h.pos += len;
+                    h.b += nb;
+                    h.steps++;
+                    cls = h.b == c.rsi ? ENDRSI : STEP;
+                }
+            }
+            if (cls == ENDRSI) {
+                const uint32_t r = tr_hyp_complete(c, g, h, tr_marked(g, t, h.pos));
+                cls = r == TR_RUN ? STEP : FIN;
+                fin = r;
+            } else if (cls == FIN) {
+                if (fin != 0xFFu) {
+                    tr_hyp_finish(g, t, w, idx, h, fin);
+                    idx += 64u;
+                }
+                cls = IDLE;
+                while (w < w1) {
+                    const uint32_t n = t.ccnt[w];
+                    if (idx < n) {
+                        tr_hyp_start(c, h, g.lo + (uint64_t)w * g.L + t.cpos[t.nbase[w] + idx]);
+                        cls = STEP;
+                        break;
+                    }
+                    idx -= n;
+                    w++;
+                }
+            }
+        } else if (cls == STEP) {
+            TrWin W;
+            tr_win_load(s, h.pos, W);
+            const bool on = tr_marked(g, t, h.pos);
+            if (h.b != 0u && on) {
+                cls = FIN;
+                fin = TR_LAND;
+            } else if (h.steps >= g.budget) {
+                cls = FIN;
+                fin = TR_FAIL;
+            } else {
+                uint32_t nb = 1;
+                bool more = false;
+                const uint32_t len = tr_hyp_parse(s, c, h, W, nb, false, &more);
+                if (!len) {
+                    cls = more ? LONG : FIN;
+                    fin = TR_FAIL;
+                } else {
+                    h.pos += len;
+                    h.b += nb;
+                    h.steps++;
+                    if (h.b == c.rsi) cls = ENDRSI;
+                }
+            }
+        }
+        // RSI ends to record: the wavefront's lanes take entries of its piece of the pool together
+        const bool want = cls == STEP && h.pend != 0u;
+        const uint64_t wm = __ballot(want);
+        if (wm) {
+            const uint32_t n = (uint32_t)__popcll(wm);
+            if (pool_cur + n > pool_end) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(t.pool_cnt, 256u);
+                pool_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                pool_end = pool_cur + 256u;
+            }
+            if (want) {
+                const uint32_t e = pool_cur + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+                if (!tr_hyp_commit(g, t, h, e)) {
+                    cls = FIN;
+                    fin = TR_FAIL;
+                }
+            }
+            pool_cur += n;
+        }
+    }
+}
+
+// one lane per node: the jump of every parked hypothesis
+__global__ void __launch_bounds__(256)
+k_hyp_land(const Cfg c, const TrGeom g, const TrTables t)
+{
+    const uint32_t w = blockIdx.x;
+    if (w >= g.ncore) return;
+    const uint32_t n = t.ccnt[w];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) tr_hyp_land(c, g, t, w, i);
+}
+
+// ---- wide walker: every node of a chunk's first window chases the records through the chunk
+__global__ void __launch_bounds__(256)
+k_twide(const TwTables t, uint32_t nwin, uint64_t end_bit, uint4 *__restrict__ wide)
+{
+    const uint32_t chunk = blockIdx.y;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t first = chunk * t.wpc;
+    if (first >= nwin || i >= t.ccnt[first] || i >= t.wcap) return;
+    const uint32_t last = first + t.wpc < nwin ? first + t.wpc : nwin;      // one past the chunk's windows
+    const uint64_t stop = t.lo + (uint64_t)last * t.core;
+    uint64_t pos = t.lo + (uint64_t)first * t.core + t.cpos[t.nbase[first] + i];
+    uint32_t cnt = 0, ok = 1;
+    while (pos < stop && pos < end_bit) {
+        TrRec rec;
+        uint32_t wv, ix;
+        if (!tw_lookup(t, pos, rec, wv, ix) || !rec.x) {
+            ok = 0;
+            break;
+        }
+        pos += tr_rec_bits(rec.x);
+        cnt += tr_rec_k(rec.x);
+    }
+    // (a chain that ends at the end of the input inside the last chunk is resolved as far as it goes:
+    // the walker takes over from its exit)
+    wide[(uint64_t)chunk * t.wcap + i] = make_uint4((uint32_t)pos, (uint32_t)(pos >> 32), cnt, ok && cnt ? 1u : 0u);
+}
+
+// RSI starts of one record at node p (RSI number r onwards): the record's own start, and for a record of
+// several RSIs the starts inside it from the pool of RSI ends
+__device__ __forceinline__ void write_record_starts(const Cfg &c, const TrTables &tt, uint64_t p, uint64_t r, TrRec rec,
+                                                    uint64_t *__restrict__ rsi_off)
+{
+    const uint32_t k = tr_rec_k(rec.x);
+    rsi_off[r] = tr_rsi_start(c, p);
+    if (k > 1u) (void)tr_rec_ends(tt, p, k, rec.y, [&](uint32_t j, uint64_t q) { rsi_off[r + 1u + j] = tr_rsi_start(c, q); });
+}
+
+// the true chain through the chunks the walker skipped: one lane per chunk follows the records and writes
+// the RSI starts
+__global__ void __launch_bounds__(64)
+k_trewalk(const Cfg c, const TwTables t, const TrTables tt, uint32_t nwin, uint32_t nchunks, uint64_t end_bit,
+         const ChunkEntry *__restrict__ entry, uint64_t *__restrict__ rsi_off)
+{
+    const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chunk >= nchunks || !entry[chunk].valid) return;
+    const uint32_t first = chunk * t.wpc;
+    const uint32_t last = first + t.wpc < nwin ? first + t.wpc : nwin;
+    const uint64_t stop = t.lo + (uint64_t)last * t.core;
+    uint64_t pos = entry[chunk].pos, r = entry[chunk].r;
+    while (pos < stop && pos < end_bit) {
+        TrRec rec;
+        uint32_t wv, ix;
+        if (!tw_lookup(t, pos, rec, wv, ix) || !rec.x) break;      // (cannot happen: k_twide went through)
+        write_record_starts(c, tt, pos, r, rec, rsi_off);
+        pos += tr_rec_bits(rec.x);
+        r += tr_rec_k(rec.x);
+    }
+}
+
+// RSI starts inside the records of several RSIs the walker took outside the wide hops
+__global__ void k_texpand(const Cfg c, const TwTables t, const TrTables tt, const IdxCarry *__restrict__ carry,
+                         const IdxHop *__restrict__ hops, uint64_t *__restrict__ rsi_off)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= carry->n_hops) return;
+    const IdxHop h = hops[i];
+    TrRec rec;
+    uint32_t wv, ix;
+    if (!tw_lookup(t, h.pos, rec, wv, ix) || tr_rec_k(rec.x) != h.cnt) return;      // (cannot happen)
+    write_record_starts(c, tt, h.pos, h.r, rec, rsi_off);
+}
+
+// ======== sparse candidates per window (low-entropy streams with short RSIs) ==========================
 // ---- sparse speculation (aec_spec2.h) ----------------------------------------------------------------
 // One workgroup of 1024 lanes per window = [lead-in | core | look-ahead].  LDS:
 //   win[nw + 2] u32 | marks[nw] u32 | rank[nw + 2] u16 | sel[nw + 2] u16 | mpre[nw + 2] u16 |
@@ -599,21 +832,6 @@ __global__ void k_expand2(const SparseTables t, const IdxCarry *__restrict__ car
     }
 }
 
-// RSI starts inside the chained hops of the walker
-__global__ void k_expand(const IdxCarry *__restrict__ carry, const IdxHop *__restrict__ hops,
-                         const IdxTables tabs, uint32_t pad_rsi, uint64_t *__restrict__ rsi_off)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= carry->n_hops) return;
-    const IdxHop h = hops[i];
-    uint64_t p = h.pos;
-    for (uint32_t j = 0; j < h.cnt; j++) {
-        rsi_off[h.r + j] = p;
-        p += tabs.T[p - tabs.lo];
-        if (pad_rsi) p = (p + 7u) & ~7ull;
-    }
-}
-
 // ---- serial RSI index -----------------------------------------------------------------------------
 // One wavefront per stream.  The walk itself is serial (every lane executes it redundantly on
 // wave-uniform values), but the stream is served from a 16 KiB LDS window that all 64 lanes refill
@@ -638,10 +856,9 @@ struct LdsWindowFetch {
 __global__ void __launch_bounds__(64)
 k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
         uint64_t start_bit, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res,
-        const uint64_t *__restrict__ chunk_off, const IdxTables tabs, IdxHop *__restrict__ hops,
-        uint32_t hop_cap, IdxCarry *carry, uint32_t first, uint32_t last, uint32_t start_block,
-        uint64_t rsi_start, uint32_t tail_slot, const SparseTables sp, ChunkEntry *__restrict__ centry,
-        const HopTables ht)
+        const uint64_t *__restrict__ chunk_off, IdxHop *__restrict__ hops, uint32_t hop_cap, IdxCarry *carry,
+        uint32_t first, uint32_t last, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
+        const TwTables sp, ChunkEntry *__restrict__ centry, const SparseTables s2)
 {
     __shared__ __attribute__((aligned(16))) uint32_t win[kIdxWindowWords];
     uint64_t r = 0;
@@ -670,8 +887,6 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         start_bit = carry->good;
         r = carry->r;
     }
-    const uint32_t b_carried = (carry && !first) ? carry->b : 0u;
-    const uint64_t start_carried = (carry && !first) ? carry->cur_start : 0ull;
     const uint32_t lane = threadIdx.x;
     const bool pp = c.flags & F_PREPROCESS;
     const uint32_t maxw = (c.id_len + 1 + c.bps + c.bs * c.bps) / 32 + 4;   // words one CDS can touch
@@ -738,6 +953,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     br.init(LdsWindowFetch{win, base}, end_bit, start_bit);
     uint64_t good = start_bit;
     uint32_t b = 0, status = DEC_OK, nh = 0;
+    uint32_t n_serial = (carry && !first) ? carry->n_serial : 0u, n_lookups = (carry && !first) ? carry->n_lookups : 0u;
     // Resumed walk (streaming callers): start_bit is a CDS boundary inside an RSI that began at
     // rsi_start and of which start_block blocks lie before start_bit.
     uint64_t cur_start = start_bit;          // start of the RSI being walked
@@ -746,20 +962,11 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         cur_start = rsi_start;
         if (lane == 0 && max_rsi) rsi_off[0] = rsi_start;
     }
-    if (b_carried) {             // the previous table chunk ended inside this RSI
-        b = b_carried;
-        cur_start = start_carried;
-    }
     if (coop) load_regs(good >> 5);
-    bool stale = false;          // the sequential reader lags behind `good` (hops moved it)
     for (;;) {
         bool hopped = false;
         if (b == 0) {
             if (r >= max_rsi) break;
-            if ((c.flags & F_PAD_RSI) && (good & 7u)) {      // reference decode.c:407-408
-                good = (good + 7u) & ~7ull;
-                hopped = true;
-            }
             // Fast hops over the speculative tables (k_spec): at an RSI start one lookup gives the
             // end of a chain of whole RSIs leaving the window (Xb/Xc; the RSI starts inside the hop
             // are filled in by k_expand), or of this RSI alone (T).  An entry of 0 = not resolved
@@ -767,14 +974,14 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             // Sparse tables (k_spec2): at a chunk's first window ONE lookup in the wide walker's table
             // takes the walk across the whole chunk (k_rewalk / k_expand2 fill in what lies inside);
             // else the window's chained hop, else this RSI alone.
-            while (sp.bitmap && r < max_rsi && good >= sp.lo && good < sp.hi && good < end_bit) {
+            while (s2.bitmap && r < max_rsi && good >= s2.lo && good < s2.hi && good < end_bit) {
                 uint2 rec;
                 uint32_t wv, ix;
-                if (!sparse_lookup(sp, good, rec, wv, ix)) break;
-                if (sp.wide && (wv % sp.wpc) == 0u) {
-                    const uint4 wd = sp.wide[(uint64_t)(wv / sp.wpc) * sp.cap + ix];
+                if (!sparse_lookup(s2, good, rec, wv, ix)) break;
+                if (s2.wide && (wv % s2.wpc) == 0u) {
+                    const uint4 wd = s2.wide[(uint64_t)(wv / s2.wpc) * s2.cap + ix];
                     if (wd.w && r + wd.z <= max_rsi) {
-                        if (lane == 0) centry[wv / sp.wpc] = ChunkEntry{good, r, 1u, 0u};
+                        if (lane == 0) centry[wv / s2.wpc] = ChunkEntry{good, r, 1u, 0u};
                         good = (uint64_t)wd.x | ((uint64_t)wd.y << 32);
                         r += wd.z;
                         hopped = true;
@@ -796,83 +1003,58 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                 }
                 hopped = true;
             }
-            while (tabs.T && r < max_rsi && good >= tabs.lo && good < tabs.hi && good < end_bit) {
-                const uint64_t i = good - tabs.lo;
-                const uint32_t xc = tabs.Xc[i], xb = tabs.Xb[i], t = tabs.T[i];
-                if (xc && r + xc <= max_rsi && nh < hop_cap) {
-                    if (lane == 0) hops[nh] = IdxHop{good, r, xc, 0u};
+            // Hops over the trunk tables (aec_trunk.h).  A record is keyed by the node where its RSI starts --
+            // with AEC_PAD_RSI where the RSI in front of it ENDS, so the lookups come before the alignment.
+            // At a chunk's first window ONE lookup in the wide walker's table takes the walk across the whole
+            // chunk (k_trewalk fills in what lies inside); else record by record.  No record = not resolved by
+            // the tables: that RSI is walked CDS by CDS below.
+            while (sp.bitmap && r < max_rsi && good >= sp.lo && good < sp.hi && good < end_bit) {
+                TrRec rec;
+                uint32_t wv, ix;
+                if (!tw_lookup(sp, good, rec, wv, ix)) break;
+                n_lookups++;
+                if (sp.wide && (wv % sp.wpc) == 0u && ix < sp.wcap) {
+                    const uint4 wd = sp.wide[(uint64_t)(wv / sp.wpc) * sp.wcap + ix];
+                    if (wd.w && r + wd.z <= max_rsi) {
+                        if (lane == 0) centry[wv / sp.wpc] = ChunkEntry{good, r, 1u, 0u};
+                        good = (uint64_t)wd.x | ((uint64_t)wd.y << 32);
+                        r += wd.z;
+                        hopped = true;
+                        continue;
+                    }
+                }
+                const uint32_t k1 = tr_rec_k(rec.x), b1 = tr_rec_bits(rec.x);
+                if (k1 == 1u) {
+                    if (lane == 0) rsi_off[r] = tr_rsi_start(c, good);
+                } else if (k1 > 1u && r + k1 <= max_rsi && nh < hop_cap) {
+                    if (lane == 0) hops[nh] = IdxHop{good, r, k1, 0u};      // (k_texpand writes the starts inside)
                     nh++;
-                    good += xb;
-                    r += xc;
-                } else if (t) {
-                    if (lane == 0) rsi_off[r] = good;
-                    good += t;
-                    r++;
-                    if (c.flags & F_PAD_RSI) good = (good + 7u) & ~7ull;
                 } else {
                     break;
                 }
+                good += b1;
+                r += k1;
                 hopped = true;
             }
             if (r >= max_rsi) break;
-            if (carry && !last && good >= (sp.bitmap ? sp.hi : (ht.h16 ? ht.hi : tabs.hi))) {   // the next table chunk continues from here
+            if (carry && !last && good >= (s2.bitmap ? s2.hi : sp.hi)) {       // the next span continues from here
                 if (lane == 0) {
                     carry->good = good;
                     carry->r = r;
                     carry->active = 1;
                     carry->n_hops = nh;
-                    carry->b = 0;
-                    carry->cur_start = good;
+                    carry->n_serial = n_serial;
+                    carry->n_lookups = n_lookups;
                 }
                 return;
+            }
+            if ((c.flags & F_PAD_RSI) && (good & 7u)) {      // reference decode.c:407-408
+                good = (good + 7u) & ~7ull;
+                hopped = true;
             }
             if (lane == 0) rsi_off[r] = good;
             cur_start = good;
-        }
-        // Hop tables (long RSIs): 256 / 64 / 16 coded data sets per lookup while that many blocks are left in
-        // the RSI; the coded data set with the reference sample and rest-of-segment runs are parsed below.
-        if (ht.h16 && !(pp && b == 0)) {
-            bool rsi_done = false;
-            while (good >= ht.lo && good < ht.hi && good < end_bit) {
-                const uint64_t i = good - ht.lo;
-                const uint32_t left = c.rsi - b;
-                const uint32_t n0 = ht.n0;
-                const uint32_t e256 = (ht.h256 && left >= 16u * n0) ? ht.h256[i] : 0u;
-                const uint32_t e64 = left >= 4u * n0 ? ht.h64[i] : 0u;
-                const uint32_t e16 = left >= n0 ? ht.h16[i] : 0u;
-                if (e256 && 16u * n0 + (e256 >> 24) <= left) {
-                    good += e256 & 0xFFFFFFu;
-                    b += 16u * n0 + (e256 >> 24);
-                } else if (e64 && 4u * n0 + (e64 >> 24) <= left) {
-                    good += e64 & 0xFFFFFFu;
-                    b += 4u * n0 + (e64 >> 24);
-                } else if (e16 && n0 + (e16 >> 13) <= left) {
-                    good += e16 & kHopBitsMask;
-                    b += n0 + (e16 >> 13);
-                } else {
-                    break;
-                }
-                hopped = true;
-                stale = true;
-                if (b >= c.rsi) {
-                    b = 0;
-                    r++;
-                    rsi_done = true;
-                    break;
-                }
-            }
-            if (rsi_done) continue;              // next RSI: back to the top (offset table, table hops)
-            if (carry && !last && good >= ht.hi) {   // the chunk ends inside this RSI: the next one goes on from here
-                if (lane == 0) {
-                    carry->good = good;
-                    carry->r = r;
-                    carry->active = 1;
-                    carry->n_hops = nh;
-                    carry->b = b;
-                    carry->cur_start = cur_start;
-                }
-                return;
-            }
+            n_serial++;
         }
         // keep the whole next CDS (and the readers' look-ahead) inside the LDS window
         if ((good >> 5) + (coop ? 66u : maxw + 2u) > base + kIdxWindowWords) {
@@ -880,10 +1062,8 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             refill(good >> 5);
             br.init(LdsWindowFetch{win, base}, end_bit, good);
             if (coop) load_regs(good >> 5);
-            stale = false;
-        } else if (hopped || stale) {
+        } else if (hopped) {
             br.init(LdsWindowFetch{win, base}, end_bit, good);
-            stale = false;
         }
         const uint32_t ref = (pp && b == 0) ? 1u : 0u;
         uint32_t nblk = 1;
@@ -953,6 +1133,8 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     if (lane == 0 && carry) {
         carry->active = 0;
         carry->n_hops = nh;
+        carry->n_serial = n_serial;
+        carry->n_lookups = n_lookups;
     }
     if (lane == 0) {
         // streaming callers: where the trailing partial RSI began, in a slot of its own behind the table
@@ -972,109 +1154,19 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     }
 }
 
-
-
-struct SpecGeom {
-    bool ok;
-    uint32_t core, look, threads;
-    size_t lds;
-    uint64_t chunk_bits;     // bit positions tabulated per k_spec launch (multiple of core)
-};
-
-constexpr size_t kSpecLdsMax = 160u * 1024u;
-constexpr uint32_t kSpecWMax = 24576;                    // largest window considered (bits)
-constexpr uint64_t kSpecChunkBits = 1ull << 25;          // 4 MiB of stream per table chunk
-
-size_t spec_lds_bytes(uint32_t core, uint32_t look)
-{
-    const uint32_t W = core + look, nw = W / 32;
-    return (size_t)(nw + 2) * 4 + (size_t)(nw + 2) * 2 * 2 + (size_t)W * 2 * 3 + (size_t)core * 2;
-}
-
-// The tables pay off when whole RSIs fit the look-ahead of a window.  `rsi_bits_hint` is the
-// caller's estimate of the average coded RSI (stream bits / expected RSIs; 0 = unknown): the
-// look-ahead is twice that, the rest of the LDS budget is the core.  RSIs longer than the look-ahead
-// are left to the serial walk, so a wrong hint costs speed only.  Small inputs get small cores so
-// that the windows still fill the chip.
-SpecGeom spec_geom(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint)
-{
-    SpecGeom g{};
-    const uint64_t worst = (uint64_t)c.rsi * (c.id_len + (uint64_t)c.bs * c.bps) + c.bps + 64;
-    if (total_bits < 4096) return g;
-    uint64_t look;
-    if (rsi_bits_hint) {
-        if (rsi_bits_hint + rsi_bits_hint / 4 + 256 > kSpecWMax - 2048) return g;
-        look = 2 * rsi_bits_hint + 1024;
-    } else {
-        if (worst > 65000) return g;
-        look = 12288;
-    }
-    if (look > worst) look = worst;
-    if (look > kSpecWMax - 2048) look = kSpecWMax - 2048;
-    if (look < 2048) look = 2048;
-    g.look = (uint32_t)((look + 31) & ~31ull);
-    // about one window per CU for small inputs, and windows of at least three RSIs (a hop of the
-    // walker costs a memory round trip: it should cover several RSIs)
-    uint64_t core = (total_bits / 256 + 1023) & ~1023ull;
-    uint64_t three = 3 * rsi_bits_hint;
-    if (three > total_bits / 64) three = total_bits / 64;      // (tiny inputs: keep 64 windows at least)
-    if (core < three) core = (three + 1023) & ~1023ull;
-    if (core < 2048) core = 2048;
-    if (core > 16384) core = 16384;
-    if (core > kSpecWMax - g.look) core = (kSpecWMax - g.look) & ~1023ull;
-    while (core >= 2048 && spec_lds_bytes((uint32_t)core, g.look) > kSpecLdsMax) core -= 1024;
-    if (core < 1024) return g;
-    g.core = (uint32_t)core;
-    g.lds = spec_lds_bytes(g.core, g.look);
-    if (g.lds > kSpecLdsMax) return g;
-    const uint32_t W = g.core + g.look;
-    g.threads = W >= 16384 ? 1024 : (W >= 8192 ? 512 : 256);
-    g.chunk_bits = (kSpecChunkBits / g.core) * g.core;
-    g.ok = true;
-    return g;
-}
-
-void allow_big_lds()
-{
-    static std::once_flag once[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) dev = 0;
-    std::call_once(once[dev], [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_spec),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSpecLdsMax);
-    });
-}
-
 }  // namespace
 
 namespace {
 
-// One set of tables (+ the walker's hop list) for a chunk of `entries` bit positions.
-struct TableSet {
-    uint16_t *T, *Xb;
-    uint8_t *Xc;
-    IdxHop *hops;
-};
-
-size_t table_set_bytes(uint64_t entries, uint64_t nwin)
+#ifdef AEC_TUNING
+static uint32_t tune(const char *name, uint32_t dflt)
 {
-    return (size_t)((entries * 5 + 15) / 16 * 16 + (2 * nwin + 16) * sizeof(IdxHop));
+    const char *e = getenv(name);
+    return e ? (uint32_t)atoi(e) : dflt;
 }
-
-TableSet table_set_at(uint8_t *p, uint64_t entries)
-{
-    TableSet t;
-    t.T = reinterpret_cast<uint16_t *>(p);
-    t.Xb = t.T + entries;
-    t.Xc = reinterpret_cast<uint8_t *>(t.Xb + entries);
-    t.hops = reinterpret_cast<IdxHop *>(p + (entries * 5 + 15) / 16 * 16);
-    return t;
-}
-
-}  // namespace
-
-namespace {
+#else
+static uint32_t tune(const char *, uint32_t dflt) { return dflt; }
+#endif
 
 // ---- sparse path: geometry and workspace ------------------------------------------------------------
 struct Sparse2Plan {
@@ -1100,14 +1192,13 @@ constexpr uint32_t kS2SuperWindows = 4096;     // windows per launch: bounds the
 Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint)
 {
     Sparse2Plan p{};
-    static const bool off = getenv("AEC_IDX_DENSE") != nullptr;          // A/B switch for measurements
+    const bool off = tune("AEC_IDX_NO_SPARSE", 0) != 0;                  // A/B switch for measurements
     if (off || (c.flags & F_PAD_RSI) || !rsi_bits_hint || total_bits < 16384) return p;
     const uint64_t samples = (uint64_t)c.rsi * c.bs;
     if (rsi_bits_hint * 2 > samples * 9) return p;                       // more than 4.5 bits per sample
     uint64_t look = (2 * rsi_bits_hint + 1024 + 31) & ~31ull;
     if (look < 4096) look = 4096;
-    static const char *e_win = getenv("AEC_S2_WINDOW");
-    uint32_t wbits = e_win ? (uint32_t)atoi(e_win) : kS2WindowBits;
+    uint32_t wbits = tune("AEC_S2_WINDOW", kS2WindowBits);
     if (wbits < 16384 || wbits > kS2WindowBits) wbits = kS2WindowBits;
     if (look + kS2Lead + 8192 > wbits) wbits = kS2WindowBits;            // long RSIs: the largest window
     if (look > kS2WindowBits - kS2Lead - 16384) return p;
@@ -1118,14 +1209,11 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     p.g.lead = kS2Lead;
     p.g.core = (uint32_t)core;
     p.g.look = (uint32_t)look;
-    static const char *e_stride = getenv("AEC_S2_STRIDE"), *e_burn = getenv("AEC_S2_BURN");
-    p.g.stride = e_stride ? (uint32_t)atoi(e_stride) : 64u;
-    p.g.burn = e_burn ? (uint32_t)atoi(e_burn) : 24u;
-    static const char *e_budget = getenv("AEC_S2_BUDGET");
-    p.g.budget = e_budget ? (uint32_t)atoi(e_budget) : 0xFFFFFFFFu;
+    p.g.stride = tune("AEC_S2_STRIDE", 64u);
+    p.g.burn = tune("AEC_S2_BURN", 24u);
+    p.g.budget = tune("AEC_S2_BUDGET", 0xFFFFFFFFu);
     const uint32_t W = p.g.lead + p.g.core + p.g.look, nw = W / 32;
-    static const char *e_capdiv = getenv("AEC_S2_CAPDIV");
-    const uint32_t capdiv = e_capdiv ? (uint32_t)atoi(e_capdiv) : 8u;
+    const uint32_t capdiv = tune("AEC_S2_CAPDIV", 8u);
     p.g.cap_lds = (W / (capdiv ? capdiv : 8u) + 63) & ~63u;
     p.g.cap_core = (p.g.core / 8 + 63) & ~63u;
     p.lds = (size_t)(nw + 2) * 4 + (size_t)nw * 4 + (size_t)(nw + 2) * 2 * 3 + (size_t)p.g.cap_lds * 2 * 5 + 64;
@@ -1156,7 +1244,7 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
 // AEC_S2_PROF=1: phase stamps of k_spec2 (diagnostics; printed by the host at exit of the first launch)
 unsigned long long *spec2_prof_buffer(uint32_t nwin, bool reset = true)
 {
-    static const bool on = getenv("AEC_S2_PROF") != nullptr;
+    static const bool on = tune("AEC_S2_PROF", 0) != 0;
     static unsigned long long *buf = nullptr;
     if (!on) return nullptr;
     if (!buf) (void)hipMalloc(reinterpret_cast<void **>(&buf), (size_t)kS2SuperWindows * 8 * sizeof(unsigned long long));
@@ -1242,8 +1330,8 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
         hipLaunchKernelGGL(k_wide, dim3((p.g.cap_core + 255) / 256, nchunks), dim3(256), 0, st, t, nwin, end_bit,
                            const_cast<uint4 *>(t.wide));
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
-                           d_res, (const uint64_t *)nullptr, IdxTables{}, hops, hop_cap, carry, first ? 1u : 0u,
-                           last ? 1u : 0u, start_block, rsi_start, tail_slot, t, centry, HopTables{});
+                           d_res, (const uint64_t *)nullptr, hops, hop_cap, carry, first ? 1u : 0u, last ? 1u : 0u,
+                           start_block, rsi_start, tail_slot, TwTables{}, centry, t);
         hipLaunchKernelGGL(k_rewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, t, nwin, nchunks, end_bit, centry, rhops,
                            nhops);
         hipLaunchKernelGGL(k_expand2, dim3((hop_cap + 255) / 256), dim3(256), 0, st, t, carry, hops,
@@ -1253,104 +1341,268 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
     }
 }
 
-}  // namespace
 
-namespace {
-
-// ---- hop path: geometry and launches ------------------------------------------------------------------
-struct HopPlan {
+// ---- geometry and workspace of the trunk index -------------------------------------------------------
+struct TrunkPlan {
     bool ok;
-    uint32_t core, look, n0;
-    size_t lds;
-    uint64_t chunk_bits;      // positions tabulated per launch (multiple of core)
-    size_t set_bytes;         // one table set: h16 + h64 + h256 for chunk_bits positions
+    uint32_t L, lead, rw, passes, budget, kmax, wpw, wpc, wcap;
+    uint32_t staged, margin;  // hypothesis walks: byte table of coded data set lengths or not, margin behind a group (bits)
+    size_t lds;               // ... and the LDS of a workgroup
+    uint32_t pcap;            // pool of RSI ends inside records
+    uint32_t nwin_max;        // windows per span (launch set): core + look-ahead
+    uint32_t nlook;           // look-ahead windows behind the core of a span that does not reach the end
+    uint32_t ncap;            // node records per span
+    // byte offsets inside the workspace (behind the 64-byte carry record)
+    size_t o_bitmap, o_pre, o_nbase, o_cpos, o_bp, o_ccnt, o_nblk, o_nros, o_entry, o_exit0, o_exit1, o_gbase, o_seam,
+        o_ros, o_rec, o_park, o_pool, o_wide, o_centry, o_hops, bytes;
 };
 
-constexpr uint32_t kHopWindowBits = 32768;
-constexpr uint64_t kHopChunkBits = 1ull << 25;       // 4 MiB of stream per table chunk (10 bytes per bit)
+constexpr size_t kTrWsWanted = 768u << 20;      // workspace asked for at most (larger inputs take several spans)
 
-// Used where neither the sparse nor the RSI tables apply: RSIs longer than any window (BASELINE config 3:
-// a megabit coded per RSI).  The look-ahead must hold the coded data sets of a base entry (16, or 4).
-HopPlan hop_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint)
+
+size_t trunk_bytes(TrunkPlan &p, uint32_t nwin)
 {
-    HopPlan p{};
-    static const bool off = getenv("AEC_IDX_NO_HOPS") != nullptr;
-    if (off || (c.flags & F_PAD_RSI) || total_bits < 65536 || c.rsi < 64) return p;
-    // average coded data set from the hint, else half the uncompressed size
-    uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 2;
-    if (cds < 32) cds = 32;
-    p.n0 = cds * 16 * 3 / 2 < kHopBitsMask ? 16u : 4u;         // (distance of a base entry: 13 bits)
-    uint64_t look = (p.n0 * cds * 3 / 2 + 1023) & ~1023ull;
-    if (look < 4096) look = 4096;
-    if (look > kHopWindowBits - 8192) return p;
-    p.look = (uint32_t)look;
-    p.core = (uint32_t)((kHopWindowBits - look) & ~1023ull);
-    const uint32_t W = p.core + p.look, nw = W / 32;
-    p.lds = (size_t)(nw + 2) * 4 + (size_t)(nw + 2) * 2 * 2 + (size_t)W * 2 * 2;
-    if (p.lds > 156 * 1024) return p;
-    p.chunk_bits = (kHopChunkBits / p.core) * p.core;
-    p.set_bytes = (size_t)((p.chunk_bits * 10 + 255) & ~255ull);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t words = (size_t)nwin * (p.L / 32);
+    const uint32_t nchunk = (nwin + p.wpc - 1) / p.wpc;
+    size_t o = 64;
+    p.o_bitmap = o; o = up(o + words * 4);
+    p.o_pre = o;    o = up(o + words * 2);
+    p.o_nbase = o;  o = up(o + ((size_t)nwin + 1) * 4);
+    p.o_cpos = o;   o = up(o + (size_t)p.ncap * 2);
+    p.o_bp = o;     o = up(o + (size_t)p.ncap * 4);
+    p.o_ccnt = o;   o = up(o + (size_t)nwin * 4);
+    p.o_nblk = o;   o = up(o + (size_t)nwin * 4);
+    p.o_nros = o;   o = up(o + (size_t)nwin * 4);
+    p.o_entry = o;  o = up(o + (size_t)nwin * 8);
+    p.o_exit0 = o;  o = up(o + (size_t)nwin * 8);
+    p.o_exit1 = o;  o = up(o + (size_t)nwin * 8);
+    p.o_gbase = o;  o = up(o + ((size_t)nwin + 1) * 8);
+    p.o_seam = o;   o = up(o + ((size_t)nwin + 1) * 4);
+    p.o_ros = o;    o = up(o + ((size_t)nwin + 1) * 4);
+    p.o_rec = o;    o = up(o + (size_t)p.ncap * sizeof(TrRec));
+    p.o_park = o;   o = up(o + (size_t)p.ncap * 4);
+    p.o_pool = o;   o = up(o + (size_t)p.pcap * sizeof(TrPoolEntry));
+    p.o_wide = o;   o = up(o + (size_t)nchunk * p.wcap * sizeof(uint4));
+    p.o_centry = o; o = up(o + (size_t)nchunk * sizeof(ChunkEntry));
+    p.o_hops = o;   o = up(o + ((size_t)nwin * 2 + 16) * sizeof(IdxHop));
+    return o;
+}
+
+// The trunk pays off as soon as the stream is long enough to give every lane a region of its own; the
+// geometry follows from the average coded data set (caller's estimate of the coded RSI / blocks per RSI):
+// the self-synchronising parse needs about 2 * cds^2 bits to fall onto another chain (measured in tests/emul:
+// 4.5 kbit at 45 bits per coded data set, 126 kbit at 253), which sizes burn-in and region.
+// ws_bytes: what the caller can give (0 = say what is wanted).
+TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, size_t ws_bytes)
+{
+    TrunkPlan p{};
+    if (total_bits < 32768) return p;
+    uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 3;
+    if (cds < 8) cds = 8;
+    if (cds > 4096) cds = 4096;
+    const uint64_t sync = 2 * cds * cds;
+    // windows: about 256 coded data sets, fewer bits for small inputs so that the lanes still fill the chip
+    uint32_t L = 2048;
+    while (L < 65536u && L < 256 * cds) L *= 2;
+    while (L > 2048u && total_bits / L < 8192) L /= 2;
+    p.L = tune("AEC_TR_L", L);
+    uint64_t lead = 4 * sync;
+    if (lead < 4096) lead = 4096;
+    if (lead > (1u << 19)) lead = 1u << 19;            // (measured: repair passes are cheaper than longer burn-ins)
+    p.lead = tune("AEC_TR_LEAD", (uint32_t)lead);
+    uint64_t rw = (4 * sync + p.L - 1) / p.L;
+    if (rw < 1) rw = 1;
+    if (rw > 8) rw = 8;
+    p.rw = tune("AEC_TR_RW", (uint32_t)rw);
+    p.passes = tune("AEC_TR_PASSES", 3);
+    // RSIs per record: a walk meets the trunk inside one RSI with probability about 1 - exp(-rsi bits / sync);
+    // enough RSIs that a true start fails once in 1e5
+    {
+        const double x = (double)(rsi_bits_hint ? rsi_bits_hint : (uint64_t)c.rsi * cds) / (double)sync;
+        double k = x > 0.01 ? 11.5 / x : 1e9;
+        if (k < 4) k = 4;
+        if (k > kTrMaxK) k = kTrMaxK;
+        (void)k;
+        p.kmax = tune("AEC_TR_KMAX", kTrMaxK);
+    }
+    const uint64_t budget = (uint64_t)p.kmax * c.rsi;
+    p.budget = tune("AEC_TR_BUDGET", (uint32_t)(budget < 65536 ? budget : 65536));
+    p.wpc = tune("AEC_TR_WPC", 64);
+    // The hypothesis walks run on staged stretches of the stream: group + margin.  Short coded data sets get the
+    // byte table (1.25 bytes of LDS per bit, stretch 96 kbit); the others stage words and marks only (0.25 bytes
+    // per bit, stretch up to 480 kbit).  The margin holds an average walk -- some 150 coded data sets where the
+    // trunk resynchronises fast, the resynchronisation distance where it does not; longer walks go on in device memory.
+    p.staged = tune("AEC_TR_NX", cds <= 96 ? 1u : 0u);
+    if (p.staged) {
+        const uint32_t stretch = tune("AEC_TR_STRETCH", 98304u);
+        uint64_t margin = 512 * cds;
+        if (margin > stretch * 2ull / 3) margin = stretch * 2ull / 3;
+        margin = (margin + 1023) & ~1023ull;
+        p.margin = tune("AEC_TR_MARGIN", (uint32_t)margin);
+        uint32_t wpg = stretch > p.margin + p.L ? (stretch - p.margin) / p.L : 1u;
+        if (wpg > 256u) wpg = 256u;
+        p.wpw = tune("AEC_TR_WPW", wpg);
+        const uint32_t bits = p.wpw * p.L + p.margin;
+        p.lds = (size_t)(bits / 32 + 8) * 4 + (size_t)(bits / 32) * 4 + (size_t)(p.wpw + 1) * 8 + bits + 64;
+    } else {
+        // device-memory walks: a window per wavefront (measured on C3 / typical shapes: more wavefronts beat
+        // longer node lists per lane -- the walks are bound by memory latency)
+        p.wpw = tune("AEC_TR_WPW", 1u);
+    }
+    p.wcap = p.L / 8 < 4096 ? p.L / 8 : 4096;
+    uint64_t look = 4 * (rsi_bits_hint ? rsi_bits_hint : (uint64_t)c.rsi * cds) + 8 * sync + 4 * p.L;
+    if (look > (1ull << 27)) look = 1ull << 27;
+    p.nlook = (uint32_t)((look + p.L - 1) / p.L);
+    // nodes: one per 1.5 coded data sets on a trunk that is mostly off the true chain, one per coded data set on
+    // it; room for 2.5 times the latter, never less than one per 64 bits
+    uint64_t per_node = cds * 2 / 5;
+    if (per_node < 8) per_node = 8;
+    if (per_node > 64) per_node = 64;
+    const uint64_t nwin_all = total_bits / p.L + 2;
+    auto bytes_for = [&](uint64_t nwin) {
+        p.ncap = (uint32_t)(nwin * p.L / per_node < 0xFFFFFF00ull ? nwin * p.L / per_node : 0xFFFFFF00ull);
+        p.pcap = p.ncap / 2u + 65536u;               // (an RSI end per node that is no RSI end itself is plenty)
+        return trunk_bytes(p, (uint32_t)nwin);
+    };
+    uint64_t nwin = nwin_all;
+    const size_t limit = ws_bytes ? ws_bytes : kTrWsWanted;
+    if (bytes_for(nwin) > limit) {
+        // as many windows as fit (bytes are linear in nwin up to rounding)
+        const size_t per = (bytes_for(4096) - bytes_for(2048)) / 2048 + 1;
+        nwin = limit / per;
+        while (nwin > p.nlook + 64 && bytes_for(nwin) > limit) nwin -= nwin / 64 + 1;
+        if (nwin < (uint64_t)p.nlook * 2 + 64 || bytes_for(nwin) > limit) return p;      // not worth it: serial walk
+    }
+    if (nwin > 0x7FFFFFFFull / 2) return p;
+    p.nwin_max = (uint32_t)nwin;
+    p.bytes = bytes_for(nwin);
     p.ok = true;
     return p;
 }
 
-void allow_big_lds_hops()
+// Index pass over the trunk tables, span by span: trunk (count, repair, scan, fill), hypotheses (walk, jump,
+// chain), wide walker, the walk itself (one wavefront: one lookup per chunk where the wide table resolves it,
+// per window or per coded data set where not), then the RSI starts inside all hops.
+void allow_big_lds_walk()
 {
     static std::once_flag once[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64) dev = 0;
     std::call_once(once[dev], [] {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_hops), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                156 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_hyp_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
             (void)hipGetLastError();
     });
 }
 
-void launch_index_hops(const Cfg &c, const HopPlan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
-                       uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
-                       uint8_t *base, const IdxSide *side, uint32_t start_block, uint64_t rsi_start,
-                       uint32_t tail_slot)
+void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
+                        uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
+                        uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot)
 {
-    allow_big_lds_hops();
     IdxCarry *carry = reinterpret_cast<IdxCarry *>(base);
-    const uint64_t lo0 = start_bit / p.core * p.core;
-    const bool multi = end_bit - lo0 > p.chunk_bits;
-    const bool piped = multi && side && side->stream;
-    hipStream_t wst = piped ? side->stream : st;
-    if (piped)
-        for (int b = 0; b < 2; b++) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
-    uint32_t i = 0;
-    for (uint64_t lo = lo0; lo < end_bit; lo += p.chunk_bits, i++) {
-        uint64_t bits = end_bit - lo;
-        if (bits > p.chunk_bits) bits = p.chunk_bits;
-        const uint32_t nwin = (uint32_t)((bits + p.core - 1) / p.core), b = i & 1u;
-        const uint64_t n = (uint64_t)nwin * p.core;
-        const bool first = lo == lo0, last = lo + p.chunk_bits >= end_bit;
-        uint8_t *set = base + 64 + (multi ? (size_t)b * p.set_bytes : 0);
-        uint16_t *h16 = reinterpret_cast<uint16_t *>(set);
-        uint32_t *h64 = reinterpret_cast<uint32_t *>(set + ((p.chunk_bits * 2 + 255) & ~255ull));
-        uint32_t *h256 = h64 + p.chunk_bits;
-        if (piped && i >= 2) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
-        hipLaunchKernelGGL(k_hops, dim3(nwin), dim3(1024), p.lds, st, c, words, nwords, end_bit, lo, p.core, p.look, h16,
-                           p.n0);
-        hipLaunchKernelGGL((k_hop_compose<true>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
-                           (const void *)h16, h64, n);
-        hipLaunchKernelGGL((k_hop_compose<false>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
-                           (const void *)h64, h256, n);
-        if (piped) {
-            (void)hipEventRecord(side->spec_done[b], st);
-            (void)hipStreamWaitEvent(wst, side->spec_done[b], 0);
+    const TrStream s{words, nwords, end_bit};
+    allow_big_lds_walk();
+    (void)trunk_bytes(p, p.nwin_max);                     // offsets for the span size
+    const uint64_t lo0 = start_bit / p.L * p.L;
+    const uint64_t nwin_all = (end_bit - lo0) / p.L + 1;
+    const bool one = nwin_all <= p.nwin_max;
+    const uint32_t ncore_span = one ? (uint32_t)nwin_all : p.nwin_max - p.nlook;
+    for (uint64_t lo = lo0; lo <= end_bit; lo += (uint64_t)ncore_span * p.L) {
+        const uint64_t left = (end_bit - lo) / p.L + 1;
+        const bool first = lo == lo0, last = left <= ncore_span || one;
+        TrGeom g{};
+        g.lo = lo;
+        g.start_bit = start_bit;
+        g.L = p.L;
+        g.lead = p.lead;
+        g.ncap = p.ncap;
+        g.rw = p.rw;
+        g.nwin = (uint32_t)(left < p.nwin_max ? left : p.nwin_max);
+        g.ncore = (uint32_t)(left < ncore_span ? left : ncore_span);
+        g.budget = p.budget;
+        g.kmax = p.kmax;
+        g.pcap = p.pcap;
+        TrTables t{};
+        t.bitmap = reinterpret_cast<uint32_t *>(base + p.o_bitmap);
+        t.pre = reinterpret_cast<uint16_t *>(base + p.o_pre);
+        t.nbase = reinterpret_cast<uint32_t *>(base + p.o_nbase);
+        t.cpos = reinterpret_cast<uint16_t *>(base + p.o_cpos);
+        t.bp = reinterpret_cast<uint32_t *>(base + p.o_bp);
+        t.ccnt = reinterpret_cast<uint32_t *>(base + p.o_ccnt);
+        t.nblk = reinterpret_cast<uint32_t *>(base + p.o_nblk);
+        t.nros = reinterpret_cast<uint32_t *>(base + p.o_nros);
+        t.entry = reinterpret_cast<uint64_t *>(base + p.o_entry);
+        t.gbase = reinterpret_cast<uint64_t *>(base + p.o_gbase);
+        t.seampre = reinterpret_cast<uint32_t *>(base + p.o_seam);
+        t.rospre = reinterpret_cast<uint32_t *>(base + p.o_ros);
+        t.rec = reinterpret_cast<TrRec *>(base + p.o_rec);
+        t.park = reinterpret_cast<uint32_t *>(base + p.o_park);
+        t.pool = reinterpret_cast<TrPoolEntry *>(base + p.o_pool);
+        t.pool_cnt = reinterpret_cast<uint32_t *>(base + 48);       // (behind the carry record)
+        uint64_t *ex[2] = {reinterpret_cast<uint64_t *>(base + p.o_exit0), reinterpret_cast<uint64_t *>(base + p.o_exit1)};
+        const uint32_t nreg = (g.nwin + g.rw - 1) / g.rw;
+        t.exit = ex[0];
+        hipLaunchKernelGGL(k_trunk, dim3((nreg + 63) / 64), dim3(64), 0, st, c, s, g, t, (const uint64_t *)nullptr, ex[0], 0u);
+        uint32_t cur = 0;
+        for (uint32_t k = 0; k < p.passes; k++) {
+            hipLaunchKernelGGL(k_trunk, dim3((nreg + 63) / 64), dim3(64), 0, st, c, s, g, t, (const uint64_t *)ex[cur],
+                               ex[cur ^ 1u], 1u);
+            cur ^= 1u;
         }
-        const HopTables ht{h16, h64, h256, lo, lo + n, p.n0};
-        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, wst, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
-                           d_res, (const uint64_t *)nullptr, IdxTables{}, (IdxHop *)nullptr, 0u, carry,
-                           first ? 1u : 0u, last ? 1u : 0u, start_block, rsi_start, tail_slot, SparseTables{},
-                           (ChunkEntry *)nullptr, ht);
-        if (piped) (void)hipEventRecord(side->walk_done[b], wst);
+        t.exit = ex[cur];
+        hipLaunchKernelGGL(k_trunk_scan, dim3(1), dim3(1024), 0, st, g, t);
+        hipLaunchKernelGGL(k_trunk, dim3((g.nwin + 63) / 64), dim3(64), 0, st, c, s, g, t, (const uint64_t *)nullptr,
+                           (uint64_t *)nullptr, 2u);
+        (void)hipMemsetAsync(t.pool_cnt, 0, 4, st);
+        const uint32_t ngroups = (g.ncore + p.wpw - 1) / p.wpw;
+        if (p.staged) {
+            const uint32_t grid = ngroups < 256u ? ngroups : 256u;                           // (one workgroup per CU)
+            hipLaunchKernelGGL((k_hyp_walk<true>), dim3(grid), dim3(1024), p.lds, st, c, s, g, t, p.wpw, p.margin, ngroups);
+        } else {
+            hipLaunchKernelGGL(k_hyp_walk_mem, dim3(ngroups), dim3(64), 0, st, c, s, g, t, p.wpw);
+        }
+        hipLaunchKernelGGL(k_hyp_land, dim3(g.ncore), dim3(256), 0, st, c, g, t);
+
+        const uint32_t nwin = g.ncore, nchunks = (nwin + p.wpc - 1) / p.wpc;
+        TwTables sp;
+        sp.bitmap = t.bitmap;
+        sp.pre = t.pre;
+        sp.nbase = t.nbase;
+        sp.ccnt = t.ccnt;
+        sp.rec = t.rec;
+        sp.cpos = t.cpos;
+        sp.lo = lo;
+        sp.hi = lo + (uint64_t)nwin * p.L;
+        sp.core = p.L;
+        sp.wide = reinterpret_cast<const uint4 *>(base + p.o_wide);
+        sp.wpc = p.wpc;
+        sp.wcap = p.wcap;
+        ChunkEntry *centry = reinterpret_cast<ChunkEntry *>(base + p.o_centry);
+        IdxHop *hops = reinterpret_cast<IdxHop *>(base + p.o_hops);
+        const uint32_t hop_cap = 2 * nwin + 8;
+        (void)hipMemsetAsync(centry, 0, (size_t)nchunks * sizeof(ChunkEntry), st);
+        hipLaunchKernelGGL(k_twide, dim3((p.wcap + 255) / 256, nchunks), dim3(256), 0, st, sp, nwin, end_bit,
+                           const_cast<uint4 *>(sp.wide));
+        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
+                           d_res, (const uint64_t *)nullptr, hops, hop_cap, carry, first ? 1u : 0u, last ? 1u : 0u,
+                           start_block, rsi_start, tail_slot, sp, centry, SparseTables{});
+        hipLaunchKernelGGL(k_trewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, c, sp, t, nwin, nchunks, end_bit, centry,
+                           d_rsi_off);
+        hipLaunchKernelGGL(k_texpand, dim3((hop_cap + 255) / 256), dim3(256), 0, st, c, sp, t, carry, hops, d_rsi_off);
+        if (last) break;
     }
-    if (piped)
-        for (int b = 0; b < 2; b++) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
+#ifdef AEC_TUNING
+    if (getenv("AEC_IDX_STATS")) {                       // (diagnostics: synchronises)
+        IdxCarry h{};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(&h, carry, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "trunk index: L %u lead %u rw %u kmax %u wpw %u nwin/span %u ncap %u | RSIs %llu, walked serially %u, "
+                "table lookups %u\n", p.L, p.lead, p.rw, p.kmax, p.wpw, p.nwin_max, p.ncap, (unsigned long long)h.r,
+                h.n_serial, h.n_lookups);
+    }
+#endif
 }
 
 }  // namespace
@@ -1361,90 +1613,37 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
     if (start_bit >= end_bit) return 0;
     const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
     if (sp.ok) return sp.bytes;
-    const SpecGeom g = spec_geom(c, end_bit - start_bit, rsi_bits_hint);
-    if (!g.ok) {
-        const HopPlan hp = hop_plan(c, end_bit - start_bit, rsi_bits_hint);
-        if (!hp.ok) return 0;
-        return 64 + hp.set_bytes * (end_bit - start_bit / hp.core * hp.core > hp.chunk_bits ? 2 : 1);
-    }
-    const uint64_t lo = start_bit / g.core * g.core;
-    uint64_t span = end_bit - lo;
-    const bool multi = span > g.chunk_bits;
-    if (multi) span = g.chunk_bits;
-    const uint64_t nwin = (span + g.core - 1) / g.core;
-    return 64 + table_set_bytes(nwin * g.core, nwin) * (multi ? 2 : 1);   // two sets: spec(i+1) beside walk(i)
+    const TrunkPlan p = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, 0);
+    return p.ok ? p.bytes : 0;
 }
 
 void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
                   uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
-                  void *d_ws, size_t ws_bytes, uint64_t rsi_bits_hint, const IdxSide *side,
-                  uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot)
+                  void *d_ws, size_t ws_bytes, uint64_t rsi_bits_hint, uint32_t start_block, uint64_t rsi_start,
+                  uint32_t tail_slot)
 {
     const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
     const uint64_t nwords = (in_bytes + 3) / 4, end_bit = (uint64_t)in_bytes * 8;
-    const size_t need = index_workspace_bytes(c, in_bytes, start_bit, rsi_bits_hint);
-    if (!need || !d_ws || ws_bytes < need) {           // serial walk only
-        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off,
-                           max_rsi, d_res, (const uint64_t *)nullptr, IdxTables{}, (IdxHop *)nullptr, 0u,
-                           (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start, tail_slot, SparseTables{}, (ChunkEntry *)nullptr,
-                           HopTables{});
-        return;
-    }
-    const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
-    if (sp.ok) {
-        launch_index_sparse(c, sp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
-                            static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot);
-        return;
-    }
-    const SpecGeom g = spec_geom(c, end_bit - start_bit, rsi_bits_hint);
-    if (!g.ok) {
-        launch_index_hops(c, hop_plan(c, end_bit - start_bit, rsi_bits_hint), words, nwords, end_bit, start_bit,
-                          d_rsi_off, max_rsi, d_res, st, static_cast<uint8_t *>(d_ws), side, start_block, rsi_start,
-                          tail_slot);
-        return;
-    }
-    allow_big_lds();
-    const uint64_t lo0 = start_bit / g.core * g.core;
-    uint64_t span = end_bit - lo0;
-    const bool multi = span > g.chunk_bits;
-    if (multi) span = g.chunk_bits;
-    const uint64_t nwin_max = (span + g.core - 1) / g.core, entries = nwin_max * g.core;
-    uint8_t *base = static_cast<uint8_t *>(d_ws);
-    IdxCarry *carry = reinterpret_cast<IdxCarry *>(base);
-    const TableSet set[2] = {table_set_at(base + 64, entries),
-                             table_set_at(base + 64 + (multi ? table_set_bytes(entries, nwin_max) : 0), entries)};
-    const uint32_t hop_cap = (uint32_t)(2 * nwin_max + 8);
-    // With several chunks the walk over chunk i (one wavefront) runs on a side stream beside the
-    // speculation over chunk i + 1 (all CUs) on the caller's stream; events order the two table sets.
-    const bool piped = multi && side && side->stream;
-    hipStream_t wst = piped ? side->stream : st;
-    if (piped)                                           // sets may still be read by an earlier call's walker
-        for (int b = 0; b < 2; b++) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
-    uint32_t i = 0;
-    for (uint64_t lo = lo0; lo < end_bit; lo += g.chunk_bits, i++) {
-        uint64_t bits = end_bit - lo;
-        if (bits > g.chunk_bits) bits = g.chunk_bits;
-        const uint32_t nwin = (uint32_t)((bits + g.core - 1) / g.core), b = i & 1u;
-        const bool first = lo == lo0, last = lo + g.chunk_bits >= end_bit;
-        const TableSet &t = set[b];
-        const IdxTables tabs{t.T, t.Xb, t.Xc, lo, lo + (uint64_t)nwin * g.core};
-        if (piped && i >= 2) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
-        hipLaunchKernelGGL(k_spec, dim3(nwin), dim3(g.threads), g.lds, st, c, words, nwords, end_bit, lo, g.core,
-                           g.look, t.T, t.Xb, t.Xc);
-        if (piped) {
-            (void)hipEventRecord(side->spec_done[b], st);
-            (void)hipStreamWaitEvent(wst, side->spec_done[b], 0);
+    // Low-entropy streams whose RSIs fit a window: candidates and RSI hypotheses per window (k_spec2); everything
+    // else: the trunk.
+    if (d_ws && ws_bytes && start_bit < end_bit) {
+        const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
+        if (sp.ok && ws_bytes >= sp.bytes) {
+            launch_index_sparse(c, sp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
+                                static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot);
+            return;
         }
-        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, wst, c, words, nwords, end_bit, start_bit, d_rsi_off,
-                           max_rsi, d_res, (const uint64_t *)nullptr, tabs, t.hops, hop_cap, carry,
-                           first ? 1u : 0u, last ? 1u : 0u, start_block, rsi_start, tail_slot, SparseTables{},
-                           (ChunkEntry *)nullptr, HopTables{});
-        hipLaunchKernelGGL(k_expand, dim3((hop_cap + 255) / 256), dim3(256), 0, wst, carry, t.hops, tabs,
-                           (c.flags & F_PAD_RSI) ? 1u : 0u, d_rsi_off);
-        if (piped) (void)hipEventRecord(side->walk_done[b], wst);
     }
-    if (piped)
-        for (int b = 0; b < 2; b++) (void)hipStreamWaitEvent(st, side->walk_done[b], 0);
+    TrunkPlan p{};
+    if (d_ws && ws_bytes && start_bit < end_bit) p = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, ws_bytes);
+    if (!p.ok) {                                       // serial walk only
+        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off,
+                           max_rsi, d_res, (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u,
+                           1u, start_block, rsi_start, tail_slot, TwTables{}, (ChunkEntry *)nullptr, SparseTables{});
+        return;
+    }
+    launch_index_trunk(c, p, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
+                       static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot);
 }
 
 void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_chunk_off,
@@ -1455,8 +1654,8 @@ void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, cons
     hipLaunchKernelGGL(k_index, dim3((uint32_t)n_chunks), dim3(64), 0, st, c,
                        reinterpret_cast<const uint32_t *>(d_in), (uint64_t)((in_bytes + 3) / 4),
                        (uint64_t)in_bytes * 8, (uint64_t)0, d_rsi_off, rsi_per_chunk, d_res, d_chunk_off,
-                       IdxTables{}, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, 0u, (uint64_t)0, 0u, SparseTables{},
-                       (ChunkEntry *)nullptr, HopTables{});
+                       (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, 0u, (uint64_t)0, 0u, TwTables{},
+                       (ChunkEntry *)nullptr, SparseTables{});
 }
 
 }  // namespace aec

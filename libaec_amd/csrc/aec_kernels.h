@@ -120,21 +120,14 @@ bool launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, 
                             hipStream_t stream, const PhaseEvents *prof = nullptr);
 
 // Enqueues the RSI index pass over one stream starting at start_bit (an RSI boundary).  With a
-// workspace of index_workspace_bytes() (0 = this configuration takes the serial walk alone) the
-// walk hops over speculative per-bit tables built by all CUs (aec_idx.hip).
-// rsi_bits_hint: estimate of the coded size of one RSI (0 = unknown); it sizes the look-ahead.
+// workspace (index_workspace_bytes() says how much is wanted, 0 = this input takes the serial walk alone;
+// less than that means more, smaller spans) the walk hops over the trunk tables built by all CUs (aec_idx.hip).
+// rsi_bits_hint: estimate of the coded size of one RSI (0 = unknown); it sizes burn-in, regions and records.
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint);
-// side (optional): a second stream and four events owned by the caller; with them the walk over one
-// chunk of the tables overlaps the speculation over the next chunk.
-struct IdxSide {
-    hipStream_t stream;
-    hipEvent_t spec_done[2], walk_done[2];
-};
 void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
                   uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t stream,
                   void *d_ws = nullptr, size_t ws_bytes = 0, uint64_t rsi_bits_hint = 0,
-                  const IdxSide *side = nullptr, uint32_t start_block = 0, uint64_t rsi_start = 0,
-                  uint32_t tail_slot = 0);
+                  uint32_t start_block = 0, uint64_t rsi_start = 0, uint32_t tail_slot = 0);
 
 // Index pass over many independent streams stored in one buffer (e.g. the chunks of an HDF5
 // dataset): stream s occupies bytes [chunk_off[s], chunk_off[s+1]) (chunk_off 4-byte aligned values,

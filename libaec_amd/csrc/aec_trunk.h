@@ -38,6 +38,9 @@
 #ifndef TR_DBG
 #define TR_DBG(...) ((void)0)
 #endif
+#ifndef TR_COUNT_STEP
+#define TR_COUNT_STEP(i) ((void)0)      // (emulator statistics)
+#endif
 
 namespace aec {
 
@@ -66,18 +69,26 @@ struct TrGeom {
     uint32_t nwin;             // windows with a trunk (core + look-ahead)
     uint32_t ncore;            // windows whose nodes get records
     uint32_t budget;           // coded data sets one hypothesis may parse
+    uint32_t kmax;             // RSIs one record may cover (<= kTrMaxK)
+    uint32_t pcap;             // entries of the pool of RSI ends inside records
     uint32_t pad;
 };
 
 // Record of a node, the layout the walkers read.
 //   x: bits [0,26) = distance to the node the record ends on, [26,32) = RSIs covered; 0 = none
-//   y: chain of records until it leaves the window: [0,24) distance, [24,32) RSIs; 0 = none
-// Between the walk and the jump a hypothesis is parked in its record: x = distance to the node the walk
-// stands on, y = kTrParked | RSIs completed << 16 | blocks of the current RSI in front of that node.
+//   y: records of several RSIs: index + 1 of the pool entry that holds the end of the LAST BUT ONE of them
+//      (each entry links to the one before: the walkers need the starts inside such a record); 0 = none
+// Between the walk and the jump a hypothesis is parked: x = distance to the node the walk stands on, and
+// park[node] = kTrParked | RSIs completed << 16 | blocks of the current RSI in front of that node.
 struct TrRec {
     uint32_t x, y;
 };
 constexpr uint32_t kTrParked = 0x80000000u;
+
+struct TrPoolEntry {           // where an RSI inside a record ends (= where the next one starts, before AEC_PAD_RSI)
+    uint32_t end;              // distance from the record's node
+    uint32_t prev;             // index + 1 of the entry of the RSI in front, 0 = that was the record's first
+};
 
 struct TrTables {
     // trunk (k_trunk)
@@ -97,6 +108,9 @@ struct TrTables {
     uint32_t *rospre;          // rest-of-segment nodes in front of the window
     // hypotheses
     TrRec *rec;                // [ncap]
+    uint32_t *park;            // [ncap]
+    TrPoolEntry *pool;         // [pcap]
+    uint32_t *pool_cnt;        // entries handed out (may run beyond pcap: then records were dropped)
 };
 
 AEC_HD uint32_t tr_word(const TrStream &s, uint64_t i)
@@ -123,15 +137,59 @@ AEC_HD uint32_t tr_popc64(uint64_t x)
 #endif
 }
 
+// 256 stream bits from the word that holds bit q on, loaded with two 16-byte requests, so that a coded data
+// set of the usual size costs ONE memory round trip (header and unary part come out of registers).
+struct TrWin {
+    uint64_t q0, q1, q2, q3;      // (named, not an array: indexing one by a lane value would put it in scratch)
+};
+
+AEC_HD void tr_win_load(const TrStream &s, uint64_t pos, TrWin &W)
+{
+    const uint64_t w = pos >> 5;
+    uint32_t x[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+    struct __attribute__((packed, aligned(4))) Q4 {
+        uint32_t a, b, c, d;
+    };
+    if (w + 8u <= s.nwords) {
+        const Q4 lo = *reinterpret_cast<const Q4 *>(s.words + w);
+        const Q4 hi = *reinterpret_cast<const Q4 *>(s.words + w + 4u);
+        x[0] = lo.a; x[1] = lo.b; x[2] = lo.c; x[3] = lo.d;
+        x[4] = hi.a; x[5] = hi.b; x[6] = hi.c; x[7] = hi.d;
+    } else
+#endif
+    {
+        for (uint32_t i = 0; i < 8u; i++) x[i] = s.words[w + i < s.nwords ? w + i : s.nwords - 1u];
+    }
+    W.q0 = ((uint64_t)bswap32(x[0]) << 32) | bswap32(x[1]);
+    W.q1 = ((uint64_t)bswap32(x[2]) << 32) | bswap32(x[3]);
+    W.q2 = ((uint64_t)bswap32(x[4]) << 32) | bswap32(x[5]);
+    W.q3 = ((uint64_t)bswap32(x[6]) << 32) | bswap32(x[7]);
+}
+
+// 64 bits at bit offset o < 128 of the 192 bits a : b : c.  (Values, not a window indexed by o: a conditional
+// between the window's fields selects an ADDRESS and puts the window in scratch.)
+AEC_HD uint64_t tr_peek3(uint64_t a, uint64_t b, uint64_t c, uint32_t o)
+{
+    const bool up = o >= 64u;
+    const uint32_t sh = o & 63u;
+    const uint64_t hi = up ? b : a, lo = up ? c : b;
+    return sh ? (hi << sh) | (lo >> (64u - sh)) : hi;
+}
+
 // Length in bits of the CDS that starts at q (0 = none ends inside the stream, or its unary part is
 // longer than kTrMaxScan).  `nz` = 0 for a CDS of one block, else the zero-block run code fs + 1
 // (reference decode.c:518-536).  Layouts: decode.c:462-502 (split), 589-644 (low entropy), 659-677
-// (uncompressed); restated in SURVEY.md Appendix A.
-AEC_HD uint32_t tr_cds(const TrStream &s, const Cfg &c, uint64_t q, uint32_t ref, uint32_t &nz)
+// (uncompressed); restated in SURVEY.md Appendix A.  W = tr_win_load(s, q).
+// from_memory = false: a unary part that goes on behind the window is not followed (returns 0, *more = true).
+AEC_HD uint32_t tr_cds(const TrStream &s, const Cfg &c, uint64_t q, uint32_t ref, uint32_t &nz, const TrWin &W,
+                       bool from_memory = true, bool *more = nullptr)
 {
     nz = 0;
     if (q + c.id_len >= s.end_bit) return 0;
-    const uint64_t H = tr_peek64(s, q);
+    const uint32_t sh = (uint32_t)(q & 31u);
+    const uint64_t q0 = W.q0, q1 = W.q1, q2 = W.q2, q3 = W.q3;
+    const uint64_t H = sh ? (q0 << sh) | (q1 >> (64u - sh)) : q0;
     const uint32_t id = (uint32_t)(H >> (64u - c.id_len));
     if (id == (1u << c.id_len) - 1u) {
         const uint32_t len = c.id_len + c.bs * c.bps;
@@ -142,22 +200,53 @@ AEC_HD uint32_t tr_cds(const TrStream &s, const Cfg &c, uint64_t q, uint32_t ref
     const uint32_t hdr = c.id_len + (low ? 1u : 0u) + ref * c.bps;
     uint32_t need = low ? (selbit ? c.bs / 2u : 1u) : c.bs - ref;
     const uint32_t add = low ? 0u : need * (id - 1u);
-    const uint64_t q1 = q + hdr;
-    uint64_t p = q1;
-    for (;;) {
-        if (p >= s.end_bit || p - q1 > kTrMaxScan) return 0;
+    // unary part: the need-th 1-bit from q + hdr on; 64 bits at a time, out of the window while it lasts
+    // Up to three 64-bit pieces of the unary part come out of the window (sh + hdr < 70: the first starts in q0
+    // or q1; the third fits if sh + hdr <= 64).  Their popcounts say which piece holds the need-th 1-bit, so
+    // ONE select does the work whatever the piece.
+    const uint32_t o = sh + hdr;
+    const uint64_t U0 = tr_peek3(q0, q1, q2, o), U1 = tr_peek3(q1, q2, q3, o);
+    const uint64_t U2 = o <= 64u ? tr_peek3(q2, q3, 0u, o) : 0u;
+    const uint32_t p0 = tr_popc64(U0), p1 = tr_popc64(U1), p2 = tr_popc64(U2);
+    const bool in0 = p0 >= need, in1 = p0 + p1 >= need, in2 = o <= 64u && p0 + p1 + p2 >= need;
+    uint32_t used = hdr;                                 // bits of the CDS in front of the unary bits still to look at
+    bool found = in0 || in1 || in2;
+    if (found) {
+        const uint64_t U = in0 ? U0 : (in1 ? U1 : U2);
+        const uint32_t skip = in0 ? 0u : (in1 ? p0 : p0 + p1);
+        used += (in0 ? 0u : (in1 ? 64u : 128u)) + spec_select64(U, need - skip) + 1u;
+    } else {
+        const uint32_t pieces = o <= 64u ? 3u : 2u;
+        need -= p0 + p1 + (o <= 64u ? p2 : 0u);
+        used += 64u * pieces;
+    }
+    if (!found && !from_memory) {
+        if (more) *more = true;
+        return 0;
+    }
+    while (!found) {                                     // long unary parts: from memory
+        const uint64_t p = q + used;
+        if (p >= s.end_bit || used > kTrMaxScan) return 0;
         const uint64_t U = tr_peek64(s, p);
         const uint32_t pc = tr_popc64(U);
         if (pc >= need) {
-            p += spec_select64(U, need) + 1u;
-            break;
+            used += spec_select64(U, need) + 1u;
+            found = true;
+        } else {
+            need -= pc;
+            used += 64u;
         }
-        need -= pc;
-        p += 64;
     }
-    if (low && !selbit) nz = (uint32_t)(p - q1);
-    const uint64_t end = p + add;
-    return end <= s.end_bit ? (uint32_t)(end - q) : 0u;
+    if (low && !selbit) nz = used - hdr;
+    const uint64_t len = (uint64_t)used + add;
+    return q + len <= s.end_bit ? (uint32_t)len : 0u;
+}
+
+AEC_HD uint32_t tr_cds(const TrStream &s, const Cfg &c, uint64_t q, uint32_t ref, uint32_t &nz)
+{
+    TrWin W;
+    tr_win_load(s, q, W);
+    return tr_cds(s, c, q, ref, nz, W);
 }
 
 // blocks covered by a CDS with run code nz (0: not a zero-block CDS) at block b of its RSI; 0 = the
@@ -295,28 +384,28 @@ AEC_HD void tr_trunk_region(const TrStream &s, const Cfg &c, const TrGeom &g, co
 // scan over the windows (serial form; the kernel does the same with a workgroup scan)
 AEC_HD void tr_scan_serial(const TrGeom &g, const TrTables &t)
 {
-    uint64_t gsum = 0;
-    uint32_t seams = 0, ros = 0, nodes = 0;
-    bool dropped = false;
+    uint64_t gsum = 0, nodes = 0;        // nodes: unclipped, so that the rule does not depend on the order
+    uint32_t seams = 0, ros = 0;
     for (uint32_t w = 0; w < g.nwin; w++) {
-        const bool fits = nodes + t.ccnt[w] <= g.ncap;      // (a window whose nodes do not fit has none)
+        // a window whose nodes do not fit the record space has none, and the window behind it is a seam
+        const bool fits = nodes + t.ccnt[w] <= g.ncap;
+        const bool seam = w == 0 || t.exit[w - 1] == kTrNone || t.exit[w - 1] != t.entry[w] || nodes > g.ncap;
+        seams += seam ? 1u : 0u;
+        t.nbase[w] = (uint32_t)(nodes < g.ncap ? nodes : g.ncap);
+        nodes += t.ccnt[w];
         if (!fits) {
             t.ccnt[w] = 0;
             t.nblk[w] = 0;
             t.nros[w] = 0;
         }
-        const bool seam = w == 0 || dropped || t.exit[w - 1] == kTrNone || t.exit[w - 1] != t.entry[w];
-        dropped = !fits;
-        seams += seam ? 1u : 0u;
-        t.nbase[w] = nodes;
         t.gbase[w] = gsum;
         t.seampre[w] = seams;
         t.rospre[w] = ros;
-        nodes += t.ccnt[w];
         gsum += t.nblk[w];
         ros += t.nros[w];
     }
-    t.nbase[g.nwin] = nodes;
+    if (nodes > g.ncap) nodes = g.ncap;
+    t.nbase[g.nwin] = (uint32_t)nodes;
     t.gbase[g.nwin] = gsum;
     t.seampre[g.nwin] = seams + 1u;
     t.rospre[g.nwin] = ros;
@@ -345,10 +434,68 @@ AEC_HD bool tr_marked(const TrGeom &g, const TrTables &t, uint64_t p)
 }
 
 // ---- 2. hypotheses ------------------------------------------------------------------------------------
+// Where a walk gets its stream bits and trunk marks from.  TrGlobal: device memory.  TrStaged: a stretch of
+// the stream a workgroup has staged in LDS (plain arrays in the emulator) together with the trunk marks and,
+// per bit position, the length of the coded data set that starts there if it is an ordinary one -- one
+// block, no reference sample, at most 255 bits -- so that such a step of a walk is ONE byte read; everything
+// else (and every position outside the stretch) takes the parse.
+struct TrGlobal {
+    const TrStream &s;
+    const TrGeom &g;
+    const TrTables &t;
+    AEC_HD bool marked(uint64_t p) const { return tr_marked(g, t, p); }
+    AEC_HD void win(uint64_t p, TrWin &W) const { tr_win_load(s, p, W); }
+    AEC_HD uint32_t fast(uint64_t) const { return 0u; }
+};
+
+struct TrStaged {
+    TrGlobal mem;
+    const uint32_t *sw;        // stream words in host order, words [0, bits / 32 + 8)
+    const uint32_t *bm;        // trunk marks, bits / 32 words
+    const uint8_t *nx;         // ordinary coded data set length per bit position, 0 = take the parse
+    uint64_t base;             // bit position of sw[0] (multiple of 32)
+    uint32_t bits;             // staged bits (multiple of 32)
+    AEC_HD bool in(uint64_t p) const { return p >= base && p - base < bits; }
+    AEC_HD bool marked(uint64_t p) const
+    {
+        if (!in(p)) return mem.marked(p);
+        const uint32_t r = (uint32_t)(p - base);
+        return (bm[r >> 5] >> (31u - (r & 31u))) & 1u;
+    }
+    AEC_HD void win(uint64_t p, TrWin &W) const
+    {
+        if (!in(p)) {
+            mem.win(p, W);
+            return;
+        }
+        const uint32_t *x = sw + ((uint32_t)(p - base) >> 5);
+        W.q0 = ((uint64_t)x[0] << 32) | x[1];
+        W.q1 = ((uint64_t)x[2] << 32) | x[3];
+        W.q2 = ((uint64_t)x[4] << 32) | x[5];
+        W.q3 = ((uint64_t)x[6] << 32) | x[7];
+    }
+    AEC_HD uint32_t fast(uint64_t p) const
+    {
+        const uint32_t e = (nx && in(p)) ? nx[(uint32_t)(p - base)] : 0u;
+        TR_COUNT_STEP(e ? 0 : (in(p) ? 1 : 2));
+        return e;
+    }
+};
+
+// entry of TrStaged::nx for bit position q (W = the window at q)
+AEC_HD uint8_t tr_fast_entry(const TrStream &s, const Cfg &c, uint64_t q, const TrWin &W)
+{
+    uint32_t nz;
+    const uint32_t len = tr_cds(s, c, q, 0u, nz, W, false);
+    return (len && !nz && len < 256u) ? (uint8_t)len : (uint8_t)0;
+}
+
 struct TrHyp {                 // one hypothesis walk in flight
     uint64_t c;                // the node tried as an RSI start
     uint64_t pos;              // where the next CDS starts
     uint32_t b, k, steps;      // blocks of the current RSI done, RSIs completed, coded data sets parsed
+    uint32_t link;             // pool entry (index + 1) of the last RSI end recorded, 0 = none
+    uint32_t pend;             // an RSI ended off the trunk at c + pend: the caller records it (tr_hyp_commit)
 };
 
 enum : uint32_t { TR_RUN = 0, TR_LAND = 1, TR_DONE = 2, TR_FAIL = 3 };
@@ -366,31 +513,76 @@ AEC_HD void tr_hyp_start(const Cfg &cfg, TrHyp &h, uint64_t c)
     h.b = 0;
     h.k = 0;
     h.steps = 0;
+    h.link = 0;
+    h.pend = 0;
 }
 
-// One CDS of the walk.  TR_LAND: the walk stands on a node with blocks of its RSI left (the jump takes
-// over); TR_DONE: h.k whole RSIs, ending on a node at h.pos.
-AEC_HD uint32_t tr_hyp_step(const TrStream &s, const Cfg &c, const TrGeom &g, const TrTables &t, TrHyp &h)
+// A walk moves on by a coded data set of `len` bits that covers `nb` blocks.  TR_DONE: h.k whole RSIs, ending
+// on a node at h.pos.  TR_RUN with h.pend set: an RSI ended off the trunk and the walk goes on -- the caller
+// records the end with tr_hyp_commit() before the next step (the kernels allocate the pool entries of a
+// wavefront together).
+// (tr_hyp_complete: the part that follows when the step completed an RSI -- h.b == c.rsi; `on_trunk` = is
+// h.pos a node)
+AEC_HD uint32_t tr_hyp_complete(const Cfg &c, const TrGeom &g, TrHyp &h, bool on_trunk)
 {
-    if (h.b != 0u && tr_marked(g, t, h.pos)) return TR_LAND;
-    if (h.steps >= g.budget) return TR_FAIL;
-    const uint32_t ref = (h.b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u;
-    uint32_t nz;
-    const uint32_t len = tr_cds(s, c, h.pos, ref, nz);
-    if (!len) return TR_FAIL;
-    const uint32_t nb = tr_blocks(c, nz, h.b);
-    if (!nb || nb > c.rsi - h.b) return TR_FAIL;
+    h.k++;
+    if (on_trunk) return TR_DONE;
+    if (h.k >= g.kmax || h.pos - h.c > 0xFFFFFFFFull) return TR_FAIL;
+    h.pend = (uint32_t)(h.pos - h.c);                     // the walk goes on: where this RSI ended is recorded
+    h.b = 0;
+    h.pos = tr_rsi_start(c, h.pos);
+    return TR_RUN;
+}
+
+template <class Src>
+AEC_HD uint32_t tr_hyp_advance(const Cfg &c, const TrGeom &g, const Src &src, TrHyp &h, uint32_t len, uint32_t nb)
+{
     h.pos += len;
     h.b += nb;
     h.steps++;
-    if (h.b == c.rsi) {
-        h.k++;
-        if (tr_marked(g, t, h.pos)) return TR_DONE;
-        if (h.k == kTrMaxK) return TR_FAIL;
-        h.b = 0;
-        h.pos = tr_rsi_start(c, h.pos);
-    }
+    if (h.b == c.rsi) return tr_hyp_complete(c, g, h, src.marked(h.pos));
     return TR_RUN;
+}
+
+// the step by the parse: W = the window at h.pos
+AEC_HD uint32_t tr_hyp_parse(const TrStream &s, const Cfg &c, const TrHyp &h, const TrWin &W, uint32_t &nb,
+                             bool from_memory = true, bool *more = nullptr)
+{
+    const uint32_t ref = (h.b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u;
+    uint32_t nz;
+    const uint32_t len = tr_cds(s, c, h.pos, ref, nz, W, from_memory, more);
+    if (!len) return 0;
+    nb = tr_blocks(c, nz, h.b);
+    return (nb && nb <= c.rsi - h.b) ? len : 0u;
+}
+
+// One coded data set of the walk.  TR_LAND: the walk stands on a node with blocks of its RSI left (the jump
+// takes over); else as tr_hyp_advance.  (The kernels run the pieces of this in separate phases of a wavefront,
+// by what a step needs: a byte of the table, the parse on staged words, or device memory.)
+template <class Src>
+AEC_HD uint32_t tr_hyp_step(const TrStream &s, const Cfg &c, const TrGeom &g, const Src &src, TrHyp &h)
+{
+    const bool first = h.b == 0u;
+    if (!first && src.marked(h.pos)) return TR_LAND;
+    if (h.steps >= g.budget) return TR_FAIL;
+    uint32_t len = (first && (c.flags & F_PREPROCESS)) ? 0u : src.fast(h.pos), nb = 1;
+    if (!len) {
+        TrWin W;
+        src.win(h.pos, W);
+        len = tr_hyp_parse(s, c, h, W, nb);
+        if (!len) return TR_FAIL;
+    }
+    return tr_hyp_advance(c, g, src, h, len, nb);
+}
+
+// records the pending RSI end in pool entry e (0xFFFFFFFF: none left -- the hypothesis fails); false = failed
+AEC_HD bool tr_hyp_commit(const TrGeom &g, const TrTables &t, TrHyp &h, uint32_t e)
+{
+    if (e >= g.pcap) return false;
+    t.pool[e] = TrPoolEntry{h.pend, h.link};
+    h.link = e + 1u;
+    h.pend = 0;
+    return true;
 }
 
 AEC_HD uint32_t tr_rec_pack(uint64_t bits, uint32_t k)
@@ -404,14 +596,20 @@ AEC_HD uint32_t tr_rec_k(uint32_t x) { return x >> 26; }
 AEC_HD void tr_hyp_finish(const TrGeom &g, const TrTables &t, uint32_t w, uint32_t idx, const TrHyp &h, uint32_t state)
 {
     TrRec r{0u, 0u};
+    uint32_t park = 0;
     const uint64_t d = h.pos - h.c;
     if (state == TR_DONE) {
         r.x = tr_rec_pack(d, h.k);
+        // (the last RSI ends on the node itself; if the walk recorded the end of the one in front, the list
+        // starts there.  A record of one RSI has no list.)
+        r.y = r.x ? h.link : 0u;
     } else if (state == TR_LAND && d <= 0xFFFFFFFFull) {
         r.x = (uint32_t)d;
-        r.y = kTrParked | (h.k << 16) | h.b;            // (b < rsi <= 4096, k < 64)
+        r.y = h.link;
+        park = kTrParked | (h.k << 16) | h.b;           // (b < rsi <= 4096, k < 64)
     }
     t.rec[t.nbase[w] + idx] = r;
+    t.park[t.nbase[w] + idx] = park;
 }
 
 // window that holds block number G of the trunk, searched from window w on (g.nwin: none)
@@ -512,6 +710,9 @@ AEC_HD uint64_t tr_jump(const Cfg &c, const TrGeom &g, const TrTables &t, uint64
         TR_DBG("jump: node w%u i%u G %llu b %u n %u nextros w%u i%u dist %lld\n", w, i, (unsigned long long)G, b, n, rw, ri, (long long)dist);
         if (dist >= n) {                             // the RSI ends in front of (or at) that run
             const uint32_t tw = tr_window_of(g, t, w, G + n);
+            TR_DBG("  target window %u (nwin %u) seam %u/%u want %llu gbase %llu ccnt %u\n", tw, g.nwin,
+                   tw < g.nwin ? t.seampre[tw] : 0u, seam0, (unsigned long long)(G + n),
+                   (unsigned long long)(tw < g.nwin ? t.gbase[tw] : 0), tw < g.nwin ? t.ccnt[tw] : 0u);
             if (tw >= g.nwin || t.seampre[tw] != seam0) return kTrNone;
             uint32_t ti;
             if (!tr_node_of(g, t, tw, (uint32_t)(G + n - t.gbase[tw]), ti)) return kTrNone;
@@ -538,31 +739,28 @@ AEC_HD uint64_t tr_jump(const Cfg &c, const TrGeom &g, const TrTables &t, uint64
 AEC_HD void tr_hyp_land(const Cfg &c, const TrGeom &g, const TrTables &t, uint32_t w, uint32_t idx)
 {
     const uint64_t at = t.nbase[w] + idx;
+    const uint32_t pk = t.park[at];
+    if (!(pk & kTrParked)) return;
     const TrRec r = t.rec[at];
-    if (!(r.y & kTrParked)) return;
     const uint64_t c0 = g.lo + (uint64_t)w * g.L + t.cpos[at];
-    const uint32_t k = (r.y >> 16) & 0x3Fu, b = r.y & 0xFFFFu;
+    const uint32_t k = (pk >> 16) & 0x3Fu, b = pk & 0xFFFFu;
     const uint64_t e = tr_jump(c, g, t, c0 + r.x, b);
-    t.rec[at] = TrRec{e == kTrNone ? 0u : tr_rec_pack(e - c0, k + 1u), 0u};
+    const uint32_t x = e == kTrNone ? 0u : tr_rec_pack(e - c0, k + 1u);
+    t.rec[at] = TrRec{x, x ? r.y : 0u};
 }
 
-// chain (k_hyp_chain): records from node (w, idx) on until the chain leaves the window
-AEC_HD void tr_hyp_chain(const TrGeom &g, const TrTables &t, uint32_t w, uint32_t idx)
+// The RSI ends inside the record of a node (k RSIs, list head y): out(j, end) for the RSIs j = k - 2 .. 0,
+// end = where RSI j of the record ends (absolute bit).  false = the list is broken (cannot happen).
+template <class Out>
+AEC_HD bool tr_rec_ends(const TrTables &t, uint64_t node_pos, uint32_t k, uint32_t y, Out out)
 {
-    const uint64_t wstart = g.lo + (uint64_t)w * g.L, wend = wstart + g.L;
-    const uint64_t at = t.nbase[w] + idx;
-    const uint64_t c0 = wstart + t.cpos[at];
-    uint64_t pos = c0;
-    uint32_t cnt = 0;
-    while (pos < wend) {
-        uint32_t pw, pi;
-        if (!tr_node_at(g, t, pos, pw, pi) || pw != w) break;
-        const uint32_t x = t.rec[t.nbase[w] + pi].x;
-        if (!x || cnt + tr_rec_k(x) > 255u || pos + tr_rec_bits(x) - c0 >= (1u << 24)) break;
-        pos += tr_rec_bits(x);
-        cnt += tr_rec_k(x);
+    for (uint32_t j = k - 1u; j-- > 0u;) {
+        if (!y) return false;
+        const TrPoolEntry e = t.pool[y - 1u];
+        out(j, node_pos + e.end);
+        y = e.prev;
     }
-    t.rec[at].y = cnt ? (cnt << 24) | (uint32_t)(pos - c0) : 0u;
+    return true;
 }
 
 // The RSI starts inside a record that covers k > 1 RSIs, parsed again from its node (the expansion of the

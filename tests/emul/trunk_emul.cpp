@@ -9,6 +9,8 @@
 #include <vector>
 
 static int g_dbg = 0;
+static unsigned long long g_cnt[4];
+#define TR_COUNT_STEP(i) (g_cnt[i]++)
 #define TR_DBG(...) do { if (g_dbg) fprintf(stderr, __VA_ARGS__); } while (0)
 #include "../../libaec_amd/csrc/aec_trunk.h"
 #include "../../libaec_amd/csrc/aec_cfg.h"
@@ -18,7 +20,8 @@ using namespace aec;
 namespace {
 
 struct Tables {
-    std::vector<uint32_t> bitmap, bp, ccnt, nblk, nros, seampre, rospre, nbase;
+    std::vector<uint32_t> bitmap, bp, ccnt, nblk, nros, seampre, rospre, nbase, park, pool_cnt;
+    std::vector<TrPoolEntry> pool;
     std::vector<uint16_t> pre, cpos;
     std::vector<uint64_t> entry, exit, exit2, gbase;
     std::vector<TrRec> rec;
@@ -40,8 +43,12 @@ struct Tables {
         seampre.assign(g.nwin + 1, 0);
         rospre.assign(g.nwin + 1, 0);
         rec.assign((size_t)g.ncap, TrRec{0, 0});
+        park.assign((size_t)g.ncap, 0);
+        pool.assign((size_t)g.pcap, TrPoolEntry{0, 0});
+        pool_cnt.assign(1, 0);
         return TrTables{bitmap.data(), pre.data(), nbase.data(), cpos.data(), bp.data(), ccnt.data(), nblk.data(), nros.data(),
-                        entry.data(), exit.data(), gbase.data(), seampre.data(), rospre.data(), rec.data()};
+                        entry.data(), exit.data(), gbase.data(), seampre.data(), rospre.data(), rec.data(), park.data(),
+                        pool.data(), pool_cnt.data()};
     }
 };
 
@@ -53,7 +60,7 @@ struct Tables {
 // 16 rest-of-segment nodes, 17 hops of the table walk from start_bit, 18 RSIs it covered, 19 serial fallbacks
 extern "C" int emul_trunk(const uint32_t *params, const uint8_t *enc, size_t enc_len, uint64_t start_bit,
                           uint32_t L, uint32_t lead, uint32_t budget, const uint64_t *offs, uint64_t n_offs,
-                          uint64_t *stats, uint32_t rw, uint32_t passes, uint32_t capdiv)
+                          uint64_t *stats, uint32_t rw, uint32_t passes, uint32_t capdiv, uint32_t staged)
 {
     Cfg c;
     if (make_cfg(params[0], params[1], params[2], params[3], 0, false, &c) != RC_OK) return -1;
@@ -69,11 +76,14 @@ extern "C" int emul_trunk(const uint32_t *params, const uint8_t *enc, size_t enc
     g.rw = rw ? rw : 1;
     g.nwin = (uint32_t)((s.end_bit - g.lo) / L + 1);
     g.ncap = (uint32_t)(((uint64_t)g.nwin * L) / (capdiv ? capdiv : 8));
+    g.pcap = g.ncap;
     g.ncore = g.nwin;
     g.budget = budget;
+    g.kmax = kTrMaxK;
     Tables T;
     TrTables t = T.view(g);
     for (int i = 0; i < 20; i++) stats[i] = 0;
+    g_cnt[0] = g_cnt[1] = g_cnt[2] = 0;
     const uint32_t nreg = (g.nwin + g.rw - 1) / g.rw;
     uint64_t *ea = T.exit.data(), *eb = T.exit2.data();
     for (uint32_t r = 0; r < nreg; r++) tr_trunk_region(s, c, g, t, r, nullptr, ea);
@@ -100,27 +110,76 @@ extern "C" int emul_trunk(const uint32_t *params, const uint8_t *enc, size_t enc
         stats[2] += t.ccnt[w];
         stats[16] += t.nros[w];
     }
-    for (uint32_t w = 0; w < g.ncore; w++)
-        for (uint32_t i = 0; i < t.ccnt[w]; i++) {
-            TrHyp h;
-            tr_hyp_start(c, h, g.lo + (uint64_t)w * L + t.cpos[t.nbase[w] + i]);
-            uint32_t st;
-            while ((st = tr_hyp_step(s, c, g, t, h)) == TR_RUN) {}
-            stats[3] += h.steps;
-            if (h.steps > stats[4]) stats[4] = h.steps;
-            stats[5] += st == TR_LAND;
-            stats[6] += st == TR_DONE;
-            stats[7] += st == TR_FAIL;
-            tr_hyp_finish(g, t, w, i, h, st);
+    auto alloc = [&]() -> uint32_t {
+        if (t.pool_cnt[0] >= g.pcap) return 0xFFFFFFFFu;
+        return t.pool_cnt[0]++;
+    };
+    const TrGlobal mem{s, g, t};
+    // staged == 0: every walk reads device memory.  Else: the walks of each group of `staged` windows run on a
+    // staged stretch (group + one more window), as the workgroups of k_hyp_walk_lds do.
+    std::vector<uint32_t> sw, bm;
+    std::vector<uint8_t> nx;
+    const bool no_table = staged >= 100;                  // (staged stretches without the byte table)
+    if (no_table) staged -= 100;
+    for (uint32_t w0 = 0; w0 < g.ncore; w0 += (staged ? staged : g.ncore)) {
+        const uint32_t w1 = staged ? (w0 + staged < g.ncore ? w0 + staged : g.ncore) : g.ncore;
+        TrStaged st{mem, nullptr, nullptr, nullptr, 0, 0};
+        if (staged) {
+            st.base = g.lo + (uint64_t)w0 * L;
+            st.bits = (w1 - w0 + 1) * L;
+            sw.assign(st.bits / 32 + 8, 0);
+            bm.assign(st.bits / 32, 0);
+            nx.assign(st.bits, 0);
+            for (uint32_t i = 0; i < st.bits / 32 + 8; i++) sw[i] = tr_word(s, (st.base >> 5) + i);
+            for (uint32_t i = 0; i < st.bits / 32; i++) {
+                const uint64_t gw = (st.base - g.lo) / 32 + i;
+                bm[i] = gw < (uint64_t)g.nwin * (L / 32) ? t.bitmap[gw] : 0u;
+            }
+            st.sw = sw.data();
+            st.bm = bm.data();
+            st.nx = no_table ? nullptr : nx.data();
+            for (uint32_t q = 0; q < st.bits && !no_table; q++) {
+                TrWin W;
+                st.win(st.base + q, W);
+                nx[q] = tr_fast_entry(s, c, st.base + q, W);
+            }
         }
+        for (uint32_t w = w0; w < w1; w++)
+            for (uint32_t i = 0; i < t.ccnt[w]; i++) {
+                TrHyp h;
+                tr_hyp_start(c, h, g.lo + (uint64_t)w * L + t.cpos[t.nbase[w] + i]);
+                uint32_t stt;
+                auto commit = [&]() {                    // (false: the pool is full, the hypothesis fails)
+                    return !h.pend || tr_hyp_commit(g, t, h, alloc());
+                };
+                if (staged) {
+                    while ((stt = tr_hyp_step(s, c, g, st, h)) == TR_RUN)
+                        if (!commit()) {
+                            stt = TR_FAIL;
+                            break;
+                        }
+                } else {
+                    while ((stt = tr_hyp_step(s, c, g, mem, h)) == TR_RUN)
+                        if (!commit()) {
+                            stt = TR_FAIL;
+                            break;
+                        }
+                }
+                stats[3] += h.steps;
+                if (h.steps > stats[4]) stats[4] = h.steps;
+                stats[5] += stt == TR_LAND;
+                stats[6] += stt == TR_DONE;
+                stats[7] += stt == TR_FAIL;
+                tr_hyp_finish(g, t, w, i, h, stt);
+            }
+    }
+    if (getenv("TR_DEBUG")) fprintf(stderr, "steps: fast %llu, parse inside the stretch %llu, parse outside %llu\n", g_cnt[0], g_cnt[1], g_cnt[2]);
     for (uint32_t w = 0; w < g.ncore; w++)
         for (uint32_t i = 0; i < t.ccnt[w]; i++) {
-            const bool parked = t.rec[t.nbase[w] + i].y & kTrParked;
+            const bool parked = t.park[t.nbase[w] + i] & kTrParked;
             tr_hyp_land(c, g, t, w, i);
             if (parked && !t.rec[t.nbase[w] + i].x) stats[8]++;
         }
-    for (uint32_t w = 0; w < g.ncore; w++)
-        for (uint32_t i = 0; i < t.ccnt[w]; i++) tr_hyp_chain(g, t, w, i);
 
     // ---- truth: the serial walk with this header's own parser, checked against the caller's RSI starts
     // (offs[0 .. n_offs - 1) = starts from the oracle, offs[n_offs - 1] = end of the stream's last CDS).
@@ -163,6 +222,17 @@ extern "C" int emul_trunk(const uint32_t *params, const uint8_t *enc, size_t enc
             continue;
         }
         const TrRec rc = t.rec[t.nbase[w] + i];
+        if (!rc.x && getenv("TR_VERBOSE")) {
+            TrHyp h;
+            tr_hyp_start(c, h, key[r]);
+            uint32_t st;
+            while ((st = tr_hyp_step(s, c, g, mem, h)) == TR_RUN && (!h.pend || tr_hyp_commit(g, t, h, alloc()))) {}
+            fprintf(stderr, "unresolved true start rsi %llu at %llu: state %u pos %llu b %u k %u steps %u\n",
+                    (unsigned long long)r, (unsigned long long)key[r], st, (unsigned long long)h.pos, h.b, h.k, h.steps);
+            g_dbg = 1;
+            if (st == TR_LAND) fprintf(stderr, "  jump -> %lld\n", (long long)tr_jump(c, g, t, h.pos, h.b));
+            g_dbg = 0;
+        }
         if (!rc.x) continue;
         stats[10]++;
         const uint32_t k = tr_rec_k(rc.x);
@@ -177,7 +247,7 @@ extern "C" int emul_trunk(const uint32_t *params, const uint8_t *enc, size_t enc
                 TrHyp h;
                 tr_hyp_start(c, h, key[r]);
                 uint32_t st;
-                while ((st = tr_hyp_step(s, c, g, t, h)) == TR_RUN) fprintf(stderr, "  step -> pos %llu b %u k %u\n", (unsigned long long)h.pos, h.b, h.k);
+                while ((st = tr_hyp_step(s, c, g, mem, h)) == TR_RUN && (!h.pend || tr_hyp_commit(g, t, h, alloc()))) fprintf(stderr, "  step -> pos %llu b %u k %u\n", (unsigned long long)h.pos, h.b, h.k);
                 fprintf(stderr, "  state %u pos %llu b %u k %u\n", st, (unsigned long long)h.pos, h.b, h.k);
                 g_dbg = 1;
                 if (st == TR_LAND) fprintf(stderr, "  jump -> %lld\n", (long long)tr_jump(c, g, t, h.pos, h.b));
@@ -195,13 +265,10 @@ extern "C" int emul_trunk(const uint32_t *params, const uint8_t *enc, size_t enc
             const bool okk = tr_rec_starts(s, c, key[r], k, [&](uint32_t j, uint64_t q) {
                 if (q != key[r0 + j + 1]) stats[12]++;
             });
-            if (!okk) stats[12]++;
-        }
-        if (rc.y) {
-            const uint32_t cnt = rc.y >> 24, bits = rc.y & 0xFFFFFFu;
-            if (r + cnt >= nk || key[r] + bits != key[r + cnt]) stats[14]++;
-        } else {
-            stats[14]++;
+            const bool okl = tr_rec_ends(t, key[r], k, rc.y, [&](uint32_t j, uint64_t q) {
+                if (q != key[r0 + j + 1]) stats[12]++;
+            });
+            if (!okk || !okl) stats[12]++;
         }
     }
     // ---- the walk the serial walker would do: hop over records from start_bit, count fallbacks
@@ -209,8 +276,8 @@ extern "C" int emul_trunk(const uint32_t *params, const uint8_t *enc, size_t enc
         uint64_t r = 0;
         while (r + 2 < nk) {
             uint32_t w, i;
-            if (tr_node_at(g, t, key[r], w, i) && t.rec[t.nbase[w] + i].y && r + (t.rec[t.nbase[w] + i].y >> 24) < nk) {
-                r += t.rec[t.nbase[w] + i].y >> 24;
+            if (tr_node_at(g, t, key[r], w, i) && t.rec[t.nbase[w] + i].x && r + tr_rec_k(t.rec[t.nbase[w] + i].x) < nk) {
+                r += tr_rec_k(t.rec[t.nbase[w] + i].x);
                 stats[17]++;
             } else {
                 stats[19]++;
