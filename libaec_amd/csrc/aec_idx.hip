@@ -753,6 +753,43 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     stamp(6);
 }
 
+#ifdef AEC_TUNING
+// (diagnostics) every record of the window tables against the plain parse of its RSI from device memory
+__global__ void k_spec_verify(const Cfg c, const TrStream s, const SparseTables t, uint32_t nwin, uint32_t *bad)
+{
+    const uint32_t w = blockIdx.x;
+    if (w >= nwin) return;
+    for (uint32_t i = threadIdx.x; i < t.ccnt[w]; i += blockDim.x) {
+        const uint2 rec = t.rec[(uint64_t)w * t.cap + i];
+        const uint64_t p = t.lo + (uint64_t)w * t.core + t.cpos[(uint64_t)w * t.cap + i];
+        // the position must be marked and have this index
+        uint2 r2;
+        uint32_t wv, ix;
+        if (!sparse_lookup(t, p, r2, wv, ix) || wv != w || ix != i) {
+            if (atomicAdd(&bad[0], 1u) < 4u) printf("window %u cand %u pos %llu: lookup says window %u index %u\n", w, i, (unsigned long long)p, wv, ix);
+            continue;
+        }
+        if (!rec.x) continue;
+        uint64_t q = p;
+        uint32_t b = 0;
+        bool ok = true;
+        while (b < c.rsi && ok) {
+            uint32_t nz;
+            const uint32_t len = tr_cds(s, c, q, (b == 0 && (c.flags & F_PREPROCESS)) ? 1u : 0u, nz);
+            const uint32_t nb = len ? tr_blocks(c, nz, b) : 0u;
+            if (!len || !nb || nb > c.rsi - b) ok = false;
+            q += len;
+            b += nb;
+        }
+        if (!ok || q - p != rec.x) {
+            if (atomicAdd(&bad[1], 1u) < 8u)
+                printf("window %u cand %u pos %llu: record %u, parse %llu (%s)\n", w, i, (unsigned long long)p, rec.x,
+                       (unsigned long long)(q - p), ok ? "ok" : "fails");
+        }
+    }
+}
+#endif
+
 // ---- wide walker: every candidate of a chunk's first window chases the window chain through the chunk
 __global__ void __launch_bounds__(256)
 k_wide(const SparseTables t, uint32_t nwin, uint64_t end_bit, uint4 *__restrict__ wide)
@@ -1284,6 +1321,7 @@ void allow_big_lds2()
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_spec2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 156 * 1024) != hipSuccess)
             (void)hipGetLastError();
+
     });
 }
 
@@ -1327,6 +1365,18 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
                            const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
                            const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin));
         spec2_prof_report(nwin, st);
+#ifdef AEC_TUNING
+        if (getenv("AEC_S2_VERIFY")) {
+            static uint32_t *d_bad = nullptr;
+            if (!d_bad) (void)hipMalloc(reinterpret_cast<void **>(&d_bad), 8);
+            (void)hipMemsetAsync(d_bad, 0, 8, st);
+            hipLaunchKernelGGL(k_spec_verify, dim3(nwin), dim3(256), 0, st, c, TrStream{words, nwords, end_bit}, t, nwin, d_bad);
+            uint32_t h[2] = {0, 0};
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, d_bad, 8, hipMemcpyDeviceToHost);
+            fprintf(stderr, "verify: %u windows, lookup mismatches %u, wrong records %u\n", nwin, h[0], h[1]);
+        }
+#endif
         hipLaunchKernelGGL(k_wide, dim3((p.g.cap_core + 255) / 256, nchunks), dim3(256), 0, st, t, nwin, end_bit,
                            const_cast<uint4 *>(t.wide));
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
