@@ -160,13 +160,15 @@ AEC_GPU_API int aec_gpu_decode_segments_async(aec_gpu_ctx *ctx, const aec_gpu_pa
  * (about 20 kbit coded), cut by the end of the input or malformed are walked serially, so the
  * result never depends on the tables.  The look-ahead is sized from the expected coded RSI:
  * (input bits / max_rsi) unless aec_gpu_set_index_hint gave a better estimate (0 = back to default).
- * The call may allocate table workspace (up to ~340 MiB for inputs of 8 MiB and more).
+ * The call may allocate table workspace (up to 768 MiB; larger inputs are indexed span by span).
  */
 AEC_GPU_API void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits);
 
 /* Release the context's workspaces that are larger than keep_bytes (they are re-allocated on
  * demand); for callers that keep a context around between jobs of very different size. */
 AEC_GPU_API void aec_gpu_trim(aec_gpu_ctx *ctx, size_t keep_bytes);
+/* Device memory the context holds for its own purposes at the moment (encoder workspace, index tables). */
+AEC_GPU_API size_t aec_gpu_held_bytes(const aec_gpu_ctx *ctx);
 AEC_GPU_API int aec_gpu_index_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
                                     size_t in_bytes, uint64_t start_bit, uint64_t *d_rsi_bit_offsets,
                                     uint64_t max_rsi, aec_gpu_dec_result *d_result, void *stream);

@@ -144,7 +144,8 @@ struct Kit {
     DevBuf d_in, d_out, d_off, d_res;
     uint8_t *h_res = nullptr;
 };
-constexpr size_t kPoolMax = 8, kKeepBytes = (size_t)256 << 20;
+// at most kPoolMax parked kits, none holding a buffer above kKeepBytes, all of them together at most kPoolBytes
+constexpr size_t kPoolMax = 8, kKeepBytes = (size_t)256 << 20, kPoolBytes = (size_t)1 << 30;
 std::mutex g_pool_mu;
 std::vector<Kit> *g_pool = nullptr;      // heap object on purpose: no destructor at exit
 
@@ -173,15 +174,27 @@ bool take_kit(int device, Kit *out)
     return false;
 }
 
+size_t kit_bytes(const Kit &k) { return k.d_in.cap + k.d_out.cap + k.d_off.cap + k.d_res.cap + aec_gpu_held_bytes(k.ctx); }
+
 void park_kit(Kit &k)
 {
+    // an error return may have left copies or kernels of this stream object enqueued: nothing of it may still
+    // run when the next owner writes the buffers
+    if (hipStreamSynchronize(k.stream) != hipSuccess) {
+        (void)hipGetLastError();
+        destroy_kit(k);
+        return;
+    }
     for (DevBuf *b : {&k.d_in, &k.d_out, &k.d_off})
         if (b->cap > kKeepBytes) b->release();
     aec_gpu_trim(k.ctx, kKeepBytes);
     {
         std::lock_guard<std::mutex> lock(g_pool_mu);
         if (!g_pool) g_pool = new (std::nothrow) std::vector<Kit>();
-        if (g_pool && g_pool->size() < kPoolMax) {
+        size_t held = kit_bytes(k);
+        if (g_pool)
+            for (const Kit &o : *g_pool) held += kit_bytes(o);
+        if (g_pool && g_pool->size() < kPoolMax && held <= kPoolBytes) {
             g_pool->push_back(k);
             k = Kit{};
             return;
@@ -202,7 +215,6 @@ void free_state(internal_state *s)
     k.d_off = s->d_off;
     k.d_res = s->d_res;
     k.h_res = s->h_res;
-    // everything enqueued for this stream object has been waited for by the calls that enqueued it
     if (k.ctx && k.stream && k.h_res && k.d_res.p) park_kit(k);
     else destroy_kit(k);
     delete s;
@@ -714,10 +726,9 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
         if (rc != RC_OK) return AEC_FAIL(rc);
     } else {
         // (per chunk: its own decode record behind the index records; the overall record is folded on the host)
-        if (!k.d_res.ensure(256)) return AEC_FAIL(AEC_MEM_ERROR);
-        DevBuf dec_recs;
-        if (!dec_recs.ensure(n * sizeof(aec_gpu_dec_result) + 64)) return AEC_FAIL(AEC_MEM_ERROR);
-        aec_gpu_dec_result *d_dec = static_cast<aec_gpu_dec_result *>(dec_recs.p);
+        // (the per-chunk decode records live behind the stream's own record in d_res, which stays with the kit)
+        if (!k.d_res.ensure(256 + n * sizeof(aec_gpu_dec_result) + 64)) return AEC_FAIL(AEC_MEM_ERROR);
+        aec_gpu_dec_result *d_dec = reinterpret_cast<aec_gpu_dec_result *>(static_cast<uint8_t *>(k.d_res.p) + 256);
         for (size_t i = 0; i < n && rc == RC_OK; i++) {
             uint64_t *offs = reinterpret_cast<uint64_t *>(meta) + i * rpc;
             const uint8_t *in_i = static_cast<const uint8_t *>(k.d_in.p) + off[i];
@@ -733,10 +744,8 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
                                           k.stream) != hipSuccess ||
             hipMemsetAsync(d_one, 0, sizeof(aec_gpu_dec_result), k.stream) != hipSuccess ||
             hipStreamSynchronize(k.stream) != hipSuccess) {
-            dec_recs.release();
             return AEC_FAIL(rc != RC_OK ? rc : AEC_MEM_ERROR);
         }
-        dec_recs.release();
         // fold the per-chunk decode status into the per-chunk index records on the host below
         std::vector<aec_gpu_dec_result> idx(n);
         if (hipMemcpy(idx.data(), d_results, n * sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost) != hipSuccess)
@@ -897,6 +906,8 @@ int aec_decode(struct aec_stream *strm, int flush)
         return decode_call(strm, flush);   // (flush is ignored by the reference, decode.c:797; here it only
                                            // says that the caller is not trickling input in)
     } catch (const std::bad_alloc &) {
+        strm->total_in -= strm->avail_in;      // (added on entry, as on every other way out)
+        strm->total_out -= strm->avail_out;
         return AEC_MEM_ERROR;
     }
 }

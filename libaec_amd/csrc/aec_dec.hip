@@ -19,6 +19,7 @@
 
 #include "aec_kernels.h"
 #include "aec_lane.h"
+#include "aec_tune.h"
 
 namespace aec {
 
@@ -459,6 +460,10 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             if (parse) {
                 if (st != DEC_OK) {
                     report(res, st, r);
+                    // (a batch of independent streams: the stream's own record says so as well -- one overall
+                    // record names only the first bad RSI of the whole batch)
+                    if (batch && st == DEC_DATA_ERROR)
+                        atomicMax(&const_cast<DecResult *>(batch)[r / rsi_per_chunk].status, (uint32_t)DEC_DATA_ERROR);
                     ok = 0u;
                 } else if (nz) {
                     zrun = nz;
@@ -507,6 +512,10 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                 const uint32_t st = parse_cds<0>(br, d, c, ref, b0 + bo, nz);
                 if (st != DEC_OK) {
                     report(res, st, r);
+                    // (a batch of independent streams: the stream's own record says so as well -- one overall
+                    // record names only the first bad RSI of the whole batch)
+                    if (batch && st == DEC_DATA_ERROR)
+                        atomicMax(&const_cast<DecResult *>(batch)[r / rsi_per_chunk].status, (uint32_t)DEC_DATA_ERROR);
                     ok = 0u;
                 } else if (nz) {
                     const uint32_t keep = d[0];
@@ -663,8 +672,7 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, uint32_t s
     // (how many average coded data sets half of the half ring -- its steady-state look-ahead -- must hold: 2.  With
     // 4, typical.dat's 720-bit blocks of 64 samples kept the full ring, 33 KB per wave and 4 waves per CU: 5.8 ms;
     // on the half ring 3.3 ms, the second attempts included.  AEC_DEC_HALF_FACTOR overrides, for measurements.)
-    static const char *e_hf = getenv("AEC_DEC_HALF_FACTOR");
-    const uint64_t hf = e_hf ? (uint64_t)atoi(e_hf) : 2;
+    const uint64_t hf = tune("AEC_DEC_HALF_FACTOR", 2);
     if (rw >= 32 && g.maxw <= rw / 2 - 3 && avg_cds_bits && avg_cds_bits * hf <= (uint64_t)rw / 2 * 32) {
         rw /= 2;
         g.needw = rw / 2;
@@ -673,8 +681,7 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, uint32_t s
     // (+ the output staging rows of k_decode for small blocks: 64 x (row + 16) bytes)
     // (AEC_DEC_LDS_PAD: extra LDS bytes per wave, a diagnostic knob for occupancy experiments; the kernel
     // never touches them)
-    static const char *e_pad = getenv("AEC_DEC_LDS_PAD");
-    const size_t pad = e_pad ? (size_t)atoi(e_pad) : 0;
+    const size_t pad = tune("AEC_DEC_LDS_PAD", 0);
     const size_t per_wave = (size_t)(rw + 2) * 64 * 4 + (stg_row_bytes ? 64 * (stg_row_bytes + 16) : 0) + pad;
     // waves per workgroup: whatever packs most waves into the 160 KiB of a CU
     uint32_t waves = 1, best = 0;
@@ -707,11 +714,11 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
     // loads in flight per block iteration (see kPend): sized for the average coded data set where the caller
     // knows it, for the worst case of large blocks where it does not
     const uint64_t avg = (total_blocks && !idx && !batch) ? end_bit / total_blocks : 0;
-    static const char *e_kp = getenv("AEC_DEC_KP");            // (diagnostic: force 2, 4 or 8)
+    const uint32_t e_kp = tune("AEC_DEC_KP", 0);               // (diagnostic: force 2, 4 or 8)
     // (measured: 2 up to the 256 bits per block they feed -- C3 at 247: 2.70 ms against 2.74 with 4 --, 8 for the
     // 720 bits of typical.dat's blocks: 5.8 ms against 7.1 with 4 and 7.8 with 2)
     int kp = BS >= 32 ? (avg == 0 || avg > 512 ? 8 : (avg > 256 ? 4 : 2)) : (avg > 256 ? 4 : 2);
-    if (e_kp) kp = atoi(e_kp) >= 8 ? (BS >= 32 ? 8 : 4) : (atoi(e_kp) >= 4 ? 4 : 2);
+    if (e_kp) kp = e_kp >= 8 ? (BS >= 32 ? 8 : 4) : (e_kp >= 4 ? 4 : 2);
 #define AEC_GO2(B, KP)                                                                                  \
     hipLaunchKernelGGL((k_decode<BS, B, SEG, KP>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
                        rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, g.needw, dump, idx, batch, rpc)

@@ -24,6 +24,7 @@
 
 #include "aec_kernels.h"
 #include "aec_lane.h"
+#include "aec_tune.h"
 
 // (grouped emission for 64-sample blocks: measured slower -- typical.dat shape 4.53 against 4.36 ms)
 #ifndef AEC_ENC_GRP64
@@ -1540,7 +1541,7 @@ FusedGeom fused_geom(const Cfg &c)
     const uint32_t maxlen = c.id_len + c.bs * c.bps + 2 + c.bps;
     g.obuf_words = ((64u * maxlen + 62u) / 32u + 4u) & ~3u;
     const size_t seg_bytes = (size_t)64 * stride * 4, obuf_bytes = (size_t)g.obuf_words * 4;
-    static const char *force = getenv("AEC_FUSED_SEGS");
+    const uint32_t force = tune("AEC_FUSED_SEGS", 0);
     g.waves = 4;
     g.segs = 1;
     for (uint32_t s : {4u, 2u, 1u}) {
@@ -1549,14 +1550,14 @@ FusedGeom fused_geom(const Cfg &c)
             break;
         }
     }
-    if (force && (atoi(force) == 1 || atoi(force) == 2 || atoi(force) == 4)) g.segs = (uint32_t)atoi(force);
+    if (force == 1 || force == 2 || force == 4) g.segs = force;
     while (g.waves > 1 && (seg_bytes * g.segs + obuf_bytes) * g.waves > 156 * 1024) g.waves >>= 1;
     g.lds_bytes = (seg_bytes * g.segs + obuf_bytes) * g.waves;
     const uint64_t per = (uint64_t)g.waves * g.segs;
     g.nparts = (uint32_t)((c.total_segs + per - 1) / per);
     g.parts_per_wg = 1u;
-    static const char *ppw = getenv("AEC_FUSED_PARTS");
-    if (ppw && atoi(ppw) >= 1 && atoi(ppw) <= 64) g.parts_per_wg = (uint32_t)atoi(ppw);
+    const uint32_t ppw = tune("AEC_FUSED_PARTS", 0);
+    if (ppw >= 1 && ppw <= 64) g.parts_per_wg = ppw;
     g.grid = (g.nparts + g.parts_per_wg - 1) / g.parts_per_wg;
     return g;
 }
@@ -1621,7 +1622,7 @@ void launch_fused_bytes(const Cfg &c, const uint8_t *in, uint32_t *out_words, ui
 // two-pass kernels stay the default and AEC_ENC_FUSED=1 selects this one (kept under test).
 bool fused_supported(const Cfg &c)
 {
-    static const bool on = getenv("AEC_ENC_FUSED") != nullptr;
+    static const bool on = tune_set("AEC_ENC_FUSED");
     return on && (c.bs == 8 || c.bs == 16 || c.bs == 32 || c.bs == 64) && c.total_segs != 0;
 }
 

@@ -392,6 +392,11 @@ void aec_gpu_trim(aec_gpu_ctx *ctx, size_t keep_bytes)
     }
 }
 
+size_t aec_gpu_held_bytes(const aec_gpu_ctx *ctx)
+{
+    return ctx ? ctx->ws_bytes + ctx->fused_bytes + ctx->idx_ws_bytes : 0;
+}
+
 int aec_gpu_index_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
                               const uint64_t *d_chunk_offsets, uint64_t n_chunks, uint64_t rsi_per_chunk,
                               uint64_t *d_rsi_bit_offsets, aec_gpu_dec_result *d_results, void *stream)

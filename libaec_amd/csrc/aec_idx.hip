@@ -34,6 +34,7 @@
 #include "aec_spec.h"
 #include "aec_spec2.h"
 #include "aec_trunk.h"
+#include "aec_tune.h"
 
 namespace aec {
 
@@ -1195,15 +1196,6 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
 
 namespace {
 
-#ifdef AEC_TUNING
-static uint32_t tune(const char *name, uint32_t dflt)
-{
-    const char *e = getenv(name);
-    return e ? (uint32_t)atoi(e) : dflt;
-}
-#else
-static uint32_t tune(const char *, uint32_t dflt) { return dflt; }
-#endif
 
 // ---- sparse path: geometry and workspace ------------------------------------------------------------
 struct Sparse2Plan {
@@ -1366,7 +1358,7 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
                            const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin));
         spec2_prof_report(nwin, st);
 #ifdef AEC_TUNING
-        if (getenv("AEC_S2_VERIFY")) {
+        if (tune_set("AEC_S2_VERIFY")) {
             static uint32_t *d_bad = nullptr;
             if (!d_bad) (void)hipMalloc(reinterpret_cast<void **>(&d_bad), 8);
             (void)hipMemsetAsync(d_bad, 0, 8, st);
@@ -1644,7 +1636,7 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
         if (last) break;
     }
 #ifdef AEC_TUNING
-    if (getenv("AEC_IDX_STATS")) {                       // (diagnostics: synchronises)
+    if (tune_set("AEC_IDX_STATS")) {                       // (diagnostics: synchronises)
         IdxCarry h{};
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(&h, carry, sizeof(h), hipMemcpyDeviceToHost);

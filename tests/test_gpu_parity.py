@@ -647,6 +647,9 @@ def test_fused_encoder_edges(env):
     import sys
     e = dict(os.environ)
     e.update(env)
+    if env:     # the variant knobs exist in the tuning build only (libaec_amd/csrc/aec_tune.h)
+        e["AEC_AMD_LIB"] = os.path.join(ROOT, "libaec_amd", "lib", "tuning", "libaec.so.0")
+        assert os.path.exists(e["AEC_AMD_LIB"])
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fused_edges.py")], env=e, capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0 and "fused edges ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

@@ -145,3 +145,33 @@ def test_sz_batch_calls_vs_reference_shim(szip):
     rc, got, st = szip.compress_batch(chunks, sizes, opts, bpp, ppb, pps)
     assert st[2] == szip.SZ_OUTBUFF_FULL and [s for i, s in enumerate(st) if i != 2] == [0] * 5
     assert got[3] == szip.compress(chunks[3], chunks[3].size * 2, opts, bpp, ppb, pps, lib=ref)[1]
+
+
+def _bits_to_bytes(bits):
+    bits = bits + "0" * (-len(bits) % 8)
+    return bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+
+
+def test_batch_of_small_chunks_reports_errors_per_chunk(szip):
+    """80 chunks of 8 KiB through SZ_BatchDecompress take the small-chunk path (every chunk walked by one wavefront,
+    ONE decode launch for all of them).  Two of the streams hold a second-extension code beyond the table
+    (reference src/decode.c:560-616: m > 90 is AEC_DATA_ERROR) -- an error only the decoder sees; each of them must
+    come back as AEC_DATA_ERROR, every other chunk intact."""
+    from test_gpu_parity import gen
+    NN, RAW = szip.SZ_NN_OPTION_MASK, szip.SZ_RAW_OPTION_MASK
+    opts, bpp, ppb, pps = NN | RAW, 8, 8, 1024
+    data = gen(2, 80 * 8192)
+    chunks = [data[i * 8192:(i + 1) * 8192] for i in range(80)]
+    rc, enc, st = szip.compress_batch(chunks, [c.size * 2 + 4096 for c in chunks], opts, bpp, ppb, pps)
+    assert rc == 0 and st == [0] * 80
+    # a hand-made stream for a whole chunk's worth of RSIs is not needed: the first coded data set decides.
+    # id 000 + selector 1 (second extension) + reference sample + a code of 95 zeros and a one, then ones
+    bad = _bits_to_bytes("000" + "1" + "10000000" + "0" * 95 + "1" + "1" * 3 + "1" * 64) + bytes(64)
+    enc = list(enc)
+    enc[7] = bad
+    enc[55] = bad
+    rc, dec, st = szip.decompress_batch(enc, [c.size for c in chunks], opts, bpp, ppb, pps)
+    assert st[7] == -3 and st[55] == -3, (rc, st[:10], st[50:60])          # AEC_DATA_ERROR
+    good = [i for i in range(80) if i not in (7, 55)]
+    assert all(st[i] == 0 for i in good), st
+    assert all(dec[i] == chunks[i].tobytes() for i in good)
