@@ -61,6 +61,25 @@ def generate(kind, nbytes, shard, threads):
     return a
 
 
+def generate_to_device(kind, nbytes, shard, d_in, piece, keep=0):
+    """The generator's walk in pieces (its state carries over: libaec_amd/csrc/datagen.c aec_gen_state), every piece
+    uploaded at once.  Returns the first `keep` bytes on the host (an empty array for keep == 0)."""
+    import torch
+    lib = C.CDLL(os.path.join(ROOT, "libaec_amd", "lib", "libaec_datagen.so"))
+    st = (C.c_uint64 * 5)()                               # aec_gen_state: s, x, i, hold | kind
+    lib.aec_gen_init(st, C.c_uint(kind), C.c_uint64(shard))
+    bps = {0: 2, 1: 4, 2: 1}[kind]
+    kept = np.empty(min(keep, nbytes), dtype=np.uint8)
+    buf = np.empty(piece, dtype=np.uint8)
+    for o in range(0, nbytes, piece):
+        n = min(piece, nbytes - o)
+        lib.aec_gen_fill(st, C.c_void_p(buf.ctypes.data), C.c_size_t(n // bps))
+        d_in[o:o + n].copy_(torch.from_numpy(buf[:n]))
+        if o < kept.size:
+            kept[o:min(o + n, kept.size)] = buf[:min(n, kept.size - o)]
+    return kept
+
+
 def typical_tiled(nbytes):
     """The non-synthetic point: tests/golden/typical.rz (the reference's data/typical.rz) decoded
     by the product library and repeated to `nbytes` (1 MiB = 32 whole RSIs, so tiles stay aligned)."""
@@ -209,7 +228,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size-mib", type=int, default=4096, help="input bytes per GPU (MiB)")
+    ap.add_argument("--size-mib", type=int, default=0,
+                    help="input bytes per GPU (MiB); default 4096 on one GPU (BASELINE config 2), 8192 per rank with "
+                         "several (config 4: 64 GiB over 8 ranks)")
     ap.add_argument("--cpu-sample-mib", type=int, default=0,
                     help="prefix of the input the one-core CPU reference codes (0 = the whole input, "
                          "1 GiB for the slow 8-bit configuration); the GPU stream is compared with all of it")
@@ -245,16 +266,22 @@ def main():
 
     from libaec_amd import gpu
 
+    if not args.size_mib:
+        args.size_mib = 4096 if world == 1 else 8192
     nbytes = args.size_mib << 20
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
-    host = typical_tiled(nbytes) if KIND < 0 else generate(KIND, nbytes, rank, threads)
-
     codec = gpu.Codec(BPS, BS, RSI, FLAGS)
     codec.reserve(nbytes)
     d_in = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     step = 256 << 20
-    for o in range(0, nbytes, step):
-        d_in[o:o + step].copy_(torch.from_numpy(host[o:o + step]))
+    if KIND >= 0 and nbytes > (4096 << 20):
+        # shards beyond 4 GiB: the same walk (seed 0x5EED0000 + rank), produced piece by piece so that the host
+        # never holds more than one piece per rank; rank 0 keeps a 4 GiB prefix for the CPU reference
+        host = generate_to_device(KIND, nbytes, rank, d_in, step, keep=(4096 << 20) if rank == 0 else 0)
+    else:
+        host = typical_tiled(nbytes) if KIND < 0 else generate(KIND, nbytes, rank, threads)
+        for o in range(0, nbytes, step):
+            d_in[o:o + step].copy_(torch.from_numpy(host[o:o + step]))
     n_rsi, n_blk = codec.rsi_count(nbytes), codec.block_count(nbytes)
     d_out = torch.empty(codec.encode_bound(nbytes), dtype=torch.uint8, device=dev)
     d_off = torch.empty(n_rsi + 1, dtype=torch.int64, device=dev)
@@ -292,7 +319,7 @@ def main():
         # four times slower per byte, a 1 GiB prefix) and EVERY byte of the GPU stream is compared with
         # what it produced (a prefix of whole RSIs codes to a prefix of the stream).
         mib = args.cpu_sample_mib or (1024 if args.config == "c5" else args.size_mib)
-        sample = host[: min(nbytes, mib << 20)]
+        sample = host[: min(nbytes, host.size, mib << 20)]
         cpu, enc_cpu = cpu_baseline(sample)
         whole = sample.size == nbytes
         ncmp = len(enc_cpu) if whole else len(enc_cpu) - 1
@@ -415,6 +442,16 @@ def main():
         one_step()
         torch.cuda.synchronize()
         assert torch.equal(d_dec[:nbytes], d_in), "sharded round trip differs"
+        # ... and the shard decoded out of the STITCHED stream (what every rank holds after the all-gather): the
+        # segment table of the shard, moved to where the shard lies in the whole stream
+        seg64 = d_seg.view(torch.int64).view(-1, 2).clone()
+        seg64[:, 0] += 8 * (my_start // 8)
+        d_dec.zero_()
+        codec.decode_segments_async(d_stream, d_stream.numel() - 64, seg64.view(torch.uint8).view(-1), n_seg, n_blk,
+                                    d_dec, d_dres)
+        dres = d_dres.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]
+        assert dres["status"] == 0 and torch.equal(d_dec[:nbytes], d_in), "shard decoded from the stitched stream differs"
+        del seg64
         if world == 1:
             ref_out = torch.empty_like(d_out)
             codec.encode_async(d_in, nbytes, ref_out, d_off, d_eres)

@@ -8,6 +8,7 @@ device kernel (aec_gpu_stitch_async).  The result must be the oracle's stream of
 and the single-device stream.  Shapes: config 2/4 (16-bit, block 16, rsi 128) and config 3 (32-bit
 signed MSB, block 32, rsi 4096), with a short last RSI and shards that start in the middle of a byte."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -122,3 +123,20 @@ def test_device_shard_step_single_rank():
     sh.step(d_in, data.size, d_out, None, d_eres)
     sh.gather_and_stitch(d_out, d_stream, d_total)
     assert int(d_total.item()) == len(want) and d_stream[:len(want)].cpu().numpy().tobytes() == want
+
+
+def test_c_recipe_over_rccl_world_1():
+    """INTEGRATION.md section 5 as a C program (tests/c/shard_rccl.c): plan, ncclAllGather of the 24-byte plan
+    records, emit at the global offset, ncclAllGather of the slices, stitch -- against librccl with a communicator of
+    one rank; the stream must be aec_buffer_encode's."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "build", "shard_rccl")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    lib = os.path.join(root, "libaec_amd", "lib")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-x", "c", "-O1", os.path.join(root, "tests", "c", "shard_rccl.c"),
+                    "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                    "-L", lib, "-l:libaec.so.0", "-L", "/opt/rocm/lib", "-lrccl", "-lamdhip64",
+                    "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "shard_rccl ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
