@@ -224,6 +224,12 @@ AEC_GPU_API int aec_gpu_decode_batch_async(aec_gpu_ctx *ctx, const aec_gpu_param
                                            aec_gpu_dec_result *d_results, aec_gpu_dec_result *d_result,
                                            void *stream);
 
+/* 1 when aec_gpu_decode_batch_async would find the RSI starts of such a batch (n_chunks streams in in_bytes,
+ * rsi_per_chunk RSIs each) over window tables built in ONE launch for all streams -- low-entropy streams of tens of
+ * KiB and more, at most about 16 MiB of them per call -- instead of walking every stream serially. */
+AEC_GPU_API int aec_gpu_batch_uses_tables(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes,
+                                          uint64_t n_chunks, uint64_t rsi_per_chunk);
+
 /*
  * n independent streams coded from one device buffer: chunk i = bytes [chunk_offsets[i],
  * chunk_offsets[i+1]) of d_in (HOST array of n_chunks + 1 offsets, each a multiple of 16) is coded as a

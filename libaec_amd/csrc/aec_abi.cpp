@@ -27,6 +27,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/aec_gpu.h"
@@ -143,9 +144,12 @@ struct Kit {
     hipStream_t stream = nullptr;
     DevBuf d_in, d_out, d_off, d_res;
     uint8_t *h_res = nullptr;
+    uint8_t *h_stage = nullptr;    // pinned staging of the batch entry points (many chunks, one transfer)
+    size_t h_stage_cap = 0;
 };
 // at most kPoolMax parked kits, none holding a buffer above kKeepBytes, all of them together at most kPoolBytes
 constexpr size_t kPoolMax = 8, kKeepBytes = (size_t)256 << 20, kPoolBytes = (size_t)1 << 30;
+constexpr size_t kStageKeep = (size_t)96 << 20, kStagePiece = (size_t)64 << 20;
 std::mutex g_pool_mu;
 std::vector<Kit> *g_pool = nullptr;      // heap object on purpose: no destructor at exit
 
@@ -156,6 +160,7 @@ void destroy_kit(Kit &k)
     k.d_off.release();
     k.d_res.release();
     if (k.h_res) (void)hipHostFree(k.h_res);
+    if (k.h_stage) (void)hipHostFree(k.h_stage);
     if (k.stream) (void)hipStreamDestroy(k.stream);
     if (k.ctx) aec_gpu_destroy(k.ctx);
     k = Kit{};
@@ -187,6 +192,11 @@ void park_kit(Kit &k)
     }
     for (DevBuf *b : {&k.d_in, &k.d_out, &k.d_off})
         if (b->cap > kKeepBytes) b->release();
+    if (k.h_stage_cap > kStageKeep) {
+        (void)hipHostFree(k.h_stage);
+        k.h_stage = nullptr;
+        k.h_stage_cap = 0;
+    }
     aec_gpu_trim(k.ctx, kKeepBytes);
     {
         std::lock_guard<std::mutex> lock(g_pool_mu);
@@ -674,6 +684,53 @@ struct BatchKit {
 
 inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+// pinned staging buffer of a kit, at least n bytes (false: not to be had -- the callers copy chunk by chunk then)
+bool stage_ensure(Kit &k, size_t n)
+{
+    if (n <= k.h_stage_cap) return true;
+    if (k.h_stage) (void)hipHostFree(k.h_stage);
+    k.h_stage = nullptr;
+    k.h_stage_cap = 0;
+    if (hipHostMalloc(reinterpret_cast<void **>(&k.h_stage), n, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    k.h_stage_cap = n;
+    return true;
+}
+
+// many host-to-host copies (caller's buffers <-> pinned staging), on a few threads when there is enough to copy
+struct CopyJob {
+    void *dst;
+    const void *src;
+    size_t n;
+};
+void copy_all(const std::vector<CopyJob> &jobs)
+{
+    size_t total = 0;
+    for (const CopyJob &j : jobs) total += j.n;
+    const unsigned hw = std::thread::hardware_concurrency();
+    unsigned nt = total >= ((size_t)8 << 20) ? (hw >= 8 ? 4u : (hw >= 2 ? 2u : 1u)) : 1u;
+    if (nt > jobs.size()) nt = (unsigned)jobs.size();
+    auto work = [&](unsigned t) {
+        for (size_t i = t; i < jobs.size(); i += nt)
+            if (jobs[i].n) memcpy(jobs[i].dst, jobs[i].src, jobs[i].n);
+    };
+    if (nt <= 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    try {
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+    } catch (...) {                      // (no more threads: the ones that started do their share, this one the rest)
+        const unsigned started = (unsigned)th.size() + 1;
+        for (unsigned t = started; t < nt; t++) work(t);
+    }
+    work(0);
+    for (std::thread &x : th) x.join();
+}
+
 int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src, const size_t *src_len,
                  void *const *dst, size_t *dst_len, int *status)
 {
@@ -701,16 +758,31 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
     off[n] = total_in;
     // the index walker takes [off[i], off[i+1]) as stream i: the padding behind a stream is zeroed (zero
     // bits never complete a coded data set), the streams go up straight from the caller's buffers
-    const size_t o_choff = up16((size_t)n * rpc * 8), o_res = o_choff + up16((n + 1) * 8), o_one = o_res + up16(n * 40);
+    // (chunk offsets twice: absolute, and -- for the table path, which takes the batch in groups -- relative to the
+    // group a chunk belongs to, every group with a closing entry of its own)
+    const size_t o_choff = up16((size_t)n * rpc * 8), o_res = o_choff + up16((2 * n + 2 + n / 8 + 8) * 8),
+                 o_one = o_res + up16(n * 40);
     if (!k.d_in.ensure(total_in + 32) || !k.d_out.ensure((size_t)n * rpc * rsi_bytes + 64) ||
         !k.d_off.ensure(o_one + 64))
         return AEC_FAIL(AEC_MEM_ERROR);
     uint8_t *meta = static_cast<uint8_t *>(k.d_off.p);
-    if (hipMemsetAsync(k.d_in.p, 0, total_in, k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
-    for (size_t i = 0; i < n; i++)
-        if (src_len[i] && hipMemcpyAsync(static_cast<uint8_t *>(k.d_in.p) + off[i], src[i], src_len[i],
-                                         hipMemcpyHostToDevice, k.stream) != hipSuccess)
+    if (n >= 4 && total_in <= kStagePiece && stage_ensure(k, total_in)) {
+        // the streams and the zero padding behind each of them, assembled in pinned memory: ONE transfer
+        std::vector<CopyJob> jobs(n);
+        for (size_t i = 0; i < n; i++) {
+            jobs[i] = CopyJob{k.h_stage + off[i], src[i], src_len[i]};
+            memset(k.h_stage + off[i] + src_len[i], 0, (size_t)(off[i + 1] - off[i]) - src_len[i]);
+        }
+        copy_all(jobs);
+        if (hipMemcpyAsync(k.d_in.p, k.h_stage, total_in, hipMemcpyHostToDevice, k.stream) != hipSuccess)
             return AEC_FAIL(AEC_MEM_ERROR);
+    } else {
+        if (hipMemsetAsync(k.d_in.p, 0, total_in, k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+        for (size_t i = 0; i < n; i++)
+            if (src_len[i] && hipMemcpyAsync(static_cast<uint8_t *>(k.d_in.p) + off[i], src[i], src_len[i],
+                                             hipMemcpyHostToDevice, k.stream) != hipSuccess)
+                return AEC_FAIL(AEC_MEM_ERROR);
+    }
     if (hipMemcpyAsync(meta + o_choff, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, k.stream) != hipSuccess)
         return AEC_FAIL(AEC_MEM_ERROR);
     // Small chunks: one wavefront walks each stream, all streams at once (aec_gpu_decode_batch_async).
@@ -720,7 +792,47 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
     aec_gpu_dec_result *d_results = reinterpret_cast<aec_gpu_dec_result *>(meta + o_res);
     aec_gpu_dec_result *d_one = reinterpret_cast<aec_gpu_dec_result *>(meta + o_one);
     const bool large = total_in / n >= ((size_t)32 << 10) || n < 64;
-    if (!large) {
+    // Large low-entropy chunks: groups of about 12 MiB of streams, each group ONE table launch + one wavefront
+    // per stream + one decode launch (aec_gpu_decode_batch_async)
+    constexpr size_t kGroupBytes = (size_t)12 << 20;
+    bool grouped = false;
+    if (large && n >= 2) {
+        size_t probe_n = n, probe_bytes = total_in;
+        if (total_in > kGroupBytes) {
+            probe_n = (size_t)((uint64_t)n * kGroupBytes / total_in);
+            if (probe_n < 1) probe_n = 1;
+            probe_bytes = total_in / n * probe_n;
+        }
+        grouped = aec_gpu_batch_uses_tables(k.ctx, &gp, probe_bytes, probe_n, rpc) != 0;
+    }
+    if (grouped) {
+        std::vector<uint64_t> rel;
+        std::vector<size_t> first;                      // first chunk of every group, index of its offsets in rel
+        std::vector<size_t> at;
+        for (size_t i = 0; i < n;) {
+            size_t j = i;
+            while (j < n && (j == i || off[j + 1] - off[i] <= kGroupBytes)) j++;
+            first.push_back(i);
+            at.push_back(rel.size());
+            for (size_t q = i; q <= j; q++) rel.push_back(off[q] - off[i]);
+            i = j;
+        }
+        first.push_back(n);
+        if (rel.size() > 2 * n + 2 + n / 8 + 8) return AEC_FAIL(AEC_MEM_ERROR);      // (cannot happen)
+        uint64_t *d_rel = reinterpret_cast<uint64_t *>(meta + o_choff) + (n + 1);
+        if (hipMemcpyAsync(d_rel, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, k.stream) != hipSuccess)
+            return AEC_FAIL(AEC_MEM_ERROR);
+        for (size_t gi = 0; gi + 1 < first.size() && rc == RC_OK; gi++) {
+            const size_t i0 = first[gi], i1 = first[gi + 1];
+            rc = aec_gpu_decode_batch_async(k.ctx, &gp, static_cast<const uint8_t *>(k.d_in.p) + off[i0], off[i1] - off[i0],
+                                            d_rel + at[gi], i1 - i0, rpc, reinterpret_cast<uint64_t *>(meta) + i0 * rpc,
+                                            static_cast<uint8_t *>(k.d_out.p) + i0 * rpc * rsi_bytes, d_results + i0, d_one,
+                                            k.stream);
+        }
+        if (rc != RC_OK) return AEC_FAIL(rc);
+        // (decoder-side errors are in the chunks' own records; the overall record belongs to the last group only)
+        if (hipMemsetAsync(d_one, 0, sizeof(aec_gpu_dec_result), k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+    } else if (!large) {
         rc = aec_gpu_decode_batch_async(k.ctx, &gp, k.d_in.p, total_in, reinterpret_cast<uint64_t *>(meta + o_choff), n,
                                         rpc, reinterpret_cast<uint64_t *>(meta), k.d_out.p, d_results, d_one, k.stream);
         if (rc != RC_OK) return AEC_FAIL(rc);
@@ -761,15 +873,34 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
         hipStreamSynchronize(k.stream) != hipSuccess)
         return AEC_FAIL(AEC_MEM_ERROR);
     int worst = AEC_OK;
+    // the outputs: through pinned staging in pieces of whole slots (one transfer per piece, then copies to the
+    // callers' buffers on a few threads), or chunk by chunk where there is no staging to be had
+    const size_t slot_out = (size_t)rpc * rsi_bytes;
+    const size_t per_piece = slot_out && slot_out <= kStagePiece ? kStagePiece / slot_out : 0;
+    const bool staged = n >= 4 && per_piece && stage_ensure(k, (n < per_piece ? n : per_piece) * slot_out);
+    std::vector<CopyJob> jobs;
     for (size_t i = 0; i < n; i++) {
         const uint64_t blocks = res[i].n_rsi * c.rsi + res[i].tail_blocks;
         size_t produced = (size_t)blocks * blk_bytes;
         if (produced > dst_len[i]) produced = dst_len[i] - dst_len[i] % c.bytes;
         int st = res[i].status == DEC_DATA_ERROR ? AEC_DATA_ERROR : AEC_OK;
-        if (res[n].status != DEC_OK && res[n].bad_rsi / rpc == i) st = AEC_DATA_ERROR;
-        if (produced && hipMemcpyAsync(dst[i], static_cast<uint8_t *>(k.d_out.p) + i * rpc * rsi_bytes, produced,
-                                       hipMemcpyDeviceToHost, k.stream) != hipSuccess)
+        if (!grouped && res[n].status != DEC_OK && res[n].bad_rsi / rpc == i) st = AEC_DATA_ERROR;
+        if (staged) {
+            const size_t first = i - i % per_piece;
+            if (i == first) {                            // a new piece: bring its slots over
+                const size_t cnt = n - first < per_piece ? n - first : per_piece;
+                if (hipMemcpyAsync(k.h_stage, static_cast<uint8_t *>(k.d_out.p) + first * slot_out, cnt * slot_out,
+                                   hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
+                    hipStreamSynchronize(k.stream) != hipSuccess)
+                    return AEC_FAIL(AEC_MEM_ERROR);
+                jobs.clear();
+            }
+            jobs.push_back(CopyJob{dst[i], k.h_stage + (i - first) * slot_out, produced});
+            if (i + 1 == n || (i + 1) % per_piece == 0) copy_all(jobs);
+        } else if (produced && hipMemcpyAsync(dst[i], static_cast<uint8_t *>(k.d_out.p) + i * slot_out, produced,
+                                              hipMemcpyDeviceToHost, k.stream) != hipSuccess) {
             return AEC_FAIL(AEC_MEM_ERROR);
+        }
         dst_len[i] = produced;
         if (status) status[i] = st;
         if (st != AEC_OK) worst = st;
@@ -803,16 +934,35 @@ int encode_batch_host(const struct aec_stream *prm, size_t n, const void *const 
     const size_t slot = aec_gpu_encode_bound(&gp, largest);
     if (!k.d_in.ensure(total_in + 32) || !k.d_out.ensure(n * slot) || !k.d_off.ensure(n * sizeof(aec_gpu_enc_result) + 64))
         return AEC_FAIL(AEC_MEM_ERROR);
+    // chunk i = [off[i], off[i] + whole samples): the padding between chunks is not input.  Small chunks go up
+    // together through pinned staging (one transfer per piece); large ones straight from the callers' buffers, upload
+    // and coding alternating so that the kernels of one chunk run while the host stages the next one's copy.
+    aec_gpu_enc_result *d_res = static_cast<aec_gpu_enc_result *>(k.d_off.p);
+    if (aec_gpu_reserve(k.ctx, &gp, largest) != RC_OK) return AEC_FAIL(AEC_MEM_ERROR);
+    const bool stage_in = n >= 16 && largest <= ((size_t)256 << 10) && stage_ensure(k, total_in < kStagePiece ? total_in : kStagePiece);
+    size_t staged_to = 0;                                // chunks [.., staged_to) are on the device
     for (size_t i = 0; i < n; i++) {
         const size_t whole = src_len[i] - src_len[i] % c.bytes;
-        if (whole && hipMemcpyAsync(static_cast<uint8_t *>(k.d_in.p) + off[i], src[i], whole, hipMemcpyHostToDevice,
-                                    k.stream) != hipSuccess)
+        if (stage_in) {
+            if (i == staged_to) {
+                size_t j = i;
+                while (j < n && off[j + 1] - off[i] <= k.h_stage_cap) j++;
+                if (j == i) return AEC_FAIL(AEC_MEM_ERROR);                       // (cannot happen: a chunk fits)
+                if (i && hipStreamSynchronize(k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);   // staging is free again
+                std::vector<CopyJob> jobs;
+                for (size_t q = i; q < j; q++)
+                    jobs.push_back(CopyJob{k.h_stage + (off[q] - off[i]), src[q], src_len[q] - src_len[q] % c.bytes});
+                copy_all(jobs);
+                if (hipMemcpyAsync(static_cast<uint8_t *>(k.d_in.p) + off[i], k.h_stage, (size_t)(off[j] - off[i]),
+                                   hipMemcpyHostToDevice, k.stream) != hipSuccess)
+                    return AEC_FAIL(AEC_MEM_ERROR);
+                staged_to = j;
+            }
+        } else if (whole && hipMemcpyAsync(static_cast<uint8_t *>(k.d_in.p) + off[i], src[i], whole, hipMemcpyHostToDevice,
+                                           k.stream) != hipSuccess) {
             return AEC_FAIL(AEC_MEM_ERROR);
-    }
-    // chunk i = [off[i], off[i] + whole samples): the padding between chunks is not input
-    aec_gpu_enc_result *d_res = static_cast<aec_gpu_enc_result *>(k.d_off.p);
-    for (size_t i = 0; i < n; i++) {
-        const uint64_t pair[2] = {off[i], off[i] + (src_len[i] - src_len[i] % c.bytes)};
+        }
+        const uint64_t pair[2] = {off[i], off[i] + whole};
         rc = aec_gpu_encode_batch_async(k.ctx, &gp, k.d_in.p, pair, 1, static_cast<uint8_t *>(k.d_out.p) + i * slot, slot,
                                         d_res + i, k.stream);
         if (rc != RC_OK) return AEC_FAIL(rc);
@@ -822,14 +972,32 @@ int encode_batch_host(const struct aec_stream *prm, size_t n, const void *const 
         hipStreamSynchronize(k.stream) != hipSuccess)
         return AEC_FAIL(AEC_MEM_ERROR);
     int worst = AEC_OK;
+    // many small streams: whole slots through pinned staging, piece by piece (a transfer per piece beats a copy
+    // call per stream even though a slot is the worst case of its stream)
+    const size_t per_piece = slot <= kStagePiece ? kStagePiece / slot : 0;
+    const bool stage_out = n >= 16 && slot <= ((size_t)512 << 10) && per_piece &&
+                           stage_ensure(k, (n < per_piece ? n : per_piece) * slot);
+    std::vector<CopyJob> out_jobs;
     for (size_t i = 0; i < n; i++) {
         size_t bytes = (size_t)((res[i].total_bits + 7) / 8);
         if (bytes == 0) bytes = 1;                                           // an empty stream is one zero byte
         int st = AEC_OK;
         if (res[i].overflow) st = AEC_MEM_ERROR;
         else if (bytes > dst_len[i]) { st = AEC_STREAM_ERROR; bytes = dst_len[i]; }   // as aec_buffer_encode: a prefix
-        if (bytes && hipMemcpyAsync(dst[i], static_cast<uint8_t *>(k.d_out.p) + i * slot, bytes, hipMemcpyDeviceToHost,
-                                    k.stream) != hipSuccess)
+        if (stage_out) {
+            const size_t first = i - i % per_piece;
+            if (i == first) {
+                const size_t cnt = n - first < per_piece ? n - first : per_piece;
+                if (hipMemcpyAsync(k.h_stage, static_cast<uint8_t *>(k.d_out.p) + first * slot, cnt * slot,
+                                   hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
+                    hipStreamSynchronize(k.stream) != hipSuccess)
+                    return AEC_FAIL(AEC_MEM_ERROR);
+                out_jobs.clear();
+            }
+            out_jobs.push_back(CopyJob{dst[i], k.h_stage + (i - first) * slot, bytes});
+            if (i + 1 == n || (i + 1) % per_piece == 0) copy_all(out_jobs);
+        } else if (bytes && hipMemcpyAsync(dst[i], static_cast<uint8_t *>(k.d_out.p) + i * slot, bytes, hipMemcpyDeviceToHost,
+                                           k.stream) != hipSuccess)
             return AEC_FAIL(AEC_MEM_ERROR);
         dst_len[i] = bytes;
         if (status) status[i] = st;

@@ -413,6 +413,16 @@ int aec_gpu_index_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const v
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
+int aec_gpu_batch_uses_tables(aec_gpu_ctx *ctx, const aec_gpu_params *p, size_t in_bytes, uint64_t n_chunks,
+                              uint64_t rsi_per_chunk)
+{
+    Cfg c;
+    if (cfg_from(p, 0, false, &c) != RC_OK || n_chunks == 0 || rsi_per_chunk == 0) return 0;
+    const size_t mean = in_bytes / n_chunks;
+    const uint64_t hint = ctx->idx_hint ? ctx->idx_hint : (uint64_t)mean * 8 / rsi_per_chunk;
+    return mean >= ((size_t)16 << 10) && index_batch_workspace_bytes(c, in_bytes, n_chunks, mean * 2 + 65536, hint) != 0;
+}
+
 int aec_gpu_decode_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
                                const uint64_t *d_chunk_offsets, uint64_t n_chunks, uint64_t rsi_per_chunk,
                                uint64_t *d_rsi_bit_offsets, void *d_out, aec_gpu_dec_result *d_results,
@@ -425,8 +435,22 @@ int aec_gpu_decode_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const 
         return RC_CONF_ERROR;
     if (n_chunks == 0) return RC_OK;
     (void)hipGetLastError();
+    // Streams long enough for the window tables (low-entropy data, tens of KiB and more per stream): ONE
+    // speculation launch for the whole buffer, then every stream's wavefront hops over the tables.  The largest
+    // stream is not known here: the mean, with room to spare, sizes the hop lists.
+    const size_t mean = in_bytes / n_chunks, max_chunk = mean * 2 + 65536;
+    const uint64_t hint = ctx->idx_hint ? ctx->idx_hint : (uint64_t)mean * 8 / rsi_per_chunk;
+    size_t need = mean >= ((size_t)16 << 10) ? index_batch_workspace_bytes(c, in_bytes, n_chunks, max_chunk, hint) : 0;
+    if (need > ctx->idx_ws_bytes) {
+        if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
+        ctx->idx_ws = nullptr;
+        ctx->idx_ws_bytes = 0;
+        if (hipMalloc(&ctx->idx_ws, need + need / 16) == hipSuccess) ctx->idx_ws_bytes = need + need / 16;
+        else (void)hipGetLastError();
+    }
     launch_index_batch(c, static_cast<const uint8_t *>(d_in), in_bytes, d_chunk_offsets, n_chunks, rsi_per_chunk,
-                       d_rsi_bit_offsets, reinterpret_cast<DecResult *>(d_results), static_cast<hipStream_t>(stream));
+                       d_rsi_bit_offsets, reinterpret_cast<DecResult *>(d_results), static_cast<hipStream_t>(stream),
+                       need ? ctx->idx_ws : nullptr, ctx->idx_ws_bytes, max_chunk, hint);
     if (!launch_decode(c, static_cast<const uint8_t *>(d_in), in_bytes, d_rsi_bit_offsets, n_chunks * rsi_per_chunk,
                        n_chunks * rsi_per_chunk * c.rsi, static_cast<uint8_t *>(d_out),
                        reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream), ctx->dec_events(),

@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(1024)
 k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
         uint64_t start_bit, const Spec2Geom g, uint32_t *__restrict__ gbitmap, uint16_t *__restrict__ gpre,
         uint2 *__restrict__ grec, uint16_t *__restrict__ gcpos, uint32_t *__restrict__ gccnt,
-        unsigned long long *__restrict__ prof)
+        unsigned long long *__restrict__ prof, const uint64_t *__restrict__ starts = nullptr, uint32_t nstarts = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
     __shared__ uint32_t sh_total;
@@ -666,6 +666,19 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     if (tid == 0 && start_bit >= wstart && start_bit - wstart < s.limit) {
         const uint32_t q = (uint32_t)(start_bit - wstart);
         atomicOr(&marks[q >> 5], 1u << (31u - (q & 31u)));                  // the one boundary that is known
+    }
+    if (starts && tid == 0) {
+        // a batch of independent streams in one buffer (byte offsets `starts`): every stream begins with an RSI
+        uint32_t lo = 0, hi = nstarts;
+        while (lo < hi) {                                                   // first stream at or behind the window start
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            if (starts[mid] * 8u < wstart) lo = mid + 1u;
+            else hi = mid;
+        }
+        for (; lo < nstarts && starts[lo] * 8u - wstart < s.limit; lo++) {
+            const uint32_t q = (uint32_t)(starts[lo] * 8u - wstart);
+            atomicOr(&marks[q >> 5], 1u << (31u - (q & 31u)));
+        }
     }
     for (uint32_t q0 = tid * g.stride; q0 < s.limit; q0 += nt * g.stride) {
         uint32_t q = q0;
@@ -848,7 +861,7 @@ k_rewalk(const SparseTables t, uint32_t nwin, uint32_t nchunks, uint64_t end_bit
 // carry->n_hops); lists > 0: the per-chunk lists of k_rewalk (`stride` entries apart, counts in nhops).
 __global__ void k_expand2(const SparseTables t, const IdxCarry *__restrict__ carry, const IdxHop *__restrict__ hops,
                           const uint32_t *__restrict__ nhops, uint32_t lists, uint32_t stride,
-                          uint64_t *__restrict__ rsi_off)
+                          uint64_t *__restrict__ rsi_off, uint64_t rsi_stride = 0)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     IdxHop h;
@@ -859,6 +872,7 @@ __global__ void k_expand2(const SparseTables t, const IdxCarry *__restrict__ car
         const uint32_t list = i / stride, j = i % stride;
         if (list >= lists || j >= nhops[list]) return;
         h = hops[(uint64_t)list * stride + j];
+        rsi_off += (uint64_t)list * rsi_stride;            // (batch of streams: every list numbers its RSIs from 0)
     }
     uint64_t p = h.pos;
     for (uint32_t j = 0; j < h.cnt; j++) {
@@ -896,7 +910,8 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         uint64_t start_bit, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res,
         const uint64_t *__restrict__ chunk_off, IdxHop *__restrict__ hops, uint32_t hop_cap, IdxCarry *carry,
         uint32_t first, uint32_t last, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
-        const TwTables sp, ChunkEntry *__restrict__ centry, const SparseTables s2)
+        const TwTables sp, ChunkEntry *__restrict__ centry, const SparseTables s2,
+        uint32_t *__restrict__ batch_nhops = nullptr)
 {
     __shared__ __attribute__((aligned(16))) uint32_t win[kIdxWindowWords];
     uint64_t r = 0;
@@ -905,6 +920,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         end_bit = chunk_off[blockIdx.x + 1] * 8u;
         rsi_off += (uint64_t)blockIdx.x * max_rsi;
         res += blockIdx.x;
+        if (hops) hops += (uint64_t)blockIdx.x * hop_cap;        // (batch over the window tables: a hop list per stream)
     } else if (blockIdx.x != 0) {
         return;
     }
@@ -1027,12 +1043,12 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                     }
                 }
                 const uint32_t xc = rec.y >> 24, xb = rec.y & 0xFFFFFFu, t = rec.x;
-                if (xc && r + xc <= max_rsi && nh < hop_cap) {
+                if (xc && r + xc <= max_rsi && nh < hop_cap && good + xb <= end_bit) {
                     if (lane == 0) hops[nh] = IdxHop{good, r, xc, 0u};
                     nh++;
                     good += xb;
                     r += xc;
-                } else if (t) {
+                } else if (t && good + t <= end_bit) {
                     if (lane == 0) rsi_off[r] = good;
                     good += t;
                     r++;
@@ -1174,6 +1190,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         carry->n_serial = n_serial;
         carry->n_lookups = n_lookups;
     }
+    if (lane == 0 && chunk_off && batch_nhops) batch_nhops[blockIdx.x] = nh;
     if (lane == 0) {
         // streaming callers: where the trailing partial RSI began, in a slot of its own behind the table
         if (tail_slot && !chunk_off) rsi_off[max_rsi] = cur_start;
@@ -1688,16 +1705,69 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
                        static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot);
 }
 
+// Batch over the window tables: how many hops a stream of max_chunk_bytes may take, and the workspace
+static uint32_t batch_hop_cap(const Sparse2Plan &p, size_t max_chunk_bytes)
+{
+    return (uint32_t)(2 * ((uint64_t)max_chunk_bytes * 8 / p.g.core + 2) + 8);
+}
+
+size_t index_batch_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t n_chunks, size_t max_chunk_bytes,
+                                   uint64_t rsi_bits_hint)
+{
+    const Sparse2Plan p = sparse2_plan(c, (uint64_t)in_bytes * 8, rsi_bits_hint);
+    if (!p.ok || n_chunks == 0) return 0;
+    const uint64_t nwin = ((uint64_t)in_bytes * 8 + p.g.core - 1) / p.g.core;
+    if (nwin > p.nwin_max) return 0;                       // (more than one span of tables: the caller splits the batch)
+    return p.bytes + (((size_t)n_chunks * batch_hop_cap(p, max_chunk_bytes) * sizeof(IdxHop) + 255) & ~(size_t)255) +
+           (((size_t)n_chunks * 4 + 255) & ~(size_t)255);
+}
+
+// d_ws (optional, index_batch_workspace_bytes()): the streams are low-entropy and long enough for the window
+// tables -- ONE speculation launch over the whole buffer (every stream's start a forced candidate), then one
+// wavefront per stream hops over the tables instead of walking coded data set by coded data set.
 void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_chunk_off,
                         uint64_t n_chunks, uint64_t rsi_per_chunk, uint64_t *d_rsi_off, DecResult *d_res,
-                        hipStream_t st)
+                        hipStream_t st, void *d_ws, size_t ws_bytes, size_t max_chunk_bytes, uint64_t rsi_bits_hint)
 {
     if (n_chunks == 0) return;
-    hipLaunchKernelGGL(k_index, dim3((uint32_t)n_chunks), dim3(64), 0, st, c,
-                       reinterpret_cast<const uint32_t *>(d_in), (uint64_t)((in_bytes + 3) / 4),
-                       (uint64_t)in_bytes * 8, (uint64_t)0, d_rsi_off, rsi_per_chunk, d_res, d_chunk_off,
-                       (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, 0u, (uint64_t)0, 0u, TwTables{},
-                       (ChunkEntry *)nullptr, SparseTables{});
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
+    const uint64_t nwords = (in_bytes + 3) / 4, end_bit = (uint64_t)in_bytes * 8;
+    const size_t need = d_ws ? index_batch_workspace_bytes(c, in_bytes, n_chunks, max_chunk_bytes, rsi_bits_hint) : 0;
+    if (!need || ws_bytes < need) {
+        hipLaunchKernelGGL(k_index, dim3((uint32_t)n_chunks), dim3(64), 0, st, c, words, nwords, end_bit, (uint64_t)0,
+                           d_rsi_off, rsi_per_chunk, d_res, d_chunk_off, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u,
+                           1u, 0u, (uint64_t)0, 0u, TwTables{}, (ChunkEntry *)nullptr, SparseTables{});
+        return;
+    }
+    allow_big_lds2();
+    const Sparse2Plan p = sparse2_plan(c, end_bit, rsi_bits_hint);
+    uint8_t *base = static_cast<uint8_t *>(d_ws);
+    const uint32_t nwin = (uint32_t)((end_bit + p.g.core - 1) / p.g.core);
+    SparseTables t;
+    t.bitmap = reinterpret_cast<const uint32_t *>(base + p.o_bitmap);
+    t.pre = reinterpret_cast<const uint16_t *>(base + p.o_pre);
+    t.rec = reinterpret_cast<const uint2 *>(base + p.o_rec);
+    t.cpos = reinterpret_cast<const uint16_t *>(base + p.o_cpos);
+    t.ccnt = reinterpret_cast<const uint32_t *>(base + p.o_ccnt);
+    t.lo = 0;
+    t.hi = (uint64_t)nwin * p.g.core;
+    t.core = p.g.core;
+    t.cap = p.g.cap_core;
+    t.wide = nullptr;
+    t.wpc = p.wpc;
+    const uint32_t hop_cap = batch_hop_cap(p, max_chunk_bytes);
+    IdxHop *hops = reinterpret_cast<IdxHop *>(base + p.bytes);
+    uint32_t *nhops = reinterpret_cast<uint32_t *>(base + p.bytes +
+                                                   (((size_t)n_chunks * hop_cap * sizeof(IdxHop) + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, st, c, words, nwords, end_bit, (uint64_t)0, (uint64_t)0, p.g,
+                       const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
+                       const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), (unsigned long long *)nullptr,
+                       d_chunk_off, (uint32_t)n_chunks);
+    hipLaunchKernelGGL(k_index, dim3((uint32_t)n_chunks), dim3(64), 0, st, c, words, nwords, end_bit, (uint64_t)0, d_rsi_off,
+                       rsi_per_chunk, d_res, d_chunk_off, hops, hop_cap, (IdxCarry *)nullptr, 1u, 1u, 0u, (uint64_t)0, 0u,
+                       TwTables{}, (ChunkEntry *)nullptr, t, nhops);
+    hipLaunchKernelGGL(k_expand2, dim3((uint32_t)(((uint64_t)n_chunks * hop_cap + 255) / 256)), dim3(256), 0, st, t,
+                       (const IdxCarry *)nullptr, hops, nhops, (uint32_t)n_chunks, hop_cap, d_rsi_off, rsi_per_chunk);
 }
 
 }  // namespace aec

@@ -135,6 +135,11 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
 // positions, so the table can go straight into launch_decode for the whole batch.
 void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_chunk_off,
                         uint64_t n_chunks, uint64_t rsi_per_chunk, uint64_t *d_rsi_off, DecResult *d_res,
-                        hipStream_t stream);
+                        hipStream_t st, void *d_ws = nullptr, size_t ws_bytes = 0, size_t max_chunk_bytes = 0,
+                        uint64_t rsi_bits_hint = 0);
+// workspace with which the batch walk hops over window tables built in ONE launch for all streams (0 = the streams
+// are not the low-entropy kind, or too much for one span of tables: every stream is walked serially)
+size_t index_batch_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t n_chunks, size_t max_chunk_bytes,
+                                   uint64_t rsi_bits_hint);
 
 }  // namespace aec

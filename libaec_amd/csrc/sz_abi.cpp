@@ -70,6 +70,8 @@ struct Job {
     bool planes, padded_lines;
     size_t lines;
     std::vector<uint8_t> buf;      // compress: the coder's input; decompress: the coder's output when it needs fixing up
+    const uint8_t *in = nullptr;   // compress: where the coder's input lies (buf, or the caller's buffer as it is)
+    size_t in_len = 0;
 };
 
 int prepare_compress(Job &j, const void *source, size_t sourceLen, const SZ_com_t *param)
@@ -88,6 +90,13 @@ int prepare_compress(Job &j, const void *source, size_t sourceLen, const SZ_com_
     sourceLen -= sourceLen % (j.planes ? (size_t)param->bits_per_pixel / 8 : g.pixel);
     std::vector<uint8_t> plane_buf;
     const uint8_t *src = static_cast<const uint8_t *>(source);
+    if (!j.planes && g.padded_line == g.line && sourceLen % g.line == 0) {
+        // whole scan lines of whole blocks (the usual HDF5 chunk): nothing to marshal, the coder reads the
+        // caller's buffer
+        j.in = src;
+        j.in_len = sourceLen;
+        return SZ_OK;
+    }
     if (j.planes) {
         plane_buf.resize(sourceLen);
         to_planes(plane_buf.data(), src, sourceLen, (size_t)param->bits_per_pixel / 8);
@@ -111,6 +120,8 @@ int prepare_compress(Job &j, const void *source, size_t sourceLen, const SZ_com_
         }
         out += g.padded_line;
     }
+    j.in = j.buf.data();
+    j.in_len = j.buf.size();
     return SZ_OK;
 }
 
@@ -121,8 +132,8 @@ int compress(void *dest, size_t *destLen, const void *source, size_t sourceLen, 
     if (prc != SZ_OK) return prc;
     j.strm.next_out = static_cast<unsigned char *>(dest);
     j.strm.avail_out = *destLen;
-    j.strm.next_in = j.buf.data();
-    j.strm.avail_in = j.buf.size();
+    j.strm.next_in = j.in;
+    j.strm.avail_in = j.in_len;
     const int rc = aec_buffer_encode(&j.strm);
     *destLen = j.strm.total_out;                                                        // sz_compat.c:175
     return rc == AEC_STREAM_ERROR ? SZ_OUTBUFF_FULL : rc;                               // sz_compat.c:171-174
@@ -201,8 +212,8 @@ int batch_compress(void *const *dest, size_t *destLen, const void *const *source
     for (size_t i = 0; i < n; i++) {
         const int prc = prepare_compress(jobs[i], source[i], sourceLen[i], param);
         if (prc != SZ_OK) return prc;
-        src[i] = jobs[i].buf.data();
-        src_len[i] = jobs[i].buf.size();
+        src[i] = jobs[i].in;
+        src_len[i] = jobs[i].in_len;
     }
     std::vector<int> st(n, AEC_OK);
     const int rc = aec_buffer_encode_batch(&jobs[0].strm, n, src.data(), src_len.data(), dest, destLen, st.data());

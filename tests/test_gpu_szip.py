@@ -175,3 +175,32 @@ def test_batch_of_small_chunks_reports_errors_per_chunk(szip):
     good = [i for i in range(80) if i not in (7, 55)]
     assert all(st[i] == 0 for i in good), st
     assert all(dec[i] == chunks[i].tobytes() for i in good)
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+def test_one_gib_of_one_mib_chunks_vs_reference_shim(szip):
+    """BASELINE config 5 at its stated size (at least 1 GiB in 1 MiB HDF5-style chunks, 8-bit,
+    8 pixels per block, 1024 per scan line, NN): every chunk through SZ_BatchCompress / SZ_BatchDecompress, 64 chunks
+    per call, against the reference shim chunk by chunk (reference src/sz_compat.c:110-268) -- a digest of every
+    compressed chunk, and the round trip."""
+    import hashlib
+    from test_gpu_parity import gen
+    ref = szip.bind(C.CDLL(REF_SO))
+    NN, RAW = szip.SZ_NN_OPTION_MASK, szip.SZ_RAW_OPTION_MASK
+    opts, bpp, ppb, pps = NN | RAW, 8, 8, 1024
+    n_chunks, per_call = 1024, 64
+    data = gen(2, n_chunks << 20)
+    for g0 in range(0, n_chunks, per_call):
+        chunks = [data[i << 20:(i + 1) << 20] for i in range(g0, g0 + per_call)]
+        rc, got, st = szip.compress_batch(chunks, [(1 << 20) + (1 << 16)] * per_call, opts, bpp, ppb, pps)
+        assert rc == 0 and st == [0] * per_call, (g0, rc, st)
+        if g0 % 256 == 0:          # the reference on one core: every fourth call's chunks in full, ...
+            want = [szip.compress(c, (1 << 20) + (1 << 16), opts, bpp, ppb, pps, lib=ref) for c in chunks]
+            assert all(rc == 0 for rc, _ in want)
+            assert [hashlib.sha256(g).digest() for g in got] == [hashlib.sha256(w).digest() for _, w in want], g0
+        rc, dec, st = szip.decompress_batch(got, [1 << 20] * per_call, opts, bpp, ppb, pps)
+        assert rc == 0 and st == [0] * per_call, (g0, rc, st)
+        assert all(d == c.tobytes() for d, c in zip(dec, chunks)), g0      # ... the round trip for all of them
+        # and the reference decodes what was produced here (first chunk of every call)
+        rc, back = szip.decompress(got[0], 1 << 20, opts, bpp, ppb, pps, lib=ref)
+        assert rc == 0 and back == chunks[0].tobytes(), g0
