@@ -60,7 +60,18 @@ struct aec_stream {
 
 #define LIBAEC_API __attribute__((visibility("default")))
 
-/* streaming interface, reference src/libaec.h:154-160 (encode.c:773-948, decode.c:694-841) */
+/* streaming interface, reference src/libaec.h:154-160 (encode.c:773-948, decode.c:694-841)
+ *
+ * WHAT the calls deliver is the reference's, byte for byte; WHEN may differ, because work goes to the device
+ * in batches:
+ *   aec_encode(AEC_NO_FLUSH) codes the whole RSIs it holds once 1 MiB is staged, or on a call that brings no new
+ *     input, or on AEC_FLUSH -- until then avail_out may stay untouched although input was taken.
+ *   aec_decode runs a batch on every call EXCEPT for a caller that feeds at most 8 new bytes per call with
+ *     AEC_NO_FLUSH while fewer than 4 KiB wait: those bytes are decoded by the next call that brings nothing new
+ *     (avail_in == 0) or passes AEC_FLUSH.  A caller that stops as soon as its input is used up must make that
+ *     last call (the reference's own callers do: src/aec.c:191-221, tests/check_aec.c:138-166), or pass
+ *     AEC_FLUSH (which the reference ignores for decoding, decode.c:797) with its last piece of input.
+ * The library has no CPU codec: without a HIP device every call returns AEC_MEM_ERROR. */
 LIBAEC_API int aec_encode_init(struct aec_stream *strm);
 LIBAEC_API int aec_encode(struct aec_stream *strm, int flush);
 LIBAEC_API int aec_encode_end(struct aec_stream *strm);
@@ -78,9 +89,10 @@ LIBAEC_API int aec_buffer_decode(struct aec_stream *strm);
  * chunk (reference src/sz_compat.c:170, 239).  Only bits_per_sample, block_size, rsi and flags of
  * `params` are read.  src[i] / src_len[i]: the i-th input; dst[i]: its output buffer, dst_len[i] its
  * capacity on entry and the bytes produced on return; status[i] (optional): AEC_OK, AEC_DATA_ERROR
- * (corrupt stream), AEC_STREAM_ERROR (encode: output did not fit, a prefix was written).  One upload,
- * one index + one decode launch (decode) or the encoder kernels per chunk (encode), one download.
- * Returns AEC_OK or the last non-OK status.
+ * (corrupt stream), AEC_STREAM_ERROR (encode: output did not fit, a prefix was written).  The chunks travel
+ * through pinned staging (one transfer per piece of 64 MiB); decode: the RSI starts of a whole group of chunks
+ * from ONE table launch (low-entropy chunks of tens of KiB and more) or one wavefront per chunk (small chunks),
+ * then one decode launch per group; encode: the encoder kernels per chunk.  Returns AEC_OK or the last non-OK status.
  */
 LIBAEC_API int aec_buffer_encode_batch(const struct aec_stream *params, size_t n, const void *const *src,
                                        const size_t *src_len, void *const *dst, size_t *dst_len, int *status);

@@ -26,8 +26,17 @@ cp $OUT/sq_c2/summary.txt $OUT/pmc_sq_c2_4GiB.txt 2>/dev/null
 python3 tests/bench_index.py --config c2 --size-mib 1 64 1024 > $OUT/bench_index.txt 2>&1
 python3 tests/bench_index.py --config c5 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
 python3 tests/bench_index.py --config c3 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
-python3 tests/bench_index.py --config typical --size-mib 64 >> $OUT/bench_index.txt 2>&1
+python3 tests/bench_index.py --config typical --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
+# kernel statistics and HBM traffic of the index pass itself (tests/bench_index.py), per configuration
+bash tests/prof_index.sh $1/idx 1024 > /dev/null 2>&1
+for c in c2 c5 c3 typical; do cp $OUT/idx/kernel_stats_index_$c.csv $OUT/kernel_stats_index_$c.csv 2>/dev/null; done
+( cd /tmp && export TMPDIR=/tmp
+  for c in c2 c3; do for m in FETCH_SIZE WRITE_SIZE; do
+    timeout -s KILL 300 rocprofv3 --pmc $m --kernel-trace --output-format csv -d $OUT/idxpmc_${c}_$m -- python3 $R/tests/bench_index.py --config $c --size-mib 1024 > /dev/null 2>&1
+  done; done )
+python3 tests/pmc_summary.py "$OUT/idxpmc_c2_*/runc/*counter_collection.csv" > $OUT/traffic_index_c2_1GiB.txt 2>&1
+python3 tests/pmc_summary.py "$OUT/idxpmc_c3_*/runc/*counter_collection.csv" > $OUT/traffic_index_c3_1GiB.txt 2>&1
 python3 tests/bench_abi_small.py > $OUT/bench_abi_small.txt 2>&1
 python3 tests/bench_sz_chunks.py > $OUT/bench_sz_chunks.txt 2>&1
 python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
-rm -rf $OUT/sq_c2 $OUT/stats_* $OUT/traffic_c2 $OUT/traffic_c3 $OUT/traffic_c5 $OUT/traffic_typical
+rm -rf $OUT/sq_c2 $OUT/stats_* $OUT/traffic_c2 $OUT/traffic_c3 $OUT/traffic_c5 $OUT/traffic_typical $OUT/idx $OUT/idxpmc_*
