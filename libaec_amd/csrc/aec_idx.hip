@@ -583,7 +583,7 @@ __global__ void k_texpand(const Cfg c, const TwTables t, const TrTables tt, cons
 // Output for the candidates inside the core: the window's part of the global bitmap / prefix table
 // and its records (SparseTables above).
 struct Spec2Geom {
-    uint32_t lead, core, look, stride, burn, cap_lds, cap_core, budget;
+    uint32_t lead, core, look, stride, burn, cap_lds, cap_core, budget, fast;
 };
 
 __global__ void __launch_bounds__(1024)
@@ -593,7 +593,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         unsigned long long *__restrict__ prof, const uint64_t *__restrict__ starts = nullptr, uint32_t nstarts = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
-    __shared__ uint32_t sh_total;
+    __shared__ uint32_t sh_total, sh_next[2];
     // (diagnostic builds of the host pass `prof`: shader-clock stamps at the phase boundaries)
     auto stamp = [&](int k) {
         if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
@@ -601,7 +601,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     stamp(0);
     const uint32_t W = g.lead + g.core + g.look, nw = W / 32u, cap = g.cap_lds;
     uint32_t *win = spec_lds;
-    uint32_t *marks = win + nw + 2;
+    uint32_t *marks = win + nw + 4;                   // (spec_cds_fast reads four words from any position)
     uint16_t *rank = reinterpret_cast<uint16_t *>(marks + nw);
     uint16_t *sel = rank + nw + 2;
     uint16_t *mpre = sel + nw + 2;
@@ -610,6 +610,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     uint16_t *chop4 = cnxt + cap;
     uint16_t *chop16 = chop4 + cap;
     uint16_t *ua = chop16 + cap;
+    uint16_t *ub = ua + cap;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const uint64_t core_abs = tab_lo + (uint64_t)blockIdx.x * g.core;
     const uint64_t gw0 = ((uint64_t)blockIdx.x * g.core) >> 5;              // first bitmap word of this window
@@ -628,7 +629,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     const uint64_t wstart = core_abs >= g.lead ? core_abs - g.lead : 0;     // multiple of 32
     const uint32_t c0 = (uint32_t)(core_abs - wstart), c1 = c0 + g.core;
     const uint64_t w0 = wstart >> 5;
-    for (uint32_t i = tid; i < nw + 2; i += nt) {
+    for (uint32_t i = tid; i < nw + 4; i += nt) {
         const uint64_t idx = w0 + i;
         win[i] = idx < nwords ? bswap32(words[idx]) : 0u;
         if (i < nw) marks[i] = 0u;
@@ -661,6 +662,21 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     const uint64_t left = end_bit - wstart;
     const SpecWin s{win, rank, sel, nw, left < W ? (uint32_t)left : W};
     stamp(1);
+    // a coded data set without / with (`ref`) a reference sample: the straight-line parse, the full one where a
+    // unary part does not end inside its 64-bit peek (rare at the coded rates this kernel is chosen for)
+    const bool use_fast = g.fast != 0;
+    auto cds = [&](uint32_t q, uint32_t ref, uint32_t &run) -> uint32_t {
+        if (!use_fast) return spec_cds(s, c, q, ref, run);
+        uint32_t len = spec_cds_fast<2>(win, s.limit, c, q, run, ref);
+        if (len == kSpecUnresolved) len = spec_cds(s, c, q, ref, run);
+        return len;
+    };
+    auto cds0 = [&](uint32_t q, uint32_t &run) -> uint32_t {
+        if (!use_fast) return spec_cds(s, c, q, 0u, run);
+        uint32_t len = spec_cds_fast<0>(win, s.limit, c, q, run);
+        if (len == kSpecUnresolved) len = spec_cds(s, c, q, 0u, run);
+        return len;
+    };
 
     // ---- 1. sync chains: burn in, then mark until a marked boundary is met
     if (tid == 0 && start_bit >= wstart && start_bit - wstart < s.limit) {
@@ -683,15 +699,16 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     for (uint32_t q0 = tid * g.stride; q0 < s.limit; q0 += nt * g.stride) {
         uint32_t q = q0;
         bool ok = true;
+        uint32_t run;
         for (uint32_t k = 0; k < g.burn && ok; k++) {
-            const uint32_t len = s2_chain_step(s, c, q);
+            const uint32_t len = q < s.limit ? cds0(q, run) : 0u;
             ok = len != 0;
             q += len;
         }
         while (ok && q < s.limit) {
             const uint32_t bit = 1u << (31u - (q & 31u));
             if (atomicOr(&marks[q >> 5], bit) & bit) break;
-            const uint32_t len = s2_chain_step(s, c, q);
+            const uint32_t len = cds0(q, run);
             ok = len != 0;
             q += len;
         }
@@ -718,7 +735,9 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     __syncthreads();
     for (uint32_t i = tid; i < ncand; i += nt) {
         const uint32_t q = cpos[i];
-        cnxt[i] = q < s.limit ? spec_nxt_entry(s, c, q) : (uint16_t)0;
+        uint32_t run = 0;
+        const uint32_t len = q < s.limit ? cds0(q, run) : 0u;
+        cnxt[i] = len ? (uint16_t)(len | (run ? kNxtZero : kNxtBlock)) : (uint16_t)0;
     }
     __syncthreads();
     stamp(3);
@@ -734,11 +753,82 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     // (Flattening this loop -- one step per lane and iteration, a finished lane taking its next candidate
     // at once -- was measured and is SLOWER here, 521k against 430k cycles per window: the iterations of
     // the merged loop pay for every path, the on-demand parse included.)
-    for (uint32_t i = i0 + tid; i < i1; i += nt) {
-        const uint32_t q = cpos[i];
-        uint32_t a = q < s.limit ? s2_unit(w, c, q, 0u, c.rsi, g.budget) : 0u;
-        if (a > 0xFFFFu) a = 0;
-        ua[i] = (uint16_t)a;
+    // s2_unit (aec_spec2.h) in two homogeneous passes, because a wavefront's loop costs what its slowest lane
+    // costs (a walk off the marked chain takes 40 parses where the average takes 10) and a loop body that holds
+    // both kinds of step pays for both: A. the parses -- first CDS with the reference sample, then on demand
+    // until the walk stands on a marked boundary -- one per lane and round, a lane that is through fetching the
+    // next candidate at once; B. the table steps from there, in the same manner.  Between the passes a candidate
+    // keeps (distance, blocks) in ua / ub; 0 in ua = unresolved.
+    if (tid == 0) sh_next[0] = sh_next[1] = i0;
+    __syncthreads();
+    {
+        const uint32_t ref_first = (c.flags & F_PREPROCESS) ? 1u : 0u, bend = c.rsi;
+        uint32_t i = 0, p0 = 0, pos = 0, b = 0, budget = 0;
+        bool have = false, first = false;
+        while (true) {
+            if (!have) {
+                i = atomicAdd(&sh_next[0], 1u);
+                if (i >= i1) break;
+                p0 = pos = cpos[i];
+                b = 0;
+                budget = g.budget;
+                first = true;
+                if (p0 >= s.limit) {
+                    ua[i] = 0;
+                    continue;
+                }
+                have = true;
+            }
+            uint32_t run;
+            const uint32_t len = cds(pos, first ? ref_first : 0u, run);
+            bool fail = len == 0u, done = false;
+            uint32_t n = 1;
+            if (!fail && run) {
+                n = spec_run_blocks(c, len - c.id_len - 1u - ((first && ref_first) ? c.bps : 0u), b);
+                fail = !n || n > bend - b;
+            }
+            if (!fail) {
+                pos += len;
+                b += n;
+                first = false;
+                if (b >= bend || (pos < s.limit && s2_marked(marks, pos))) done = true;
+                else if (pos >= s.limit || budget == 0u) fail = true;
+                else budget--;
+            }
+            if (done && pos - p0 > 0xFFFFu) fail = true;
+            if (fail || done) {
+                ua[i] = fail ? (uint16_t)0 : (uint16_t)(pos - p0);
+                ub[i] = (uint16_t)b;
+                have = false;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t bend = c.rsi;
+        uint32_t i = 0, p0 = 0, pos = 0, b = 0;
+        bool have = false;
+        while (true) {
+            if (!have) {
+                i = atomicAdd(&sh_next[1], 1u);
+                if (i >= i1) break;
+                const uint32_t d = ua[i];
+                b = ub[i];
+                p0 = cpos[i];
+                pos = p0 + d;
+                if (!d || b >= bend) continue;
+                have = true;
+            }
+            uint32_t none = 0;
+            if (!s2_step(w, c, pos, b, bend, none)) {
+                ua[i] = 0;
+                have = false;
+            } else if (b >= bend) {
+                const uint32_t a = pos - p0;
+                ua[i] = a > 0xFFFFu ? (uint16_t)0 : (uint16_t)a;
+                have = false;
+            }
+        }
     }
     __syncthreads();
     stamp(5);
@@ -1258,11 +1348,12 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     p.g.stride = tune("AEC_S2_STRIDE", 64u);
     p.g.burn = tune("AEC_S2_BURN", 24u);
     p.g.budget = tune("AEC_S2_BUDGET", 0xFFFFFFFFu);
+    p.g.fast = tune("AEC_S2_FAST", 1u);
     const uint32_t W = p.g.lead + p.g.core + p.g.look, nw = W / 32;
     const uint32_t capdiv = tune("AEC_S2_CAPDIV", 8u);
     p.g.cap_lds = (W / (capdiv ? capdiv : 8u) + 63) & ~63u;
     p.g.cap_core = (p.g.core / 8 + 63) & ~63u;
-    p.lds = (size_t)(nw + 2) * 4 + (size_t)nw * 4 + (size_t)(nw + 2) * 2 * 3 + (size_t)p.g.cap_lds * 2 * 5 + 64;
+    p.lds = (size_t)(nw + 4) * 4 + (size_t)nw * 4 + (size_t)(nw + 2) * 2 * 3 + (size_t)p.g.cap_lds * 2 * 6 + 64;
     if (p.lds > 156 * 1024) return p;
     const uint64_t nwin_total = (total_bits + core + core - 1) / core;    // (+ one: the range starts on a core boundary)
     p.nwin_max = (uint32_t)(nwin_total < kS2SuperWindows ? nwin_total : kS2SuperWindows);

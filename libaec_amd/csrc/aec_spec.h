@@ -179,6 +179,76 @@ AEC_HD uint32_t spec_cds(const SpecWin &s, const Cfg &c, uint32_t q, uint32_t re
     return len < 4096u ? len : 0u;
 }
 
+// ---- the common case in straight-line code --------------------------------------------------------
+// spec_cds pays for its widest path on every step (~300 instructions per wavefront step on the device: the
+// rank / select fallback and its loops are entered as soon as one lane needs them).  spec_cds_fast resolves a
+// CDS whose unary part ends inside ONE 64-bit peek -- all of them at the optimal k -- from four consecutive
+// window words and nothing else (~100 instructions, no branch); the callers queue the rest for spec_cds.
+// Returns the length exactly as spec_cds does, 0 when spec_cds would return 0 for a reason seen here (the CDS
+// leaves the window), kSpecUnresolved when the peek does not hold the end of the unary part.
+// The window needs 4 readable words behind its last one.
+constexpr uint32_t kSpecUnresolved = 0xFFFFFFFFu;
+
+struct SpecQuad {
+    uint32_t a, b, c, d;
+};
+
+AEC_HD SpecQuad spec_quad(const uint32_t *win, uint32_t w)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    struct __attribute__((packed, aligned(4))) Q { uint32_t a, b, c, d; };
+    const Q t = *reinterpret_cast<const Q *>(win + w);
+    return SpecQuad{t.a, t.b, t.c, t.d};
+#else
+    return SpecQuad{win[w], win[w + 1], win[w + 2], win[w + 3]};
+#endif
+}
+
+// upper 32 bits of (a : b) << s, 0 <= s < 32
+AEC_HD uint32_t spec_shl_hi(uint32_t a, uint32_t b, uint32_t s)
+{
+    return (uint32_t)(((((uint64_t)a << 32) | b) << s) >> 32);
+}
+
+// REF = 0 / 1: without / with a reference sample; REF = 2: as `ref` says (one code path for both)
+template <uint32_t REF>
+AEC_HD uint32_t spec_cds_fast(const uint32_t *win, uint32_t limit, const Cfg &c, uint32_t q, uint32_t &run,
+                              uint32_t ref = 0)
+{
+    run = 0;
+    if (REF < 2u) ref = REF;
+    const uint32_t sh = q & 31u;
+    const SpecQuad w = spec_quad(win, q >> 5);
+    const uint32_t h = spec_shl_hi(w.a, w.b, sh);
+    const uint32_t id = h >> (32u - c.id_len);
+    const bool unc = id == (1u << c.id_len) - 1u, low = id == 0u;
+    const uint32_t selbit = (h >> (31u - c.id_len)) & 1u;
+    const uint32_t off1 = c.id_len + (low ? 1u : 0u) + ((ref && !unc) ? c.bps : 0u);
+    const uint32_t n = low ? (selbit ? c.bs / 2u : 1u) : c.bs - ref;
+    const uint32_t add = low ? 0u : n * (id - 1u);
+    uint32_t hi, lo;
+    if (REF) {                                    // behind the reference sample: a second read
+        const uint32_t t = q + off1;
+        const SpecQuad v = spec_quad(win, t >> 5);
+        hi = spec_shl_hi(v.a, v.b, t & 31u);
+        lo = spec_shl_hi(v.b, v.c, t & 31u);
+    } else {                                      // sh + off1 <= 37: inside the four words
+        const uint32_t s1 = sh + off1;
+        const bool up = s1 >= 32u;
+        const uint32_t a = up ? w.b : w.a, b = up ? w.c : w.b, cc = up ? w.d : w.c;
+        hi = spec_shl_hi(a, b, s1 & 31u);
+        lo = spec_shl_hi(b, cc, s1 & 31u);
+    }
+    const uint32_t pc = spec_popc(hi) + spec_popc(lo);
+    const uint32_t e = spec_select64(((uint64_t)hi << 32) | lo, n) + 1u;      // (garbage while pc < n)
+    const uint32_t len = unc ? c.id_len + c.bs * c.bps : off1 + e + add;
+    const bool in = q + c.id_len + 1u <= limit;
+    if (in && !unc && pc < n) return kSpecUnresolved;
+    if (!in || q + len > limit || len >= 4096u) return 0u;
+    if (low && !selbit) run = e;
+    return len;
+}
+
 AEC_HD uint16_t spec_nxt_entry(const SpecWin &s, const Cfg &c, uint32_t q)
 {
     uint32_t run;

@@ -436,6 +436,59 @@ extern "C" int emul_spec2(const uint32_t *p, const uint8_t *in, size_t in_len, c
     return 0;
 }
 
+// spec_cds_fast against spec_cds at EVERY bit position of the stream's windows (with and without a reference
+// sample): wherever the fast parse answers, the answers must be the same.  out[0] = positions compared,
+// out[1] = unresolved by the fast parse, out[2] = mismatches, out[3] = first mismatching absolute bit.
+extern "C" int emul_cds_fast_check(const uint32_t *p, const uint8_t *in, size_t in_len, uint32_t W, uint64_t *out)
+{
+    Cfg c;
+    int rc = make_cfg(p[0], p[1], p[2], p[3], 0, false, &c);
+    if (rc) return rc;
+    const uint64_t end_bit = (uint64_t)in_len * 8;
+    const uint32_t nw = W / 32;
+    std::vector<uint32_t> words((in_len + 3) / 4 + 1, 0);
+    memcpy(words.data(), in, in_len);
+    std::vector<uint32_t> win(nw + 4);
+    std::vector<uint16_t> rank(nw + 1), sel(nw + 2);
+    out[0] = out[1] = out[2] = 0;
+    out[3] = ~0ull;
+    for (uint64_t wstart = 0; wstart < end_bit; wstart += W / 2) {
+        for (uint32_t i = 0; i < nw + 4; i++) {
+            const uint64_t idx = wstart / 32 + i;
+            win[i] = idx < words.size() ? bswap32(words[idx]) : 0u;
+        }
+        rank[0] = 0;
+        for (uint32_t i = 0; i < nw; i++) rank[i + 1] = (uint16_t)(rank[i] + __builtin_popcount(win[i]));
+        for (uint32_t i = 0; i < nw; i++) {
+            const uint32_t lo = rank[i], hi = rank[i + 1], m = (lo + 31u) >> 5;
+            if (32u * m + 1u <= hi && 32u * m + 1u > lo) sel[m] = (uint16_t)i;
+        }
+        SpecWin s{win.data(), rank.data(), sel.data(), nw, (uint32_t)std::min<uint64_t>(W, end_bit - wstart)};
+        for (uint32_t q = 0; q < s.limit; q++) {
+            for (uint32_t ref = 0; ref < 2; ref++) {
+                uint32_t run_s, run_f;
+                const uint32_t ls = spec_cds(s, c, q, ref, run_s);
+                const uint32_t lf = ref ? spec_cds_fast<1>(s.win, s.limit, c, q, run_f)
+                                        : spec_cds_fast<0>(s.win, s.limit, c, q, run_f);
+                uint32_t run_g;
+                const uint32_t lg = spec_cds_fast<2>(s.win, s.limit, c, q, run_g, ref);
+                if (lg != lf || run_g != run_f) {
+                    if (!out[2]) out[3] = wstart + q;
+                    out[2]++;
+                }
+                out[0]++;
+                if (lf == kSpecUnresolved) {
+                    out[1]++;
+                } else if (lf != ls || (lf && run_f != run_s)) {
+                    if (!out[2]) out[3] = wstart + q;
+                    out[2]++;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 // statistics helper for tests: for start positions q0 = first, first + step, ... the number of CDS
 // parses (chain steps, no reference sample) until the chain from q0 lands on a TRUE boundary
 // (truth[] = 1 at true coded-data-set boundaries), capped at max_steps; out[i] = steps or 0xFFFF.

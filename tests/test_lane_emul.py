@@ -259,3 +259,29 @@ def test_sparse_speculation_vs_oracle(emul, bps, bs, rsi, flags, scale, core, lo
             assert i + cnt <= len(o) - 1 and s + d == o[i + cnt], (i, cnt, d)
     assert marked[0], "the known start of the stream is always a candidate"
     assert miss <= full // 20, (miss, full)       # (a missed start only costs speed: that RSI is walked serially)
+
+
+@pytest.mark.parametrize("bps,bs,rsi,flags,scale", [
+    (16, 16, 128, AEC_DATA_PREPROCESS, 1.5),                     # BASELINE config 2 shape
+    (8, 8, 128, AEC_DATA_PREPROCESS, 1.5),                       # config 5 shape
+    (32, 32, 64, AEC_DATA_PREPROCESS | AEC_DATA_MSB | AEC_DATA_SIGNED, 40.0),
+    (12, 64, 16, AEC_DATA_PREPROCESS, 300.0),                    # long unary parts: many unresolved
+    (2, 8, 16, 0, 1.0),                                          # id_len 1
+    (24, 16, 7, AEC_DATA_PREPROCESS | AEC_DATA_3BYTE, 3.0),
+])
+def test_fast_cds_parse_agrees_with_the_full_one(emul, bps, bs, rsi, flags, scale):
+    """spec_cds_fast (the straight-line parse the window kernels take first) against spec_cds at every bit
+    position, with and without a reference sample: where it answers, it answers the same."""
+    rng = np.random.default_rng(bps * 7 + bs)
+    n = bs * rsi * 12 + 5
+    vals = random_walk_samples(rng, n, bps, flags, scale=scale, zero_frac=0.15, jump_frac=0.002)
+    data = pack_samples(vals, bps, flags)
+    rc, enc, *_ = oracle_encode(data, bps, bs, rsi, flags)
+    enc_a = np.frombuffer(enc, dtype=np.uint8)[: 40000]
+    p = (C.c_uint32 * 4)(bps, bs, rsi, flags)
+    out = (C.c_uint64 * 4)()
+    emul.emul_cds_fast_check.restype = C.c_int
+    rc = emul.emul_cds_fast_check(p, C.c_void_p(enc_a.ctypes.data), C.c_size_t(enc_a.size), C.c_uint32(16384), out)
+    assert rc == 0
+    assert out[0] > 0 and out[2] == 0, list(out)
+    print(f"bps {bps} bs {bs}: {out[0]} positions, {out[1] / out[0]:.3f} unresolved by the fast parse")
