@@ -583,7 +583,7 @@ __global__ void k_texpand(const Cfg c, const TwTables t, const TrTables tt, cons
 // Output for the candidates inside the core: the window's part of the global bitmap / prefix table
 // and its records (SparseTables above).
 struct Spec2Geom {
-    uint32_t lead, core, look, stride, burn, cap_lds, cap_core, budget, fast;
+    uint32_t lead, core, look, stride, burn, cap_lds, cap_core, fast;
 };
 
 __global__ void __launch_bounds__(1024)
@@ -763,7 +763,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     __syncthreads();
     {
         const uint32_t ref_first = (c.flags & F_PREPROCESS) ? 1u : 0u, bend = c.rsi;
-        uint32_t i = 0, p0 = 0, pos = 0, b = 0, budget = 0;
+        uint32_t i = 0, p0 = 0, pos = 0, b = 0;
         bool have = false, first = false;
         while (true) {
             if (!have) {
@@ -771,7 +771,6 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                 if (i >= i1) break;
                 p0 = pos = cpos[i];
                 b = 0;
-                budget = g.budget;
                 first = true;
                 if (p0 >= s.limit) {
                     ua[i] = 0;
@@ -792,8 +791,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                 b += n;
                 first = false;
                 if (b >= bend || (pos < s.limit && s2_marked(marks, pos))) done = true;
-                else if (pos >= s.limit || budget == 0u) fail = true;
-                else budget--;
+                else if (pos >= s.limit) fail = true;
             }
             if (done && pos - p0 > 0xFFFFu) fail = true;
             if (fail || done) {
@@ -804,6 +802,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         }
     }
     __syncthreads();
+    stamp(7);
     {
         const uint32_t bend = c.rsi;
         uint32_t i = 0, p0 = 0, pos = 0, b = 0;
@@ -1347,7 +1346,6 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     p.g.look = (uint32_t)look;
     p.g.stride = tune("AEC_S2_STRIDE", 64u);
     p.g.burn = tune("AEC_S2_BURN", 24u);
-    p.g.budget = tune("AEC_S2_BUDGET", 0xFFFFFFFFu);
     p.g.fast = tune("AEC_S2_FAST", 1u);
     const uint32_t W = p.g.lead + p.g.core + p.g.look, nw = W / 32;
     const uint32_t capdiv = tune("AEC_S2_CAPDIV", 8u);
@@ -1406,9 +1404,12 @@ void spec2_prof_report(uint32_t nwin, hipStream_t st)
         for (int k = 0; k < 6; k++) d[k] += (double)(h[(size_t)w * 8 + k + 1] - h[(size_t)w * 8 + k]);
         n++;
     }
+    double pa = 0;
+    for (uint32_t w = 0; w + 1 < nwin; w++)
+        if (h[(size_t)w * 8 + 6]) pa += (double)(h[(size_t)w * 8 + 7] - h[(size_t)w * 8 + 4]);
     fprintf(stderr, "k_spec2 phases (shader-clock ticks per window, %u windows): load+rank %.0f | chains %.0f | "
-            "prefix+cand nxt %.0f | hop4+hop16 %.0f | units %.0f | chain+write %.0f\n", n, d[0] / n, d[1] / n,
-            d[2] / n, d[3] / n, d[4] / n, d[5] / n);
+            "prefix+cand nxt %.0f | hop4+hop16 %.0f | units %.0f (parses %.0f) | chain+write %.0f\n", n, d[0] / n,
+            d[1] / n, d[2] / n, d[3] / n, d[4] / n, pa / n, d[5] / n);
 }
 
 void allow_big_lds2()

@@ -111,6 +111,9 @@ static unsigned long long s2_counters[8];
 #ifndef S2_NOTE
 #define S2_NOTE(pos) ((void)0)      // (emulator statistics: positions parsed on demand)
 #endif
+#ifndef S2_HIST
+#define S2_HIST(parses, steps) ((void)0)   // (emulator statistics: on-demand parses and table steps of a unit walk)
+#endif
 
 // `budget`: on-demand parses this walk may still spend (a bogus hypothesis wanders off the marked chain
 // for dozens of codes; a true one is back on it after the few codes behind an RSI start that no sync
@@ -164,6 +167,9 @@ AEC_HD bool s2_step(const S2Win &w, const Cfg &c, uint32_t &pos, uint32_t &b, ui
 AEC_HD uint32_t s2_unit(const S2Win &w, const Cfg &c, uint32_t p, uint32_t b0, uint32_t bend, uint32_t budget)
 {
     uint32_t pos = p, b = b0;
+    uint32_t n_parse = 0, n_table = 0;
+    (void)n_parse;
+    (void)n_table;
     S2_COUNT(4);
     if (b0 == 0) {
         if (!spec_walk_init(c, spec_first_entry(w.s, c, p), p, pos, b)) return 0;
@@ -174,6 +180,7 @@ AEC_HD uint32_t s2_unit(const S2Win &w, const Cfg &c, uint32_t p, uint32_t b0, u
         if (s2_marked(w.marks, pos)) break;
         if (budget == 0) { S2_COUNT(5); return 0; }
         budget--;
+        n_parse++;
         S2_COUNT(3);
         S2_NOTE(pos);
         const uint32_t e1 = spec_nxt_entry(w.s, c, pos);
@@ -188,8 +195,11 @@ AEC_HD uint32_t s2_unit(const S2Win &w, const Cfg &c, uint32_t p, uint32_t b0, u
         b += n;
     }
     uint32_t none = 0;                                   // (no on-demand parse from here on)
-    while (b < bend)
+    while (b < bend) {
         if (!s2_step(w, c, pos, b, bend, none)) return 0;
+        n_table++;
+    }
+    S2_HIST(n_parse, n_table);
     return pos - p;
 }
 

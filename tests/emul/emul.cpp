@@ -321,6 +321,16 @@ extern "C" int emul_spec(const uint32_t *p, const uint8_t *in, size_t in_len, ui
 static std::unordered_set<uint64_t> s2_noted;      // distinct (window, position) pairs parsed on demand
 static uint64_t s2_note_window = 0;
 #define S2_NOTE(pos) (s2_noted.insert((s2_note_window << 24) | (pos)))
+static unsigned long long s2_hist_parse[256], s2_hist_table[256];
+#define S2_HIST(parses, steps) (s2_hist_parse[(parses) < 255 ? (parses) : 255]++, s2_hist_table[(steps) < 255 ? (steps) : 255]++)
+extern "C" void emul_s2_hist(unsigned long long *parse, unsigned long long *table)
+{
+    for (int i = 0; i < 256; i++) {
+        parse[i] = s2_hist_parse[i];
+        table[i] = s2_hist_table[i];
+        s2_hist_parse[i] = s2_hist_table[i] = 0;
+    }
+}
 #include "../../libaec_amd/csrc/aec_spec2.h"
 // step statistics of the unit walks (hop16, hop4, table single, on-demand single, units)
 extern "C" void emul_s2_counters(unsigned long long *out, int reset)
