@@ -44,7 +44,10 @@ typedef struct aec_gpu_dec_result {
     uint64_t end_bit;      /* index pass: bit position after the last complete coded data set */
     uint32_t status;       /* 0 ok, 1 input ended inside a coded data set, 2 corrupt stream */
     uint32_t pad;          /* index pass: 1 = stopped because the input ended; aec_gpu_decode_indexed_async:
-                              samples released from the coded data set the input ends in */
+                              samples released from the coded data set the input ends in (bits 0..30).
+                              Decode records: bit 31 = a coded data set longer than any libaec's encoder
+                              writes was met and the batch went through the sequential decoder (informational:
+                              the output is complete and exact either way) */
     uint64_t bad_rsi;      /* lowest RSI with status != 0 */
 } aec_gpu_dec_result;
 

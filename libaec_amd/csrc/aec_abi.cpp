@@ -124,6 +124,7 @@ struct internal_state {
     uint32_t walk_blocks;          // blocks of that RSI in front of walk_bit
     uint64_t delivered;            // samples of that RSI already handed out
     size_t walked_len;             // d_len at the last index pass (anything beyond it is new)
+    uint64_t span_mul;             // widening of the batch's input span (coded data sets beyond the encoder's bound)
     bool more;                     // the last batch stopped at its RSI bound: decodable input remains
     bool launched;                 // at least one batch has run
     int sticky_error;
@@ -258,6 +259,7 @@ int init_common(struct aec_stream *strm, bool enc)
     s->walk_blocks = 0;
     s->delivered = 0;
     s->walked_len = 0;
+    s->span_mul = 1;
     s->more = false;
     s->launched = false;
     s->sticky_error = AEC_OK;
@@ -420,7 +422,9 @@ int decode_run(internal_state *s, struct aec_stream *strm)
     const uint64_t avail_bits = (uint64_t)s->d_len * 8 - rsi_rel;
     if (max_rsi > avail_bits / min_rsi_bits + 2) max_rsi = avail_bits / min_rsi_bits + 2;
     // the part of the resident stream this batch can need
-    uint64_t span = walk_rel / 8 + max_rsi * worst_rsi_bytes(c) + 64;
+    // (worst_rsi_bytes is what an ENCODER makes of an RSI at most; the format allows longer ones: should the
+    // walker run out of input inside the span while more is resident, the next batch looks further)
+    uint64_t span = walk_rel / 8 + max_rsi * worst_rsi_bytes(c) * s->span_mul + 64;
     const size_t in_bytes = span < s->d_len ? (size_t)span : s->d_len;
     if (!s->d_off.ensure((max_rsi + 2) * 8) || !s->d_out.ensure(max_rsi * rsi_bytes + blk_bytes + 64))
         return AEC_FAIL(AEC_MEM_ERROR);
@@ -471,7 +475,7 @@ int decode_run(internal_state *s, struct aec_stream *strm)
         }
     }
     // samples released from the coded data set the input ends in (reference decode.c:423-460)
-    const uint32_t part = (!corrupt && idx.pad == 1) ? dec.pad : 0u;
+    const uint32_t part = (!corrupt && idx.pad == 1) ? (dec.pad & 0x7FFFFFFFu) : 0u;   // (bit 31: slow path ran)
     const uint64_t blocks = good_rsi * c.rsi + tail_blocks;
     const size_t total = (size_t)blocks * blk_bytes + (size_t)part * c.bytes;
     if (total > skip) {
@@ -502,7 +506,14 @@ int decode_run(internal_state *s, struct aec_stream *strm)
                 return AEC_FAIL(AEC_MEM_ERROR);
         }
     }
-    if (corrupt) return AEC_DATA_ERROR;
+    if (corrupt) {
+        if (getenv("AEC_ABI_TRACE"))
+            fprintf(stderr, "libaec (MI355X): AEC_DATA_ERROR: walker status %u after %llu RSIs + %llu blocks (bit %llu), "
+                    "decoder status %u at RSI %llu\n", idx.status, (unsigned long long)idx.n_rsi,
+                    (unsigned long long)idx.tail_blocks, (unsigned long long)idx.end_bit, dec.status,
+                    (unsigned long long)dec.bad_rsi);
+        return AEC_DATA_ERROR;
+    }
     if (idx.n_rsi) s->rsi_bits_seen = (idx.end_bit - rsi_rel) / (idx.n_rsi + (idx.tail_blocks ? 1 : 0));
 
     // advance: the walker resumes behind the last complete coded data set
@@ -516,6 +527,8 @@ int decode_run(internal_state *s, struct aec_stream *strm)
         s->delivered = part;
     }
     s->walked_len = in_bytes;
+    if (idx.pad == 1 && in_bytes < s->d_len) s->span_mul = s->span_mul < (1u << 20) ? s->span_mul * 4 : s->span_mul;
+    else s->span_mul = 1;
     // stopped at the bound with input left: the caller's next call (or this one, if it still has
     // room) goes on from here
     s->more = idx.n_rsi >= max_rsi || in_bytes < s->d_len;

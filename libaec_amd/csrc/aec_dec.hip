@@ -424,6 +424,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             const bool live = bb < nb && ok;
             const uint32_t ref = (pp && b0 + bb == 0) ? 1u : 0u;
             src.limit = landed;
+            src.starve = 0u;
             uint32_t nz = 0;
             const bool parse = live && zrun == 0;
             // lanes inside a zero run (and finished lanes) get d = 0 from the same code path
@@ -457,7 +458,16 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                 p = p_save;
                 nz = 0;
             }
-            if (parse) {
+            // The block took bits the ring never held: a coded data set longer than any the reference encoder
+            // writes (the ring is sized for those; the format itself knows no bound).  Whatever came out is
+            // void, status included: the item is decoded again from the stream itself (k_decode_redo).
+            // (a status raised while reads went beyond the ring -- stale slots look like a cut or corrupt stream --
+            // is no verdict either)
+            const bool over = parse && (((p + 31u) >> 5) > landed || (st != DEC_OK && src.starved()));
+            if (over) {
+                atomicOr(&res->pad, kDecRedo);
+                ok = 0u;
+            } else if (parse) {
                 if (st != DEC_OK) {
                     report(res, st, r);
                     // (a batch of independent streams: the stream's own record says so as well -- one overall
@@ -510,7 +520,10 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             if (zrun == 0) {
                 uint32_t nz = 0;
                 const uint32_t st = parse_cds<0>(br, d, c, ref, b0 + bo, nz);
-                if (st != DEC_OK) {
+                if (br.src.starved()) {                           // (as above: not a verdict on the stream)
+                    atomicOr(&res->pad, kDecRedo);
+                    ok = 0u;
+                } else if (st != DEC_OK) {
                     report(res, st, r);
                     // (a batch of independent streams: the stream's own record says so as well -- one overall
                     // record names only the first bad RSI of the whole batch)
@@ -538,6 +551,87 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     if (STG && (b % G) != 0) flush(b / G);             // rows of the last, partial group
 }
 
+// ---- coded data sets longer than the ring ------------------------------------------------------------
+// k_decode flags the batch (kDecRedo in the record's pad) when a lane met a coded data set that outgrew its
+// ring.  This kernel is enqueued behind every k_decode and returns at once unless the flag is up; then it
+// decodes EVERY item of the batch again, one lane per item, bit by bit from the stream where it lies
+// (BitReader + parse_cds, the sequential reader the index pass and the emulator use): slow, but the answer for
+// any stream the format allows -- a foreign encoder that picks k = 0 for large residuals is within its rights.
+// Items and results as in k_decode (same tables, same output, same status record).
+template <bool SEG>
+__global__ void __launch_bounds__(64)
+k_decode_redo(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
+              const uint64_t *__restrict__ rsi_off, const SegEntry *__restrict__ seg_table, uint64_t n_rsi,
+              uint64_t total_blocks, uint8_t *__restrict__ out, DecResult *res, const DecResult *__restrict__ idx,
+              const DecResult *__restrict__ batch, uint32_t rsi_per_chunk)
+{
+    if (!(*reinterpret_cast<volatile uint32_t *>(&res->pad) & kDecRedo)) return;
+    if (idx) {
+        const uint64_t whole = idx->n_rsi, tail = idx->tail_blocks;
+        n_rsi = whole + (tail ? 1u : 0u);
+        total_blocks = whole * c.rsi + tail;
+    }
+    const bool pp = c.flags & F_PREPROCESS;
+    const size_t blk_bytes = (size_t)c.bs * c.bytes;
+    for (uint64_t r = (uint64_t)blockIdx.x * 64u + threadIdx.x; r < n_rsi; r += (uint64_t)gridDim.x * 64u) {
+        uint32_t nb = 0, b0 = 0, x = 0;
+        uint64_t start = 0, first_blk = 0;
+        if (SEG) {
+            const uint64_t rsi_idx = r / c.segs_per_rsi;
+            b0 = (uint32_t)(r - rsi_idx * c.segs_per_rsi) * 64u;
+            uint64_t left = total_blocks - rsi_idx * c.rsi;
+            if (left > c.rsi) left = c.rsi;
+            nb = left - b0 > 64 ? 64u : (uint32_t)(left - b0);
+            const SegEntry e = seg_table[r];
+            start = e.bit;
+            x = (c.flags & F_SIGNED) ? sign_extend(e.prev, c.bps) : e.prev;
+            first_blk = rsi_idx * c.rsi + b0;
+        } else if (batch) {
+            const uint64_t sidx = r / rsi_per_chunk;
+            const uint32_t rin = (uint32_t)(r - sidx * rsi_per_chunk);
+            const uint64_t whole = batch[sidx].n_rsi, tail = batch[sidx].tail_blocks;
+            nb = rin < whole ? c.rsi : (rin == whole ? (uint32_t)tail : 0u);
+            start = nb ? rsi_off[r] : 0;
+            first_blk = r * c.rsi;
+        } else {
+            const uint64_t left = total_blocks - r * c.rsi;
+            nb = left > c.rsi ? c.rsi : (uint32_t)left;
+            start = rsi_off[r];
+            first_blk = r * c.rsi;
+        }
+        uint8_t *dst = out + (size_t)first_blk * blk_bytes;
+        BitReader br;
+        br.init(words, nwords, end_bit, start);
+        uint32_t d[kMaxBlockSize];
+        uint32_t zrun = 0;
+        for (uint32_t bo = 0; bo < nb; bo++) {                    // (the sample-by-sample path of k_decode)
+            bool rf = pp && b0 + bo == 0;
+            if (zrun == 0) {
+                uint32_t nz = 0;
+                const uint32_t st = parse_cds<0>(br, d, c, rf ? 1u : 0u, b0 + bo, nz);
+                if (st != DEC_OK) {
+                    report(res, st, r);
+                    if (batch && st == DEC_DATA_ERROR)
+                        atomicMax(&const_cast<DecResult *>(batch)[r / rsi_per_chunk].status, (uint32_t)DEC_DATA_ERROR);
+                    break;
+                }
+                if (nz) {
+                    const uint32_t keep = d[0];
+                    for (uint32_t i = 0; i < kMaxBlockSize; i++) d[i] = 0;
+                    if (rf) d[0] = keep;
+                    zrun = nz - 1;
+                }
+            } else {
+                zrun--;
+                rf = false;
+            }
+            store_block_generic(dst, d, c, rf, x);
+            dst += blk_bytes;
+            if (rf) d[0] = 0;
+        }
+    }
+}
+
 // ---- the coded data set the input ends in ------------------------------------------------------------
 // The reference's resumable readers release every sample whose bits have arrived, also from a coded
 // data set that is cut by the end of the input (reference src/decode.c:342-400 bits_ask / fs_ask,
@@ -557,6 +651,7 @@ k_decode_partial(const Cfg c, const uint32_t *__restrict__ words, uint64_t nword
     const bool pp = c.flags & F_PREPROCESS, sgn = c.flags & F_SIGNED, msb = c.flags & F_MSB;
     const uint32_t b = (uint32_t)idx->tail_blocks;
     const uint32_t ref = (pp && b == 0) ? 1u : 0u;
+    const uint32_t redo_flag = res->pad & kDecRedo;          // (k_decode's note that the slow path ran: kept)
     BitReader r;
     r.init(words, nwords, end_bit, idx->end_bit);
     auto has = [&](uint32_t n) { return r.pos + n <= end_bit; };
@@ -618,7 +713,7 @@ k_decode_partial(const Cfg c, const uint32_t *__restrict__ words, uint64_t nword
         for (uint32_t t = 0; t < c.bytes; t++)
             out[(first + i) * c.bytes + t] = (uint8_t)(v >> (8 * (msb ? c.bytes - 1 - t : t)));
     }
-    res->pad = cnt;
+    res->pad = cnt | redo_flag;
 }
 
 __global__ void k_dec_result_init(DecResult *res)
@@ -771,6 +866,10 @@ static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
     }
     }
     if (prof) (void)hipEventRecord(prof->ev[6], st);
+    // (behind the timed kernel: returns at once unless k_decode raised kDecRedo)
+    const uint64_t redo_waves = (n_items + 63) / 64;
+    hipLaunchKernelGGL((k_decode_redo<SEG>), dim3((uint32_t)(redo_waves < 2048 ? redo_waves : 2048)), dim3(64), 0, st, c,
+                       words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, d_idx, d_batch, rpc);
     return true;
 }
 

@@ -814,6 +814,9 @@ AEC_HD bool se_lookup(uint32_t m, uint32_t &sum, uint32_t &second)
 
 // Decode status codes shared by the kernels and the host
 enum : uint32_t { DEC_OK = 0, DEC_NEED_INPUT = 1, DEC_DATA_ERROR = 2 };
+// bit 31 of a decode record's `pad`: a coded data set outgrew a lane's look-ahead and the batch was decoded again
+// by the sequential path (aec_dec.hip: k_decode_redo); the low bits keep their meaning
+constexpr uint32_t kDecRedo = 0x80000000u;
 
 // Parses one CDS.  d receives the block's samples for SPLIT / SE / UNCOMP (d[0] is the
 // reference sample on a reference block).  For a zero run `nzero_blocks` receives the number

@@ -167,6 +167,10 @@ extern "C" int emul_trunk(const uint32_t *params, const uint8_t *enc, size_t enc
                 }
                 stats[3] += h.steps;
                 if (h.steps > stats[4]) stats[4] = h.steps;
+                if (const char *hp = getenv("TR_HIST")) {      // (diagnostics: walk lengths, one per line)
+                    static FILE *hf = fopen(hp, "w");
+                    if (hf) fprintf(hf, "%u %u %u\n", w, h.steps, (unsigned)stt);
+                }
                 stats[5] += stt == TR_LAND;
                 stats[6] += stt == TR_DONE;
                 stats[7] += stt == TR_FAIL;

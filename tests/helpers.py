@@ -270,3 +270,31 @@ def random_walk_samples(rng, n, bps, flags, scale=3.0, zero_frac=0.1, jump_frac=
         cur = int(jump_vals[j]) if jumps[j] else min(hi, max(lo, cur + int(steps[j])))
         x[j] = cur
     return x
+
+
+def craft_overlong_stream(rng, bps, bs, rsi, n_rsi, id_len, long_frac, long_hi, pp=True):
+    """A VALID CCSDS 121 stream no libaec encoder would write: some blocks take split option k = 0 for large
+    mapped residuals, so that their coded data sets are many times longer than the uncompressed option
+    (fundamental sequences of up to `long_hi` zeros each).  Returns the bytes."""
+    bits = []
+
+    def put(v, n):
+        bits.extend(((v >> (n - 1 - i)) & 1) for i in range(n))
+
+    for r in range(n_rsi):
+        for b in range(rsi):
+            ref = pp and b == 0
+            long_one = rng.random() < long_frac
+            k = 0 if long_one else int(rng.integers(0, 3))
+            put(k + 1, id_len)                                   # split option k
+            if ref:
+                put(int(rng.integers(0, 1 << bps)), bps)
+            vals = rng.integers(0, long_hi if long_one else 6, bs - (1 if ref else 0))
+            for v in vals:
+                put(1, int(v >> k) + 1)                          # fundamental sequence: zeros, then a one
+            if k:
+                for v in vals:
+                    put(int(v) & ((1 << k) - 1), k)
+    while len(bits) % 8:
+        bits.append(0)
+    return np.packbits(np.array(bits, dtype=np.uint8)).tobytes()

@@ -12,7 +12,7 @@ from helpers import (AEC_DATA_3BYTE, AEC_DATA_MSB, AEC_DATA_PREPROCESS, AEC_DATA
                      AEC_FLUSH, AEC_MEM_ERROR, AEC_NO_FLUSH, AEC_NOT_ENFORCE, AEC_OK,
                      AEC_RESTRICTED, AEC_STREAM_ERROR, ROOT, bytes_per_sample, have_ref,
                      max_encoded_size, oracle_decode, oracle_encode, pack_samples,
-                     random_walk_samples, ref_decode, ref_encode, unpack_samples)
+                     random_walk_samples, ref_decode, ref_encode, unpack_samples, craft_overlong_stream)
 
 pytestmark = pytest.mark.gpu
 
@@ -653,3 +653,51 @@ def test_fused_encoder_edges(env):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fused_edges.py")], env=e, capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0 and "fused edges ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+@pytest.mark.parametrize("bps,bs,rsi,n_rsi,long_hi", [
+    (16, 16, 8, 200, 120),      # coded data sets of up to 1900 bits where the encoder's bound is 277
+    (8, 8, 128, 20, 200),
+    (32, 32, 16, 40, 400),      # up to 12 800 bits in one coded data set (bound: 1062)
+    (16, 64, 4, 60, 150),
+])
+def test_overlong_coded_data_sets_of_a_foreign_encoder(api, bps, bs, rsi, n_rsi, long_hi):
+    """The format does not bound the length of a coded data set -- only sensible encoders do (reference
+    decode.c:462-502 decodes fundamental sequences of any length).  The block-parallel decoder keeps a
+    bounded look-ahead per lane; a coded data set that does not fit must still come out right."""
+    rng = np.random.default_rng(bps + bs)
+    id_len = {8: 3, 16: 4, 32: 5}[bps]
+    enc = craft_overlong_stream(rng, bps, bs, rsi, n_rsi, id_len, 0.05, long_hi)
+    nbytes = n_rsi * rsi * bs * bytes_per_sample(bps, PP)
+    rc_o, dec_o, _ = oracle_decode(enc, bps, bs, rsi, PP, nbytes)
+    assert rc_o == AEC_OK and len(dec_o) == nbytes
+    if have_ref():
+        rc_r, dec_r = ref_decode(enc, bps, bs, rsi, PP, nbytes)
+        assert rc_r == AEC_OK and dec_r == dec_o
+    rc, dec = api.aec_buffer_decode(enc, bps, bs, rsi, PP, nbytes)
+    assert rc == AEC_OK
+    assert dec == dec_o
+    # the same through the streaming interface, input and output in pieces
+    from libaec_amd.api import Decoder
+    d = Decoder(bps, bs, rsi, PP)
+    got_all = bytearray()
+    pos = 0
+    while pos < len(enc):
+        chunk = enc[pos:pos + 4093]
+        off = 0
+        while True:
+            rc, used, got = d.call(chunk[off:], 65536, AEC_NO_FLUSH)
+            assert rc == AEC_OK
+            got_all += got
+            off += used
+            if off >= len(chunk) and not got:
+                break
+        pos += 4093
+    while len(got_all) < nbytes:
+        rc, used, got = d.call(b"", 65536, AEC_FLUSH)
+        assert rc == AEC_OK
+        if not got:
+            break
+        got_all += got
+    d.end()
+    assert bytes(got_all) == dec_o

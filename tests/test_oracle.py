@@ -199,3 +199,20 @@ def test_pad_rsi_decode():
     if have_ref():
         rc, dec = ref_decode(stream, bps, bs, rsi, flags | 32, data.size)
         assert rc == AEC_OK and dec == data.tobytes()
+
+
+@pytest.mark.parametrize("bps,bs,rsi,n_rsi,long_hi", [(16, 16, 8, 40, 120), (8, 8, 128, 4, 200), (32, 32, 16, 8, 400)])
+def test_overlong_coded_data_sets_oracle_vs_reference(bps, bs, rsi, n_rsi, long_hi):
+    """Streams with coded data sets far longer than any the reference ENCODER writes (split option k = 0 for
+    large residuals) are valid input for its decoder (decode.c:462-502); the oracle must agree on them, since
+    the GPU tests use it as the checker for exactly these streams."""
+    from helpers import craft_overlong_stream
+    rng = np.random.default_rng(bps + bs)
+    enc = craft_overlong_stream(rng, bps, bs, rsi, n_rsi, {8: 3, 16: 4, 32: 5}[bps], 0.1, long_hi)
+    nbytes = n_rsi * rsi * bs * bytes_per_sample(bps, AEC_DATA_PREPROCESS)
+    rc_o, dec_o, _ = oracle_decode(enc, bps, bs, rsi, AEC_DATA_PREPROCESS, nbytes)
+    assert rc_o == AEC_OK and len(dec_o) == nbytes
+    if not have_ref():
+        pytest.skip("oracle/_ref not built")
+    rc_r, dec_r = ref_decode(enc, bps, bs, rsi, AEC_DATA_PREPROCESS, nbytes)
+    assert rc_r == AEC_OK and dec_r == dec_o
