@@ -246,6 +246,26 @@ AEC_GPU_API int aec_gpu_encode_batch_async(aec_gpu_ctx *ctx, const aec_gpu_param
                                            size_t slot_bytes, aec_gpu_enc_result *d_results, void *stream);
 
 /*
+ * The same for n_chunks EQUAL chunks of whole RSIs lying back to back in d_in (chunk i = bytes [i * chunk_bytes,
+ * (i + 1) * chunk_bytes)) -- HDF5's chunks through the SZIP filter (src/sz_compat.c:170) -- as ONE launch set for
+ * the whole batch instead of one per chunk: the streams come out back to back in d_out, each zero-padded to a
+ * byte as aec_buffer_encode pads it; d_chunks[i] = where stream i starts (bits, a multiple of 8) and its length
+ * in bits, d_result->total_bits = the end of the last one, d_result->overflow = 1 if that lies beyond out_cap
+ * (the sum of aec_gpu_encode_bound(chunk_bytes) always suffices).  aec_gpu_uniform_batch_ok says whether a
+ * geometry can be taken this way (whole RSIs, at most 2048 segments of 64 blocks per chunk); if not, or for
+ * unequal chunks, use aec_gpu_encode_batch_async.
+ */
+typedef struct aec_gpu_batch_chunk {
+    uint64_t base_bits;
+    uint64_t bits;
+} aec_gpu_batch_chunk;
+AEC_GPU_API int aec_gpu_uniform_batch_ok(const aec_gpu_params *p, size_t chunk_bytes, uint64_t n_chunks);
+AEC_GPU_API int aec_gpu_encode_uniform_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                                   size_t chunk_bytes, uint64_t n_chunks, void *d_out, size_t out_cap,
+                                                   aec_gpu_batch_chunk *d_chunks, aec_gpu_enc_result *d_result,
+                                                   void *stream);
+
+/*
  * Measurement hooks (bench.py): with profiling enabled the context records HIP events on the
  * caller's stream around its kernels, one event set per call (a ring of 32), so a timed loop
  * needs no synchronisation inside it; aec_gpu_phase_ms waits for them and returns the device

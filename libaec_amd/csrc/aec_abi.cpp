@@ -718,12 +718,27 @@ struct CopyJob {
     const void *src;
     size_t n;
 };
+thread_local bool t_in_part = false;          // this thread is one of run_parts' workers: no threads of its own
+
+// Waiting for a kit's stream inside the batch paths.  With several host threads each waiting on a stream of its own,
+// hipStreamSynchronize was measured to return up to 9 ms late now and then (2.4 ms batches taking 10); polling the
+// stream does not.
+hipError_t batch_sync(hipStream_t st)
+{
+    if (!t_in_part) return hipStreamSynchronize(st);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        std::this_thread::yield();
+    }
+}
+
 void copy_all(const std::vector<CopyJob> &jobs)
 {
     size_t total = 0;
     for (const CopyJob &j : jobs) total += j.n;
     const unsigned hw = std::thread::hardware_concurrency();
-    unsigned nt = total >= ((size_t)8 << 20) ? (hw >= 8 ? 4u : (hw >= 2 ? 2u : 1u)) : 1u;
+    unsigned nt = total >= ((size_t)8 << 20) && !t_in_part ? (hw >= 8 ? 4u : (hw >= 2 ? 2u : 1u)) : 1u;
     if (nt > jobs.size()) nt = (unsigned)jobs.size();
     auto work = [&](unsigned t) {
         for (size_t i = t; i < jobs.size(); i += nt)
@@ -742,6 +757,50 @@ void copy_all(const std::vector<CopyJob> &jobs)
     }
     work(0);
     for (std::thread &x : th) x.join();
+}
+
+// A large batch as several parts side by side: every part is a batch of its own on its own kit (HIP stream,
+// context, buffers), driven by its own host thread -- the uploads of one part run beside the kernels and the
+// downloads of the others, and the launch sequences of many small chunks (5 launches per coded chunk, ~3 us of
+// host time each) are issued from several threads.  part(lo, hi) handles chunks [lo, hi) and returns what the
+// batch call would return for them; the call returns the hard error of a part if there is one, else the
+// status of the last chunk that has one (as one batch does).
+template <class Part>
+int run_parts(size_t n, size_t total_bytes, Part part)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    size_t parts = total_bytes / ((size_t)4 << 20);
+    // (at most 4: with 8, every part's synchronisation spinning on a core, the same batch took 9 ms instead of 2.4
+    // on the 16 cores of the test machine)
+    if (parts > 4) parts = 4;
+    if (hw && parts > hw / 4) parts = hw / 4;
+    if (parts > n / 4) parts = n / 4;
+    if (parts <= 1 || t_in_part) return part((size_t)0, n);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+    std::vector<int> rcs(parts, AEC_OK);
+    auto work = [&](size_t t) {
+        (void)hipSetDevice(device);
+        t_in_part = true;
+        try { rcs[t] = part(n * t / parts, n * (t + 1) / parts); }
+        catch (const std::bad_alloc &) { rcs[t] = AEC_MEM_ERROR; }
+        t_in_part = false;
+    };
+    std::vector<std::thread> th;
+    size_t started = 1;
+    try {
+        for (; started < parts; started++) th.emplace_back(work, started);
+    } catch (...) {                      // (no more threads: this one does the rest of the parts in turn)
+    }
+    work(0);
+    for (size_t t = started; t < parts; t++) work(t);
+    for (std::thread &x : th) x.join();
+    int rc = AEC_OK;
+    for (size_t t = 0; t < parts; t++)
+        if (rcs[t] != AEC_OK) rc = rcs[t];
+    for (size_t t = 0; t < parts; t++)
+        if (rcs[t] == AEC_MEM_ERROR || rcs[t] == AEC_CONF_ERROR) rc = rcs[t];
+    return rc;
 }
 
 int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src, const size_t *src_len,
@@ -868,7 +927,7 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
         if (rc != RC_OK || hipMemcpyAsync(dec.data(), d_dec, n * sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost,
                                           k.stream) != hipSuccess ||
             hipMemsetAsync(d_one, 0, sizeof(aec_gpu_dec_result), k.stream) != hipSuccess ||
-            hipStreamSynchronize(k.stream) != hipSuccess) {
+            batch_sync(k.stream) != hipSuccess) {
             return AEC_FAIL(rc != RC_OK ? rc : AEC_MEM_ERROR);
         }
         // fold the per-chunk decode status into the per-chunk index records on the host below
@@ -883,7 +942,7 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
     std::vector<aec_gpu_dec_result> res(n + 1);
     if (hipMemcpyAsync(res.data(), meta + o_res, n * sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
         hipMemcpyAsync(&res[n], meta + o_one, sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
-        hipStreamSynchronize(k.stream) != hipSuccess)
+        batch_sync(k.stream) != hipSuccess)
         return AEC_FAIL(AEC_MEM_ERROR);
     int worst = AEC_OK;
     // the outputs: through pinned staging in pieces of whole slots (one transfer per piece, then copies to the
@@ -904,7 +963,7 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
                 const size_t cnt = n - first < per_piece ? n - first : per_piece;
                 if (hipMemcpyAsync(k.h_stage, static_cast<uint8_t *>(k.d_out.p) + first * slot_out, cnt * slot_out,
                                    hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
-                    hipStreamSynchronize(k.stream) != hipSuccess)
+                    batch_sync(k.stream) != hipSuccess)
                     return AEC_FAIL(AEC_MEM_ERROR);
                 jobs.clear();
             }
@@ -918,7 +977,7 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
         if (status) status[i] = st;
         if (st != AEC_OK) worst = st;
     }
-    if (hipStreamSynchronize(k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+    if (batch_sync(k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
     return worst;
 }
 
@@ -944,6 +1003,94 @@ int encode_batch_host(const struct aec_stream *prm, size_t n, const void *const 
         if (whole > largest) largest = whole;
     }
     off[n] = total_in;
+    // Equal chunks of whole RSIs (what HDF5 hands the SZIP filter): ONE launch set for all of them, the streams
+    // back to back on the device, one transfer each way (aec_gpu_encode_uniform_batch_async)
+    {
+        bool equal = n >= 2 && src_len[0] && src_len[0] % c.bytes == 0;
+        for (size_t i = 1; i < n && equal; i++) equal = src_len[i] == src_len[0];
+        const size_t len = src_len[0];
+        if (equal && aec_gpu_uniform_batch_ok(&gp, len, n)) {
+            const size_t bound = up16(aec_gpu_encode_bound(&gp, len)), cap = n * bound;
+            const size_t o_rec = up16(n * sizeof(aec_gpu_batch_chunk));
+            if (!k.d_in.ensure(n * len + 32) || !k.d_out.ensure(cap) || !k.d_off.ensure(o_rec + 64))
+                return AEC_FAIL(AEC_MEM_ERROR);
+            aec_gpu_batch_chunk *d_chunks = static_cast<aec_gpu_batch_chunk *>(k.d_off.p);
+            aec_gpu_enc_result *d_one = reinterpret_cast<aec_gpu_enc_result *>(static_cast<uint8_t *>(k.d_off.p) + o_rec);
+            // up: through pinned staging in pieces (host copies on a few threads, one transfer per piece)
+            const size_t per_up = len <= kStagePiece ? kStagePiece / len : 0;
+            // (also large chunks: copies from and to pageable memory issued by several threads at once were measured
+            // erratic -- 2.4 or 9 ms for the same 64 MiB -- while pinned transfers plus plain memcpy are steady)
+            const bool stage_up = per_up && stage_ensure(k, (n < per_up ? n : per_up) * len);
+            for (size_t i = 0; i < n;) {
+                if (stage_up) {
+                    const size_t cnt = n - i < per_up ? n - i : per_up;
+                    if (i && batch_sync(k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+                    std::vector<CopyJob> jobs;
+                    for (size_t q = 0; q < cnt; q++) jobs.push_back(CopyJob{k.h_stage + q * len, src[i + q], len});
+                    copy_all(jobs);
+                    if (hipMemcpyAsync(static_cast<uint8_t *>(k.d_in.p) + i * len, k.h_stage, cnt * len, hipMemcpyHostToDevice,
+                                       k.stream) != hipSuccess)
+                        return AEC_FAIL(AEC_MEM_ERROR);
+                    i += cnt;
+                } else {
+                    if (hipMemcpyAsync(static_cast<uint8_t *>(k.d_in.p) + i * len, src[i], len, hipMemcpyHostToDevice,
+                                       k.stream) != hipSuccess)
+                        return AEC_FAIL(AEC_MEM_ERROR);
+                    i++;
+                }
+            }
+            rc = aec_gpu_encode_uniform_batch_async(k.ctx, &gp, k.d_in.p, len, n, k.d_out.p, cap, d_chunks, d_one, k.stream);
+            if (rc != RC_OK) return AEC_FAIL(rc);
+
+            std::vector<aec_gpu_batch_chunk> rec(n);
+            aec_gpu_enc_result one{};
+            if (hipMemcpyAsync(rec.data(), d_chunks, n * sizeof(aec_gpu_batch_chunk), hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
+                hipMemcpyAsync(&one, d_one, sizeof(one), hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
+                batch_sync(k.stream) != hipSuccess)
+                return AEC_FAIL(AEC_MEM_ERROR);
+            if (one.overflow) return AEC_FAIL(AEC_MEM_ERROR);                     // (cannot happen: cap is the sum of the bounds)
+
+            // down: the packed streams in pieces of whole streams through the staging buffer
+            int worst = AEC_OK;
+            const size_t total = (size_t)(one.total_bits / 8);
+            const bool stage_down = stage_ensure(k, total < kStagePiece ? (total ? total : 16) : kStagePiece);
+            for (size_t i = 0; i < n;) {
+                const size_t lo = (size_t)(rec[i].base_bits / 8);
+                size_t j = i, hi = lo;
+                while (j < n && (size_t)(rec[j].base_bits / 8) + (size_t)((rec[j].bits + 7) / 8) - lo <= k.h_stage_cap) {
+                    hi = (size_t)(rec[j].base_bits / 8) + (size_t)((rec[j].bits + 7) / 8);
+                    j++;
+                }
+                const bool piece = stage_down && j > i;
+                if (piece) {
+                    if (hipMemcpyAsync(k.h_stage, static_cast<uint8_t *>(k.d_out.p) + lo, hi - lo, hipMemcpyDeviceToHost,
+                                       k.stream) != hipSuccess ||
+                        batch_sync(k.stream) != hipSuccess)
+                        return AEC_FAIL(AEC_MEM_ERROR);
+                } else {
+                    j = i + 1;
+                }
+                std::vector<CopyJob> jobs;
+                for (size_t q = i; q < j; q++) {
+                    size_t bytes = (size_t)((rec[q].bits + 7) / 8);
+                    int st = AEC_OK;
+                    if (bytes > dst_len[q]) { st = AEC_STREAM_ERROR; bytes = dst_len[q]; }     // as aec_buffer_encode: a prefix
+                    const size_t at = (size_t)(rec[q].base_bits / 8);
+                    if (piece) jobs.push_back(CopyJob{dst[q], k.h_stage + (at - lo), bytes});
+                    else if (bytes && hipMemcpyAsync(dst[q], static_cast<uint8_t *>(k.d_out.p) + at, bytes, hipMemcpyDeviceToHost,
+                                                     k.stream) != hipSuccess)
+                        return AEC_FAIL(AEC_MEM_ERROR);
+                    dst_len[q] = bytes;
+                    if (status) status[q] = st;
+                    if (st != AEC_OK) worst = st;
+                }
+                copy_all(jobs);
+                i = j;
+            }
+            if (batch_sync(k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+            return worst;
+        }
+    }
     const size_t slot = aec_gpu_encode_bound(&gp, largest);
     if (!k.d_in.ensure(total_in + 32) || !k.d_out.ensure(n * slot) || !k.d_off.ensure(n * sizeof(aec_gpu_enc_result) + 64))
         return AEC_FAIL(AEC_MEM_ERROR);
@@ -961,7 +1108,7 @@ int encode_batch_host(const struct aec_stream *prm, size_t n, const void *const 
                 size_t j = i;
                 while (j < n && off[j + 1] - off[i] <= k.h_stage_cap) j++;
                 if (j == i) return AEC_FAIL(AEC_MEM_ERROR);                       // (cannot happen: a chunk fits)
-                if (i && hipStreamSynchronize(k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);   // staging is free again
+                if (i && batch_sync(k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);   // staging is free again
                 std::vector<CopyJob> jobs;
                 for (size_t q = i; q < j; q++)
                     jobs.push_back(CopyJob{k.h_stage + (off[q] - off[i]), src[q], src_len[q] - src_len[q] % c.bytes});
@@ -982,7 +1129,7 @@ int encode_batch_host(const struct aec_stream *prm, size_t n, const void *const 
     }
     std::vector<aec_gpu_enc_result> res(n);
     if (hipMemcpyAsync(res.data(), d_res, n * sizeof(aec_gpu_enc_result), hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
-        hipStreamSynchronize(k.stream) != hipSuccess)
+        batch_sync(k.stream) != hipSuccess)
         return AEC_FAIL(AEC_MEM_ERROR);
     int worst = AEC_OK;
     // many small streams: whole slots through pinned staging, piece by piece (a transfer per piece beats a copy
@@ -1003,7 +1150,7 @@ int encode_batch_host(const struct aec_stream *prm, size_t n, const void *const 
                 const size_t cnt = n - first < per_piece ? n - first : per_piece;
                 if (hipMemcpyAsync(k.h_stage, static_cast<uint8_t *>(k.d_out.p) + first * slot, cnt * slot,
                                    hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
-                    hipStreamSynchronize(k.stream) != hipSuccess)
+                    batch_sync(k.stream) != hipSuccess)
                     return AEC_FAIL(AEC_MEM_ERROR);
                 out_jobs.clear();
             }
@@ -1016,7 +1163,7 @@ int encode_batch_host(const struct aec_stream *prm, size_t n, const void *const 
         if (status) status[i] = st;
         if (st != AEC_OK) worst = st;
     }
-    if (hipStreamSynchronize(k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+    if (batch_sync(k.stream) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
     return worst;
 }
 
@@ -1027,15 +1174,25 @@ extern "C" {
 int aec_buffer_decode_batch(const struct aec_stream *params, size_t n, const void *const *src, const size_t *src_len,
                             void *const *dst, size_t *dst_len, int *status)
 {
-    try { return decode_batch(params, n, src, src_len, dst, dst_len, status); }
-    catch (const std::bad_alloc &) { return AEC_MEM_ERROR; }
+    try {
+        size_t total = 0;
+        for (size_t i = 0; i < n; i++) total += dst_len[i];
+        return run_parts(n, total, [&](size_t lo, size_t hi) {
+            return decode_batch(params, hi - lo, src + lo, src_len + lo, dst + lo, dst_len + lo, status ? status + lo : nullptr);
+        });
+    } catch (const std::bad_alloc &) { return AEC_MEM_ERROR; }
 }
 
 int aec_buffer_encode_batch(const struct aec_stream *params, size_t n, const void *const *src, const size_t *src_len,
                             void *const *dst, size_t *dst_len, int *status)
 {
-    try { return encode_batch_host(params, n, src, src_len, dst, dst_len, status); }
-    catch (const std::bad_alloc &) { return AEC_MEM_ERROR; }
+    try {
+        size_t total = 0;
+        for (size_t i = 0; i < n; i++) total += src_len[i];
+        return run_parts(n, total, [&](size_t lo, size_t hi) {
+            return encode_batch_host(params, hi - lo, src + lo, src_len + lo, dst + lo, dst_len + lo, status ? status + lo : nullptr);
+        });
+    } catch (const std::bad_alloc &) { return AEC_MEM_ERROR; }
 }
 
 int aec_encode_init(struct aec_stream *strm)

@@ -894,6 +894,91 @@ k_scan_apply(const uint32_t *__restrict__ seg_bits, const uint16_t *__restrict__
     }
 }
 
+// ---- a batch of equal, RSI-aligned chunks as ONE launch set ---------------------------------------------
+// The chunks of a batch (aec_gpu_encode_uniform_batch_async) lie back to back in the input and are analysed
+// and packed as one long input -- an RSI never looks across its borders -- with two differences, both in the
+// scan: the k carried into a chunk is 0, and a chunk's stream starts on the byte behind the end of the one in
+// front (every stream zero-padded to a byte as aec_buffer_encode pads it).  A chunk has at most kScanChunk
+// segments, so one workgroup scans one chunk: totals, then the chunks' bases (one workgroup), then the start
+// bit and k of every segment.
+__global__ void __launch_bounds__(256)
+k_batch_reduce(const uint32_t *__restrict__ seg_bits, uint32_t segs, BatchChunk *__restrict__ chunks)
+{
+    __shared__ ScanVal sh[4];
+    const uint64_t first = (uint64_t)blockIdx.x * segs;
+    ScanVal acc = scan_identity();
+#pragma unroll
+    for (uint32_t i = 0; i < kScanItems; i++) {
+        const uint32_t s = threadIdx.x * kScanItems + i;
+        if (s < segs) acc.bits += seg_bits[first + s];
+    }
+    ScanVal total;
+    block_excl_scan(acc, total, sh);
+    if (threadIdx.x == 0) chunks[blockIdx.x].bits = total.bits;
+}
+
+__global__ void __launch_bounds__(256)
+k_batch_bases(BatchChunk *chunks, uint64_t n, uint64_t cap_bytes, EncResult *res)
+{
+    __shared__ ScanVal sh[4];
+    const uint64_t per = (n + 255) / 256;
+    const uint64_t lo = (uint64_t)threadIdx.x * per;
+    uint64_t hi = lo + per;
+    if (hi > n) hi = n;
+    ScanVal acc = scan_identity();
+    for (uint64_t i = lo; i < hi; i++) acc.bits += (chunks[i].bits + 7) / 8;
+    ScanVal total;
+    ScanVal run = block_excl_scan(acc, total, sh);
+    for (uint64_t i = lo; i < hi; i++) {
+        chunks[i].base_bits = run.bits * 8;
+        run.bits += (chunks[i].bits + 7) / 8;
+    }
+    if (threadIdx.x == 0) {
+        res->total_bits = total.bits * 8;
+        res->k_out = 0;
+        res->overflow = total.bits > cap_bytes ? 1u : 0u;
+        res->k_lo = 0;
+        res->k_hi = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_batch_apply(const uint32_t *__restrict__ seg_bits, const uint16_t *__restrict__ seg_clamp, uint32_t segs,
+              const BatchChunk *__restrict__ chunks, uint64_t *__restrict__ seg_start, uint8_t *__restrict__ seg_kin,
+              uint32_t *__restrict__ out_words, uint64_t cap_words, uint32_t segs_per_wave)
+{
+    __shared__ ScanVal sh[4];
+    const uint64_t first = (uint64_t)blockIdx.x * segs;
+    ScanVal item[kScanItems];
+    ScanVal acc = scan_identity();
+#pragma unroll
+    for (uint32_t i = 0; i < kScanItems; i++) {
+        const uint32_t s = threadIdx.x * kScanItems + i;
+        item[i] = (s < segs) ? ScanVal{seg_bits[first + s], seg_clamp[first + s]} : scan_identity();
+        acc = scan_then(acc, item[i]);
+    }
+    ScanVal total;
+    ScanVal run = block_excl_scan(acc, total, sh);
+    const uint64_t base = chunks[blockIdx.x].base_bits;
+#pragma unroll
+    for (uint32_t i = 0; i < kScanItems; i++) {
+        const uint32_t s = threadIdx.x * kScanItems + i;
+        if (s < segs) {
+            const uint64_t bit = base + run.bits;
+            seg_start[first + s] = bit;
+            seg_kin[first + s] = (uint8_t)kclamp_apply(clamp_unpack(run.cl), 0u);
+            // (as k_scan_apply: the word a wave's first segment starts in is shared with its neighbour)
+            if (((first + s) % segs_per_wave) == 0 && (bit >> 5) < cap_words) out_words[bit >> 5] = 0u;
+        }
+        run = scan_then(run, item[i]);
+    }
+    if (threadIdx.x == 0) {                         // the chunk's open last word (+ one: its byte padding)
+        const uint64_t end = base + total.bits;
+        for (uint64_t w = end >> 5; w <= (end >> 5) + 1; w++)
+            if (w < cap_words) out_words[w] = 0u;
+    }
+}
+
 // segment table for segment-parallel decoding: start bit + preceding raw sample per segment
 __global__ void __launch_bounds__(256)
 k_seg_table(const Cfg c, const uint8_t *__restrict__ in, const uint64_t *__restrict__ seg_start,
@@ -1708,6 +1793,30 @@ void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out
         if (nseg) dispatch(true, c, d_in, ws, out_words, cap_words, fast_ok, st);
         mark(4);
     }
+}
+
+// c describes the concatenation of n_chunks chunks of segs_per_chunk segments each (whole RSIs)
+bool batch_uniform_ok(const Cfg &c, uint64_t segs_per_chunk)
+{
+    if (segs_per_chunk == 0 || segs_per_chunk > kScanChunk || c.total_segs % segs_per_chunk) return false;
+    return segs_per_chunk % make_geom(c, true).segs_per_wave == 0;       // no wavefront works across a chunk border
+}
+
+void launch_encode_uniform_batch(const Cfg &c, const uint8_t *d_in, uint64_t segs_per_chunk, uint8_t *d_out,
+                                 size_t out_cap, const EncWorkspace &ws, BatchChunk *d_chunks, EncResult *d_res,
+                                 hipStream_t st)
+{
+    uint32_t *out_words = reinterpret_cast<uint32_t *>(d_out);
+    const uint64_t cap_words = out_cap / 4;
+    const uint32_t n = (uint32_t)(c.total_segs / segs_per_chunk);
+    const uint32_t fast_ok = ((reinterpret_cast<uintptr_t>(d_in) & 15u) == 0 &&
+                              ((uint64_t)c.rsi * c.bs * c.bytes) % 16 == 0) ? 1u : 0u;
+    dispatch(false, c, d_in, ws, nullptr, 0, fast_ok, st);
+    hipLaunchKernelGGL(k_batch_reduce, dim3(n), dim3(256), 0, st, ws.seg_bits, (uint32_t)segs_per_chunk, d_chunks);
+    hipLaunchKernelGGL(k_batch_bases, dim3(1), dim3(256), 0, st, d_chunks, (uint64_t)n, (uint64_t)out_cap, d_res);
+    hipLaunchKernelGGL(k_batch_apply, dim3(n), dim3(256), 0, st, ws.seg_bits, ws.seg_clamp, (uint32_t)segs_per_chunk,
+                       d_chunks, ws.seg_start, ws.seg_kin, out_words, cap_words, make_geom(c, true).segs_per_wave);
+    dispatch(true, c, d_in, ws, out_words, cap_words, fast_ok, st);
 }
 
 }  // namespace aec

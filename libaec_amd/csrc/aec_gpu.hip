@@ -477,6 +477,49 @@ int aec_gpu_encode_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const 
     return RC_OK;
 }
 
+int aec_gpu_encode_uniform_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t chunk_bytes,
+                                       uint64_t n_chunks, void *d_out, size_t out_cap, aec_gpu_batch_chunk *d_chunks,
+                                       aec_gpu_enc_result *d_result, void *stream)
+{
+    static_assert(sizeof(aec_gpu_batch_chunk) == sizeof(BatchChunk), "public mirror of BatchChunk");
+    if (!n_chunks || !chunk_bytes || (reinterpret_cast<uintptr_t>(d_out) & 15u) || (out_cap & 15u) || out_cap < 16)
+        return RC_CONF_ERROR;
+    Cfg one, c;
+    int rc = cfg_from(p, chunk_bytes, true, &one);
+    if (rc != RC_OK) return rc;
+    const size_t rsi_bytes = (size_t)one.rsi * one.bs * one.bytes;
+    if (chunk_bytes % rsi_bytes) return RC_CONF_ERROR;                       // whole RSIs only
+    rc = cfg_from(p, chunk_bytes * n_chunks, true, &c);
+    if (rc != RC_OK) return rc;
+    if (!batch_uniform_ok(c, one.total_segs)) return RC_CONF_ERROR;          // (aec_gpu_uniform_batch_ok says so beforehand)
+    rc = reserve_two_pass(ctx, c);
+    if (rc != RC_OK) return rc;
+    (void)hipGetLastError();
+    size_t o[6];
+    enc_workspace_bytes(c, &o[0], &o[1], &o[2], &o[3], &o[4], &o[5]);
+    uint8_t *base = static_cast<uint8_t *>(ctx->ws);
+    EncWorkspace ws{};
+    ws.meta = reinterpret_cast<uint32_t *>(base + o[0]);
+    ws.seg_bits = reinterpret_cast<uint32_t *>(base + o[1]);
+    ws.seg_clamp = reinterpret_cast<uint16_t *>(base + o[2]);
+    ws.seg_start = reinterpret_cast<uint64_t *>(base + o[3]);
+    ws.seg_kin = base + o[4];
+    ws.partials = reinterpret_cast<ScanPartial *>(base + o[5]);
+    launch_encode_uniform_batch(c, static_cast<const uint8_t *>(d_in), one.total_segs, static_cast<uint8_t *>(d_out),
+                                out_cap, ws, reinterpret_cast<BatchChunk *>(d_chunks),
+                                reinterpret_cast<EncResult *>(d_result), static_cast<hipStream_t>(stream));
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
+}
+
+int aec_gpu_uniform_batch_ok(const aec_gpu_params *p, size_t chunk_bytes, uint64_t n_chunks)
+{
+    Cfg one, c;
+    if (!n_chunks || !chunk_bytes || cfg_from(p, chunk_bytes, true, &one) != RC_OK) return 0;
+    if (chunk_bytes % ((size_t)one.rsi * one.bs * one.bytes)) return 0;
+    if (cfg_from(p, chunk_bytes * n_chunks, true, &c) != RC_OK) return 0;
+    return batch_uniform_ok(c, one.total_segs) ? 1 : 0;
+}
+
 int aec_gpu_profile(aec_gpu_ctx *ctx, int enable)
 {
     if (enable) {

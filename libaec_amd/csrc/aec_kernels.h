@@ -90,6 +90,18 @@ void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out
                    uint32_t phases = ENC_ALL, SegEntry *d_seg_table = nullptr,
                    const ShardCarry *d_carry = nullptr);
 
+// A batch of n equal chunks of whole RSIs, back to back in d_in, as one launch set (aec_enc.hip): every chunk is a
+// stream of its own (k = 0, zero-padded to a byte), the streams lie back to back in d_out; d_chunks[i] says where
+// chunk i's stream starts and how long it is, d_res->total_bits where the last one ends (overflow: beyond out_cap).
+struct BatchChunk {
+    uint64_t base_bits;     // multiple of 8
+    uint64_t bits;
+};
+bool batch_uniform_ok(const Cfg &c, uint64_t segs_per_chunk);
+void launch_encode_uniform_batch(const Cfg &c, const uint8_t *d_in, uint64_t segs_per_chunk, uint8_t *d_out,
+                                 size_t out_cap, const EncWorkspace &ws, BatchChunk *d_chunks, EncResult *d_res,
+                                 hipStream_t stream);
+
 // One stream over several devices (aec_shard.hip): carry-in of shard `rank` from the plan records of
 // all shards; reassembly of the gathered slices into one stream.
 void launch_shard_carry(const EncResult *d_plans, uint32_t rank, ShardCarry *d_carry, hipStream_t stream);

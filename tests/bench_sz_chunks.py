@@ -2,7 +2,8 @@
 """Chunked SZIP throughput (run on the GPU box): an HDF5-style dataset of 1 MiB chunks of 8-bit pixels
 (BASELINE config 5 shape) through (a) one SZ_BufftoBuff call per chunk, (b) SZ_BatchCompress /
 SZ_BatchDecompress with all chunks in one call, (c) the reference shim on one core.  Host buffers in and
-out (pageable): these are PCIe-inclusive rates."""
+out (pageable, allocated and touched beforehand): the time is that of the library calls alone, as a C caller
+such as HDF5's filter sees it -- PCIe both ways included, Python's own copies not; best of 6 calls."""
 import ctypes as C
 import os
 import sys
@@ -28,33 +29,64 @@ def run(n, chunk):
     opts = szip.SZ_NN_OPTION_MASK | szip.SZ_RAW_OPTION_MASK
     data = gen(2, n * chunk)
     chunks = [data[i * chunk:(i + 1) * chunk] for i in range(n)]
-    sizes = [chunk * 2] * n
-    szip.compress(chunks[0], chunk * 2, opts, 8, 8, 1024)                      # warm up
+    lib = szip.library()
+    prm = szip.SZ_com_t(opts, 8, 8, 1024)
 
-    def timed(fn, reps=3):
-        best = 1e9
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            out = fn()
-            best = min(best, time.perf_counter() - t0)
-        return best, out
+    def one_by_one(lib_, name, srcs, cap):
+        """n calls of SZ_BufftoBuff*: returns (seconds of the calls, outputs)"""
+        fn = getattr(lib_, name)
+        fn.restype = C.c_int
+        outs = [np.ones(cap, dtype=np.uint8) for _ in srcs]
+        lens = [C.c_size_t(cap) for _ in srcs]
+        t0 = time.perf_counter()
+        for s, o, ln in zip(srcs, outs, lens):
+            rc = fn(C.c_void_p(o.ctypes.data), C.byref(ln), C.c_void_p(s.ctypes.data), C.c_size_t(s.size), C.byref(prm))
+            assert rc == 0
+        t = time.perf_counter() - t0
+        return t, [o[:ln.value] for o, ln in zip(outs, lens)]
 
-    t, comp = timed(lambda: [szip.compress(c, chunk * 2, opts, 8, 8, 1024)[1] for c in chunks])
-    print(f"compress   {n} x {chunk >> 10} KiB, one call per chunk : {t * 1e3:8.2f} ms  {n * chunk / t / 1e9:7.2f} GB/s")
-    t, (rc, comp_b, st) = timed(lambda: szip.compress_batch(chunks, sizes, opts, 8, 8, 1024))
-    assert rc == 0 and comp_b == comp
-    print(f"compress   {n} x {chunk >> 10} KiB, SZ_BatchCompress       : {t * 1e3:8.2f} ms  {n * chunk / t / 1e9:7.2f} GB/s")
-    t, dec = timed(lambda: [szip.decompress(c, chunk, opts, 8, 8, 1024)[1] for c in comp])
-    assert dec == [c.tobytes() for c in chunks]
-    print(f"decompress {n} x {chunk >> 10} KiB, one call per chunk : {t * 1e3:8.2f} ms  {n * chunk / t / 1e9:7.2f} GB/s")
-    t, (rc, dec_b, st) = timed(lambda: szip.decompress_batch(comp, [chunk] * n, opts, 8, 8, 1024))
-    assert rc == 0 and dec_b == dec
-    print(f"decompress {n} x {chunk >> 10} KiB, SZ_BatchDecompress     : {t * 1e3:8.2f} ms  {n * chunk / t / 1e9:7.2f} GB/s")
+    def batch(name, srcs, cap):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        k = len(srcs)
+        outs = [np.ones(cap, dtype=np.uint8) for _ in srcs]
+        src = (C.c_void_p * k)(*[a.ctypes.data for a in srcs])
+        src_len = (C.c_size_t * k)(*[a.size for a in srcs])
+        dst = (C.c_void_p * k)(*[o.ctypes.data for o in outs])
+        dst_len = (C.c_size_t * k)(*[cap] * k)
+        status = (C.c_int * k)()
+        t0 = time.perf_counter()
+        rc = fn(dst, dst_len, src, src_len, C.c_size_t(k), C.byref(prm), status)
+        t = time.perf_counter() - t0
+        assert rc == 0 and not any(status)
+        return t, [o[:dst_len[i]] for i, o in enumerate(outs)]
+
+    def best(fn, reps=6):
+        """steady state: the first calls of a process (kits, code objects, pinned staging; the batch entry points
+        need three calls to settle: ~180, 9, 9 ms, then the figures below) are not what a dataset of thousands of
+        chunks sees"""
+        res = [fn() for _ in range(reps)]
+        return min(r[0] for r in res), res[-1][1]
+
+    one_by_one(lib, "SZ_BufftoBuffCompress", chunks[:1], chunk * 2)            # warm up
+    gb = n * chunk / 1e9
+    t, comp = best(lambda: one_by_one(lib, "SZ_BufftoBuffCompress", chunks, chunk * 2))
+    print(f"compress   {n} x {chunk >> 10} KiB, one call per chunk : {t * 1e3:8.2f} ms  {gb / t:7.2f} GB/s")
+    t, comp_b = best(lambda: batch("SZ_BatchCompress", chunks, chunk * 2))
+    assert all(np.array_equal(a, b) for a, b in zip(comp, comp_b))
+    print(f"compress   {n} x {chunk >> 10} KiB, SZ_BatchCompress       : {t * 1e3:8.2f} ms  {gb / t:7.2f} GB/s")
+    comp = [np.ascontiguousarray(c) for c in comp]
+    t, dec = best(lambda: one_by_one(lib, "SZ_BufftoBuffDecompress", comp, chunk))
+    assert all(np.array_equal(a, b) for a, b in zip(dec, chunks))
+    print(f"decompress {n} x {chunk >> 10} KiB, one call per chunk : {t * 1e3:8.2f} ms  {gb / t:7.2f} GB/s")
+    t, dec_b = best(lambda: batch("SZ_BatchDecompress", comp, chunk))
+    assert all(np.array_equal(a, b) for a, b in zip(dec_b, chunks))
+    print(f"decompress {n} x {chunk >> 10} KiB, SZ_BatchDecompress     : {t * 1e3:8.2f} ms  {gb / t:7.2f} GB/s")
     if have_ref():
-        ref = szip.bind(C.CDLL(REF_SO))
-        t, _ = timed(lambda: [szip.compress(c, chunk * 2, opts, 8, 8, 1024, lib=ref)[1] for c in chunks[:8]], 1)
+        ref = C.CDLL(REF_SO)
+        t, _ = one_by_one(ref, "SZ_BufftoBuffCompress", chunks[:8], chunk * 2)
         print(f"compress   reference shim, one core          : {t / 8 * n * 1e3:8.2f} ms  {8 * chunk / t / 1e9:7.2f} GB/s")
-        t, _ = timed(lambda: [szip.decompress(c, chunk, opts, 8, 8, 1024, lib=ref)[1] for c in comp[:8]], 1)
+        t, _ = one_by_one(ref, "SZ_BufftoBuffDecompress", comp[:8], chunk)
         print(f"decompress reference shim, one core          : {t / 8 * n * 1e3:8.2f} ms  {8 * chunk / t / 1e9:7.2f} GB/s")
 
 
