@@ -92,7 +92,10 @@ LIBAEC_API int aec_buffer_decode(struct aec_stream *strm);
  * (corrupt stream), AEC_STREAM_ERROR (encode: output did not fit, a prefix was written).  The chunks travel
  * through pinned staging (one transfer per piece of 64 MiB); decode: the RSI starts of a whole group of chunks
  * from ONE table launch (low-entropy chunks of tens of KiB and more) or one wavefront per chunk (small chunks),
- * then one decode launch per group; encode: the encoder kernels per chunk.  Returns AEC_OK or the last non-OK status.
+ * then one decode launch per group; encode: equal chunks of whole RSIs -- the usual HDF5 case -- are analysed,
+ * scanned and packed by ONE launch set for all of them (aec_gpu_encode_uniform_batch_async), other shapes by the
+ * encoder kernels chunk after chunk.  Batches of more than a few MiB run as up to four parts side by side, each on
+ * a HIP stream of its own.  Returns AEC_OK or the last non-OK status.
  */
 LIBAEC_API int aec_buffer_encode_batch(const struct aec_stream *params, size_t n, const void *const *src,
                                        const size_t *src_len, void *const *dst, size_t *dst_len, int *status);
