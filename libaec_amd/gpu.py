@@ -68,6 +68,10 @@ def _lib():
         lib.aec_gpu_decode_segments_async.argtypes = [vp, pp, vp, sz, vp, u64, u64, vp, vp, vp]
         lib.aec_gpu_index_batch_async.restype = C.c_int
         lib.aec_gpu_index_batch_async.argtypes = [vp, pp, vp, sz, vp, u64, u64, vp, vp, vp]
+        lib.aec_gpu_uniform_batch_ok.restype = C.c_int
+        lib.aec_gpu_uniform_batch_ok.argtypes = [pp, sz, u64]
+        lib.aec_gpu_encode_uniform_batch_async.restype = C.c_int
+        lib.aec_gpu_encode_uniform_batch_async.argtypes = [vp, pp, vp, sz, u64, vp, sz, vp, vp, vp]
         lib.aec_gpu_index_async.restype = C.c_int
         lib.aec_gpu_index_async.argtypes = [vp, pp, vp, sz, u64, vp, u64, vp, vp]
         _bound = True
@@ -237,6 +241,29 @@ class Codec:
             C.c_void_p(d_results.data_ptr()), self._stream(stream))
         if rc != 0:
             raise RuntimeError(f"aec_gpu_index_batch_async failed ({rc})")
+
+    def encode_uniform_batch(self, d_in, chunk_bytes, n_chunks):
+        """n equal chunks of whole RSIs, back to back in d_in, as one launch set (include/aec_gpu.h:
+        aec_gpu_encode_uniform_batch_async).  Returns (d_out, records) with records[i] = (base_bits, bits) of
+        stream i inside d_out; synchronises."""
+        torch = self.torch
+        if not self.lib.aec_gpu_uniform_batch_ok(C.byref(self.p), chunk_bytes, n_chunks):
+            raise ValueError("not a uniform batch (whole RSIs, at most 2048 segments per chunk)")
+        cap = (self.encode_bound(chunk_bytes) + 15) // 16 * 16 * n_chunks
+        d_out = torch.empty(cap, dtype=torch.uint8, device=d_in.device)
+        d_rec = torch.zeros(n_chunks * 2, dtype=torch.int64, device=d_in.device)
+        d_res = torch.zeros(ENC_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=d_in.device)
+        rc = self.lib.aec_gpu_encode_uniform_batch_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), chunk_bytes, n_chunks,
+            C.c_void_p(d_out.data_ptr()), cap, C.c_void_p(d_rec.data_ptr()), C.c_void_p(d_res.data_ptr()),
+            self._stream(None))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_encode_uniform_batch_async failed ({rc})")
+        rec = d_rec.cpu().numpy().reshape(n_chunks, 2)
+        res = d_res.cpu().numpy().view(ENC_RESULT_DTYPE)[0]
+        if res["overflow"]:
+            raise RuntimeError("encode overflow")
+        return d_out, rec
 
     # ---- convenience (synchronising) -------------------------------------------------------------
     def encode(self, d_in, start_bit=0, k_in=0):

@@ -701,3 +701,33 @@ def test_overlong_coded_data_sets_of_a_foreign_encoder(api, bps, bs, rsi, n_rsi,
         got_all += got
     d.end()
     assert bytes(got_all) == dec_o
+
+
+@pytest.mark.parametrize("bps,bs,rsi,flags,n_rsi,n_chunks", [
+    (8, 8, 128, PP, 64, 40),              # the SZIP shape: 64 KiB chunks
+    (16, 16, 128, PP, 8, 33),
+    (32, 32, 16, PP | MSB | SGN, 4, 17),
+    (12, 64, 5, PP, 3, 9),
+])
+def test_uniform_batch_encode_device_api(gpu, bps, bs, rsi, flags, n_rsi, n_chunks):
+    """aec_gpu_encode_uniform_batch_async: n equal chunks as ONE launch set -- every stream must be what the
+    oracle makes of its chunk alone (k from 0, zero-padded to a byte), the streams back to back."""
+    import torch
+    rng = np.random.default_rng(bps * 3 + n_chunks)
+    nb = bytes_per_sample(bps, flags)
+    chunk_samples = bs * rsi * n_rsi
+    vals = random_walk_samples(rng, chunk_samples * n_chunks, bps, flags, scale=2.5, zero_frac=0.2)
+    data = pack_samples(vals, bps, flags)
+    chunk_bytes = chunk_samples * nb
+    codec = gpu.Codec(bps, bs, rsi, flags)
+    d_in = torch.from_numpy(np.ascontiguousarray(data)).to("cuda:0")
+    d_out, rec = codec.encode_uniform_batch(d_in, chunk_bytes, n_chunks)
+    out = d_out.cpu().numpy()
+    at = 0
+    for i in range(n_chunks):
+        rc, want, *_ = oracle_encode(data[i * chunk_bytes:(i + 1) * chunk_bytes], bps, bs, rsi, flags)
+        assert rc == AEC_OK
+        base, bits = int(rec[i, 0]), int(rec[i, 1])
+        assert base == at * 8 and (bits + 7) // 8 == len(want), (i, base, bits, len(want))
+        assert out[at:at + len(want)].tobytes() == want, i
+        at += len(want)
