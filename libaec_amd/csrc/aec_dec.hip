@@ -371,7 +371,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
 
     // Blocks of 8 samples: UNR = 2 of them per loop iteration -- the ring top-up, the landing of the loads
     // in flight and the issue of the next ones are paid once per 16 samples like for the larger blocks.
-    constexpr uint32_t UNR = dec_unroll(BS);
+    constexpr uint32_t UNR = (STG && G % dec_unroll(BS) != 0) ? 1u : dec_unroll(BS);   // (a row holds whole top-up groups)
     // The loop body covers one whole staging group (OU top-ups of UNR blocks = the G blocks of a row), so
     // the flush at its end is straight-line code: the wait that lands the loads in flight can then be
     // counted past the flush's stores (vmcnt(n), n = the stores behind the loads) instead of draining
