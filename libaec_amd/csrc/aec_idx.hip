@@ -583,7 +583,7 @@ __global__ void k_texpand(const Cfg c, const TwTables t, const TrTables tt, cons
 // Output for the candidates inside the core: the window's part of the global bitmap / prefix table
 // and its records (SparseTables above).
 struct Spec2Geom {
-    uint32_t lead, core, look, stride, burn, cap_lds, cap_core, fast;
+    uint32_t lead, core, look, stride, burn, cap_lds, cap_core, fast, refill;
 };
 
 __global__ void __launch_bounds__(1024)
@@ -593,7 +593,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         unsigned long long *__restrict__ prof, const uint64_t *__restrict__ starts = nullptr, uint32_t nstarts = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
-    __shared__ uint32_t sh_total, sh_next[2];
+    __shared__ uint32_t sh_total, sh_next[2], sh_part[16];
     // (diagnostic builds of the host pass `prof`: shader-clock stamps at the phase boundaries)
     auto stamp = [&](int k) {
         if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
@@ -609,7 +609,8 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     uint16_t *cnxt = cpos + cap;
     uint16_t *chop4 = cnxt + cap;
     uint16_t *chop16 = chop4 + cap;
-    uint16_t *ua = chop16 + cap;
+    uint16_t *csucc = chop16 + cap;
+    uint16_t *ua = csucc + cap;
     uint16_t *ub = ua + cap;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const uint64_t core_abs = tab_lo + (uint64_t)blockIdx.x * g.core;
@@ -635,22 +636,34 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         if (i < nw) marks[i] = 0u;
     }
     __syncthreads();
-    // prefix counts of 1-bits (and, further down, of marks) per word: one wave, 64 words per round
+    // prefix counts of 1-bits (and, further down, of marks) per word: every wavefront scans its slice of the
+    // words (64 per round), then adds what the slices in front of it hold  (contains two barriers)
     auto prefix16 = [&](const uint32_t *src, uint16_t *dst) {
-        if (tid < 64) {
-            uint32_t carry = 0;
-            for (uint32_t base = 0; base < nw; base += 64) {
-                const uint32_t i = base + tid;
-                const uint32_t pc = i < nw ? (uint32_t)__popc(src[i]) : 0u;
-                const uint32_t incl = wave_incl_sum_dpp(pc);
-                if (i < nw) dst[i + 1] = (uint16_t)(carry + incl);
-                carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            }
-            if (tid == 0) {
-                dst[0] = 0;
-                sh_total = carry;
-            }
+        const uint32_t nwv = nt >> 6, wv = tid >> 6, ln = tid & 63u;
+        const uint32_t per = ((nw + nwv - 1u) / nwv + 63u) & ~63u;          // words per wavefront
+        const uint32_t lo = wv * per, hi = lo + per < nw ? lo + per : nw;
+        uint32_t carry = 0;
+        for (uint32_t base = lo; base < hi; base += 64) {
+            const uint32_t i = base + ln;
+            const uint32_t pc = i < hi ? (uint32_t)__popc(src[i]) : 0u;
+            const uint32_t incl = wave_incl_sum_dpp(pc);
+            if (i < hi) dst[i + 1] = (uint16_t)(carry + incl);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
+        if (ln == 0) sh_part[wv] = carry;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t v = 0; v < nwv; v++) {
+            const uint32_t t = sh_part[v];
+            before += v < wv ? t : 0u;
+            all += t;
+        }
+        for (uint32_t i = lo + ln; i < hi; i += 64) dst[i + 1] = (uint16_t)(dst[i + 1] + before);
+        if (tid == 0) {
+            dst[0] = 0;
+            sh_total = all;
+        }
+        __syncthreads();
     };
     prefix16(win, rank);
     __syncthreads();
@@ -665,10 +678,10 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     // a coded data set without / with (`ref`) a reference sample: the straight-line parse, the full one where a
     // unary part does not end inside its 64-bit peek (rare at the coded rates this kernel is chosen for)
     const bool use_fast = g.fast != 0;
-    auto cds = [&](uint32_t q, uint32_t ref, uint32_t &run) -> uint32_t {
-        if (!use_fast) return spec_cds(s, c, q, ref, run);
-        uint32_t len = spec_cds_fast<2>(win, s.limit, c, q, run, ref);
-        if (len == kSpecUnresolved) len = spec_cds(s, c, q, ref, run);
+    auto cds1 = [&](uint32_t q, uint32_t &run) -> uint32_t {
+        if (!use_fast) return spec_cds(s, c, q, 1u, run);
+        uint32_t len = spec_cds_fast<1>(win, s.limit, c, q, run);
+        if (len == kSpecUnresolved) len = spec_cds(s, c, q, 1u, run);
         return len;
     };
     auto cds0 = [&](uint32_t q, uint32_t &run) -> uint32_t {
@@ -741,10 +754,12 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     }
     __syncthreads();
     stamp(3);
-    S2Win w{s, marks, mpre, cnxt, chop4, chop16, ncand};
-    for (uint32_t i = tid; i < ncand; i += nt) chop4[i] = s2_hop4(w, c, cpos, i);
+    S2Win w{s, marks, mpre, cnxt, csucc, chop4, chop16, cpos, ncand};
+    for (uint32_t i = tid; i < ncand; i += nt) csucc[i] = s2_succ(w, i);
     __syncthreads();
-    for (uint32_t i = tid; i < ncand; i += nt) chop16[i] = s2_hop16(w, cpos, i);
+    for (uint32_t i = tid; i < ncand; i += nt) chop4[i] = s2_hop4(w, c, i);
+    __syncthreads();
+    for (uint32_t i = tid; i < ncand; i += nt) chop16[i] = s2_hop16(w, i);
     __syncthreads();
     stamp(4);
     // ---- 3. the RSI hypothesis at every candidate of the core
@@ -760,36 +775,75 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     // next candidate at once; B. the table steps from there, in the same manner.  Between the passes a candidate
     // keeps (distance, blocks) in ua / ub; 0 in ua = unresolved.
     if (tid == 0) sh_next[0] = sh_next[1] = i0;
-    __syncthreads();
+    // A0. the first coded data set of every hypothesis (with the reference sample): one per lane, all alike
     {
         const uint32_t ref_first = (c.flags & F_PREPROCESS) ? 1u : 0u, bend = c.rsi;
-        uint32_t i = 0, p0 = 0, pos = 0, b = 0;
-        bool have = false, first = false;
-        while (true) {
-            if (!have) {
-                i = atomicAdd(&sh_next[0], 1u);
-                if (i >= i1) break;
-                p0 = pos = cpos[i];
-                b = 0;
-                first = true;
-                if (p0 >= s.limit) {
-                    ua[i] = 0;
-                    continue;
+        for (uint32_t i = i0 + tid; i < i1; i += nt) {
+            const uint32_t p0 = cpos[i];
+            uint32_t delta = 0, bb = 0;
+            if (p0 < s.limit) {
+                uint32_t run;
+                const uint32_t len = ref_first ? cds1(p0, run) : cds0(p0, run);
+                bool fail = len == 0u;
+                uint32_t n = 1;
+                if (!fail && run) {
+                    n = spec_run_blocks(c, len - c.id_len - 1u - (ref_first ? c.bps : 0u), 0u);
+                    fail = !n || n > bend;
                 }
-                have = true;
+                if (!fail) {
+                    const uint32_t pos = p0 + len;
+                    if (n >= bend || (pos < s.limit && s2_marked(marks, pos))) {
+                        delta = len;
+                        bb = n;
+                    } else if (pos < s.limit) {
+                        delta = len;
+                        bb = n | 0x8000u;                       // still off the marked chain: pass A1
+                    }
+                }
             }
+            ua[i] = (uint16_t)delta;
+            ub[i] = (uint16_t)bb;
+        }
+    }
+    __syncthreads();
+    // A1. catch-up: on-demand parses (no reference sample) until the walk stands on a marked boundary
+    {
+        const uint32_t bend = c.rsi;
+        uint32_t i = 0, p0 = 0, pos = 0, b = 0;
+        bool have = false, out = false;
+        while (true) {
+            // (taking the next candidate costs three dependent LDS round trips: idle lanes wait until kS2Refill of
+            // them can do it together -- or nothing else is left to do)
+            const uint64_t idle = __ballot(!have && !out), busy = __ballot(have);
+            if (!(idle | busy)) break;
+            if (idle && ((uint32_t)__popcll(idle) >= g.refill || !busy)) {
+                if (!have && !out) {
+                    i = atomicAdd(&sh_next[0], 1u);
+                    if (i >= i1) {
+                        out = true;
+                    } else {
+                        const uint32_t bb = ub[i];
+                        if (bb & 0x8000u) {
+                            p0 = cpos[i];
+                            pos = p0 + ua[i];
+                            b = bb & 0x7FFFu;
+                            have = true;
+                        }
+                    }
+                }
+            }
+            if (!have) continue;
             uint32_t run;
-            const uint32_t len = cds(pos, first ? ref_first : 0u, run);
+            const uint32_t len = cds0(pos, run);
             bool fail = len == 0u, done = false;
             uint32_t n = 1;
             if (!fail && run) {
-                n = spec_run_blocks(c, len - c.id_len - 1u - ((first && ref_first) ? c.bps : 0u), b);
+                n = spec_run_blocks(c, len - c.id_len - 1u, b);
                 fail = !n || n > bend - b;
             }
             if (!fail) {
                 pos += len;
                 b += n;
-                first = false;
                 if (b >= bend || (pos < s.limit && s2_marked(marks, pos))) done = true;
                 else if (pos >= s.limit) fail = true;
             }
@@ -803,27 +857,35 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     }
     __syncthreads();
     stamp(7);
+    // B. table steps (aec_spec2.h: s2_table_step, tables linked by candidate index) from where pass A left the walk
     {
         const uint32_t bend = c.rsi;
-        uint32_t i = 0, p0 = 0, pos = 0, b = 0;
-        bool have = false;
+        uint32_t i = 0, idx = 0, b = 0;
+        bool have = false, out = false;
         while (true) {
-            if (!have) {
-                i = atomicAdd(&sh_next[1], 1u);
-                if (i >= i1) break;
-                const uint32_t d = ua[i];
-                b = ub[i];
-                p0 = cpos[i];
-                pos = p0 + d;
-                if (!d || b >= bend) continue;
-                have = true;
+            const uint64_t idle = __ballot(!have && !out), busy = __ballot(have);
+            if (!(idle | busy)) break;
+            if (idle && ((uint32_t)__popcll(idle) >= g.refill || !busy)) {
+                if (!have && !out) {
+                    i = atomicAdd(&sh_next[1], 1u);
+                    if (i >= i1) {
+                        out = true;
+                    } else {
+                        const uint32_t d = ua[i];
+                        b = ub[i];
+                        if (d && b < bend) {
+                            idx = s2_index(w, (uint32_t)cpos[i] + d);
+                            if (idx == kS2NoIndex) ua[i] = 0;   // (cannot happen: pass A stopped on a marked boundary)
+                            else have = true;
+                        }
+                    }
+                }
             }
-            uint32_t none = 0;
-            if (!s2_step(w, c, pos, b, bend, none)) {
-                ua[i] = 0;
-                have = false;
-            } else if (b >= bend) {
-                const uint32_t a = pos - p0;
+            if (!have) continue;
+            uint32_t end = 0;
+            const uint32_t st = s2_table_step(w, c, idx, b, bend, end);
+            if (st != 1u) {
+                const uint32_t a = st == 2u ? end - cpos[i] : 0u;
                 ua[i] = a > 0xFFFFu ? (uint16_t)0 : (uint16_t)a;
                 have = false;
             }
@@ -1347,11 +1409,12 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     p.g.stride = tune("AEC_S2_STRIDE", 64u);
     p.g.burn = tune("AEC_S2_BURN", 24u);
     p.g.fast = tune("AEC_S2_FAST", 1u);
+    p.g.refill = tune("AEC_S2_REFILL", 16u);
     const uint32_t W = p.g.lead + p.g.core + p.g.look, nw = W / 32;
     const uint32_t capdiv = tune("AEC_S2_CAPDIV", 8u);
     p.g.cap_lds = (W / (capdiv ? capdiv : 8u) + 63) & ~63u;
     p.g.cap_core = (p.g.core / 8 + 63) & ~63u;
-    p.lds = (size_t)(nw + 4) * 4 + (size_t)nw * 4 + (size_t)(nw + 2) * 2 * 3 + (size_t)p.g.cap_lds * 2 * 6 + 64;
+    p.lds = (size_t)(nw + 4) * 4 + (size_t)nw * 4 + (size_t)(nw + 2) * 2 * 3 + (size_t)p.g.cap_lds * 2 * 7 + 64;
     if (p.lds > 156 * 1024) return p;
     const uint64_t nwin_total = (total_bits + core + core - 1) / core;    // (+ one: the range starts on a core boundary)
     p.nwin_max = (uint32_t)(nwin_total < kS2SuperWindows ? nwin_total : kS2SuperWindows);
@@ -1430,42 +1493,108 @@ void allow_big_lds2()
 // (every candidate of every chunk's first window), the walk (one wavefront: one lookup per chunk where
 // the wide table resolves it, per window or per coded data set where not), then the true chain through
 // the skipped chunks and the RSI starts inside all hops.
+// spans from which on the pipeline is worth a second set of tables (a quarter of a GB; below, e.g. for the
+// 256 MiB calls of the streaming ABI, one set is kept and the spans run behind one another)
+constexpr uint64_t kS2PipeSpans = 4;
+
+// A side stream with its events, for the span pipeline below.  Created on first use, kept for the life of the process
+// (a few per device: concurrent callers each take their own), never destroyed while work may be pending.
+struct SideStream {
+    int device = -1;
+    hipStream_t st = nullptr;
+    hipEvent_t start = nullptr, tab[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+};
+std::mutex g_side_mu;
+std::vector<SideStream> *g_side_free = nullptr;
+
+bool side_take(SideStream *out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    {
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        if (g_side_free)
+            for (size_t i = 0; i < g_side_free->size(); i++)
+                if ((*g_side_free)[i].device == dev) {
+                    *out = (*g_side_free)[i];
+                    g_side_free->erase(g_side_free->begin() + (ptrdiff_t)i);
+                    return true;
+                }
+    }
+    SideStream s;
+    s.device = dev;
+    bool ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess;
+    for (hipEvent_t *e : {&s.start, &s.tab[0], &s.tab[1], &s.done[0], &s.done[1]})
+        ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        return false;                                   // (what was created is lost: a one-time leak of a failed start)
+    }
+    *out = s;
+    return true;
+}
+
+void side_give(const SideStream &s)
+{
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    if (!g_side_free) g_side_free = new (std::nothrow) std::vector<SideStream>();
+    if (g_side_free) g_side_free->push_back(s);
+}
+
+// Spans of at most nwin_max windows.  With room for two sets of tables the spans are pipelined over two streams: the
+// table kernel of span s + 1 (k_spec2: all CUs) runs on a side stream beside the walkers of span s (k_wide, k_index,
+// k_rewalk, k_expand2: a few hundred wavefronts down to one, 16 % of the time of a span when they ran behind one another), ordered by
+// events; `st` has waited for everything the side stream did when the last walker is enqueued.
 void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
-                         uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot)
+                         uint8_t *base, size_t ws_bytes, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot)
 {
     allow_big_lds2();
     IdxCarry *carry = reinterpret_cast<IdxCarry *>(base);
     const uint64_t lo0 = start_bit / p.g.core * p.g.core;
     const uint64_t span = (uint64_t)p.nwin_max * p.g.core;
-    for (uint64_t lo = lo0; lo < end_bit; lo += span) {
+    const uint64_t nspans = (end_bit - lo0 + span - 1) / span;
+    SideStream side;
+    bool piped = nspans >= kS2PipeSpans && ws_bytes >= 2 * p.bytes && !spec2_prof_buffer(0, false);
+#ifdef AEC_TUNING
+    if (tune_set("AEC_S2_VERIFY") || tune("AEC_S2_PIPE", 1) == 0) piped = false;
+#endif
+    piped = piped && side_take(&side);
+    if (piped) {
+        (void)hipEventRecord(side.start, st);                       // the input is whatever `st` has produced so far
+        (void)hipStreamWaitEvent(side.st, side.start, 0);
+    }
+    uint64_t si = 0;
+    for (uint64_t lo = lo0; lo < end_bit; lo += span, si++) {
         const uint64_t bits = end_bit - lo < span ? end_bit - lo : span;
         const uint32_t nwin = (uint32_t)((bits + p.g.core - 1) / p.g.core);
         const uint32_t nchunks = (nwin + p.wpc - 1) / p.wpc;
         const bool first = lo == lo0, last = lo + span >= end_bit;
+        const uint32_t set = piped ? (uint32_t)(si & 1u) : 0u;
+        uint8_t *tb = base + (size_t)set * p.bytes;                  // (the carry record lives in set 0's header)
+        hipStream_t ts = piped ? side.st : st;                       // stream of the table kernels
         SparseTables t;
-        t.bitmap = reinterpret_cast<const uint32_t *>(base + p.o_bitmap);
-        t.pre = reinterpret_cast<const uint16_t *>(base + p.o_pre);
-        t.rec = reinterpret_cast<const uint2 *>(base + p.o_rec);
-        t.cpos = reinterpret_cast<const uint16_t *>(base + p.o_cpos);
-        t.ccnt = reinterpret_cast<const uint32_t *>(base + p.o_ccnt);
+        t.bitmap = reinterpret_cast<const uint32_t *>(tb + p.o_bitmap);
+        t.pre = reinterpret_cast<const uint16_t *>(tb + p.o_pre);
+        t.rec = reinterpret_cast<const uint2 *>(tb + p.o_rec);
+        t.cpos = reinterpret_cast<const uint16_t *>(tb + p.o_cpos);
+        t.ccnt = reinterpret_cast<const uint32_t *>(tb + p.o_ccnt);
         t.lo = lo;
         t.hi = lo + (uint64_t)nwin * p.g.core;
         t.core = p.g.core;
         t.cap = p.g.cap_core;
-        t.wide = reinterpret_cast<const uint4 *>(base + p.o_wide);
+        t.wide = reinterpret_cast<const uint4 *>(tb + p.o_wide);
         t.wpc = p.wpc;
-        ChunkEntry *centry = reinterpret_cast<ChunkEntry *>(base + p.o_centry);
-        IdxHop *hops = reinterpret_cast<IdxHop *>(base + p.o_hops);
-        IdxHop *rhops = reinterpret_cast<IdxHop *>(base + p.o_rhops);
-        uint32_t *nhops = reinterpret_cast<uint32_t *>(base + p.o_nhops);
+        ChunkEntry *centry = reinterpret_cast<ChunkEntry *>(tb + p.o_centry);
+        IdxHop *hops = reinterpret_cast<IdxHop *>(tb + p.o_hops);
+        IdxHop *rhops = reinterpret_cast<IdxHop *>(tb + p.o_rhops);
+        uint32_t *nhops = reinterpret_cast<uint32_t *>(tb + p.o_nhops);
         const uint32_t hop_cap = 2 * nwin + 8;
-        (void)hipMemsetAsync(base + p.o_wide, 0, (size_t)nchunks * p.g.cap_core * sizeof(uint4), st);
-        (void)hipMemsetAsync(centry, 0, (size_t)nchunks * sizeof(ChunkEntry), st);
-        hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, st, c, words, nwords, end_bit, lo, start_bit, p.g,
+        if (piped && si >= 2) (void)hipStreamWaitEvent(ts, side.done[set], 0);      // the walkers of span si - 2 are through
+        hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, ts, c, words, nwords, end_bit, lo, start_bit, p.g,
                            const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
                            const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin));
-        spec2_prof_report(nwin, st);
+        spec2_prof_report(nwin, ts);
 #ifdef AEC_TUNING
         if (tune_set("AEC_S2_VERIFY")) {
             static uint32_t *d_bad = nullptr;
@@ -1478,6 +1607,13 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
             fprintf(stderr, "verify: %u windows, lookup mismatches %u, wrong records %u\n", nwin, h[0], h[1]);
         }
 #endif
+        if (piped) {
+            (void)hipEventRecord(side.tab[set], ts);
+            (void)hipStreamWaitEvent(st, side.tab[set], 0);
+        }
+        // (the chunk-level chase has a few hundred wavefronts: with the walkers, beside the next span's k_spec2)
+        (void)hipMemsetAsync(tb + p.o_wide, 0, (size_t)nchunks * p.g.cap_core * sizeof(uint4), st);
+        (void)hipMemsetAsync(centry, 0, (size_t)nchunks * sizeof(ChunkEntry), st);
         hipLaunchKernelGGL(k_wide, dim3((p.g.cap_core + 255) / 256, nchunks), dim3(256), 0, st, t, nwin, end_bit,
                            const_cast<uint4 *>(t.wide));
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
@@ -1489,7 +1625,9 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
                            (const uint32_t *)nullptr, 0u, 0u, d_rsi_off);
         hipLaunchKernelGGL(k_expand2, dim3((nchunks * p.wpc * 2 + 255) / 256), dim3(256), 0, st, t, carry, rhops, nhops,
                            nchunks, p.wpc * 2, d_rsi_off);
+        if (piped) (void)hipEventRecord(side.done[set], st);
     }
+    if (piped) side_give(side);
 }
 
 
@@ -1765,7 +1903,11 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
     const uint64_t end_bit = (uint64_t)in_bytes * 8;
     if (start_bit >= end_bit) return 0;
     const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
-    if (sp.ok) return sp.bytes;
+    if (sp.ok) {
+        // (many spans of windows: two sets of tables, so that the spans can be pipelined -- launch_index_sparse)
+        const uint64_t span = (uint64_t)sp.nwin_max * sp.g.core;
+        return end_bit - start_bit > (kS2PipeSpans - 1) * span ? 2 * sp.bytes : sp.bytes;
+    }
     const TrunkPlan p = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, 0);
     return p.ok ? p.bytes : 0;
 }
@@ -1783,7 +1925,7 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
         const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
         if (sp.ok && ws_bytes >= sp.bytes) {
             launch_index_sparse(c, sp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
-                                static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot);
+                                static_cast<uint8_t *>(d_ws), ws_bytes, start_block, rsi_start, tail_slot);
             return;
         }
     }

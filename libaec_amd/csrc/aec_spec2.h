@@ -27,6 +27,8 @@
 namespace aec {
 
 constexpr uint32_t kS2NoIndex = 0xFFFFFFFFu;
+constexpr uint16_t kS2NoSucc = 0xFFFFu;
+constexpr uint32_t kS2HopIdxMask = 0x1FFFu;      // (a window has at most 8192 candidates)
 
 // Window-relative views (LDS on the device, host arrays in the emulator).  Bit q of the window is bit
 // (31 - q % 32) of word q / 32, for the stream words and for the mark bitmap alike.
@@ -35,8 +37,11 @@ struct S2Win {
     const uint32_t *marks;   // candidate bitmap, s.nwords words
     const uint16_t *mpre;    // mpre[w] = candidates in words [0, w)
     const uint16_t *cnxt;    // per candidate: CDS entry as in aec_spec.h nxt[] (len | kind), 0 = none
-    const uint16_t *chop4;   // per candidate: 4 CDSes on (aec_spec.h hop entry), 0 = none
-    const uint16_t *chop16;  // per candidate: 16 CDSes on
+    const uint16_t *csucc;   // per candidate: index of the candidate its CDS ends at, kS2NoSucc = none (unmarked / outside)
+    const uint16_t *chop4;   // per candidate: 4 CDSes on -- bits [0,13) INDEX of the candidate reached (never 0: a hop
+                             // goes forward), bits [13,16) blocks covered beyond the nominal count; 0 = none
+    const uint16_t *chop16;  // per candidate: 16 CDSes on, same format
+    const uint16_t *cpos;    // per candidate: its bit position
     uint32_t ncand;
 };
 
@@ -59,49 +64,6 @@ AEC_HD uint32_t s2_chain_step(const SpecWin &s, const Cfg &c, uint32_t q)
     return spec_cds(s, c, q, 0, run);
 }
 
-// hop over 4 CDSes from candidate `idx` through MARKED positions (0 = leaves the marked chain, a
-// rest-of-segment run inside, or too long for the entry format)
-AEC_HD uint16_t s2_hop4(const S2Win &w, const Cfg &c, const uint16_t *cpos, uint32_t idx)
-{
-    uint32_t pos = cpos[idx], extra = 0, i = idx;
-    const uint32_t q = pos;
-    for (int k = 0; k < 4; k++) {
-        if (i == kS2NoIndex) return 0;
-        const uint32_t e = w.cnxt[i];
-        const uint32_t len = e & 0xFFFu, code = len - c.id_len - 1u;
-        const bool zero = e & kNxtZero;
-        if (!e || (zero && code == 5u)) return 0;
-        extra += zero ? (code < 5u ? code : code - 1u) - 1u : 0u;
-        pos += len;
-        if (k < 3) {
-            if (pos >= w.s.limit) return 0;
-            i = s2_index(w, pos);
-        }
-    }
-    return spec_hop_pack(pos - q, extra);
-}
-
-AEC_HD uint16_t s2_hop16(const S2Win &w, const uint16_t *cpos, uint32_t idx)
-{
-    uint32_t pos = cpos[idx], extra = 0, i = idx;
-    const uint32_t q = pos;
-    for (int k = 0; k < 4; k++) {
-        if (i == kS2NoIndex) return 0;
-        const uint32_t e = w.chop4[i];
-        if (!e) return 0;
-        pos += e & kHopBitsMask;
-        extra += e >> 13;
-        if (k < 3) {
-            if (pos >= w.s.limit) return 0;
-            i = s2_index(w, pos);
-        }
-    }
-    return spec_hop_pack(pos - q, extra);
-}
-
-// One step of a unit walk at `pos` with `b` blocks of the RSI done, never beyond `bend` blocks: the
-// widest table entry that fits if pos is a candidate, else the CDS end computed on demand.
-// false = unresolved (leaves the window, malformed, a zero run overrunning the unit).
 #if !defined(__HIPCC__) && defined(AEC_S2_COUNT)
 #define S2_COUNT(i) (s2_counters[i]++)
 static unsigned long long s2_counters[8];
@@ -115,47 +77,94 @@ static unsigned long long s2_counters[8];
 #define S2_HIST(parses, steps) ((void)0)   // (emulator statistics: on-demand parses and table steps of a unit walk)
 #endif
 
-// `budget`: on-demand parses this walk may still spend (a bogus hypothesis wanders off the marked chain
-// for dozens of codes; a true one is back on it after the few codes behind an RSI start that no sync
-// chain has covered yet).
-AEC_HD bool s2_step(const S2Win &w, const Cfg &c, uint32_t &pos, uint32_t &b, uint32_t bend, uint32_t &budget)
+// Tables linked by candidate INDEX: a table step is then one read (no search for the candidate at a position),
+// and a hop is not limited by the bits it covers.
+AEC_HD uint16_t s2_hop_pack(uint32_t idx, uint32_t extra)
 {
-    if (pos >= w.s.limit) return false;
+    return (idx != 0u && idx <= kS2HopIdxMask && extra <= 7u) ? (uint16_t)(idx | (extra << 13)) : (uint16_t)0;
+}
+
+// successor of candidate idx through its own CDS
+AEC_HD uint16_t s2_succ(const S2Win &w, uint32_t idx)
+{
+    const uint32_t e = w.cnxt[idx];
+    if (!e) return kS2NoSucc;
+    const uint32_t pos = (uint32_t)w.cpos[idx] + (e & 0xFFFu);
+    if (pos >= w.s.limit) return kS2NoSucc;
+    const uint32_t j = s2_index(w, pos);
+    return j == kS2NoIndex ? kS2NoSucc : (uint16_t)j;
+}
+
+// hop over 4 CDSes from candidate `idx` through MARKED positions (0 = leaves the marked chain, a
+// rest-of-segment run inside, or more than 7 extra blocks)
+AEC_HD uint16_t s2_hop4(const S2Win &w, const Cfg &c, uint32_t idx)
+{
+    uint32_t extra = 0, i = idx;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t e = w.cnxt[i];
+        const uint32_t len = e & 0xFFFu, code = len - c.id_len - 1u;
+        const bool zero = e & kNxtZero;
+        if (!e || (zero && code == 5u)) return 0;
+        extra += zero ? (code < 5u ? code : code - 1u) - 1u : 0u;
+        const uint32_t nx = w.csucc[i];
+        if (nx == kS2NoSucc) return 0;
+        i = nx;
+    }
+    return s2_hop_pack(i, extra);
+}
+
+AEC_HD uint16_t s2_hop16(const S2Win &w, uint32_t idx)
+{
+    uint32_t extra = 0, i = idx;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t e = w.chop4[i];
+        if (!e) return 0;
+        extra += e >> 13;
+        i = e & kS2HopIdxMask;
+    }
+    return s2_hop_pack(i, extra);
+}
+
+// One table step of a unit walk standing on candidate `idx` with `b` blocks of the RSI done, never beyond `bend`:
+// the widest table entry that fits.  Returns 1 = went on (idx, b updated), 2 = the unit is complete, `end` is
+// where it ends (a last single CDS may end on an unmarked position), 0 = unresolved (leaves the marked chain or
+// the window, malformed, a zero run overrunning the unit).
+AEC_HD uint32_t s2_table_step(const S2Win &w, const Cfg &c, uint32_t &idx, uint32_t &b, uint32_t bend, uint32_t &end)
+{
     const uint32_t left = bend - b;
-    const uint32_t idx = s2_index(w, pos);
-    uint32_t e1;
-    if (idx != kS2NoIndex) {
-        const uint32_t e16 = w.chop16[idx], e4 = w.chop4[idx];
-        if (e16 && 16u + (e16 >> 13) <= left) {
-            S2_COUNT(0);
-            pos += e16 & kHopBitsMask;
-            b += 16u + (e16 >> 13);
-            return true;
-        }
-        if (e4 && 4u + (e4 >> 13) <= left) {
-            S2_COUNT(1);
-            pos += e4 & kHopBitsMask;
-            b += 4u + (e4 >> 13);
-            return true;
-        }
-        S2_COUNT(2);
-        e1 = w.cnxt[idx];
+    const uint32_t e16 = w.chop16[idx], e4 = w.chop4[idx], e1 = w.cnxt[idx];
+    if (e16 && 16u + (e16 >> 13) <= left) {
+        S2_COUNT(0);
+        b += 16u + (e16 >> 13);
+        idx = e16 & kS2HopIdxMask;
+    } else if (e4 && 4u + (e4 >> 13) <= left) {
+        S2_COUNT(1);
+        b += 4u + (e4 >> 13);
+        idx = e4 & kS2HopIdxMask;
     } else {
-        S2_COUNT(3);
-        if (budget == 0) return false;
-        budget--;
-        e1 = spec_nxt_entry(w.s, c, pos);
+        S2_COUNT(2);
+        if (!e1) return 0;
+        const uint32_t len = e1 & 0xFFFu;
+        uint32_t n = 1;
+        if (e1 & kNxtZero) {
+            n = spec_run_blocks(c, len - c.id_len - 1u, b);
+            if (!n || n > left) return 0;
+        }
+        b += n;
+        if (b >= bend) {
+            end = (uint32_t)w.cpos[idx] + len;
+            return 2;
+        }
+        const uint32_t nx = w.csucc[idx];
+        if (nx == kS2NoSucc) return 0;
+        idx = nx;
+        return 1;
     }
-    if (!e1) return false;
-    const uint32_t len = e1 & 0xFFFu;
-    uint32_t n = 1;
-    if (e1 & kNxtZero) {
-        n = spec_run_blocks(c, len - c.id_len - 1u, b);
-        if (!n || n > left) return false;
+    if (b >= bend) {
+        end = w.cpos[idx];
+        return 2;
     }
-    pos += len;
-    b += n;
-    return true;
+    return 1;
 }
 
 // Length in bits of the blocks [b0, bend) of an RSI coded from p on (the first CDS carries the
@@ -194,10 +203,16 @@ AEC_HD uint32_t s2_unit(const S2Win &w, const Cfg &c, uint32_t p, uint32_t b0, u
         pos += len;
         b += n;
     }
-    uint32_t none = 0;                                   // (no on-demand parse from here on)
-    while (b < bend) {
-        if (!s2_step(w, c, pos, b, bend, none)) return 0;
-        n_table++;
+    if (b < bend) {                                      // (no on-demand parse from here on)
+        uint32_t idx = s2_index(w, pos), end = 0;
+        if (idx == kS2NoIndex) return 0;
+        for (;;) {
+            const uint32_t st = s2_table_step(w, c, idx, b, bend, end);
+            if (!st) return 0;
+            n_table++;
+            if (st == 2u) break;
+        }
+        pos = end;
     }
     S2_HIST(n_parse, n_table);
     return pos - p;

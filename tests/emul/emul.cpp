@@ -406,13 +406,14 @@ extern "C" int emul_spec2(const uint32_t *p, const uint8_t *in, size_t in_len, c
         mpre[0] = 0;
         for (uint32_t i = 0; i < nw; i++) mpre[i + 1] = (uint16_t)(mpre[i] + __builtin_popcount(marks[i]));
         const uint32_t ncand = mpre[nw];
-        std::vector<uint16_t> cpos(ncand + 1), cnxt(ncand + 1), chop4(ncand + 1), chop16(ncand + 1);
+        std::vector<uint16_t> cpos(ncand + 1), cnxt(ncand + 1), csucc(ncand + 1), chop4(ncand + 1), chop16(ncand + 1);
         for (uint32_t q = 0, i = 0; q < W; q++)
             if (s2_marked(marks.data(), q)) cpos[i++] = (uint16_t)q;
-        S2Win w{s, marks.data(), mpre.data(), cnxt.data(), chop4.data(), chop16.data(), ncand};
+        S2Win w{s, marks.data(), mpre.data(), cnxt.data(), csucc.data(), chop4.data(), chop16.data(), cpos.data(), ncand};
         for (uint32_t i = 0; i < ncand; i++) cnxt[i] = cpos[i] < s.limit ? spec_nxt_entry(s, c, cpos[i]) : 0;
-        for (uint32_t i = 0; i < ncand; i++) chop4[i] = s2_hop4(w, c, cpos.data(), i);
-        for (uint32_t i = 0; i < ncand; i++) chop16[i] = s2_hop16(w, cpos.data(), i);
+        for (uint32_t i = 0; i < ncand; i++) csucc[i] = s2_succ(w, i);
+        for (uint32_t i = 0; i < ncand; i++) chop4[i] = s2_hop4(w, c, i);
+        for (uint32_t i = 0; i < ncand; i++) chop16[i] = s2_hop16(w, i);
         // 3. units and chains for the candidates of the core
         std::vector<uint32_t> ua(ncand + 1, 0), um(ncand + 1, 0);
         for (uint32_t i = 0; i < ncand; i++) {
