@@ -433,6 +433,17 @@ def test_full_size_round_trip_config2(gpu):
     assert int(off[pre // (rsi * bs * 2)]) == bits
     d_dec, status = codec.decode(d_out, nbytes, d_off, codec.rsi_count(total), codec.block_count(total))
     assert status == 0 and torch.equal(d_dec, d_in)
+    del d_dec
+    # the RSI starts found again from the stream ALONE (30 spans of window tables, pipelined over two streams):
+    # the same table as the encoder's
+    nr = codec.rsi_count(total)
+    d_idx = torch.zeros(nr + 2, dtype=torch.int64, device=d_in.device)
+    d_res = torch.zeros(40, dtype=torch.uint8, device=d_in.device)
+    codec.index_async(d_out, nbytes, 0, d_idx, nr, d_res)
+    torch.cuda.synchronize()
+    res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.uint64)
+    assert int(res[0]) == nr                                    # n_rsi
+    assert torch.equal(d_idx[:nr], d_off[:nr])
 
 
 def test_segment_parallel_decode(gpu):
