@@ -582,6 +582,9 @@ __global__ void k_texpand(const Cfg c, const TwTables t, const TrTables tt, cons
 //   cpos[cap] u16 | cnxt[cap] u16 | chop4[cap] u16 | chop16[cap] u16 | ua[cap] u16
 // Output for the candidates inside the core: the window's part of the global bitmap / prefix table
 // and its records (SparseTables above).
+constexpr uint32_t kS2BridgeCap = 1u << 18;  // hypotheses per span k_bridge takes on (more: left to the walker)
+constexpr uint32_t kS2BridgeAfter = 16;      // RSIs the walker had to walk itself before k_bridge steps in
+
 struct Spec2Geom {
     uint32_t lead, core, look, stride, burn, cap_lds, cap_core, fast, refill;
 };
@@ -590,7 +593,8 @@ __global__ void __launch_bounds__(1024)
 k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
         uint64_t start_bit, const Spec2Geom g, uint32_t *__restrict__ gbitmap, uint16_t *__restrict__ gpre,
         uint2 *__restrict__ grec, uint16_t *__restrict__ gcpos, uint32_t *__restrict__ gccnt,
-        unsigned long long *__restrict__ prof, const uint64_t *__restrict__ starts = nullptr, uint32_t nstarts = 0)
+        unsigned long long *__restrict__ prof, const uint64_t *__restrict__ starts = nullptr, uint32_t nstarts = 0,
+        uint32_t *__restrict__ blist = nullptr, uint32_t *__restrict__ blist_cnt = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
     __shared__ uint32_t sh_total, sh_next[2], sh_part[16];
@@ -678,6 +682,8 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     // a coded data set without / with (`ref`) a reference sample: the straight-line parse, the full one where a
     // unary part does not end inside its 64-bit peek (rare at the coded rates this kernel is chosen for)
     const bool use_fast = g.fast != 0;
+    // (a walk that fails this close to the end of the window may have run out of it -- see kS2Limited)
+    auto near_end = [&](uint32_t pos) { return pos + 4096u > s.limit; };
     auto cds1 = [&](uint32_t q, uint32_t &run) -> uint32_t {
         if (!use_fast) return spec_cds(s, c, q, 1u, run);
         uint32_t len = spec_cds_fast<1>(win, s.limit, c, q, run);
@@ -780,7 +786,9 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         const uint32_t ref_first = (c.flags & F_PREPROCESS) ? 1u : 0u, bend = c.rsi;
         for (uint32_t i = i0 + tid; i < i1; i += nt) {
             const uint32_t p0 = cpos[i];
-            uint32_t delta = 0, bb = 0;
+            // (ub = kS2Limited with ua = 0: the walk ran out of the window -- an RSI longer than the look-ahead -- as
+            // opposed to a hypothesis the data refutes: k_bridge parses those from the stream)
+            uint32_t delta = 0, bb = near_end(p0) ? kS2Limited : 0u;     // (a first coded data set that does not fit)
             if (p0 < s.limit) {
                 uint32_t run;
                 const uint32_t len = ref_first ? cds1(p0, run) : cds0(p0, run);
@@ -789,9 +797,11 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                 if (!fail && run) {
                     n = spec_run_blocks(c, len - c.id_len - 1u - (ref_first ? c.bps : 0u), 0u);
                     fail = !n || n > bend;
+                    if (fail) bb = 0;
                 }
                 if (!fail) {
                     const uint32_t pos = p0 + len;
+                    bb = pos >= s.limit ? kS2Limited : 0u;
                     if (n >= bend || (pos < s.limit && s2_marked(marks, pos))) {
                         delta = len;
                         bb = n;
@@ -822,10 +832,10 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                     if (i >= i1) {
                         out = true;
                     } else {
-                        const uint32_t bb = ub[i];
-                        if (bb & 0x8000u) {
+                        const uint32_t bb = ub[i], d0 = ua[i];
+                        if ((bb & 0x8000u) && d0) {              // (d0 = 0: failed in pass A0, ub holds the reason)
                             p0 = cpos[i];
-                            pos = p0 + ua[i];
+                            pos = p0 + d0;
                             b = bb & 0x7FFFu;
                             have = true;
                         }
@@ -840,6 +850,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             if (!fail && run) {
                 n = spec_run_blocks(c, len - c.id_len - 1u, b);
                 fail = !n || n > bend - b;
+                if (fail) n = 0;                                // (refuted, not out of the window)
             }
             if (!fail) {
                 pos += len;
@@ -849,8 +860,11 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             }
             if (done && pos - p0 > 0xFFFFu) fail = true;
             if (fail || done) {
+                // (out of the window: the coded data set itself does not fit, the walk stands beyond the window, or
+                // the RSI is longer than a record holds)
+                const bool lim = n != 0u && (len == 0u ? near_end(pos) : (pos >= s.limit || done));
                 ua[i] = fail ? (uint16_t)0 : (uint16_t)(pos - p0);
-                ub[i] = (uint16_t)b;
+                ub[i] = fail ? (uint16_t)(lim ? kS2Limited : 0u) : (uint16_t)b;
                 have = false;
             }
         }
@@ -875,7 +889,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                         b = ub[i];
                         if (d && b < bend) {
                             idx = s2_index(w, (uint32_t)cpos[i] + d);
-                            if (idx == kS2NoIndex) ua[i] = 0;   // (cannot happen: pass A stopped on a marked boundary)
+                            if (idx == kS2NoIndex) { ua[i] = 0; ub[i] = 0; }   // (cannot happen: pass A stopped on a marked boundary)
                             else have = true;
                         }
                     }
@@ -887,6 +901,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             if (st != 1u) {
                 const uint32_t a = st == 2u ? end - cpos[i] : 0u;
                 ua[i] = a > 0xFFFFu ? (uint16_t)0 : (uint16_t)a;
+                ub[i] = (st == 0u || (st == 2u && a > 0xFFFFu)) ? (uint16_t)kS2Limited : (uint16_t)0;   // (read only where ua is 0)
                 have = false;
             }
         }
@@ -907,7 +922,13 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             cnt++;
         }
         const uint64_t at = (uint64_t)blockIdx.x * g.cap_core + (i - i0);
-        grec[at] = make_uint2(ua[i], cnt ? ((cnt << 24) | (pos - cpos[i])) : 0u);
+        // (y = 1: no chain -- a count of 0 -- and the note for k_bridge that the hypothesis ran out of the window)
+        const bool limited = !cnt && !ua[i] && ub[i] == kS2Limited;
+        grec[at] = make_uint2(ua[i], cnt ? ((cnt << 24) | (pos - cpos[i])) : (limited ? 1u : 0u));
+        if (limited && blist) {                               // k_bridge's work list
+            const uint32_t slot = atomicAdd(blist_cnt, 1u);
+            if (slot < kS2BridgeCap) blist[slot] = (uint32_t)at;
+        }
         gcpos[at] = (uint16_t)(cpos[i] - c0);
     }
     for (uint32_t i = tid; i < cw; i += nt) {
@@ -955,6 +976,70 @@ __global__ void k_spec_verify(const Cfg c, const TrStream s, const SparseTables 
 }
 #endif
 
+// RSIs the window tables could not resolve because the walk ran out of its window -- longer than the look-ahead:
+// incompressible stretches in an otherwise low-entropy stream -- parsed coded data set by coded data set from the
+// stream where it lies, one lane per hypothesis on the list k_spec2 leaves (all of them around such a stretch, the
+// true RSI start among them; empty on well-behaved streams).  Without it every such RSI costs the walker a serial
+// walk AND the chunk-level lookup of its 256 windows: 1 in 1000 RSIs of this kind doubled the index time.
+// (16 bytes per memory round trip instead of 4: the parse below waits for nothing else)
+struct QuadFetch {
+    const uint32_t *words;
+    uint64_t nwords;
+    mutable uint64_t have = ~0ull;
+    mutable uint32_t q[4] = {0, 0, 0, 0};
+    __device__ uint32_t operator()(uint64_t idx) const
+    {
+        if ((idx >> 2) != have) {
+            have = idx >> 2;
+            const uint64_t b = have << 2;
+            if (b + 4 <= nwords) {
+                struct __attribute__((packed, aligned(4))) Q { uint32_t a, b, c, d; };
+                const Q v = *reinterpret_cast<const Q *>(words + b);
+                q[0] = v.a; q[1] = v.b; q[2] = v.c; q[3] = v.d;
+            } else {
+                for (uint32_t k = 0; k < 4; k++) q[k] = b + k < nwords ? words[b + k] : 0u;
+            }
+        }
+        return bswap32(q[idx & 3u]);
+    }
+};
+
+__device__ void bridge_one(const Cfg &c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
+                           const SparseTables &t, uint2 *__restrict__ rec_out, uint32_t at)
+{
+    const uint32_t w = at / t.cap;
+    if (t.rec[at].x || t.rec[at].y != 1u) return;
+    const uint64_t pos = t.lo + (uint64_t)w * t.core + t.cpos[at];
+    if (pos >= end_bit) return;
+    BitReaderT<QuadFetch> br;
+    br.init(QuadFetch{words, nwords}, end_bit, pos);
+    const bool pp = c.flags & F_PREPROCESS;
+    // (an RSI of the reference encoder is at most all blocks uncompressed; whatever is longer is left to the walker)
+    const uint64_t longest = (uint64_t)c.rsi * (c.id_len + (uint64_t)c.bs * c.bps) + c.bps + 64u;
+    uint32_t b = 0;
+    while (b < c.rsi) {
+        uint32_t nblk = 1;
+        if (skip_cds(br, c, (pp && b == 0) ? 1u : 0u, b, nblk) != DEC_OK) return;
+        b += nblk;
+        if (br.pos - pos > longest) return;
+    }
+    if (b == c.rsi && br.pos <= end_bit) rec_out[at].x = (uint32_t)(br.pos - pos);
+}
+
+__global__ void __launch_bounds__(64)
+k_bridge(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, const SparseTables t,
+         uint2 *__restrict__ rec_out, const uint32_t *__restrict__ blist, const uint32_t *__restrict__ blist_cnt,
+         const IdxCarry *__restrict__ carry, uint32_t first_span, uint32_t min_serial)
+{
+    // Only for streams that need it: well-behaved streams have a dozen such hypotheses per window too (wrong phases
+    // whose zero runs come out long), each a parse of several average RSIs for nothing.  The walker counts the
+    // RSIs it had to walk itself; from kS2BridgeAfter of them on the rest of the stream is bridged.
+    if (first_span || carry->n_serial < min_serial) return;
+    const uint32_t n = *blist_cnt < kS2BridgeCap ? *blist_cnt : kS2BridgeCap;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        bridge_one(c, words, nwords, end_bit, t, rec_out, blist[j]);
+}
+
 // ---- wide walker: every candidate of a chunk's first window chases the window chain through the chunk
 __global__ void __launch_bounds__(256)
 k_wide(const SparseTables t, uint32_t nwin, uint64_t end_bit, uint4 *__restrict__ wide)
@@ -970,12 +1055,20 @@ k_wide(const SparseTables t, uint32_t nwin, uint64_t end_bit, uint4 *__restrict_
     while (pos < stop && pos < end_bit) {
         uint2 rec;
         uint32_t wv, ix;
-        if (!sparse_lookup(t, pos, rec, wv, ix) || !(rec.y >> 24)) {
+        if (!sparse_lookup(t, pos, rec, wv, ix)) {
             ok = 0;
             break;
         }
-        pos += rec.y & 0xFFFFFFu;
-        cnt += rec.y >> 24;
+        if (rec.y >> 24) {
+            pos += rec.y & 0xFFFFFFu;
+            cnt += rec.y >> 24;
+        } else if (rec.x && pos + rec.x <= end_bit) {       // no chain from here (k_bridge's records): this RSI alone
+            pos += rec.x;
+            cnt++;
+        } else {
+            ok = 0;
+            break;
+        }
     }
     // (a chain that ends at the end of the input inside the last chunk is resolved as far as it goes:
     // the walker takes over from its exit)
@@ -985,7 +1078,8 @@ k_wide(const SparseTables t, uint32_t nwin, uint64_t end_bit, uint4 *__restrict_
 // the true chain through the chunks the walker skipped: one lane per chunk records the window hops
 __global__ void __launch_bounds__(64)
 k_rewalk(const SparseTables t, uint32_t nwin, uint32_t nchunks, uint64_t end_bit,
-         const ChunkEntry *__restrict__ entry, IdxHop *__restrict__ hops, uint32_t *__restrict__ nhops)
+         const ChunkEntry *__restrict__ entry, IdxHop *__restrict__ hops, uint32_t *__restrict__ nhops,
+         uint64_t *__restrict__ rsi_off)
 {
     const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= nchunks) return;
@@ -996,13 +1090,21 @@ k_rewalk(const SparseTables t, uint32_t nwin, uint32_t nchunks, uint64_t end_bit
         const uint64_t stop = t.lo + (uint64_t)last * t.core;
         uint64_t pos = entry[chunk].pos, r = entry[chunk].r;
         IdxHop *out = hops + (uint64_t)chunk * t.wpc * 2u;
-        while (pos < stop && pos < end_bit && n < t.wpc * 2u) {
+        while (pos < stop && pos < end_bit) {
             uint2 rec;
             uint32_t wv, ix;
-            if (!sparse_lookup(t, pos, rec, wv, ix) || !(rec.y >> 24)) break;   // (cannot happen: k_wide went through)
-            out[n++] = IdxHop{pos, r, rec.y >> 24, 0u};
-            pos += rec.y & 0xFFFFFFu;
-            r += rec.y >> 24;
+            if (!sparse_lookup(t, pos, rec, wv, ix)) break;                      // (cannot happen: k_wide went through)
+            if ((rec.y >> 24) && n < t.wpc * 2u) {
+                out[n++] = IdxHop{pos, r, rec.y >> 24, 0u};
+                pos += rec.y & 0xFFFFFFu;
+                r += rec.y >> 24;
+            } else if (rec.x) {                  // a single RSI (no chain, or no room for another hop): written here
+                rsi_off[r] = pos;
+                pos += rec.x;
+                r++;
+            } else {
+                break;
+            }
         }
     }
     nhops[chunk] = n;
@@ -1374,7 +1476,7 @@ struct Sparse2Plan {
     uint32_t wpc;             // windows per chunk of the wide walker
     uint32_t nchunk_max;
     // byte offsets inside the workspace (behind the 64-byte carry record)
-    size_t o_bitmap, o_pre, o_rec, o_cpos, o_ccnt, o_wide, o_centry, o_hops, o_rhops, o_nhops, bytes;
+    size_t o_bitmap, o_pre, o_rec, o_cpos, o_ccnt, o_wide, o_centry, o_hops, o_rhops, o_nhops, o_blist, bytes;
 };
 
 constexpr uint32_t kS2WindowBits = 65536;      // lead-in + core + look-ahead (16-bit positions in LDS)
@@ -1434,6 +1536,7 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     p.o_hops = o;   o = up(o + ((size_t)p.nwin_max * 2 + 16) * sizeof(IdxHop));
     p.o_rhops = o;  o = up(o + (size_t)p.nchunk_max * p.wpc * 2 * sizeof(IdxHop));
     p.o_nhops = o;  o = up(o + (size_t)p.nchunk_max * 4);
+    p.o_blist = o;  o = up(o + (size_t)kS2BridgeCap * 4);
     p.bytes = o;
     p.ok = true;
     return p;
@@ -1591,9 +1694,12 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
         uint32_t *nhops = reinterpret_cast<uint32_t *>(tb + p.o_nhops);
         const uint32_t hop_cap = 2 * nwin + 8;
         if (piped && si >= 2) (void)hipStreamWaitEvent(ts, side.done[set], 0);      // the walkers of span si - 2 are through
+        uint32_t *blist = reinterpret_cast<uint32_t *>(tb + p.o_blist), *blist_cnt = reinterpret_cast<uint32_t *>(tb + 56);
+        (void)hipMemsetAsync(blist_cnt, 0, 4, ts);
         hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, ts, c, words, nwords, end_bit, lo, start_bit, p.g,
                            const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
-                           const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin));
+                           const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin),
+                           (const uint64_t *)nullptr, 0u, blist, blist_cnt);
         spec2_prof_report(nwin, ts);
 #ifdef AEC_TUNING
         if (tune_set("AEC_S2_VERIFY")) {
@@ -1604,7 +1710,10 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
             uint32_t h[2] = {0, 0};
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(h, d_bad, 8, hipMemcpyDeviceToHost);
-            fprintf(stderr, "verify: %u windows, lookup mismatches %u, wrong records %u\n", nwin, h[0], h[1]);
+            uint32_t nb = 0;
+            (void)hipMemcpy(&nb, blist_cnt, 4, hipMemcpyDeviceToHost);
+            fprintf(stderr, "verify: %u windows, lookup mismatches %u, wrong records %u; hypotheses for k_bridge: %u\n", nwin, h[0],
+                    h[1], nb);
         }
 #endif
         if (piped) {
@@ -1614,13 +1723,17 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
         // (the chunk-level chase has a few hundred wavefronts: with the walkers, beside the next span's k_spec2)
         (void)hipMemsetAsync(tb + p.o_wide, 0, (size_t)nchunks * p.g.cap_core * sizeof(uint4), st);
         (void)hipMemsetAsync(centry, 0, (size_t)nchunks * sizeof(ChunkEntry), st);
+        if (tune("AEC_S2_BRIDGE", 1))
+            hipLaunchKernelGGL(k_bridge, dim3(1024), dim3(64), 0, st, c, words, nwords, end_bit, t,
+                               const_cast<uint2 *>(t.rec), blist, blist_cnt, carry, first ? 1u : 0u,
+                               (uint32_t)tune("AEC_S2_BRIDGE_AFTER", kS2BridgeAfter));
         hipLaunchKernelGGL(k_wide, dim3((p.g.cap_core + 255) / 256, nchunks), dim3(256), 0, st, t, nwin, end_bit,
                            const_cast<uint4 *>(t.wide));
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
                            d_res, (const uint64_t *)nullptr, hops, hop_cap, carry, first ? 1u : 0u, last ? 1u : 0u,
                            start_block, rsi_start, tail_slot, TwTables{}, centry, t);
         hipLaunchKernelGGL(k_rewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, t, nwin, nchunks, end_bit, centry, rhops,
-                           nhops);
+                           nhops, d_rsi_off);
         hipLaunchKernelGGL(k_expand2, dim3((hop_cap + 255) / 256), dim3(256), 0, st, t, carry, hops,
                            (const uint32_t *)nullptr, 0u, 0u, d_rsi_off);
         hipLaunchKernelGGL(k_expand2, dim3((nchunks * p.wpc * 2 + 255) / 256), dim3(256), 0, st, t, carry, rhops, nhops,

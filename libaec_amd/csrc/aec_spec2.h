@@ -28,6 +28,7 @@ namespace aec {
 
 constexpr uint32_t kS2NoIndex = 0xFFFFFFFFu;
 constexpr uint16_t kS2NoSucc = 0xFFFFu;
+constexpr uint32_t kS2Limited = 0xFFFFu;          // k_spec2's note in ub[]: the walk left the window (see k_bridge)
 constexpr uint32_t kS2HopIdxMask = 0x1FFFu;      // (a window has at most 8192 candidates)
 
 // Window-relative views (LDS on the device, host arrays in the emulator).  Bit q of the window is bit
@@ -127,8 +128,8 @@ AEC_HD uint16_t s2_hop16(const S2Win &w, uint32_t idx)
 
 // One table step of a unit walk standing on candidate `idx` with `b` blocks of the RSI done, never beyond `bend`:
 // the widest table entry that fits.  Returns 1 = went on (idx, b updated), 2 = the unit is complete, `end` is
-// where it ends (a last single CDS may end on an unmarked position), 0 = unresolved (leaves the marked chain or
-// the window, malformed, a zero run overrunning the unit).
+// where it ends (a last single CDS may end on an unmarked position), 0 = unresolved because the walk leaves the
+// WINDOW, 3 = not an RSI (a zero run overrunning the unit), 4 = unresolved because it leaves the marked chain.
 AEC_HD uint32_t s2_table_step(const S2Win &w, const Cfg &c, uint32_t &idx, uint32_t &b, uint32_t bend, uint32_t &end)
 {
     const uint32_t left = bend - b;
@@ -143,12 +144,12 @@ AEC_HD uint32_t s2_table_step(const S2Win &w, const Cfg &c, uint32_t &idx, uint3
         idx = e4 & kS2HopIdxMask;
     } else {
         S2_COUNT(2);
-        if (!e1) return 0;
+        if (!e1) return (uint32_t)w.cpos[idx] + 4096u > w.s.limit ? 0u : 4u;
         const uint32_t len = e1 & 0xFFFu;
         uint32_t n = 1;
         if (e1 & kNxtZero) {
             n = spec_run_blocks(c, len - c.id_len - 1u, b);
-            if (!n || n > left) return 0;
+            if (!n || n > left) return 3;
         }
         b += n;
         if (b >= bend) {
@@ -156,7 +157,7 @@ AEC_HD uint32_t s2_table_step(const S2Win &w, const Cfg &c, uint32_t &idx, uint3
             return 2;
         }
         const uint32_t nx = w.csucc[idx];
-        if (nx == kS2NoSucc) return 0;
+        if (nx == kS2NoSucc) return (uint32_t)w.cpos[idx] + len >= w.s.limit ? 0u : 4u;
         idx = nx;
         return 1;
     }
@@ -208,7 +209,7 @@ AEC_HD uint32_t s2_unit(const S2Win &w, const Cfg &c, uint32_t p, uint32_t b0, u
         if (idx == kS2NoIndex) return 0;
         for (;;) {
             const uint32_t st = s2_table_step(w, c, idx, b, bend, end);
-            if (!st) return 0;
+            if (st != 1u && st != 2u) return 0;
             n_table++;
             if (st == 2u) break;
         }

@@ -18,7 +18,7 @@ import bench  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--size-mib", type=int, default=256)
+    ap.add_argument("--size-mib", type=int, default=1024)
     ap.add_argument("--noise-permille", type=int, nargs="+", default=[0, 1, 10, 50])
     args = ap.parse_args()
     import torch

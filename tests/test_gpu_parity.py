@@ -742,3 +742,34 @@ def test_uniform_batch_encode_device_api(gpu, bps, bs, rsi, flags, n_rsi, n_chun
         assert base == at * 8 and (bits + 7) // 8 == len(want), (i, base, bits, len(want))
         assert out[at:at + len(want)].tobytes() == want, i
         at += len(want)
+
+
+def test_index_bridges_rsis_longer_than_the_look_ahead(gpu):
+    """A low-entropy stream with incompressible RSIs sprinkled in (each several times the average coded RSI, more
+    than the window tables' look-ahead): the RSI starts found from the stream alone must equal the encoder's table,
+    whether the unresolved RSIs are walked by the serial walker (first span) or parsed by k_bridge (from the span
+    behind the 16th such RSI on)."""
+    import torch
+    n = 384 << 20
+    free, _ = torch.cuda.mem_get_info()
+    if free < 4 << 30:
+        pytest.skip("not enough device memory")
+    bps, bs, rsi, flags = 16, 16, 128, PP
+    data = gen(0, n)
+    rsi_bytes = rsi * bs * 2
+    nr = n // rsi_bytes
+    rng = np.random.default_rng(3)
+    for r in rng.choice(nr, size=nr // 100, replace=False):
+        data[r * rsi_bytes:(r + 1) * rsi_bytes] = rng.integers(0, 256, rsi_bytes, dtype=np.uint8)
+    codec = gpu.Codec(bps, bs, rsi, flags)
+    d_in = torch.from_numpy(data).cuda()
+    d_out, nbytes, tb, _, d_off = codec.encode(d_in)
+    d_idx = torch.zeros(nr + 2, dtype=torch.int64, device=d_in.device)
+    d_res = torch.zeros(40, dtype=torch.uint8, device=d_in.device)
+    codec.index_async(d_out, nbytes, 0, d_idx, nr, d_res)
+    torch.cuda.synchronize()
+    res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.uint64)
+    assert int(res[0]) == nr
+    assert torch.equal(d_idx[:nr], d_off[:nr])
+    d_dec, status = codec.decode(d_out, nbytes, d_idx, nr, codec.block_count(n))
+    assert status == 0 and torch.equal(d_dec, d_in)
