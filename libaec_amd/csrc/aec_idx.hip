@@ -850,7 +850,6 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             if (!fail && run) {
                 n = spec_run_blocks(c, len - c.id_len - 1u, b);
                 fail = !n || n > bend - b;
-                if (fail) n = 0;                                // (refuted, not out of the window)
             }
             if (!fail) {
                 pos += len;
@@ -860,11 +859,10 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             }
             if (done && pos - p0 > 0xFFFFu) fail = true;
             if (fail || done) {
-                // (out of the window: the coded data set itself does not fit, the walk stands beyond the window, or
-                // the RSI is longer than a record holds)
-                const bool lim = n != 0u && (len == 0u ? near_end(pos) : (pos >= s.limit || done));
+                // (a walk that fails this close to the end of the window, or is longer than a record holds, has
+                // probably run out of the window: kS2Limited)
                 ua[i] = fail ? (uint16_t)0 : (uint16_t)(pos - p0);
-                ub[i] = fail ? (uint16_t)(lim ? kS2Limited : 0u) : (uint16_t)b;
+                ub[i] = fail ? (uint16_t)((near_end(pos) || done) ? kS2Limited : 0u) : (uint16_t)b;
                 have = false;
             }
         }
