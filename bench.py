@@ -533,6 +533,11 @@ def main():
                            "stream); decode_bare is the rate from the stream alone",
         }
         out.update({k: v for k, v in extras.items() if v is not None})
+        if "decode_bare" in out:
+            # encode + decode WITHOUT the side table (what north_star asks of a stream any producer wrote): the timed
+            # encode of the step, then index pass + lane-per-RSI decode of the bare stream
+            b = out["decode_bare"]
+            b["encode_plus_decode_GBps"] = round(nbytes / ((enc_ms + b["index_ms"] + b["decode_ms"]) * 1e-3) / 1e9, 2)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
