@@ -242,6 +242,9 @@ def main():
                          "decode (index pass + lane-per-RSI decode, no encoder side information), "
                          "PCIe-inclusive ABI rate")
     ap.add_argument("--extras", action="store_true", help="(kept for old command lines: extras are on by default)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test mode: all ranks on cuda:0, exchange over gloo through the host (the whole N > 1 path on "
+                         "a box with one GPU; NOT a scaling measurement)")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: independent shard streams, no exchange and no all-gather")
     ap.add_argument("--overlap", action="store_true",
@@ -259,10 +262,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (the codec has no CPU path)"
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from libaec_amd import gpu
 
@@ -381,7 +389,8 @@ def main():
         codec.encode_plan_async(d_in, nbytes, d_eres)
         r0 = d_eres.cpu().numpy().view(gpu.ENC_RESULT_DTYPE)[0]
         if world > 1:
-            plans0 = shard.exchange_plans(int(r0["total_bits"]), int(r0["k_lo"]), int(r0["k_hi"]), device=dev)
+            plans0 = shard.exchange_plans(int(r0["total_bits"]), int(r0["k_lo"]), int(r0["k_hi"]),
+                                          device="cpu" if args.share_gpu else dev)
         else:
             plans0 = [(int(r0["total_bits"]), int(r0["k_lo"]), int(r0["k_hi"]))]
         slot = shard.slot_bytes(plans0)
@@ -457,6 +466,19 @@ def main():
             codec.encode_async(d_in, nbytes, ref_out, d_off, d_eres)
             assert torch.equal(ref_out[:cbytes], d_stream[:cbytes]), "stitched stream != single stream"
             del ref_out
+        elif args.share_gpu and rank == 0 and KIND >= 0 and world * nbytes <= (8 << 30):
+            # (test mode) the stream all ranks stitched together must be what ONE encoder makes of the inputs of
+            # all ranks one behind the other (every rank's input is its seeded walk: generated again here)
+            whole = torch.empty(world * nbytes, dtype=torch.uint8, device=dev)
+            for r in range(world):
+                h = generate(KIND, nbytes, r, threads)
+                whole[r * nbytes:(r + 1) * nbytes].copy_(torch.from_numpy(h))
+            c2 = gpu.Codec(BPS, BS, RSI, FLAGS)
+            w_out, w_bytes, w_bits, _, _ = c2.encode(whole)
+            total = int(d_total.cpu().item()) if d_total is not None else w_bytes
+            assert total == w_bytes and torch.equal(w_out[:w_bytes], d_stream[:w_bytes]), \
+                "stream stitched from all ranks != single-encoder stream of the concatenated inputs"
+            del whole, w_out, c2
 
     lib = gpu._lib()
     lib.aec_gpu_profile.argtypes = [C.c_void_p, C.c_int]
@@ -477,7 +499,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -512,7 +534,9 @@ def main():
             "config": {"workload": f"{args.config}: {wl_name} {args.size_mib} MiB per GPU, {BPS}-bit, block {BS}, rsi {RSI}, "
                                    f"flags {FLAGS}; step = encode + decode (segment table)"
                                    + ("; one stream over all ranks: plan, exchange, emit at the global bit "
-                                      "offset, RCCL all-gather + stitch overlapped with decode" if sharded else ""),
+                                      "offset, RCCL all-gather + stitch overlapped with decode" if sharded else "")
+                                   + ("; TEST MODE: all ranks share cuda:0 and exchange over gloo through the host -- "
+                                      "the N > 1 code path, not a scaling measurement" if args.share_gpu else ""),
                        "bits_per_sample": BPS, "block_size": BS, "rsi": RSI, "flags": FLAGS,
                        "input_bytes_per_gpu": nbytes, "compressed_bytes_rank0": cbytes,
                        "ratio": round(nbytes / cbytes, 3), "bit_exact_vs_cpu": exact,

@@ -99,6 +99,19 @@ def stitch(gathered: torch.Tensor, slot: int, plans: Sequence[Tuple[int, int, in
     return out, nbytes
 
 
+def _all_gather_bytes(out: torch.Tensor, local: torch.Tensor, group=None) -> None:
+    """out[r * n : (r + 1) * n] = rank r's `local` (n bytes, device tensors).  RCCL gathers them where they lie; any
+    other backend (gloo: ranks that share ONE GPU in a test) goes through host copies."""
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return
+    world = dist.get_world_size(group)
+    mine = local.detach().cpu().contiguous()
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine, group=group)
+    out.copy_(torch.cat(got).to(out.device))
+
+
 class DeviceShard:
     """One rank's part of a stream coded on `world` devices, all on the device (no host sync per step).
 
@@ -120,7 +133,7 @@ class DeviceShard:
     def step(self, d_in, nbytes, d_out, d_off, d_eres):
         self.codec.encode_plan_async(d_in, nbytes, d_eres)
         if self.world > 1:
-            dist.all_gather_into_tensor(self.d_plans, d_eres[:24], group=self.group)
+            _all_gather_bytes(self.d_plans, d_eres[:24], self.group)
         else:
             self.d_plans.copy_(d_eres[:24])
         self.codec.encode_emit_planned_async(d_in, nbytes, d_out, d_off, d_eres, self.d_plans, self.rank)
@@ -128,7 +141,7 @@ class DeviceShard:
     def gather_and_stitch(self, d_out, d_stream, d_total=None):
         view = self.d_gathered[: self.world * self.slot]
         if self.world > 1:
-            dist.all_gather_into_tensor(view, d_out[: self.slot], group=self.group)
+            _all_gather_bytes(view, d_out[: self.slot], self.group)
         else:
             view.copy_(d_out[: self.slot])
         self.gpu.stitch_async(self.d_gathered, self.slot, self.d_plans, self.world, d_stream, d_total)

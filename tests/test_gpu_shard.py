@@ -140,3 +140,28 @@ def test_c_recipe_over_rccl_world_1():
                     "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "shard_rccl ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_sharded_path_with_ranks_sharing_one_gpu(world):
+    """BASELINE config 4's path end to end with N > 1 PROCESSES: plan, exchange of the 24-byte records, emit at the
+    global bit offset, all-gather of the slices, stitch, decode of every rank's shard out of the stitched stream --
+    bench.py under torch.distributed.run with all ranks on cuda:0 and gloo (through the host) in place of RCCL,
+    which needs a GPU per rank.  bench.py asserts the round trips itself and, on rank 0, that the stitched stream is
+    byte for byte what ONE encoder makes of the inputs of all ranks one behind the other."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29500 + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", str(world), "--share-gpu", "--size-mib", "256", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == world and out["value"] > 0
+    assert "one bit-exact stream" in out["config"]["parallelism"]
