@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Random sweep of the bare-stream path on the GPU box (not a pytest: minutes): random parameters and data
+shapes, index pass against the encoder's offset table, decode from the found offsets against the input.
+
+    python tests/fuzz_index_gpu.py [--cases 60] [--seed 1]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import (AEC_DATA_MSB, AEC_DATA_PREPROCESS, AEC_DATA_SIGNED, bytes_per_sample, pack_samples,  # noqa: E402
+                     random_walk_samples)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=-1, help="run this case alone (the others only draw their random numbers)")
+    return run(ap.parse_args())
+
+
+def run(args):
+    import torch
+    from libaec_amd import gpu
+    rng = np.random.default_rng(args.seed)
+    bad = 0
+    for case in range(args.cases):
+        bps = int(rng.choice([8, 10, 12, 16, 16, 16, 24, 32]))
+        bs = int(rng.choice([8, 16, 16, 32, 64]))
+        rsi = int(rng.choice([1, 5, 16, 64, 128, 128, 256, 1024, 4096]))
+        flags = AEC_DATA_PREPROCESS if rng.random() < 0.85 else 0
+        if rng.random() < 0.3:
+            flags |= AEC_DATA_MSB
+        if rng.random() < 0.3 and bps > 1:
+            flags |= AEC_DATA_SIGNED
+        nb = bytes_per_sample(bps, flags)
+        target = int(rng.choice([1, 4, 16, 48])) << 20
+        n = max(bs * rsi * 3, target // nb)
+        n -= n % bs if rng.random() < 0.7 else 0
+        scale = float(rng.choice([0.3, 1.0, 2.0, 8.0, 60.0, 400.0]))
+        # tile a random walk so that generating stays cheap
+        base_n = min(n, 1 << 20)
+        vals = random_walk_samples(rng, base_n, bps, flags, scale=scale, zero_frac=float(rng.choice([0.0, 0.1, 0.5])),
+                                   jump_frac=float(rng.choice([0.0, 0.001, 0.02])))
+        base = pack_samples(vals, bps, flags)
+        data = np.tile(base, (n * nb + base.size - 1) // base.size)[: n * nb].copy()
+        if rng.random() < 0.4:                                   # incompressible stretches
+            for _ in range(int(rng.integers(1, 12))):
+                o = int(rng.integers(0, max(1, data.size - 70000)))
+                ln = int(rng.integers(1000, 70000))
+                o -= o % nb
+                cnt = min(ln, data.size - o) // nb
+                lo, hi = (-(1 << (bps - 1)), 1 << (bps - 1)) if flags & AEC_DATA_SIGNED else (0, 1 << bps)
+                data[o:o + cnt * nb] = pack_samples(rng.integers(lo, hi, cnt), bps, flags)    # (valid samples only)
+        if args.only >= 0 and case != args.only:
+            continue
+        codec = gpu.Codec(bps, bs, rsi, flags)
+        d_in = torch.from_numpy(data).cuda()
+        d_out, nbytes, tb, _, d_off = codec.encode(d_in)
+        nr, nblk = codec.rsi_count(data.size), codec.block_count(data.size)
+        d_idx = torch.zeros(nr + 2, dtype=torch.int64, device=d_in.device)
+        d_res = torch.zeros(40, dtype=torch.uint8, device=d_in.device)
+        codec.index_async(d_out, nbytes, 0, d_idx, nr, d_res)
+        torch.cuda.synchronize()
+        res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.uint64)
+        whole = nblk // rsi
+        why = ""
+        ok = int(res[0]) in (nr, whole)
+        if not ok:
+            why = f"n_rsi {int(res[0])} want {nr} or {whole}; tail_blocks {int(res[1])} end_bit {int(res[2])} of {tb} status/pad {res[3]:#x}"
+        elif not bool(torch.equal(d_idx[:whole], d_off[:whole])):
+            ok = False
+            neq = (d_idx[:whole] != d_off[:whole]).nonzero()
+            first = int(neq[0])
+            why = f"{neq.numel()} of {whole} offsets differ, first at RSI {first}: {int(d_idx[first])} want {int(d_off[first])}"
+        if ok:
+            # stream and decoded bytes against the oracle (the reference's own behaviour, also where a container holds
+            # more bits than a sample: it does not give the input back there)
+            from helpers import oracle_decode, oracle_encode
+            rc, enc, *_ = oracle_encode(data, bps, bs, rsi, flags)
+            if enc != d_out[:nbytes].cpu().numpy().tobytes():
+                ok, why = False, "stream differs from the oracle's"
+            else:
+                d_dec, status = codec.decode(d_out, nbytes, d_idx, nr, nblk)      # (from the offsets the index pass found)
+                rc2, dec_o, _ = oracle_decode(enc, bps, bs, rsi, flags, nblk * bs * nb)
+                if status != 0 or d_dec.cpu().numpy().tobytes() != dec_o:
+                    ok, why = False, f"decode differs from the oracle's (status {status})"
+        print(f"case {case}: bps {bps} bs {bs} rsi {rsi} flags {flags} n {n} scale {scale} ratio "
+              f"{data.size / nbytes:.2f}: {'ok' if ok else 'MISMATCH ' + why}", flush=True)
+        bad += 0 if ok else 1
+        del d_in, d_out, d_off, d_idx
+    print("mismatches:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -773,3 +773,14 @@ def test_index_bridges_rsis_longer_than_the_look_ahead(gpu):
     assert torch.equal(d_idx[:nr], d_off[:nr])
     d_dec, status = codec.decode(d_out, nbytes, d_idx, nr, codec.block_count(n))
     assert status == 0 and torch.equal(d_dec, d_in)
+
+
+def test_random_sweep_of_the_bare_stream_path(gpu):
+    """tests/fuzz_index_gpu.py, 30 cases: random parameters (bits per sample 8..32 in their containers, block sizes,
+    RSIs of 1..4096 blocks, byte order, signedness, with and without the preprocessor), random-walk data of several
+    entropies with zero stretches, jumps and incompressible pieces, 1..48 MiB: the stream against the oracle's, the
+    RSI starts found from the stream alone against the encoder's table, the bytes decoded from the found starts
+    against the oracle's."""
+    import argparse
+    import fuzz_index_gpu
+    assert fuzz_index_gpu.run(argparse.Namespace(cases=30, seed=5, only=-1)) == 0
