@@ -204,3 +204,12 @@ def test_one_gib_of_one_mib_chunks_vs_reference_shim(szip):
         # and the reference decodes what was produced here (first chunk of every call)
         rc, back = szip.decompress(got[0], 1 << 20, opts, bpp, ppb, pps, lib=ref)
         assert rc == 0 and back == chunks[0].tobytes(), g0
+
+
+def test_random_sweep_of_the_batch_entry_points(szip):
+    """tests/fuzz_batch_gpu.py, 25 cases: aec_buffer_encode_batch / aec_buffer_decode_batch with random parameters
+    and 1..300 chunks per call -- equal chunks of whole RSIs (ONE launch set for all of them), equal ragged ones,
+    random sizes, tiny and large mixed, an output buffer too small for its stream -- every chunk against the oracle."""
+    import argparse
+    import fuzz_batch_gpu
+    assert fuzz_batch_gpu.run(argparse.Namespace(cases=25, seed=9)) == 0
