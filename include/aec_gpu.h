@@ -40,7 +40,9 @@ typedef struct aec_gpu_enc_result {
 
 typedef struct aec_gpu_dec_result {
     uint64_t n_rsi;        /* index pass: complete RSIs found */
-    uint64_t tail_blocks;  /* index pass: complete blocks of the trailing partial RSI */
+    uint64_t tail_blocks;  /* index pass: complete blocks of the trailing partial RSI; decode records: the lowest
+                              failing block of the batch (numbered from the first RSI), ~0 if none -- every block
+                              in front of it is decoded and valid */
     uint64_t end_bit;      /* index pass: bit position after the last complete coded data set */
     uint32_t status;       /* 0 ok, 1 input ended inside a coded data set, 2 corrupt stream */
     uint32_t pad;          /* index pass: 1 = stopped because the input ended; aec_gpu_decode_indexed_async:

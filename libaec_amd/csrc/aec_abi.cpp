@@ -414,6 +414,7 @@ int decode_run(internal_state *s, struct aec_stream *strm)
     const uint64_t base_bits = s->base * 8;
     const uint64_t walk_rel = s->walk_bit - base_bits, rsi_rel = s->rsi_start_bit - base_bits;
     const size_t skip = (size_t)s->delivered * c.bytes;   // bytes of the current RSI already handed out
+    const size_t want_out = strm->avail_out;              // (what the caller asks of THIS call)
 
     // bound of the batch: the room offered (at least kMinBatchOut), and no more than the input can hold
     const size_t room = (strm->avail_out > kMinBatchOut ? strm->avail_out : kMinBatchOut) + skip;
@@ -470,8 +471,11 @@ int decode_run(internal_state *s, struct aec_stream *strm)
     if (dec.status != DEC_OK) {
         corrupt = true;
         if (dec.bad_rsi <= good_rsi) {
+            // (the decode record's tail_blocks: the lowest failing block of the batch -- the blocks of its RSI in
+            // front of it are decoded and good)
+            const uint64_t bad_block = dec.tail_blocks;
             good_rsi = dec.bad_rsi;
-            tail_blocks = 0;
+            tail_blocks = (bad_block != ~0ull && bad_block / c.rsi == good_rsi) ? bad_block % c.rsi : 0;
         }
     }
     // samples released from the coded data set the input ends in (reference decode.c:423-460)
@@ -506,6 +510,24 @@ int decode_run(internal_state *s, struct aec_stream *strm)
                 return AEC_FAIL(AEC_MEM_ERROR);
         }
     }
+    // A coded data set that cannot be accepted -- a zero run overrunning its RSI (found by the walker), a
+    // second-extension code beyond the table (found by the decoder) -- BEHIND everything this call was asked for is
+    // not this call's error: the reference stops when the output is full (decode.c:797-831) and only meets it
+    // when it is asked for more, as the next call here will.  The walk then resumes at the coded data set the walker
+    // stopped at, or at the start of the RSI the decoder gave up.
+    uint64_t res_rsi = idx.n_rsi, res_tail = idx.tail_blocks, res_end = idx.end_bit;
+    bool more_behind = false;
+    if (corrupt && want_out && total >= skip + want_out) {
+        corrupt = false;
+        if (dec.status != DEC_OK) {
+            uint64_t off = 0;
+            if (hipMemcpy(&off, d_off + good_rsi, 8, hipMemcpyDeviceToHost) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
+            res_rsi = good_rsi;
+            res_tail = 0;                                   // (the walker starts the RSI again; its good blocks are `delivered`)
+            res_end = off;
+            more_behind = true;
+        }
+    }
     if (corrupt) {
         if (getenv("AEC_ABI_TRACE"))
             fprintf(stderr, "libaec (MI355X): AEC_DATA_ERROR: walker status %u after %llu RSIs + %llu blocks (bit %llu), "
@@ -514,24 +536,24 @@ int decode_run(internal_state *s, struct aec_stream *strm)
                     (unsigned long long)dec.bad_rsi);
         return AEC_DATA_ERROR;
     }
-    if (idx.n_rsi) s->rsi_bits_seen = (idx.end_bit - rsi_rel) / (idx.n_rsi + (idx.tail_blocks ? 1 : 0));
+    if (res_rsi) s->rsi_bits_seen = (res_end - rsi_rel) / (res_rsi + (res_tail ? 1 : 0));
 
     // advance: the walker resumes behind the last complete coded data set
-    s->walk_bit = base_bits + idx.end_bit;
-    s->walk_blocks = (uint32_t)idx.tail_blocks;
-    if (idx.tail_blocks) {
+    s->walk_bit = base_bits + res_end;
+    s->walk_blocks = (uint32_t)res_tail;
+    if (res_tail) {
         s->rsi_start_bit = base_bits + tail_start;
-        s->delivered = idx.tail_blocks * c.bs + part;
+        s->delivered = res_tail * c.bs + part;
     } else {
         s->rsi_start_bit = s->walk_bit;
-        s->delivered = part;
+        s->delivered = more_behind ? tail_blocks * c.bs : part;
     }
     s->walked_len = in_bytes;
     if (idx.pad == 1 && in_bytes < s->d_len) s->span_mul = s->span_mul < (1u << 20) ? s->span_mul * 4 : s->span_mul;
     else s->span_mul = 1;
     // stopped at the bound with input left: the caller's next call (or this one, if it still has
     // room) goes on from here
-    s->more = idx.n_rsi >= max_rsi || in_bytes < s->d_len;
+    s->more = idx.n_rsi >= max_rsi || in_bytes < s->d_len || more_behind;
 
     // drop the consumed front of the resident stream once it is the larger part (the copy must not overlap)
     const uint64_t keep_from = (s->rsi_start_bit / 8 - s->base) & ~(uint64_t)15;

@@ -116,11 +116,14 @@ __device__ __forceinline__ void store_block_generic(uint8_t *dst, const uint32_t
     }
 }
 
-__device__ __forceinline__ void report(DecResult *res, uint32_t status, uint64_t rsi)
+__device__ __forceinline__ void report(DecResult *res, uint32_t status, uint64_t rsi, uint64_t block)
 {
-    // worst status wins (DATA_ERROR > NEED_INPUT > OK); remember the lowest failing RSI
+    // worst status wins (DATA_ERROR > NEED_INPUT > OK); remember the lowest failing RSI and -- in the decode record's
+    // tail_blocks, which the decoder has no other use for -- the lowest failing block of the batch: everything in
+    // front of it is decoded and valid (reference: every sample preceding an error is delivered)
     atomicMax(&res->status, status);
     atomicMin(reinterpret_cast<unsigned long long *>(&res->bad_rsi), (unsigned long long)rsi);
+    atomicMin(reinterpret_cast<unsigned long long *>(&res->tail_blocks), (unsigned long long)block);
 }
 
 // ---- compressed-stream staging ------------------------------------------------------------------
@@ -469,7 +472,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                 ok = 0u;
             } else if (parse) {
                 if (st != DEC_OK) {
-                    report(res, st, r);
+                    report(res, st, r, first_blk + bb);
                     // (a batch of independent streams: the stream's own record says so as well -- one overall
                     // record names only the first bad RSI of the whole batch)
                     if (batch && st == DEC_DATA_ERROR)
@@ -524,7 +527,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                     atomicOr(&res->pad, kDecRedo);
                     ok = 0u;
                 } else if (st != DEC_OK) {
-                    report(res, st, r);
+                    report(res, st, r, first_blk + bo);
                     // (a batch of independent streams: the stream's own record says so as well -- one overall
                     // record names only the first bad RSI of the whole batch)
                     if (batch && st == DEC_DATA_ERROR)
@@ -549,6 +552,9 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     }
     }
     if (STG && (b % G) != 0) flush(b / G);             // rows of the last, partial group
+    // The predictor state behind the LAST item of the batch, as the reference carries it (32 bits, not cut to the
+    // sample width: on damaged streams it leaves the range): k_decode_partial continues from it.
+    if (!SEG && active && r + 1 == n_rsi) res->end_bit = x;
 }
 
 // ---- coded data sets longer than the ring ------------------------------------------------------------
@@ -610,7 +616,7 @@ k_decode_redo(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, 
                 uint32_t nz = 0;
                 const uint32_t st = parse_cds<0>(br, d, c, rf ? 1u : 0u, b0 + bo, nz);
                 if (st != DEC_OK) {
-                    report(res, st, r);
+                    report(res, st, r, first_blk + bo);
                     if (batch && st == DEC_DATA_ERROR)
                         atomicMax(&const_cast<DecResult *>(batch)[r / rsi_per_chunk].status, (uint32_t)DEC_DATA_ERROR);
                     break;
@@ -629,6 +635,7 @@ k_decode_redo(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, 
             dst += blk_bytes;
             if (rf) d[0] = 0;
         }
+        if (!SEG && r + 1 == n_rsi) res->end_bit = x;       // (as k_decode: the state k_decode_partial continues from)
     }
 }
 
@@ -674,7 +681,7 @@ k_decode_partial(const Cfg c, const uint32_t *__restrict__ words, uint64_t nword
                 uint32_t m = 0, sum = 0, second = 0;
                 if (!unary_ok(m)) break;
                 if (!se_lookup(m, sum, second)) {            // beyond the table: corrupt (decode.c:589-616)
-                    report(res, DEC_DATA_ERROR, idx->n_rsi);
+                    report(res, DEC_DATA_ERROR, idx->n_rsi, idx->n_rsi * c.rsi + idx->tail_blocks);
                     break;
                 }
                 if ((i & 1u) == 0) d[cnt++] = sum - second, i++;
@@ -700,11 +707,10 @@ k_decode_partial(const Cfg c, const uint32_t *__restrict__ words, uint64_t nword
     if (cnt >= bs) cnt = bs - 1;                             // (a complete block is the index pass's business)
     // inverse predictor (reference decode.c:67-141) continuing from the sample in front, byte-order store
     const uint64_t first = (idx->n_rsi * c.rsi + b) * (uint64_t)bs;       // sample index in `out`
+    // (the predictor state k_decode left behind the blocks in front -- not the sample in the output, which is cut to
+    // the sample width)
     uint32_t x = 0;
-    if (pp && !ref && cnt) {
-        const uint32_t prev = load_sample_bytes(out + (first - 1) * c.bytes, c.bytes, msb);
-        x = sgn ? sign_extend(prev & low_mask32(bps), bps) : prev & low_mask32(bps);
-    }
+    if (pp && !ref && cnt) x = (uint32_t)res->end_bit;
     for (uint32_t i = 0; i < cnt; i++) {
         uint32_t v;
         if (!pp) v = d[i];
@@ -719,7 +725,7 @@ k_decode_partial(const Cfg c, const uint32_t *__restrict__ words, uint64_t nword
 __global__ void k_dec_result_init(DecResult *res)
 {
     res->n_rsi = 0;
-    res->tail_blocks = 0;
+    res->tail_blocks = ~0ull;          // (decode records: the lowest failing block of the batch, see report())
     res->end_bit = 0;
     res->status = DEC_OK;
     res->pad = 0;

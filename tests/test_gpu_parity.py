@@ -784,3 +784,15 @@ def test_random_sweep_of_the_bare_stream_path(gpu):
     import argparse
     import fuzz_index_gpu
     assert fuzz_index_gpu.run(argparse.Namespace(cases=30, seed=5, only=-1)) == 0
+
+
+def test_random_sweep_of_corrupted_streams(api):
+    """tests/fuzz_corrupt_gpu.py, 60 cases: bit flips, cuts with garbage tails and overwritten stretches in valid
+    streams through aec_buffer_decode.  Where the oracle (the reference's behaviour: it decodes until the output
+    is full and only then looks no further) returns AEC_OK the product returns the same bytes -- also when the
+    damage made coded data sets the walker or the decoder must refuse BEHIND the output asked for, and when the
+    predictor state has left the sample range by the time the input ends inside a coded data set -- and where it
+    returns AEC_DATA_ERROR, so does the product."""
+    import argparse
+    import fuzz_corrupt_gpu
+    assert fuzz_corrupt_gpu.run(argparse.Namespace(cases=60, seed=13)) == 0
