@@ -519,13 +519,13 @@ int decode_run(internal_state *s, struct aec_stream *strm)
     bool more_behind = false;
     if (corrupt && want_out && total >= skip + want_out) {
         corrupt = false;
+        more_behind = true;                                 // (the next call that offers room meets the error)
         if (dec.status != DEC_OK) {
             uint64_t off = 0;
             if (hipMemcpy(&off, d_off + good_rsi, 8, hipMemcpyDeviceToHost) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
             res_rsi = good_rsi;
             res_tail = 0;                                   // (the walker starts the RSI again; its good blocks are `delivered`)
             res_end = off;
-            more_behind = true;
         }
     }
     if (corrupt) {
@@ -546,7 +546,7 @@ int decode_run(internal_state *s, struct aec_stream *strm)
         s->delivered = res_tail * c.bs + part;
     } else {
         s->rsi_start_bit = s->walk_bit;
-        s->delivered = more_behind ? tail_blocks * c.bs : part;
+        s->delivered = (more_behind && dec.status != DEC_OK) ? tail_blocks * c.bs : part;
     }
     s->walked_len = in_bytes;
     if (idx.pad == 1 && in_bytes < s->d_len) s->span_mul = s->span_mul < (1u << 20) ? s->span_mul * 4 : s->span_mul;

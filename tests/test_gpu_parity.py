@@ -796,3 +796,16 @@ def test_random_sweep_of_corrupted_streams(api):
     import argparse
     import fuzz_corrupt_gpu
     assert fuzz_corrupt_gpu.run(argparse.Namespace(cases=60, seed=13)) == 0
+
+
+def test_random_sweep_of_the_streaming_calls(api):
+    """tests/fuzz_stream_gpu.py, 40 cases: aec_encode / aec_decode in random pieces (7 bytes .. 1 MiB of input and of
+    room per call), the same calls against the compiled reference: same coded stream; same decoded bytes and return
+    code for valid and damaged streams.  Where the reference's own answer depends on the room it is handed (a zero
+    run past the end of its RSI is only refused when the room holds the whole run, decode.c:543-544) the product
+    gives the answer of the reference with ample room, in pieces as in one call."""
+    import argparse
+    import fuzz_stream_gpu
+    if not have_ref():
+        pytest.skip("oracle/_ref not built")
+    assert fuzz_stream_gpu.run(argparse.Namespace(cases=40, seed=1, dump="", ref_only=False)) == 0
