@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT; O=$PWD/gpurun_out/$1; mkdir -p $O; R=$PWD
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/tests/bench_abi_small.py > $O/out.txt 2>&1
-f=$(find $O/trace -name "*kernel_trace.csv" | head -1)
+f=$(find $O -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY' > $O/summary.txt
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
