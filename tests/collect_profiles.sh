@@ -40,7 +40,7 @@ python3 tests/pmc_summary.py "$OUT/idxpmc_c3_*/runc/*counter_collection.csv" > $
 for c in c2 c5; do
   AEC_AMD_LIB=$R/libaec_amd/lib/tuning/libaec.so.0 AEC_S2_PROF=1 python3 tests/bench_index.py --config $c --size-mib 1024 2>&1 | grep -v amdgpu > $OUT/k_spec2_phases_$c.txt
 done
-python3 tests/bench_index_mixed.py 2>&1 | grep -v amdgpu > $OUT/bench_index_mixed_1GiB.txt
+python3 tests/bench_index_mixed.py 2>&1 | grep -v amdgpu > $OUT/bench_index_mixed.txt
 python3 tests/bench_abi_small.py > $OUT/bench_abi_small.txt 2>&1
 python3 tests/bench_sz_chunks.py > $OUT/bench_sz_chunks.txt 2>&1
 python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
