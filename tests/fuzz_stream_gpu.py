@@ -20,7 +20,7 @@ from helpers import (AEC_DATA_MSB, AEC_DATA_PREPROCESS, AEC_DATA_SIGNED, AEC_FLU
                      bytes_per_sample, have_ref, oracle_encode, pack_samples, random_walk_samples, ref_lib)
 
 
-def drive(lib, kind, data, params, plan, out_room_total):
+def drive(lib, kind, data, params, plan, out_room_total, ample=False):
     """kind 'encode' / 'decode'; plan = [(input bytes offered, output room offered), ...] cycled until the input is
     used up, then flush calls until nothing comes any more.  Returns (last rc, bytes)."""
     st = AecStream()
@@ -35,12 +35,12 @@ def drive(lib, kind, data, params, plan, out_room_total):
     src = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
     out = bytearray()
     pos, rc, step, done = 0, AEC_OK, 0, False
-    buf = np.zeros(1 << 20, dtype=np.uint8)
+    buf = np.zeros(out_room_total if ample else 1 << 20, dtype=np.uint8)       # (ample: everything in ONE call)
     while rc == AEC_OK and len(out) < out_room_total and not done:
         n_in, room = plan[step % len(plan)]
         step += 1
         n_in = min(n_in, src.size - pos)
-        room = min(room, buf.size, out_room_total - len(out))
+        room = buf.size if ample else min(room, buf.size, out_room_total - len(out))
         st.next_in = src.ctypes.data + pos
         st.avail_in = n_in
         st.next_out = buf.ctypes.data
@@ -62,6 +62,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="1..4 M samples per case, pieces of 4 KiB .. 3 MiB")
     ap.add_argument("--dump", default="", help="directory: write every case's (damaged) stream there")
     ap.add_argument("--ref-only", action="store_true", help="drive the reference on both sides (case generation without a GPU)")
     return run(ap.parse_args())
@@ -90,11 +91,11 @@ def run(args):
         if rng.random() < 0.3:
             flags |= AEC_DATA_SIGNED
         nb = bytes_per_sample(bps, flags)
-        n = int(rng.choice([3000, 30000, 120000]))
+        n = int(rng.choice([1000000, 2500000, 4000000] if args.big else [3000, 30000, 120000]))
         vals = random_walk_samples(rng, n, bps, flags, scale=float(rng.choice([0.5, 3.0, 50.0])), zero_frac=0.2, jump_frac=0.002)
         data = pack_samples(vals, bps, flags)
         params = (bps, bs, rsi, flags)
-        ch = [nb * 7, 64, 1000, 4096, 70000, 1 << 20]
+        ch = [4096, 70000, 300000, 1 << 20, 3 << 20] if args.big else [nb * 7, 64, 1000, 4096, 70000, 1 << 20]
         plan = [(int(rng.choice(ch)), int(rng.choice(ch))) for _ in range(int(rng.integers(1, 6)))]
         why = ""
         # encode: same calls, same stream
@@ -131,7 +132,7 @@ def run(args):
                 # whole run.  The arbiter is therefore the reference in ONE call with ample room, which the product must
                 # match both in pieces and in one call.
                 one = [(1 << 30, 1 << 20)]
-                rc_r1, dec_r1 = drive(ref, "decode", enc, params, one, out_total + (1 << 20))
+                rc_r1, dec_r1 = drive(ref, "decode", enc, params, one, out_total + (1 << 20), ample=True)
                 rc_p1, dec_p1 = drive(prod, "decode", enc, params, one, out_total)
                 k1 = next((i for i in range(min(len(dec_r1), len(dec_p1))) if dec_r1[i] != dec_p1[i]), -1)
                 if rc_r != rc_p and rc_r1 == rc_p and rc_p1 == rc_p:

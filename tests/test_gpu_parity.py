@@ -808,4 +808,4 @@ def test_random_sweep_of_the_streaming_calls(api):
     import fuzz_stream_gpu
     if not have_ref():
         pytest.skip("oracle/_ref not built")
-    assert fuzz_stream_gpu.run(argparse.Namespace(cases=40, seed=1, dump="", ref_only=False)) == 0
+    assert fuzz_stream_gpu.run(argparse.Namespace(cases=40, seed=1, dump="", ref_only=False, big=False)) == 0
