@@ -11,7 +11,13 @@ GPU, block 16, rsi 128, AEC_DATA_PREPROCESS (generator: libaec_amd/csrc/datagen.
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-With N > 1 the ranks code ONE stream (weak scaling: 4 GiB per rank): every rank plans its shard,
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks ITSELF
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a child
+process, before this process has touched HIP), passes rank 0's JSON line through and exits with the child's
+code; under torchrun (WORLD_SIZE set) it is one rank of that world.
+
+With N > 1 the ranks code ONE stream (weak scaling: 8 GiB per rank, BASELINE configuration 4 = 64 GiB over
+8 ranks; 4 GiB on one GPU): every rank plans its shard,
 the 24-byte plan records are all-gathered as they lie in HBM, each rank derives its start bit and
 carried k on the device and emits its shard at the global bit offset, and ONE RCCL all-gather per step
 plus a stitch kernel reassemble the byte-exact stream on every rank, on a side stream that overlaps
@@ -223,6 +229,22 @@ def abi_end_to_end(host_sample):
                     "libaec.so.0: init, H2D, kernels (decode: + RSI index pass), D2H, end"}
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process (one rank per GPU, rendezvous on
+    127.0.0.1) and hand its output and exit code on.  Nothing in this process has touched HIP at this point, and it
+    never does: replacing a process that has initialised the GPU is not allowed on the pool, a child is."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,6 +274,8 @@ def main():
     ap.add_argument("--shard-path", action="store_true",
                     help="run the plan/exchange/emit/gather/stitch path even with one GPU")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     global BPS, BS, RSI, FLAGS, KIND
     wl_name, KIND, BPS, BS, RSI, FLAGS = CONFIGS[args.config]
 

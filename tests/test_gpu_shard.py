@@ -165,3 +165,22 @@ def test_bench_sharded_path_with_ranks_sharing_one_gpu(world):
     out = json.loads(line)
     assert out["n_gpus"] == world and out["value"] > 0
     assert "one bit-exact stream" in out["config"]["parallelism"]
+
+
+def test_bench_starts_its_ranks_itself():
+    """`python bench.py --gpus 2` WITHOUT torchrun (the form of the driver's N = 1 command with another N): bench.py
+    must start the two ranks itself and rank 0's line must say n_gpus == 2.  (--share-gpu: the test box has one GPU.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--size-mib", "256",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "one bit-exact stream" in out["config"]["parallelism"]
