@@ -150,7 +150,7 @@ struct Kit {
 };
 // at most kPoolMax parked kits, none holding a buffer above kKeepBytes, all of them together at most kPoolBytes
 constexpr size_t kPoolMax = 8, kKeepBytes = (size_t)256 << 20, kPoolBytes = (size_t)1 << 30;
-constexpr size_t kStageKeep = (size_t)96 << 20, kStagePiece = (size_t)64 << 20;
+constexpr size_t kStageKeep = (size_t)96 << 20, kStagePiece = (size_t)64 << 20, kPoolPinned = (size_t)192 << 20;
 std::mutex g_pool_mu;
 std::vector<Kit> *g_pool = nullptr;      // heap object on purpose: no destructor at exit
 
@@ -199,12 +199,21 @@ void park_kit(Kit &k)
         k.h_stage_cap = 0;
     }
     aec_gpu_trim(k.ctx, kKeepBytes);
+    aec_gpu_set_index_hint(k.ctx, 0);
     {
         std::lock_guard<std::mutex> lock(g_pool_mu);
         if (!g_pool) g_pool = new (std::nothrow) std::vector<Kit>();
-        size_t held = kit_bytes(k);
+        size_t held = kit_bytes(k), pinned = k.h_stage_cap;
         if (g_pool)
-            for (const Kit &o : *g_pool) held += kit_bytes(o);
+            for (const Kit &o : *g_pool) {
+                held += kit_bytes(o);
+                pinned += o.h_stage_cap;
+            }
+        if (pinned > kPoolPinned && k.h_stage) {     // page-locked host memory of all parked kits together is bounded too
+            (void)hipHostFree(k.h_stage);
+            k.h_stage = nullptr;
+            k.h_stage_cap = 0;
+        }
         if (g_pool && g_pool->size() < kPoolMax && held <= kPoolBytes) {
             g_pool->push_back(k);
             k = Kit{};
@@ -517,7 +526,10 @@ int decode_run(internal_state *s, struct aec_stream *strm)
     // stopped at, or at the start of the RSI the decoder gave up.
     uint64_t res_rsi = idx.n_rsi, res_tail = idx.tail_blocks, res_end = idx.end_bit;
     bool more_behind = false;
-    if (corrupt && want_out && total >= skip + want_out) {
+    // (a call that offers NO room defers what the walker found -- the reference's m_zero_block only refuses a run when
+    // avail_out holds it, decode.c:542-544 -- but not a second-extension code beyond the table, which the reference
+    // reports whatever the room, decode.c:589-616)
+    if (corrupt && total >= skip + want_out && (want_out || dec.status == DEC_OK)) {
         corrupt = false;
         more_behind = true;                                 // (the next call that offers room meets the error)
         if (dec.status != DEC_OK) {
@@ -682,12 +694,12 @@ int decode_call(struct aec_stream *strm, int flush)
                              s->d_len <= s->walked_len && s->stage.size() < kDecTrickle;
         if (trickle) break;
         const size_t out_before = strm->avail_out, q_before = s->outq.size();
-        const uint64_t walk_before = s->walk_bit;
+        const uint64_t walk_before = s->walk_bit, span_before = s->span_mul;
         rc = decode_run(s, strm);
         if (rc == AEC_DATA_ERROR) s->sticky_error = rc;
         if (rc != AEC_OK) break;
         const bool progressed = out_before != strm->avail_out || q_before != s->outq.size() ||
-                                walk_before != s->walk_bit;
+                                walk_before != s->walk_bit || s->span_mul > span_before;   // (a wider span is tried at once)
         if (!progressed) break;           // what is here needs more input before anything else comes out
     }
     if (rc == AEC_DATA_ERROR) drain(strm, s, bytes);   // the samples in front of the error are delivered
@@ -838,6 +850,7 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
     BatchKit bk(device);
     if (!bk.ok) return AEC_FAIL(AEC_MEM_ERROR);
     Kit &k = bk.k;
+    aec_gpu_set_index_hint(k.ctx, 0);      // (a kit from the pool: whatever its last stream measured is not this batch's)
     const size_t blk_bytes = (size_t)c.bs * c.bytes, rsi_bytes = (size_t)c.rsi * blk_bytes;
     // geometry: every stream gets room for the RSIs of the largest one
     uint64_t rpc = 1;
@@ -852,9 +865,10 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
     off[n] = total_in;
     // the index walker takes [off[i], off[i+1]) as stream i: the padding behind a stream is zeroed (zero
     // bits never complete a coded data set), the streams go up straight from the caller's buffers
-    // (chunk offsets twice: absolute, and -- for the table path, which takes the batch in groups -- relative to the
-    // group a chunk belongs to, every group with a closing entry of its own)
-    const size_t o_choff = up16((size_t)n * rpc * 8), o_res = o_choff + up16((2 * n + 2 + n / 8 + 8) * 8),
+    // (chunk offsets twice: the n + 1 absolute ones, and -- for the table path, which takes the batch in groups --
+    // relative to the group a chunk belongs to, every group with a closing entry of its own: n + G entries for G <= n
+    // groups, so the region holds 3 n + 4)
+    const size_t o_choff = up16((size_t)n * rpc * 8), o_res = o_choff + up16((3 * n + 4) * 8),
                  o_one = o_res + up16(n * 40);
     if (!k.d_in.ensure(total_in + 32) || !k.d_out.ensure((size_t)n * rpc * rsi_bytes + 64) ||
         !k.d_off.ensure(o_one + 64))
@@ -912,7 +926,7 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
             i = j;
         }
         first.push_back(n);
-        if (rel.size() > 2 * n + 2 + n / 8 + 8) return AEC_FAIL(AEC_MEM_ERROR);      // (cannot happen)
+        if (n + 1 + rel.size() > 3 * n + 4) return AEC_FAIL(AEC_MEM_ERROR);          // (cannot happen: rel holds n + G <= 2 n)
         uint64_t *d_rel = reinterpret_cast<uint64_t *>(meta + o_choff) + (n + 1);
         if (hipMemcpyAsync(d_rel, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, k.stream) != hipSuccess)
             return AEC_FAIL(AEC_MEM_ERROR);

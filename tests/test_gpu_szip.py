@@ -213,3 +213,25 @@ def test_random_sweep_of_the_batch_entry_points(szip):
     import argparse
     import fuzz_batch_gpu
     assert fuzz_batch_gpu.run(argparse.Namespace(cases=25, seed=9)) == 0
+
+
+@pytest.mark.parametrize("n,mib", [(48, 35), (112, 21)])
+def test_batch_decode_with_few_chunks_per_group(n, mib):
+    """aec_buffer_decode_batch with FEW large streams per 12-MiB group and MANY groups per part (round-3 ADVICE: the
+    group-relative chunk offsets outgrew their region and the last chunk of a part came back empty with AEC_OK).
+    48 streams of ~6.2 MiB (one per group, 12 groups in each of the four parts) and 112 of ~3.7 MiB, low-entropy
+    16-bit data: every chunk must come back whole and equal to what went in."""
+    import torch  # noqa: F401
+    from fuzz_batch_gpu import batch
+    from libaec_amd import api
+    from test_gpu_parity import gen
+    lib = api.library()
+    bps, bs, rsi, flags = 16, 16, 128, 8
+    data = gen(0, mib << 20)
+    rc, enc = api.aec_buffer_encode(data, bps, bs, rsi, flags)
+    assert rc == 0
+    stream = np.frombuffer(enc, dtype=np.uint8).copy()
+    rc, dec, st = batch(lib, "aec_buffer_decode_batch", (bps, bs, rsi, flags), [stream] * n, [data.size] * n)
+    assert rc == 0 and st == [0] * n, (rc, st)
+    for i, d in enumerate(dec):
+        assert d.size == data.size and np.array_equal(d, data), f"chunk {i} of {n}: {d.size} bytes"
