@@ -369,14 +369,18 @@ def main():
         # looks like.  Index pass (speculative tables + walk) + lane-per-RSI decode, timed together.
         d_idx = torch.zeros(n_rsi + 2, dtype=torch.int64, device=dev)
         d_ires = torch.zeros(40, dtype=torch.uint8, device=dev)
+        # (long RSIs: the index pass also leaves the segment starts and the decoder takes a lane per segment, the
+        # sample in front of each from a summing pass -- include/aec_gpu.h: aec_gpu_index_segments_async)
+        d_sbits = torch.zeros((n_rsi + 2) * codec.segments_per_rsi(), dtype=torch.int64, device=dev)
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         t_idx, t_dec = [], []
         for _ in range(3):
             d_idx.zero_()
+            d_dec.zero_()
             e0.record()
-            codec.index_async(d_out, cbytes, 0, d_idx, n_rsi + 1, d_ires)
+            codec.index_segments_async(d_out, cbytes, 0, d_idx, d_sbits, n_rsi + 1, d_ires)
             e1.record()
-            codec.decode_async(d_out, cbytes, d_idx, n_rsi, n_blk, d_dec, d_dres)
+            codec.decode_bare_async(d_out, cbytes, d_idx, d_sbits, n_rsi, n_blk, None, d_dec, d_dres)
             e2.record()
             torch.cuda.synchronize()
             t_idx.append(e0.elapsed_time(e1))
@@ -387,9 +391,9 @@ def main():
         ti, td = sorted(t_idx)[1], sorted(t_dec)[1]
         extras["decode_bare"] = {"GBps": round(nbytes / ((ti + td) * 1e-3) / 1e9, 2), "index_ms": round(ti, 3),
                                  "decode_ms": round(td, 3),
-                                 "note": "aec_gpu_index_async + aec_gpu_decode_async (one lane per RSI) on the "
-                                         "stream alone, median of 3"}
-        del d_idx
+                                 "note": "aec_gpu_index_segments_async + aec_gpu_decode_bare_async (a lane per RSI; per "
+                                         "segment where RSIs hold four and more) on the stream alone, median of 3"}
+        del d_idx, d_sbits
         extras["abi_end_to_end"] = abi_end_to_end(host[: 256 << 20])
     del host
 

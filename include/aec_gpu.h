@@ -200,6 +200,32 @@ AEC_GPU_API int aec_gpu_decode_indexed_async(aec_gpu_ctx *ctx, const aec_gpu_par
                                              void *d_out, aec_gpu_dec_result *d_result, void *stream);
 
 /*
+ * Bare streams with LONG RSIs (32-bit / block 32 / rsi 4096: 512 KiB per RSI, 8192 RSIs in 4 GiB): a lane per RSI
+ * leaves the device idle, and the reference's format has no entry points inside an RSI (src/decode.c:402-421).
+ * aec_gpu_index_segments_async is aec_gpu_index_resume_async (start_block 0: a plain index pass from an RSI start)
+ * that also leaves the start bit of every SEGMENT of 64 blocks of the RSIs it finds:
+ * d_seg_bits[r * aec_gpu_segments_per_rsi() + j], (max_rsi + 1) * aec_gpu_segments_per_rsi() entries, ~0 where it
+ * does not know one (streams it does not index over the trunk tables: all of them).  aec_gpu_decode_bare_async
+ * then decodes with one lane per segment: a first pass sums the predictor's steps per segment (inside the sample
+ * range the inverse predictor of src/decode.c:96-134 is a running sum; where a sample comes within reach of the
+ * range's ends the RSI is decoded by one lane as before), which gives every segment the sample in front of it,
+ * the second pass decodes.  Counts: from d_index_result on the device when given (as aec_gpu_decode_indexed_async,
+ * incl. the samples of the coded data set the input ends in), else max_rsi RSIs holding total_blocks blocks.
+ * Both calls on the same context, the decode behind the index pass whose tables it takes.
+ */
+AEC_GPU_API unsigned int aec_gpu_segments_per_rsi(const aec_gpu_params *p);
+AEC_GPU_API int aec_gpu_index_segments_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                             size_t in_bytes, uint64_t start_bit, unsigned int start_block,
+                                             uint64_t rsi_start_bit, uint64_t *d_rsi_bit_offsets,
+                                             uint64_t *d_seg_bits, uint64_t max_rsi, aec_gpu_dec_result *d_result,
+                                             void *stream);
+AEC_GPU_API int aec_gpu_decode_bare_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in,
+                                          size_t in_bytes, const uint64_t *d_rsi_bit_offsets,
+                                          const uint64_t *d_seg_bits, uint64_t max_rsi, uint64_t total_blocks,
+                                          const aec_gpu_dec_result *d_index_result, void *d_out,
+                                          aec_gpu_dec_result *d_result, void *stream);
+
+/*
  * Many independent streams in one launch -- the shape of an HDF5 / netCDF dataset stored as SZIP
  * chunks, where the parallelism of decoding comes from the chunks.  Stream s occupies bytes
  * [d_chunk_offsets[s], d_chunk_offsets[s+1]) of d_in (n_chunks + 1 entries, every offset a multiple

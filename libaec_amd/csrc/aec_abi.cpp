@@ -98,7 +98,7 @@ struct internal_state {
     int device;
     aec_gpu_ctx *ctx;
     hipStream_t stream;
-    DevBuf d_in, d_out, d_off, d_res;
+    DevBuf d_in, d_out, d_off, d_res, d_seg;   // (d_seg: segment starts beside the RSI starts, long RSIs only)
     uint8_t *h_res;                // pinned: 256 bytes of records, then kBounce bytes of bounce buffer
 
     std::vector<uint8_t> stage;    // encoder: input not yet coded; decoder: input not yet on the device
@@ -143,7 +143,7 @@ struct Kit {
     int device = -1;
     aec_gpu_ctx *ctx = nullptr;
     hipStream_t stream = nullptr;
-    DevBuf d_in, d_out, d_off, d_res;
+    DevBuf d_in, d_out, d_off, d_res, d_seg;
     uint8_t *h_res = nullptr;
     uint8_t *h_stage = nullptr;    // pinned staging of the batch entry points (many chunks, one transfer)
     size_t h_stage_cap = 0;
@@ -160,6 +160,7 @@ void destroy_kit(Kit &k)
     k.d_out.release();
     k.d_off.release();
     k.d_res.release();
+    k.d_seg.release();
     if (k.h_res) (void)hipHostFree(k.h_res);
     if (k.h_stage) (void)hipHostFree(k.h_stage);
     if (k.stream) (void)hipStreamDestroy(k.stream);
@@ -180,7 +181,10 @@ bool take_kit(int device, Kit *out)
     return false;
 }
 
-size_t kit_bytes(const Kit &k) { return k.d_in.cap + k.d_out.cap + k.d_off.cap + k.d_res.cap + aec_gpu_held_bytes(k.ctx); }
+size_t kit_bytes(const Kit &k)
+{
+    return k.d_in.cap + k.d_out.cap + k.d_off.cap + k.d_res.cap + k.d_seg.cap + aec_gpu_held_bytes(k.ctx);
+}
 
 void park_kit(Kit &k)
 {
@@ -191,7 +195,7 @@ void park_kit(Kit &k)
         destroy_kit(k);
         return;
     }
-    for (DevBuf *b : {&k.d_in, &k.d_out, &k.d_off})
+    for (DevBuf *b : {&k.d_in, &k.d_out, &k.d_off, &k.d_seg})
         if (b->cap > kKeepBytes) b->release();
     if (k.h_stage_cap > kStageKeep) {
         (void)hipHostFree(k.h_stage);
@@ -234,6 +238,7 @@ void free_state(internal_state *s)
     k.d_out = s->d_out;
     k.d_off = s->d_off;
     k.d_res = s->d_res;
+    k.d_seg = s->d_seg;
     k.h_res = s->h_res;
     if (k.ctx && k.stream && k.h_res && k.d_res.p) park_kit(k);
     else destroy_kit(k);
@@ -284,6 +289,7 @@ int init_common(struct aec_stream *strm, bool enc)
         s->d_out = k.d_out;
         s->d_off = k.d_off;
         s->d_res = k.d_res;
+        s->d_seg = k.d_seg;
         s->h_res = k.h_res;
         aec_gpu_set_index_hint(s->ctx, 0);
     } else if (s->device < 0 || aec_gpu_create(&s->ctx) != RC_OK || hipStreamCreate(&s->stream) != hipSuccess ||
@@ -438,6 +444,11 @@ int decode_run(internal_state *s, struct aec_stream *strm)
     const size_t in_bytes = span < s->d_len ? (size_t)span : s->d_len;
     if (!s->d_off.ensure((max_rsi + 2) * 8) || !s->d_out.ensure(max_rsi * rsi_bytes + blk_bytes + 64))
         return AEC_FAIL(AEC_MEM_ERROR);
+    // RSIs of four segments and more: the index pass also leaves the segment starts, and the decoder takes a lane per
+    // segment instead of one per RSI (include/aec_gpu.h: aec_gpu_index_segments_async; without the table -- no memory
+    // for it -- a lane per RSI as before)
+    uint64_t *d_seg = nullptr;
+    if (c.segs_per_rsi >= 4 && s->d_seg.ensure((max_rsi + 2) * c.segs_per_rsi * 8)) d_seg = static_cast<uint64_t *>(s->d_seg.p);
 
     aec_gpu_dec_result *d_idx = static_cast<aec_gpu_dec_result *>(s->d_res.p), *d_dec = d_idx + 1;
     uint64_t *d_off = static_cast<uint64_t *>(s->d_off.p);
@@ -450,11 +461,15 @@ int decode_run(internal_state *s, struct aec_stream *strm)
         hint = ((uint64_t)s->d_len * 8 - rsi_rel) / expect;
     }
     aec_gpu_set_index_hint(s->ctx, hint + hint / 2);
-    int rc = aec_gpu_index_resume_async(s->ctx, &s->prm, s->d_in.p, in_bytes, walk_rel, s->walk_blocks, rsi_rel,
-                                        d_off, max_rsi, d_idx, s->stream);
+    int rc = d_seg ? aec_gpu_index_segments_async(s->ctx, &s->prm, s->d_in.p, in_bytes, walk_rel, s->walk_blocks, rsi_rel,
+                                                  d_off, d_seg, max_rsi, d_idx, s->stream)
+                   : aec_gpu_index_resume_async(s->ctx, &s->prm, s->d_in.p, in_bytes, walk_rel, s->walk_blocks, rsi_rel,
+                                                d_off, max_rsi, d_idx, s->stream);
     if (rc != RC_OK) return AEC_FAIL(rc);
-    rc = aec_gpu_decode_indexed_async(s->ctx, &s->prm, s->d_in.p, in_bytes, d_off, max_rsi, d_idx, s->d_out.p,
-                                      d_dec, s->stream);
+    rc = d_seg ? aec_gpu_decode_bare_async(s->ctx, &s->prm, s->d_in.p, in_bytes, d_off, d_seg, max_rsi, 0, d_idx,
+                                           s->d_out.p, d_dec, s->stream)
+               : aec_gpu_decode_indexed_async(s->ctx, &s->prm, s->d_in.p, in_bytes, d_off, max_rsi, d_idx, s->d_out.p,
+                                              d_dec, s->stream);
     if (rc != RC_OK) return AEC_FAIL(rc);
     // records, the start of the trailing partial RSI, and the first output bytes: one synchronisation
     uint8_t *bounce = s->h_res + 256;

@@ -203,6 +203,51 @@ __device__ __forceinline__ void ring_put4(uint32_t *col, uint32_t slot0, uint32_
     }
 }
 
+// ---- decoding a bare stream segment by segment (launch_decode_bare) ---------------------------------------
+// What the summing pass leaves per segment.  With u = (sample in front of the segment) - xmin:  the samples of the
+// segment are u + (prefix sums of the steps) exactly when lo <= u <= hi, and then the sample behind the segment is
+// u + sum.  (For the first segment of an RSI u is the reference sample `ref` itself and the sums start behind it.)
+struct SegSum {
+    int64_t sum, lo, hi;
+    uint64_t end;          // bit behind the segment's last coded data set
+    uint32_t ref;          // first segment of an RSI: the reference sample (raw)
+    uint32_t ok;           // 1 = all blocks parsed, the segment ends on a coded data set
+};
+
+// accumulator of the summing pass: 32 bits carry a segment of up to 4096 samples of at most 16 bits
+template <int BYTES>
+struct SumAcc {
+    typedef int64_t type;
+    static constexpr int64_t kLo = -((int64_t)1 << 60), kHi = (int64_t)1 << 60;
+};
+template <>
+struct SumAcc<1> {
+    typedef int32_t type;
+    static constexpr int32_t kLo = -(1 << 30), kHi = 1 << 30;
+};
+template <>
+struct SumAcc<2> {
+    typedef int32_t type;
+    static constexpr int32_t kLo = -(1 << 30), kHi = 1 << 30;
+};
+
+// one block of mapped residuals d[] into the running sum P and the bounds (reference decode.c:96-134: the step is
+// two-sided, +d/2 or -(d+1)/2, while half = ceil(d/2) <= min(x - xmin, xmax - x))
+template <int BS, typename ACC>
+__device__ __forceinline__ void seg_accumulate(const uint32_t *d, bool first_is_ref, ACC R, ACC &P, ACC &lo, ACC &hi)
+{
+#pragma unroll
+    for (int i = 0; i < BS; i++) {
+        const uint32_t v = (i == 0 && first_is_ref) ? 0u : d[i];     // (the reference sample is no step)
+        const ACC h = (ACC)((v >> 1) + (v & 1u));
+        const ACC step = (v & 1u) ? -h : h;
+        const ACC nlo = h - P, nhi = R - h - P;
+        lo = nlo > lo ? nlo : lo;
+        hi = nhi < hi ? nhi : hi;
+        P += step;
+    }
+}
+
 // Build-time knobs of k_decode for A/B runs (tests/ab_build.sh builds a variant library, AEC_AMD_LIB selects it);
 // the defaults are the measured best:
 //   AEC_STG_ROW / AEC_STG_ROW8   bytes per output staging row for 16- / 32-byte blocks and for 8-byte blocks (0 = none)
@@ -237,20 +282,31 @@ __host__ __device__ constexpr uint32_t stg_row(int blk) { return blk == 8 ? (AEC
 // for the short coded data sets of compressible data; streams that average more per block (large blocks,
 // high-entropy data: typical.dat's 64-sample blocks at 720 bits) would drain the ring and fall into the
 // synchronous refill -- an HBM round trip per 16 bytes -- every iteration, so they run with 4 or 8.
-template <int BS, int BYTES, bool SEG, int kPend>
+//
+// SUMS (with SEG): the first of the two passes that decode a BARE stream segment by segment (launch_decode_bare).
+// The items are segments whose start bits the index pass found (rsi_off[item], ~0 = unknown) -- but the sample in
+// front of a segment is what only decoding gives.  Inside the range the inverse predictor is a running sum
+// (reference decode.c:96-134: x += d / 2 or x -= (d + 1) / 2 as long as the step stays within the room on both
+// sides), so a lane parses its segment, sums the steps and records for which predecessors the running sum IS the
+// predictor (SegSum: lo <= predecessor - xmin <= hi); nothing is written to `out` or `res`.  k_seg_scan then
+// chains the sums along each RSI, and the second pass is this kernel with SEG alone.
+template <int BS, int BYTES, bool SEG, int kPend, bool SUMS = false>
 __global__ void __launch_bounds__(256, AEC_DEC_MINW)
 k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
          const uint64_t *__restrict__ rsi_off, const SegEntry *__restrict__ seg_table, uint64_t n_rsi,
          uint64_t total_blocks, uint8_t *__restrict__ out, DecResult *res, uint32_t ring_words, uint32_t maxw,
          uint32_t needw, uint8_t *__restrict__ dump, const DecResult *__restrict__ idx,
-         const DecResult *__restrict__ batch, uint32_t rsi_per_chunk)
+         const DecResult *__restrict__ batch, uint32_t rsi_per_chunk, SegSum *__restrict__ sums,
+         const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_cnt)
 {
+    static_assert(!SUMS || (SEG && BS != 0), "the summing pass runs per segment on the templated block sizes");
     // item counts straight from the record the index pass left on the device (the grid was sized for
     // the most it could find): no host round trip between the two passes
     if (idx) {
         const uint64_t whole = idx->n_rsi, tail = idx->tail_blocks;
         n_rsi = whole + (tail ? 1u : 0u);
         total_blocks = whole * c.rsi + tail;
+        if (SEG) n_rsi *= c.segs_per_rsi;             // (items are segments)
     }
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -263,7 +319,7 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     // out transposed: 4 lanes per row, whole 64-byte sectors per store instruction.  (Rows of 128
     // bytes -- whole lines -- were slower: 3.26 ms against 2.75 ms at C2, the LDS costs waves.)
     constexpr int BLK = BS * BYTES;
-    constexpr bool STG = stg_on(BLK);
+    constexpr bool STG = !SUMS && stg_on(BLK);
     constexpr uint32_t kStgRow = stg_row(BLK), kStgStride = kStgRow + 16u;   // 16 bytes of padding: conflict-free rows
     constexpr uint32_t G = STG ? kStgRow / (uint32_t)(BLK ? BLK : 1) : 1u;
     const uint32_t wave_words = (ring_words + 2u) * 64u + (STG ? (64u * kStgStride) / 4u : 0u);
@@ -272,8 +328,12 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     uint8_t *stage = reinterpret_cast<uint8_t *>(wbase + (ring_words + 2u) * 64u);
     const uint32_t mask = ring_words - 1;
 
-    const uint64_t r = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 64u + lane;
-    const bool active = r < n_rsi;
+    uint64_t r = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave) * 64u + lane;
+    bool active = r < n_rsi;
+    if (!SEG && list) {                               // the items are the RSIs of a list (launch_decode_bare: the
+        active = r < *list_cnt;                       // RSIs that could not be taken segment by segment)
+        r = active ? list[r] : 0u;
+    }
     constexpr int DN = BS ? BS : (int)kMaxBlockSize;
     const uint32_t bs = BS ? (uint32_t)BS : c.bs;
     const bool pp = c.flags & F_PREPROCESS;
@@ -284,12 +344,20 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
         if (SEG) {
             const uint64_t rsi_idx = (r >> 32) ? r / c.segs_per_rsi : (uint64_t)((uint32_t)r / c.segs_per_rsi);
             b0 = (uint32_t)(r - rsi_idx * c.segs_per_rsi) * 64u;
-            uint64_t left = total_blocks - rsi_idx * c.rsi;
+            uint64_t left = total_blocks > rsi_idx * c.rsi ? total_blocks - rsi_idx * c.rsi : 0u;
             if (left > c.rsi) left = c.rsi;
-            nb = left - b0 > 64 ? 64u : (uint32_t)(left - b0);
-            const SegEntry e = seg_table[r];
-            start = e.bit;
-            x = (c.flags & F_SIGNED) ? sign_extend(e.prev, c.bps) : e.prev;
+            nb = left <= b0 ? 0u : (left - b0 > 64 ? 64u : (uint32_t)(left - b0));
+            if (SUMS) {
+                start = rsi_off[r];
+            } else {
+                const SegEntry e = seg_table[r];
+                start = e.bit;
+                x = (c.flags & F_SIGNED) ? sign_extend(e.prev, c.bps) : e.prev;
+            }
+            if (start == ~0ull) {                     // (a segment the table does not know: not this pass's)
+                start = 0;
+                nb = 0;
+            }
             first_blk = rsi_idx * c.rsi + b0;
         } else if (batch) {
             // batch of independent streams: stream s owns RSIs [s * rsi_per_chunk, (s + 1) * rsi_per_chunk) of
@@ -371,6 +439,11 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     uint32_t d[DN];
     uint32_t zrun = 0;
     uint32_t ok = 1u;                                     // (a VGPR, like pv[])
+    // SUMS: running sum of the predictor steps, and the bounds on (predecessor - xmin) inside which it is exact
+    typedef typename SumAcc<BYTES>::type acc_t;
+    const acc_t acc_R = (acc_t)(((uint64_t)1 << c.bps) - 1u);
+    acc_t acc_P = 0, acc_lo = SumAcc<BYTES>::kLo, acc_hi = SumAcc<BYTES>::kHi;
+    uint32_t sum_ref = 0, sum_bad = 0, sum_done = 0;
 
     // Blocks of 8 samples: UNR = 2 of them per loop iteration -- the ring top-up, the landing of the loads
     // in flight and the issue of the next ones are paid once per 16 samples like for the larger blocks.
@@ -467,12 +540,19 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
             // (a status raised while reads went beyond the ring -- stale slots look like a cut or corrupt stream --
             // is no verdict either)
             const bool over = parse && (((p + 31u) >> 5) > landed || (st != DEC_OK && src.starved()));
-            if (over) {
+            if (SUMS) {                                   // (no verdicts here: such a segment's RSI takes the other path)
+                if (parse && (over || st != DEC_OK)) {
+                    sum_bad = 1u;
+                    ok = 0u;
+                } else if (parse && nz) {
+                    zrun = nz;
+                }
+            } else if (over) {
                 atomicOr(&res->pad, kDecRedo);
                 ok = 0u;
             } else if (parse) {
                 if (st != DEC_OK) {
-                    report(res, st, r, first_blk + bb);
+                    report(res, st, SEG ? (first_blk + bb) / c.rsi : r, first_blk + bb);
                     // (a batch of independent streams: the stream's own record says so as well -- one overall
                     // record names only the first bad RSI of the whole batch)
                     if (batch && st == DEC_DATA_ERROR)
@@ -501,7 +581,16 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
                     pend[j] = load_words4_nb(words, idx, nwords_vec);
                 }
             }
-            if (STG) {
+            if (SUMS) {
+                const bool st_ok = live && ok;
+                const bool rf = ref != 0 && parse;
+                if (st_ok) {
+                    if (rf) sum_ref = d[0];
+                    if (c.flags & F_PREPROCESS) seg_accumulate<DN, acc_t>(d, rf, acc_R, acc_P, acc_lo, acc_hi);
+                    sum_done++;
+                }
+                zrun -= (st_ok && zrun) ? 1u : 0u;
+            } else if (STG) {
                 const bool st_ok = live && ok;
                 store_block<DN, (BYTES ? BYTES : 1)>(stage + lane * kStgStride + (bb % G) * (uint32_t)BLK, d, c,
                                                      ref != 0 && parse, x);
@@ -552,9 +641,25 @@ k_decode(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     }
     }
     if (STG && (b % G) != 0) flush(b / G);             // rows of the last, partial group
+    if (SUMS) {
+        // good: every block of the segment parsed, and no zero run reaches beyond it (then the next segment does
+        // not start on a coded data set and the RSI is not one to take segment by segment)
+        if (active) {
+            SegSum o;
+            o.sum = (int64_t)acc_P;
+            o.lo = (int64_t)acc_lo;
+            o.hi = (int64_t)acc_hi;
+            o.end = a0 * 32u + p;
+            o.ref = sum_ref;
+            o.ok = (nb != 0u && !sum_bad && sum_done == nb && zrun == 0u) ? 1u : 0u;
+            sums[r] = o;
+        }
+        return;
+    }
     // The predictor state behind the LAST item of the batch, as the reference carries it (32 bits, not cut to the
     // sample width: on damaged streams it leaves the range): k_decode_partial continues from it.
-    if (!SEG && active && r + 1 == n_rsi) res->end_bit = x;
+    if (!SEG && active && (list ? first_blk + nb == total_blocks : r + 1 == n_rsi)) res->end_bit = x;
+    if (SEG && active && nb && first_blk + nb == total_blocks) res->end_bit = x;
 }
 
 // ---- coded data sets longer than the ring ------------------------------------------------------------
@@ -569,26 +674,31 @@ __global__ void __launch_bounds__(64)
 k_decode_redo(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
               const uint64_t *__restrict__ rsi_off, const SegEntry *__restrict__ seg_table, uint64_t n_rsi,
               uint64_t total_blocks, uint8_t *__restrict__ out, DecResult *res, const DecResult *__restrict__ idx,
-              const DecResult *__restrict__ batch, uint32_t rsi_per_chunk)
+              const DecResult *__restrict__ batch, uint32_t rsi_per_chunk, const uint32_t *__restrict__ list,
+              const uint32_t *__restrict__ list_cnt)
 {
     if (!(*reinterpret_cast<volatile uint32_t *>(&res->pad) & kDecRedo)) return;
     if (idx) {
         const uint64_t whole = idx->n_rsi, tail = idx->tail_blocks;
         n_rsi = whole + (tail ? 1u : 0u);
         total_blocks = whole * c.rsi + tail;
+        if (SEG) n_rsi *= c.segs_per_rsi;
     }
+    if (!SEG && list) n_rsi = *list_cnt;
     const bool pp = c.flags & F_PREPROCESS;
     const size_t blk_bytes = (size_t)c.bs * c.bytes;
-    for (uint64_t r = (uint64_t)blockIdx.x * 64u + threadIdx.x; r < n_rsi; r += (uint64_t)gridDim.x * 64u) {
+    for (uint64_t r_lin = (uint64_t)blockIdx.x * 64u + threadIdx.x; r_lin < n_rsi; r_lin += (uint64_t)gridDim.x * 64u) {
+        const uint64_t r = (!SEG && list) ? list[r_lin] : r_lin;
         uint32_t nb = 0, b0 = 0, x = 0;
         uint64_t start = 0, first_blk = 0;
         if (SEG) {
             const uint64_t rsi_idx = r / c.segs_per_rsi;
             b0 = (uint32_t)(r - rsi_idx * c.segs_per_rsi) * 64u;
-            uint64_t left = total_blocks - rsi_idx * c.rsi;
+            uint64_t left = total_blocks > rsi_idx * c.rsi ? total_blocks - rsi_idx * c.rsi : 0u;
             if (left > c.rsi) left = c.rsi;
-            nb = left - b0 > 64 ? 64u : (uint32_t)(left - b0);
+            nb = left <= b0 ? 0u : (left - b0 > 64 ? 64u : (uint32_t)(left - b0));
             const SegEntry e = seg_table[r];
+            if (e.bit == ~0ull) continue;                         // (not an item of this batch: launch_decode_bare)
             start = e.bit;
             x = (c.flags & F_SIGNED) ? sign_extend(e.prev, c.bps) : e.prev;
             first_blk = rsi_idx * c.rsi + b0;
@@ -635,7 +745,9 @@ k_decode_redo(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, 
             dst += blk_bytes;
             if (rf) d[0] = 0;
         }
-        if (!SEG && r + 1 == n_rsi) res->end_bit = x;       // (as k_decode: the state k_decode_partial continues from)
+        // (as k_decode: the state k_decode_partial continues from)
+        if (!SEG && (list ? first_blk + nb == total_blocks : r + 1 == n_rsi)) res->end_bit = x;
+        if (SEG && nb && first_blk + nb == total_blocks) res->end_bit = x;
     }
 }
 
@@ -802,27 +914,36 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, uint32_t s
     return g;
 }
 
-template <int BS, bool SEG>
+// what launch_decode_bare adds to a launch: the summing pass's output, or the list of RSIs to take
+struct BareArgs {
+    SegSum *sums = nullptr;
+    const uint32_t *list = nullptr, *list_cnt = nullptr;
+    uint64_t avg_hint = 0;         // bits per coded data set where the counts come from an index record
+};
+
+template <int BS, bool SEG, bool SUMS = false>
 void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          const uint64_t *rsi_off, const SegEntry *seg_table, uint64_t n_rsi,
                          uint64_t total_blocks, uint8_t *out, DecResult *res, hipStream_t st, uint8_t *dump,
-                         const DecResult *idx, const DecResult *batch, uint32_t rpc)
+                         const DecResult *idx, const DecResult *batch, uint32_t rpc, const BareArgs &ba = BareArgs())
 {
     const uint32_t blk = (uint32_t)BS * c.bytes;
-    // (counts taken from the index record: the average coded data set is not known here -- full ring)
-    const DecGeom g = dec_geom(c, n_rsi, (total_blocks && !idx && !batch) ? end_bit / total_blocks : 0, stg_on((int)blk) ? stg_row((int)blk) : 0u);
+    // (counts taken from the index record: the average coded data set is not known here unless the caller says
+    // so -- full ring)
+    const uint64_t avg = (total_blocks && !idx && !batch) ? end_bit / total_blocks : ba.avg_hint;
+    const DecGeom g = dec_geom(c, n_rsi, avg, (!SUMS && stg_on((int)blk)) ? stg_row((int)blk) : 0u);
     const dim3 block(64 * g.waves), grid(g.grid);
     // loads in flight per block iteration (see kPend): sized for the average coded data set where the caller
     // knows it, for the worst case of large blocks where it does not
-    const uint64_t avg = (total_blocks && !idx && !batch) ? end_bit / total_blocks : 0;
     const uint32_t e_kp = tune("AEC_DEC_KP", 0);               // (diagnostic: force 2, 4 or 8)
     // (measured: 2 up to the 256 bits per block they feed -- C3 at 247: 2.70 ms against 2.74 with 4 --, 8 for the
     // 720 bits of typical.dat's blocks: 5.8 ms against 7.1 with 4 and 7.8 with 2)
     int kp = BS >= 32 ? (avg == 0 || avg > 512 ? 8 : (avg > 256 ? 4 : 2)) : (avg > 256 ? 4 : 2);
     if (e_kp) kp = e_kp >= 8 ? (BS >= 32 ? 8 : 4) : (e_kp >= 4 ? 4 : 2);
 #define AEC_GO2(B, KP)                                                                                  \
-    hipLaunchKernelGGL((k_decode<BS, B, SEG, KP>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
-                       rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, g.needw, dump, idx, batch, rpc)
+    hipLaunchKernelGGL((k_decode<BS, B, SEG, KP, SUMS>), grid, block, g.lds_bytes, st, c, words, nwords, end_bit, \
+                       rsi_off, seg_table, n_rsi, total_blocks, out, res, g.ring_words, g.maxw, g.needw, dump, idx, batch, rpc, \
+                       ba.sums, ba.list, ba.list_cnt)
 #define AEC_GO(B)                                                                                   \
     do {                                                                                            \
         if (kp == 2) AEC_GO2(B, 2);                                                                 \
@@ -867,7 +988,8 @@ static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
     {
         const DecGeom g = dec_geom(c, n_items, 0, 0u);   // the sample-by-sample reader has no second attempt: full ring
         hipLaunchKernelGGL((k_decode<0, 0, SEG, 2>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
-                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, g.needw, dump, d_idx, d_batch, rpc);
+                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, g.needw, dump, d_idx, d_batch, rpc,
+                           (SegSum *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
         break;
     }
     }
@@ -875,8 +997,70 @@ static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
     // (behind the timed kernel: returns at once unless k_decode raised kDecRedo)
     const uint64_t redo_waves = (n_items + 63) / 64;
     hipLaunchKernelGGL((k_decode_redo<SEG>), dim3((uint32_t)(redo_waves < 2048 ? redo_waves : 2048)), dim3(64), 0, st, c,
-                       words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, d_idx, d_batch, rpc);
+                       words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, d_idx, d_batch, rpc,
+                       (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     return true;
+}
+
+// ---- a bare stream segment by segment ------------------------------------------------------------------
+// One lane per RSI: are its segments all known, parsed, and does each end where the next one starts (the last
+// one where the next RSI does)?  Does the running sum hold for every one of them, given the sample the sums of
+// the segments in front lead to?  Then its entries of the segment table are filled in -- start bit and the sample
+// in front, what k_decode<SEG> takes.  If not (a zero run across a segment border, a sample at the edge of the
+// range where the predictor clips, decode.c:96-134, a coded data set beyond the look-ahead, anything damaged) the
+// RSI goes to the list of those that are decoded by one lane from their start, and its entries say so (~0).
+__global__ void __launch_bounds__(256)
+k_seg_scan(const Cfg c, const uint64_t *__restrict__ rsi_off, const uint64_t *__restrict__ seg_bits,
+           const SegSum *__restrict__ sums, uint64_t n_rsi, uint64_t total_blocks, const DecResult *__restrict__ idx,
+           SegEntry *__restrict__ table, uint32_t *__restrict__ list, uint32_t *__restrict__ list_cnt)
+{
+    if (idx) {
+        const uint64_t whole = idx->n_rsi, tail = idx->tail_blocks;
+        n_rsi = whole + (tail ? 1u : 0u);
+        total_blocks = whole * c.rsi + tail;
+    }
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rsi) return;
+    uint64_t left = total_blocks > r * c.rsi ? total_blocks - r * c.rsi : 0u;
+    if (left > c.rsi) left = c.rsi;
+    const uint32_t nseg = (uint32_t)((left + 63u) / 64u), S = c.segs_per_rsi;
+    const uint64_t *bits = seg_bits + r * S;
+    const SegSum *su = sums + r * S;
+    SegEntry *e = table + r * S;
+    bool good = nseg != 0u && bits[0] == rsi_off[r];
+    for (uint32_t j = 0; j < nseg && good; j++) {
+        good = bits[j] != ~0ull && su[j].ok != 0u;
+        if (good && j + 1u < nseg) good = su[j].end == bits[j + 1u];
+    }
+    if (good) {
+        const uint64_t end = su[nseg - 1u].end;
+        if (r + 1u < n_rsi) good = ((c.flags & F_PAD_RSI) ? (end + 7u) & ~7ull : end) == rsi_off[r + 1u];
+        else if (idx) good = end == idx->end_bit;
+    }
+    const uint32_t mask = c.bps >= 32u ? 0xFFFFFFFFu : (1u << c.bps) - 1u;
+    if (good) {
+        const bool sgn = c.flags & F_SIGNED;
+        const uint32_t ref = su[0].ref;
+        // u = sample - xmin (xmin = -2^(bps-1) for signed samples, 0 else)
+        int64_t u = sgn ? (int64_t)(int32_t)sign_extend(ref, c.bps) + ((int64_t)1 << (c.bps - 1u)) : (int64_t)ref;
+        const int64_t xmin = sgn ? -((int64_t)1 << (c.bps - 1u)) : 0;
+        for (uint32_t j = 0; j < nseg; j++) {
+            if ((c.flags & F_PREPROCESS) && (u < su[j].lo || u > su[j].hi)) {
+                good = false;
+                break;
+            }
+            e[j].bit = bits[j];
+            e[j].prev = j ? (uint32_t)(uint64_t)(u + xmin) & mask : 0u;
+            e[j].pad = 0;
+            u += su[j].sum;
+        }
+    }
+    if (!good) {
+        for (uint32_t j = 0; j < S; j++) e[j] = SegEntry{~0ull, 0u, 0u};
+        list[atomicAdd(list_cnt, 1u)] = (uint32_t)r;
+    } else {
+        for (uint32_t j = nseg; j < S; j++) e[j] = SegEntry{~0ull, 0u, 0u};
+    }
 }
 
 bool launch_decode(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
@@ -892,6 +1076,80 @@ void launch_decode_partial(const Cfg &c, const uint8_t *d_in, size_t in_bytes, c
 {
     hipLaunchKernelGGL(k_decode_partial, dim3(1), dim3(64), 0, st, c, reinterpret_cast<const uint32_t *>(d_in),
                        (uint64_t)((in_bytes + 3) / 4), (uint64_t)in_bytes * 8, d_idx, d_out, d_res);
+}
+
+// Workspace of launch_decode_bare for up to max_rsi RSIs: sums and table per segment, list per RSI, counter.
+bool decode_bare_supported(const Cfg &c)
+{
+    // (worth it from four segments per RSI on; the templated block sizes)
+    return c.segs_per_rsi >= 4u && (c.bs == 8u || c.bs == 16u || c.bs == 32u || c.bs == 64u);
+}
+
+size_t decode_bare_workspace_bytes(const Cfg &c, uint64_t max_rsi)
+{
+    const uint64_t nseg = max_rsi * c.segs_per_rsi;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return up(nseg * sizeof(SegSum)) + up(nseg * sizeof(SegEntry)) + up(max_rsi * 4) + 256;
+}
+
+// A bare stream whose index pass also found the segment starts (d_seg_bits[r * segs_per_rsi + j], ~0 = unknown):
+// summing pass, scan per RSI, one lane per segment for the RSIs that can be taken that way, one lane per RSI for
+// the rest.  Same contract as launch_decode otherwise (d_idx: counts from the index record on the device).
+bool launch_decode_bare(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
+                        const uint64_t *d_seg_bits, uint64_t n_rsi, uint64_t total_blocks, uint8_t *d_out,
+                        DecResult *d_res, hipStream_t st, const PhaseEvents *prof, const DecResult *d_idx, void *d_ws,
+                        size_t ws_bytes, uint64_t avg_cds_hint)
+{
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
+    if (!decode_bare_supported(c) || !vec_ok || !d_seg_bits || !d_ws || ws_bytes < decode_bare_workspace_bytes(c, n_rsi))
+        return launch_decode(c, d_in, in_bytes, d_rsi_off, n_rsi, total_blocks, d_out, d_res, st, prof, d_idx);
+    uint8_t *dump = dump_buffer();
+    if (!dump) return false;
+    hipLaunchKernelGGL(k_dec_result_init, dim3(1), dim3(1), 0, st, d_res);
+    if (n_rsi == 0) return true;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const uint64_t n_items = n_rsi * c.segs_per_rsi;
+    uint8_t *w = static_cast<uint8_t *>(d_ws);
+    SegSum *sums = reinterpret_cast<SegSum *>(w);
+    SegEntry *table = reinterpret_cast<SegEntry *>(w + up(n_items * sizeof(SegSum)));
+    uint32_t *list = reinterpret_cast<uint32_t *>(w + up(n_items * sizeof(SegSum)) + up(n_items * sizeof(SegEntry)));
+    uint32_t *list_cnt = list + ((up(n_rsi * 4)) / 4);
+    (void)hipMemsetAsync(list_cnt, 0, 4, st);
+    if (prof) (void)hipEventRecord(prof->ev[5], st);
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
+    const uint64_t nwords = (in_bytes + 3) / 4;
+    const uint64_t end_bit = (uint64_t)in_bytes * 8;
+    BareArgs a_sum, a_seg, a_list;
+    a_sum.sums = sums;
+    a_list.list = list;
+    a_list.list_cnt = list_cnt;
+    a_sum.avg_hint = a_seg.avg_hint = a_list.avg_hint = avg_cds_hint;
+#define AEC_BARE(BS)                                                                                                   \
+    launch_decode_bytes<BS, true, true>(c, words, nwords, end_bit, d_seg_bits, nullptr, n_items, total_blocks, nullptr, \
+                                        d_res, st, dump, d_idx, nullptr, 0u, a_sum);                                   \
+    hipLaunchKernelGGL(k_seg_scan, dim3((uint32_t)((n_rsi + 255) / 256)), dim3(256), 0, st, c, d_rsi_off, d_seg_bits,  \
+                       sums, n_rsi, total_blocks, d_idx, table, list, list_cnt);                                       \
+    launch_decode_bytes<BS, true, false>(c, words, nwords, end_bit, nullptr, table, n_items, total_blocks, d_out,      \
+                                         d_res, st, dump, d_idx, nullptr, 0u, a_seg);                                  \
+    launch_decode_bytes<BS, false, false>(c, words, nwords, end_bit, d_rsi_off, nullptr, n_rsi, total_blocks, d_out,   \
+                                          d_res, st, dump, d_idx, nullptr, 0u, a_list)
+    switch (c.bs) {
+    case 8: AEC_BARE(8); break;
+    case 16: AEC_BARE(16); break;
+    case 32: AEC_BARE(32); break;
+    default: AEC_BARE(64); break;
+    }
+#undef AEC_BARE
+    if (prof) (void)hipEventRecord(prof->ev[6], st);
+    // (behind the timed kernels: return at once unless a k_decode raised kDecRedo)
+    const uint64_t w_seg = (n_items + 63) / 64, w_rsi = (n_rsi + 63) / 64;
+    hipLaunchKernelGGL((k_decode_redo<true>), dim3((uint32_t)(w_seg < 2048 ? w_seg : 2048)), dim3(64), 0, st, c, words,
+                       nwords, end_bit, (const uint64_t *)nullptr, table, n_items, total_blocks, d_out, d_res, d_idx,
+                       (const DecResult *)nullptr, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL((k_decode_redo<false>), dim3((uint32_t)(w_rsi < 2048 ? w_rsi : 2048)), dim3(64), 0, st, c, words,
+                       nwords, end_bit, d_rsi_off, (const SegEntry *)nullptr, n_rsi, total_blocks, d_out, d_res, d_idx,
+                       (const DecResult *)nullptr, 0u, list, list_cnt);
+    return true;
 }
 
 bool launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const SegEntry *d_seg_table,

@@ -38,6 +38,10 @@ struct aec_gpu_ctx {
     void *idx_ws;          // speculative index tables (aec_idx.hip), grown on demand
     size_t idx_ws_bytes;
     uint64_t idx_hint;     // caller's estimate of the coded RSI size in bits (0 = derive from max_rsi)
+    uint64_t idx_used_hint;  // ... and what the last index pass worked with (sizes the rings of the decode behind it)
+    bool seg_filled;       // the last index pass with a segment-start table filled it (it ran over the trunk tables)
+    void *dec_ws;          // workspace of the segment-wise decode of bare streams (aec_dec.hip: launch_decode_bare)
+    size_t dec_ws_bytes;
     ShardCarry *carry;     // device record: what precedes this context's shard (emit_planned)
     void *fused;           // control block of the single-pass encoder (ticket, fail flag, look-back granules)
     size_t fused_bytes;
@@ -68,6 +72,10 @@ int aec_gpu_create(aec_gpu_ctx **out)
     ctx->idx_ws = nullptr;
     ctx->idx_ws_bytes = 0;
     ctx->idx_hint = 0;
+    ctx->idx_used_hint = 0;
+    ctx->seg_filled = false;
+    ctx->dec_ws = nullptr;
+    ctx->dec_ws_bytes = 0;
     ctx->carry = nullptr;
     ctx->fused = nullptr;
     ctx->fused_bytes = 0;
@@ -83,6 +91,7 @@ void aec_gpu_destroy(aec_gpu_ctx *ctx)
     if (!ctx) return;
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->idx_ws) (void)hipFree(ctx->idx_ws);
+    if (ctx->dec_ws) (void)hipFree(ctx->dec_ws);
     if (ctx->carry) (void)hipFree(ctx->carry);
     if (ctx->fused) (void)hipFree(ctx->fused);
     for (auto &set : ctx->ev)
@@ -299,7 +308,7 @@ int aec_gpu_decode_segments_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, con
 static int index_common(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
                         uint64_t start_bit, uint32_t start_block, uint64_t rsi_start_bit,
                         uint64_t *d_rsi_bit_offsets, uint64_t max_rsi, aec_gpu_dec_result *d_result, void *stream,
-                        uint32_t tail_slot)
+                        uint32_t tail_slot, uint64_t *d_seg_bits = nullptr)
 {
     Cfg c;
     const int rc = cfg_from(p, 0, false, &c);
@@ -321,9 +330,13 @@ static int index_common(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d
         if (hipMalloc(&ctx->idx_ws, want) == hipSuccess) ctx->idx_ws_bytes = want;
         else (void)hipGetLastError();
     }
-    launch_index(c, static_cast<const uint8_t *>(d_in), in_bytes, start_bit, d_rsi_bit_offsets, max_rsi,
-                 reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream), ctx->idx_ws,
-                 ctx->idx_ws_bytes, hint, start_block, rsi_start_bit, tail_slot);
+    ctx->idx_used_hint = hint;
+    if (d_seg_bits && !decode_bare_supported(c)) d_seg_bits = nullptr;
+    if (d_seg_bits && hipMemsetAsync(d_seg_bits, 0xFF, (size_t)(max_rsi + 1) * c.segs_per_rsi * 8, static_cast<hipStream_t>(stream)) != hipSuccess)
+        return RC_MEM_ERROR;
+    ctx->seg_filled = launch_index(c, static_cast<const uint8_t *>(d_in), in_bytes, start_bit, d_rsi_bit_offsets, max_rsi,
+                                   reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream), ctx->idx_ws,
+                                   ctx->idx_ws_bytes, hint, start_block, rsi_start_bit, tail_slot, d_seg_bits);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess && getenv("AEC_ABI_TRACE"))
         fprintf(stderr, "aec_gpu_index_async: %s (in_bytes %zu start %llu max_rsi %llu hint %llu ws %zu)\n",
@@ -371,6 +384,55 @@ int aec_gpu_decode_indexed_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, cons
     return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
 }
 
+unsigned int aec_gpu_segments_per_rsi(const aec_gpu_params *p)
+{
+    Cfg c;
+    return cfg_from(p, 0, false, &c) == RC_OK ? c.segs_per_rsi : 0u;
+}
+
+int aec_gpu_index_segments_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                                 uint64_t start_bit, unsigned int start_block, uint64_t rsi_start_bit,
+                                 uint64_t *d_rsi_bit_offsets, uint64_t *d_seg_bits, uint64_t max_rsi,
+                                 aec_gpu_dec_result *d_result, void *stream)
+{
+    return index_common(ctx, p, d_in, in_bytes, start_bit, start_block, start_block ? rsi_start_bit : start_bit,
+                        d_rsi_bit_offsets, max_rsi, d_result, stream, 1u, d_seg_bits);
+}
+
+int aec_gpu_decode_bare_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,
+                              const uint64_t *d_rsi_bit_offsets, const uint64_t *d_seg_bits, uint64_t max_rsi,
+                              uint64_t total_blocks, const aec_gpu_dec_result *d_index_result, void *d_out,
+                              aec_gpu_dec_result *d_result, void *stream)
+{
+    Cfg c;
+    const int rc = cfg_from(p, 0, false, &c);
+    if (rc != RC_OK) return rc;
+    if ((reinterpret_cast<uintptr_t>(d_in) & 3u) || d_index_result == d_result) return RC_CONF_ERROR;
+    (void)hipGetLastError();
+    // (segment starts the last index pass of this context did not fill are no use: every RSI by one lane then)
+    const bool seg = d_seg_bits && ctx->seg_filled && decode_bare_supported(c);
+    if (seg) {
+        const size_t need = decode_bare_workspace_bytes(c, max_rsi);
+        if (need > ctx->dec_ws_bytes) {
+            if (ctx->dec_ws) (void)hipFree(ctx->dec_ws);
+            ctx->dec_ws = nullptr;
+            ctx->dec_ws_bytes = 0;
+            if (hipMalloc(&ctx->dec_ws, need + need / 8) == hipSuccess) ctx->dec_ws_bytes = need + need / 8;
+            else (void)hipGetLastError();
+        }
+    }
+    const DecResult *idx = reinterpret_cast<const DecResult *>(d_index_result);
+    if (!launch_decode_bare(c, static_cast<const uint8_t *>(d_in), in_bytes, d_rsi_bit_offsets, seg ? d_seg_bits : nullptr,
+                            max_rsi, idx ? max_rsi * c.rsi : total_blocks, static_cast<uint8_t *>(d_out),
+                            reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream), ctx->dec_events(),
+                            idx, ctx->dec_ws, ctx->dec_ws_bytes, ctx->idx_used_hint / c.rsi))
+        return RC_MEM_ERROR;
+    if (idx)
+        launch_decode_partial(c, static_cast<const uint8_t *>(d_in), in_bytes, idx, static_cast<uint8_t *>(d_out),
+                              reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream));
+    return hipGetLastError() == hipSuccess ? RC_OK : RC_MEM_ERROR;
+}
+
 void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits) { ctx->idx_hint = rsi_bits; }
 
 void aec_gpu_trim(aec_gpu_ctx *ctx, size_t keep_bytes)
@@ -390,11 +452,16 @@ void aec_gpu_trim(aec_gpu_ctx *ctx, size_t keep_bytes)
         ctx->idx_ws = nullptr;
         ctx->idx_ws_bytes = 0;
     }
+    if (ctx->dec_ws && ctx->dec_ws_bytes > keep_bytes) {
+        (void)hipFree(ctx->dec_ws);
+        ctx->dec_ws = nullptr;
+        ctx->dec_ws_bytes = 0;
+    }
 }
 
 size_t aec_gpu_held_bytes(const aec_gpu_ctx *ctx)
 {
-    return ctx ? ctx->ws_bytes + ctx->fused_bytes + ctx->idx_ws_bytes : 0;
+    return ctx ? ctx->ws_bytes + ctx->fused_bytes + ctx->idx_ws_bytes + ctx->dec_ws_bytes : 0;
 }
 
 int aec_gpu_index_batch_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d_in, size_t in_bytes,

@@ -126,7 +126,10 @@ struct IdxCarry {          // walker state between the spans of one stream
     uint64_t good, r;
     uint32_t active, n_hops;
     uint32_t n_serial, n_lookups;     // statistics: RSIs walked coded data set by coded data set, table hops taken
+    uint64_t r_prev;                  // RSIs in front of the span the walker took last (k_seg_starts: its RSIs are
+                                      // [r_prev, r) while the walk goes on, [r_prev, what the result record says) else)
 };
+static_assert(sizeof(IdxCarry) <= 48, "the carry record shares 64 bytes with the pool counter at offset 48");
 
 // ---- trunk (aec_trunk.h) -------------------------------------------------------------------------------
 // mode 0: first pass (burn-in + count), 1: repair pass (count), 2: fill (one lane per WINDOW)
@@ -573,6 +576,46 @@ __global__ void k_texpand(const Cfg c, const TwTables t, const TrTables tt, cons
     uint32_t wv, ix;
     if (!tw_lookup(t, h.pos, rec, wv, ix) || tr_rec_k(rec.x) != h.cnt) return;      // (cannot happen)
     write_record_starts(c, tt, h.pos, h.r, rec, rsi_off);
+}
+
+// Segment starts of the RSIs the walk found in this span (aec_trunk.h: tr_seg_walk, tr_jump_to), for decoders
+// that take a lane per segment (aec_dec.hip: launch_decode_bare): seg_bits[r * segs_per_rsi + j] = start bit of
+// segment j of RSI r; entries it cannot give stay as the caller initialised them (~0).  One wavefront per RSI:
+// lane 0 walks from the RSI start until it stands on the trunk, then every lane takes one of the remaining
+// segments -- a search in the block numbering of the trunk each.
+__global__ void __launch_bounds__(64)
+k_seg_starts(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const uint64_t *__restrict__ rsi_off,
+             const IdxCarry *__restrict__ carry, const DecResult *__restrict__ res, uint64_t *__restrict__ seg_bits,
+             uint64_t cap_rsi)
+{
+    const uint32_t lane = threadIdx.x, S = c.segs_per_rsi;
+    const uint64_t r0 = carry->r_prev;
+    const bool on = carry->active != 0u;                    // (the walk goes on in the next span: all RSIs whole)
+    const uint64_t whole = on ? carry->r : res->n_rsi;
+    const uint32_t tail = on ? 0u : (uint32_t)res->tail_blocks;
+    const uint64_t r1 = whole + (tail ? 1u : 0u);
+    for (uint64_t r = r0 + blockIdx.x; r < r1 && r < cap_rsi; r += gridDim.x) {
+        const uint32_t nblocks = r < whole ? c.rsi : tail;
+        uint64_t *out = seg_bits + r * S;
+        uint64_t pos = rsi_off[r];
+        uint32_t b = 0;
+        int ok = 1;
+        if (lane == 0) ok = tr_seg_walk(s, c, g, t, pos, b, nblocks, [&](uint32_t j, uint64_t q) { out[j] = q; }) ? 1 : 0;
+        ok = __builtin_amdgcn_readfirstlane(ok);
+        pos = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pos >> 32)) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pos);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        if (!ok) {
+            if (lane == 0) out[0] = ~0ull;                  // (no first segment = the RSI is not taken by segments)
+            continue;
+        }
+        // segments b / 64 + 1 ... : one jump each
+        const uint32_t nseg = (nblocks + 63u) / 64u;
+        for (uint32_t j = b / 64u + 1u + lane; j < nseg; j += 64u) {
+            const uint64_t e = tr_jump_to(c, g, t, pos, b, j * 64u);
+            out[j] = e == kTrNone ? ~0ull : e;
+        }
+    }
 }
 
 // ======== sparse candidates per window (low-entropy streams with short RSIs) ==========================
@@ -1193,6 +1236,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         r = carry->r;
     }
     const uint32_t lane = threadIdx.x;
+    if (carry && !chunk_off && lane == 0) carry->r_prev = r;
     const bool pp = c.flags & F_PREPROCESS;
     const uint32_t maxw = (c.id_len + 1 + c.bps + c.bs * c.bps) / 32 + 4;   // words one CDS can touch
 
@@ -1901,7 +1945,7 @@ void allow_big_lds_walk()
 
 void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                         uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
-                        uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot)
+                        uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot, uint64_t *d_seg_bits)
 {
     IdxCarry *carry = reinterpret_cast<IdxCarry *>(base);
     const TrStream s{words, nwords, end_bit};
@@ -1993,6 +2037,13 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
         hipLaunchKernelGGL(k_trewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, c, sp, t, nwin, nchunks, end_bit, centry,
                            d_rsi_off);
         hipLaunchKernelGGL(k_texpand, dim3((hop_cap + 255) / 256), dim3(256), 0, st, c, sp, t, carry, hops, d_rsi_off);
+        if (d_seg_bits) {
+            // (at most one RSI per minimal coded RSI of the span; a wavefront each, the rest in turn)
+            const uint64_t most = (uint64_t)g.ncore * g.L / ((uint64_t)c.segs_per_rsi * (c.id_len + 2u)) + 2u;
+            const uint32_t grid = (uint32_t)(most < 4096u ? most : 4096u);
+            hipLaunchKernelGGL(k_seg_starts, dim3(grid), dim3(64), 0, st, c, s, g, t, d_rsi_off, carry, d_res, d_seg_bits,
+                               max_rsi + 1u);
+        }
         if (last) break;
     }
 #ifdef AEC_TUNING
@@ -2023,10 +2074,10 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
     return p.ok ? p.bytes : 0;
 }
 
-void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
+bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
                   uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
                   void *d_ws, size_t ws_bytes, uint64_t rsi_bits_hint, uint32_t start_block, uint64_t rsi_start,
-                  uint32_t tail_slot)
+                  uint32_t tail_slot, uint64_t *d_seg_bits)
 {
     const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
     const uint64_t nwords = (in_bytes + 3) / 4, end_bit = (uint64_t)in_bytes * 8;
@@ -2037,7 +2088,7 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
         if (sp.ok && ws_bytes >= sp.bytes) {
             launch_index_sparse(c, sp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
                                 static_cast<uint8_t *>(d_ws), ws_bytes, start_block, rsi_start, tail_slot);
-            return;
+            return false;
         }
     }
     TrunkPlan p{};
@@ -2046,10 +2097,13 @@ void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off,
                            max_rsi, d_res, (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u,
                            1u, start_block, rsi_start, tail_slot, TwTables{}, (ChunkEntry *)nullptr, SparseTables{});
-        return;
+        return false;
     }
+    // (segment starts: the caller has set the table to ~0; the RSI the walk resumes in has none -- its first
+    // blocks lie in front of the walk)
     launch_index_trunk(c, p, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
-                       static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot);
+                       static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot, d_seg_bits);
+    return d_seg_bits != nullptr;
 }
 
 // Batch over the window tables: how many hops a stream of max_chunk_bytes may take, and the workspace

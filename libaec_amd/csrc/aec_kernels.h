@@ -131,15 +131,32 @@ bool launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, 
                             uint64_t n_seg, uint64_t total_blocks, uint8_t *d_out, DecResult *d_res,
                             hipStream_t stream, const PhaseEvents *prof = nullptr);
 
+// A bare stream segment by segment: like launch_decode with the segment starts an index pass found beside the RSI
+// starts (launch_index with d_seg_bits: entry [r * segs_per_rsi + j], ~0 = unknown) -- a summing pass gives every
+// segment the sample in front of it (inside the range the inverse predictor is a running sum), then one lane per
+// segment; RSIs that cannot be taken that way are decoded by one lane each.  Falls back to launch_decode where
+// decode_bare_supported() says no or the workspace (decode_bare_workspace_bytes) is missing.
+// avg_cds_hint: bits per coded data set (0 = unknown), sizes rings and loads in flight when d_idx is given.
+bool decode_bare_supported(const Cfg &c);
+size_t decode_bare_workspace_bytes(const Cfg &c, uint64_t max_rsi);
+bool launch_decode_bare(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
+                        const uint64_t *d_seg_bits, uint64_t n_rsi, uint64_t total_blocks, uint8_t *d_out,
+                        DecResult *d_res, hipStream_t stream, const PhaseEvents *prof, const DecResult *d_idx,
+                        void *d_ws, size_t ws_bytes, uint64_t avg_cds_hint);
+
 // Enqueues the RSI index pass over one stream starting at start_bit (an RSI boundary).  With a
 // workspace (index_workspace_bytes() says how much is wanted, 0 = this input takes the serial walk alone;
 // less than that means more, smaller spans) the walk hops over the trunk tables built by all CUs (aec_idx.hip).
 // rsi_bits_hint: estimate of the coded size of one RSI (0 = unknown); it sizes burn-in, regions and records.
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint);
-void launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
+// d_seg_bits (optional; (max_rsi + 1) * segs_per_rsi entries, set to ~0 by the caller): where the index runs over
+// the trunk tables it also leaves the start bit of every segment of the RSIs it finds (launch_decode_bare); the
+// return value says whether it did.
+bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
                   uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t stream,
                   void *d_ws = nullptr, size_t ws_bytes = 0, uint64_t rsi_bits_hint = 0,
-                  uint32_t start_block = 0, uint64_t rsi_start = 0, uint32_t tail_slot = 0);
+                  uint32_t start_block = 0, uint64_t rsi_start = 0, uint32_t tail_slot = 0,
+                  uint64_t *d_seg_bits = nullptr);
 
 // Index pass over many independent streams stored in one buffer (e.g. the chunks of an HDF5
 // dataset): stream s occupies bytes [chunk_off[s], chunk_off[s+1]) (chunk_off 4-byte aligned values,

@@ -694,15 +694,18 @@ AEC_HD uint64_t tr_G(const TrGeom &g, const TrTables &t, uint32_t w, uint32_t i)
     return t.gbase[w] + (t.bp[t.nbase[w] + i] & kTrBpMask);
 }
 
-// The jump: from node at `pos` with b blocks of the RSI done to the node where the RSI ends.
-// kTrNone = unresolved (seam, end of the tables, zero run across the end, dead node on the way).
-AEC_HD uint64_t tr_jump(const Cfg &c, const TrGeom &g, const TrTables &t, uint64_t pos, uint32_t b)
+// The jump: from node at `pos` with b blocks of the RSI done to the node in front of block `target` of the RSI
+// (target = c.rsi: where the RSI ends; or a multiple of 64: where a segment starts -- a rest-of-segment run ends on
+// one of those, so it never jumps over the target).
+// kTrNone = unresolved (seam, end of the tables, zero run across the target, dead node on the way).
+AEC_HD uint64_t tr_jump_to(const Cfg &c, const TrGeom &g, const TrTables &t, uint64_t pos, uint32_t b, uint32_t target)
 {
     uint32_t w, i;
-    if (!tr_node_at(g, t, pos, w, i)) return kTrNone;
+    if (b > target || !tr_node_at(g, t, pos, w, i)) return kTrNone;
+    if (b == target) return pos;
     const uint32_t seam0 = t.seampre[w];
     for (uint32_t guard = 0; guard <= c.rsi / 32u + 2u; guard++) {
-        const uint32_t n = c.rsi - b;
+        const uint32_t n = target - b;
         const uint64_t G = tr_G(g, t, w, i);
         uint32_t rw = 0, ri = 0;
         uint64_t dist = ~0ull;                       // blocks between this node and the next rest-of-segment run
@@ -730,9 +733,46 @@ AEC_HD uint64_t tr_jump(const Cfg &c, const TrGeom &g, const TrTables &t, uint64
         if (!tr_node_of(g, t, tw, (uint32_t)(Gn - t.gbase[tw]), ti)) return kTrNone;
         w = tw;
         i = ti;
-        if (b == c.rsi) return g.lo + (uint64_t)w * g.L + t.cpos[t.nbase[w] + i];
+        if (b == target) return g.lo + (uint64_t)w * g.L + t.cpos[t.nbase[w] + i];
+        if (b > target) return kTrNone;
     }
     return kTrNone;
+}
+
+AEC_HD uint64_t tr_jump(const Cfg &c, const TrGeom &g, const TrTables &t, uint64_t pos, uint32_t b)
+{
+    return tr_jump_to(c, g, t, pos, b, c.rsi);
+}
+
+// ---- segment starts of a known RSI ------------------------------------------------------------------------
+// The RSI that starts at `pos` (a true RSI start, found by the walk) and holds `nblocks` blocks (c.rsi, fewer for
+// the RSI the input ends in): where do its segments of 64 blocks start?  The decoder can then take a lane per
+// segment instead of one per RSI (aec_dec.hip: launch_decode_bare).  First part, tr_seg_walk: the coded data
+// sets from the RSI start on, one by one -- the first with its reference sample -- until the walk stands on a
+// node of the trunk; out(j, bit) for every segment start passed.  Second part: from that node (pos, b) every
+// later segment start is ONE jump in the block numbering of the trunk, tr_jump_to(.., 64 j), independent of the
+// others.  false = not to be had: a coded data set that does not parse, or a zero-block run across a segment
+// border (legal for a decoder, reference decode.c:518-558; the reference's encoder ends runs there,
+// encode.c:649) -- the decoder then takes the RSI as one item.
+template <class Out>
+AEC_HD bool tr_seg_walk(const TrStream &s, const Cfg &c, const TrGeom &g, const TrTables &t, uint64_t &pos, uint32_t &b,
+                        uint32_t nblocks, Out out)
+{
+    b = 0;
+    out(0u, pos);
+    while (b < nblocks) {
+        if (b != 0u && tr_marked(g, t, pos)) return true;
+        const uint32_t ref = (b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u;
+        uint32_t nz;
+        const uint32_t len = tr_cds(s, c, pos, ref, nz);
+        if (!len) return false;
+        const uint32_t nb = tr_blocks(c, nz, b);
+        if (!nb || nb > nblocks - b || (b % 64u) + nb > 64u) return false;
+        pos += len;
+        b += nb;
+        if ((b % 64u) == 0u && b < nblocks) out(b / 64u, pos);
+    }
+    return true;
 }
 
 // jump (k_hyp_land): resolves a parked hypothesis

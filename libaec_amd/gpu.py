@@ -74,6 +74,12 @@ def _lib():
         lib.aec_gpu_encode_uniform_batch_async.argtypes = [vp, pp, vp, sz, u64, vp, sz, vp, vp, vp]
         lib.aec_gpu_index_async.restype = C.c_int
         lib.aec_gpu_index_async.argtypes = [vp, pp, vp, sz, u64, vp, u64, vp, vp]
+        lib.aec_gpu_segments_per_rsi.restype = C.c_uint
+        lib.aec_gpu_segments_per_rsi.argtypes = [pp]
+        lib.aec_gpu_index_segments_async.restype = C.c_int
+        lib.aec_gpu_index_segments_async.argtypes = [vp, pp, vp, sz, u64, C.c_uint, u64, vp, vp, u64, vp, vp]
+        lib.aec_gpu_decode_bare_async.restype = C.c_int
+        lib.aec_gpu_decode_bare_async.argtypes = [vp, pp, vp, sz, vp, vp, u64, u64, vp, vp, vp, vp]
         _bound = True
     return lib
 
@@ -230,6 +236,32 @@ class Codec:
             self._stream(stream))
         if rc != 0:
             raise RuntimeError(f"aec_gpu_index_async failed ({rc})")
+
+    def segments_per_rsi(self):
+        return int(self.lib.aec_gpu_segments_per_rsi(C.byref(self.p)))
+
+    def index_segments_async(self, d_in, in_bytes, start_bit, d_offsets, d_seg_bits, max_rsi, d_result, stream=None,
+                             start_block=0, rsi_start_bit=0):
+        """index pass that also leaves the segment starts: d_offsets int64 (max_rsi + 1), d_seg_bits int64
+        ((max_rsi + 1) * segments_per_rsi())"""
+        rc = self.lib.aec_gpu_index_segments_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes, start_bit, start_block, rsi_start_bit,
+            C.c_void_p(d_offsets.data_ptr()), C.c_void_p(d_seg_bits.data_ptr()), max_rsi,
+            C.c_void_p(d_result.data_ptr()), self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_index_segments_async failed ({rc})")
+
+    def decode_bare_async(self, d_in, in_bytes, d_offsets, d_seg_bits, max_rsi, total_blocks, d_index_result, d_out,
+                          d_result, stream=None):
+        """decode behind index_segments_async, a lane per segment where the index pass found the segment starts;
+        d_index_result: the index record (counts taken on the device) or None (max_rsi RSIs, total_blocks blocks)"""
+        rc = self.lib.aec_gpu_decode_bare_async(
+            self.ctx, C.byref(self.p), C.c_void_p(d_in.data_ptr()), in_bytes, C.c_void_p(d_offsets.data_ptr()),
+            C.c_void_p(d_seg_bits.data_ptr()) if d_seg_bits is not None else None, max_rsi, total_blocks,
+            C.c_void_p(d_index_result.data_ptr()) if d_index_result is not None else None,
+            C.c_void_p(d_out.data_ptr()), C.c_void_p(d_result.data_ptr()), self._stream(stream))
+        if rc != 0:
+            raise RuntimeError(f"aec_gpu_decode_bare_async failed ({rc})")
 
     def index_batch_async(self, d_in, in_bytes, d_chunk_offsets, n_chunks, rsi_per_chunk, d_offsets, d_results,
                           stream=None):

@@ -293,3 +293,91 @@ extern "C" int emul_trunk(const uint32_t *params, const uint8_t *enc, size_t enc
     if (stats[12] || stats[14]) bad++;
     return bad ? 1 : 0;
 }
+
+// Segment starts of every RSI (aec_trunk.h: tr_seg_walk + tr_jump_to, the lane functions of k_seg_starts) against
+// the serial walk.  stats[]: 0 RSIs checked, 1 RSIs whose segment starts all came out, 2 segment starts that differ
+// from the serial walk (must be 0), 3 RSIs given up (zero run across a segment border, end of the tables),
+// 4 segments checked, 5 coded data sets the walks parsed before they stood on the trunk (sum)
+extern "C" int emul_segments(const uint32_t *params, const uint8_t *enc, size_t enc_len, uint32_t L, uint32_t lead,
+                             uint32_t rw, uint32_t passes, const uint64_t *offs, uint64_t n_offs, uint64_t *stats)
+{
+    Cfg c;
+    if (make_cfg(params[0], params[1], params[2], params[3], 0, false, &c) != RC_OK) return -1;
+    std::vector<uint32_t> words((enc_len + 3) / 4 + 1, 0);
+    memcpy(words.data(), enc, enc_len);
+    const TrStream s{words.data(), (enc_len + 3) / 4, (uint64_t)enc_len * 8};
+    TrGeom g{};
+    g.lo = 0;
+    g.start_bit = 0;
+    g.L = L;
+    g.lead = lead;
+    g.rw = rw ? rw : 1;
+    g.nwin = (uint32_t)(s.end_bit / L + 1);
+    g.ncap = (uint32_t)(((uint64_t)g.nwin * L) / 8);
+    g.pcap = g.ncap;
+    g.ncore = g.nwin;
+    g.budget = 65536;
+    g.kmax = kTrMaxK;
+    Tables T;
+    TrTables t = T.view(g);
+    for (int i = 0; i < 6; i++) stats[i] = 0;
+    const uint32_t nreg = (g.nwin + g.rw - 1) / g.rw;
+    uint64_t *ea = T.exit.data(), *eb = T.exit2.data();
+    for (uint32_t r = 0; r < nreg; r++) tr_trunk_region(s, c, g, t, r, nullptr, ea);
+    for (uint32_t p = 0; p < passes; p++) {
+        for (uint32_t r = 0; r < nreg; r++) tr_trunk_region(s, c, g, t, r, ea, eb);
+        std::swap(ea, eb);
+    }
+    t.exit = ea;
+    tr_scan_serial(g, t);
+    for (uint32_t w = 0; w < g.nwin; w++) tr_trunk_window(s, c, g, t, w, t.entry[w], nullptr, TR_FILL);
+    int bad = 0;
+    for (uint64_t r = 0; r + 1 < n_offs; r++) {           // offs[n_offs - 1] = end of the stream
+        // truth: the serial walk of this RSI
+        std::vector<uint64_t> truth;
+        uint64_t q = offs[r];
+        uint32_t b = 0;
+        bool clean = true;                                 // no zero run across a segment border
+        truth.push_back(q);
+        while (b < c.rsi && q < offs[r + 1]) {
+            uint32_t nz;
+            const uint32_t len = tr_cds(s, c, q, (b == 0 && (c.flags & F_PREPROCESS)) ? 1u : 0u, nz);
+            const uint32_t nb = len ? tr_blocks(c, nz, b) : 0;
+            if (!len || !nb || nb > c.rsi - b) return 3;
+            if ((b % 64u) + nb > 64u) clean = false;
+            q += len;
+            b += nb;
+            if ((b % 64u) == 0u && b < c.rsi && q < offs[r + 1]) truth.push_back(q);
+        }
+        const uint32_t nblocks = b;
+        stats[0]++;
+        std::vector<uint64_t> got((nblocks + 63u) / 64u, ~0ull);
+        uint64_t pos = offs[r];
+        uint32_t bw = 0;
+        unsigned steps = 0;
+        bool ok = tr_seg_walk(s, c, g, t, pos, bw, nblocks, [&](uint32_t j, uint64_t p) { got[j] = p; });
+        (void)steps;
+        if (ok)
+            for (uint32_t j = bw / 64u + 1u; j < got.size(); j++) {
+                const uint64_t e = tr_jump_to(c, g, t, pos, bw, j * 64u);
+                if (e == kTrNone) ok = false;
+                got[j] = e;
+            }
+        stats[5] += bw;
+        if (!ok) {
+            stats[3]++;
+            continue;
+        }
+        if (!clean) bad++;                                 // (must have been given up)
+        stats[1]++;
+        for (size_t j = 0; j < got.size(); j++) {
+            stats[4]++;
+            if (j >= truth.size() || got[j] != truth[j]) {
+                if (stats[2]++ < 5)
+                    fprintf(stderr, "segment %zu of RSI %llu: %llu, serial walk %llu\n", j, (unsigned long long)r,
+                            (unsigned long long)got[j], (unsigned long long)(j < truth.size() ? truth[j] : 0));
+            }
+        }
+    }
+    return (bad || stats[2]) ? 1 : 0;
+}

@@ -809,3 +809,61 @@ def test_random_sweep_of_the_streaming_calls(api):
     if not have_ref():
         pytest.skip("oracle/_ref not built")
     assert fuzz_stream_gpu.run(argparse.Namespace(cases=40, seed=1, dump="", ref_only=False, big=False)) == 0
+
+
+def test_bare_stream_decodes_by_segments(gpu):
+    """A bare stream with long RSIs (BASELINE config 3 shape: 64 segments per RSI): the index pass leaves the segment
+    starts beside the RSI starts (aec_gpu_index_segments_async; the reference has no entry points inside an RSI,
+    src/decode.c:402-421) and the decoder takes a lane per segment, the sample in front of each from a summing pass
+    (inside the range the inverse predictor of decode.c:96-134 is a running sum).  Output = what a lane per RSI gives =
+    the input; also for data that CLIPS at the ends of the range (those RSIs go back to a lane per RSI), a short last
+    RSI, rsi not a multiple of 64, no preprocessor, and the reference's sample shape (4 segments per RSI)."""
+    import torch
+    rng = np.random.default_rng(77)
+
+    def clipping(n, bps, signed):
+        # a walk that keeps running into both ends of the range: the predictor's one-sided branch (decode.c:96-134)
+        lo, hi = (-(1 << (bps - 1)), (1 << (bps - 1)) - 1) if signed else (0, (1 << bps) - 1)
+        v = np.cumsum(rng.integers(-40, 41, n) * (1 << max(0, bps - 12)))
+        v = np.clip(v - v.min() // 2 + lo, lo, hi)
+        v[: n // 3] = np.clip(v[: n // 3], lo + (hi - lo) // 4, hi)          # (a stretch that stays inside)
+        return v
+
+    cases = [
+        (32, 32, 4096, PP | MSB | SGN, gen(1, 24 << 20)),                                     # config 3 shape
+        (32, 32, 4096, PP | MSB | SGN, gen(1, (3 << 20) + 32 * 4 * 70 + 4)),                 # ... with a short last RSI
+        (32, 32, 4096, PP | SGN, pack_samples(clipping(32 * 4096 * 6, 32, True), 32, PP | SGN)),
+        (16, 16, 1000, PP, pack_samples(clipping(16 * 1000 * 9 + 5, 16, False), 16, PP)),
+        (16, 16, 1000, PP, gen(0, 16 * 1000 * 2 * 40)),                                       # zero-block runs, rest-of-segment codes
+        (16, 64, 256, PP | MSB, gen(0, 8 << 20)),                                             # 4 segments per RSI
+        (8, 8, 300, PP, gen(2, 8 * 300 * 50 + 8 * 17)),
+        (16, 32, 512, 0, gen(0, 4 << 20)),                                                    # no preprocessor
+    ]
+    for bps, bs, rsi, flags, data in cases:
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        codec = gpu.Codec(bps, bs, rsi, flags)
+        d_in = torch.from_numpy(data).cuda()
+        d_out, nbytes, tb, k_out, d_off = codec.encode(d_in)
+        nrsi, nblk = codec.rsi_count(data.size), codec.block_count(data.size)
+        nb = bytes_per_sample(bps, flags)
+        d_ref, st = codec.decode(d_out, nbytes, d_off, nrsi, nblk)                            # a lane per RSI
+        assert st == 0
+        spr = codec.segments_per_rsi()
+        assert spr == (rsi + 63) // 64
+        for with_record in (False, True):
+            d_idx = torch.zeros(nrsi + 2, dtype=torch.int64, device="cuda")
+            d_sb = torch.zeros((nrsi + 2) * spr, dtype=torch.int64, device="cuda")
+            d_ires = torch.zeros(40, dtype=torch.uint8, device="cuda")
+            d_res = torch.zeros(40, dtype=torch.uint8, device="cuda")
+            d_dec = torch.zeros(nrsi * rsi * bs * nb + 64 * bs * nb, dtype=torch.uint8, device="cuda")
+            codec.index_segments_async(d_out, nbytes, 0, d_idx, d_sb, nrsi + 1, d_ires)
+            codec.decode_bare_async(d_out, nbytes, d_idx, d_sb, nrsi + 1 if with_record else nrsi, nblk,
+                                    d_ires if with_record else None, d_dec, d_res)
+            ires = d_ires.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]
+            res = d_res.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]
+            assert int(ires["n_rsi"]) * rsi + int(ires["tail_blocks"]) == nblk, (bps, bs, rsi, flags, ires)
+            assert torch.equal(d_idx[:nrsi], d_off[:nrsi])
+            assert res["status"] == 0, (bps, bs, rsi, flags, res)
+            assert torch.equal(d_dec[: nblk * bs * nb], d_ref[: nblk * bs * nb]), (bps, bs, rsi, flags, with_record)
+        if not (flags & SGN and bps % 8):
+            assert torch.equal(d_ref[: data.size], d_in), (bps, bs, rsi, flags)

@@ -133,3 +133,36 @@ def test_pad_rsi(emul):
     for staged in (0, 2):
         d = run(emul, enc, offs, len(enc) * 8, bps, bs, rsi, flags, 4096, 8192, staged=staged)
         assert d["rsis_covered"] == d["true_checked"] and d["fallbacks"] <= 30, d
+
+
+@pytest.mark.parametrize("bps,bs,rsi,flags,L,lead,rw,holds", [
+    (32, 32, 4096, 8 | 4 | 1, 65536, 262144, 8, False),    # config 3 shape: 64 segments per RSI
+    (16, 16, 1024, 8, 16384, 16384, 1, True),               # low entropy with zero-block runs (rest-of-segment codes)
+    (16, 64, 256, 8 | 4, 65536, 262144, 4, False),          # the reference's sample shape: 4 segments per RSI
+    (8, 8, 300, 8, 8192, 4096, 1, True),                    # an RSI that is no whole number of segments
+])
+def test_segment_starts(emul, bps, bs, rsi, flags, L, lead, rw, holds):
+    """aec_trunk.h tr_seg_walk + tr_jump_to (k_seg_starts): the start bit of every 64-block segment of every RSI, from
+    the RSI start and the trunk tables, against the serial walk -- what lets the decoder take a lane per segment of
+    a bare stream (reference src/decode.c:402-421 has no entry points inside an RSI)."""
+    rng = np.random.default_rng(bps * 77 + rsi)
+    n = 3 << 20 if rsi >= 4096 else 3 << 19
+    vals = lowent(rng, n, bps)
+    if not holds:
+        vals = np.clip((1 << (bps - 1)) + np.cumsum(rng.integers(-3, 4, size=n) * rng.integers(0, 50, size=n)), 0, (1 << bps) - 1)
+    if flags & helpers.AEC_DATA_SIGNED:
+        vals = vals - (1 << (bps - 1))
+    data = helpers.pack_samples(vals, bps, flags)
+    rc, enc, _, offs, tb = helpers.oracle_encode(data, bps, bs, rsi, flags)
+    assert rc == 0
+    emul.emul_segments.restype = C.c_int
+    enc_a = np.frombuffer(enc, dtype=np.uint8)
+    o = np.concatenate([np.asarray(offs, dtype=np.uint64), np.array([tb], dtype=np.uint64)])
+    p = (C.c_uint32 * 4)(bps, bs, rsi, flags)
+    stats = np.zeros(6, dtype=np.uint64)
+    rc = emul.emul_segments(p, C.c_void_p(enc_a.ctypes.data), C.c_size_t(enc_a.size), C.c_uint32(L), C.c_uint32(lead),
+                            C.c_uint32(rw), C.c_uint32(3), C.c_void_p(o.ctypes.data), C.c_uint64(o.size),
+                            C.c_void_p(stats.ctypes.data))
+    checked, resolved, wrong, given_up, segs, steps = (int(x) for x in stats)
+    assert rc == 0 and wrong == 0, (rc, stats)
+    assert checked == len(offs) and resolved >= checked - 2 - checked // 20, stats
