@@ -444,11 +444,11 @@ int decode_run(internal_state *s, struct aec_stream *strm)
     const size_t in_bytes = span < s->d_len ? (size_t)span : s->d_len;
     if (!s->d_off.ensure((max_rsi + 2) * 8) || !s->d_out.ensure(max_rsi * rsi_bytes + blk_bytes + 64))
         return AEC_FAIL(AEC_MEM_ERROR);
-    // RSIs of four segments and more: the index pass also leaves the segment starts, and the decoder takes a lane per
+    // RSIs of eight segments and more: the index pass also leaves the segment starts, and the decoder takes a lane per
     // segment instead of one per RSI (include/aec_gpu.h: aec_gpu_index_segments_async; without the table -- no memory
     // for it -- a lane per RSI as before)
     uint64_t *d_seg = nullptr;
-    if (c.segs_per_rsi >= 4 && s->d_seg.ensure((max_rsi + 2) * c.segs_per_rsi * 8)) d_seg = static_cast<uint64_t *>(s->d_seg.p);
+    if (c.segs_per_rsi >= 8 && s->d_seg.ensure((max_rsi + 2) * c.segs_per_rsi * 8)) d_seg = static_cast<uint64_t *>(s->d_seg.p);
 
     aec_gpu_dec_result *d_idx = static_cast<aec_gpu_dec_result *>(s->d_res.p), *d_dec = d_idx + 1;
     uint64_t *d_off = static_cast<uint64_t *>(s->d_off.p);

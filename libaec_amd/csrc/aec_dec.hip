@@ -1081,8 +1081,10 @@ void launch_decode_partial(const Cfg &c, const uint8_t *d_in, size_t in_bytes, c
 // Workspace of launch_decode_bare for up to max_rsi RSIs: sums and table per segment, list per RSI, counter.
 bool decode_bare_supported(const Cfg &c)
 {
-    // (worth it from four segments per RSI on; the templated block sizes)
-    return c.segs_per_rsi >= 4u && (c.bs == 8u || c.bs == 16u || c.bs == 32u || c.bs == 64u);
+    // (from eight segments per RSI on: an RSI in which a sample comes within reach of the ends of the range falls
+    // back to one lane, and with the reference's sample file -- four segments per RSI -- that is every other RSI;
+    // the templated block sizes)
+    return c.segs_per_rsi >= 8u && (c.bs == 8u || c.bs == 16u || c.bs == 32u || c.bs == 64u);
 }
 
 size_t decode_bare_workspace_bytes(const Cfg &c, uint64_t max_rsi)

@@ -34,6 +34,7 @@
 #include "aec_spec.h"
 #include "aec_spec2.h"
 #include "aec_trunk.h"
+#include "aec_coop.h"
 #include "aec_tune.h"
 
 namespace aec {
@@ -144,6 +145,94 @@ k_trunk(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const u
     }
     const uint32_t nreg = (g.nwin + g.rw - 1u) / g.rw;
     if (i < nreg) tr_trunk_region(s, c, g, t, i, mode ? exit_prev : nullptr, exit_out, TR_COUNT);
+}
+
+// The count passes of the trunk with a WAVEFRONT per region (aec_coop.h) instead of a lane: a region is a serial
+// chain of a few thousand coded data sets (burn-in + its windows), and the first pass took as long as one lane
+// needs for that from device memory.  Same arithmetic and same tables as tr_trunk_region / tr_trunk_window in
+// TR_COUNT mode; the words of bitmap and prefix table between two nodes are written by the lanes side by side.
+constexpr uint32_t kTrunkCoopWin = 2048;
+template <class CW>
+__device__ __forceinline__ uint64_t coop_trunk_window(CW &cw, const Cfg &c, const TrGeom &g, const TrTables &t, uint32_t w,
+                                                      uint64_t pos, uint64_t *exit_out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wstart = g.lo + (uint64_t)w * g.L, wend = wstart + g.L;
+    const uint32_t nw = g.L / 32u;
+    uint32_t *bm = t.bitmap + (uint64_t)w * nw;
+    uint16_t *pre = t.pre + (uint64_t)w * nw;
+    if (lane == 0) t.entry[w] = pos;
+    uint32_t cnt = 0, blocks = 0, ros = 0, wi = 0, wv = 0, wpre = 0;
+    bool full = false;
+    while (pos != kTrNone && pos < wend) {
+        uint32_t nzc;
+        const uint32_t len = cw.cds(c, pos, 0u, nzc);
+        if (!full && blocks > kTrBpMask - 64u) full = true;
+        if (!full) {
+            const uint32_t rel = (uint32_t)(pos - wstart), word = rel >> 5;
+            if (wi < word) {
+                for (uint32_t k = wi + lane; k < word; k += 64u) {
+                    bm[k] = k == wi ? wv : 0u;
+                    pre[k] = (uint16_t)(k == wi ? wpre : cnt);
+                }
+                wi = word;
+                wv = 0;
+                wpre = cnt;
+            }
+            uint32_t nb = 1;
+            if (!len) nb = 0;
+            else if (nzc == 5u) ros++;
+            else if (nzc) nb = nzc > 5u ? nzc - 1u : nzc;
+            wv |= 0x80000000u >> (rel & 31u);
+            cnt++;
+            blocks += nb;
+        }
+        pos = len ? pos + len : kTrNone;
+    }
+    for (uint32_t k = wi + lane; k < nw; k += 64u) {
+        bm[k] = k == wi ? wv : 0u;
+        pre[k] = (uint16_t)(k == wi ? wpre : cnt);
+    }
+    if (lane == 0) {
+        exit_out[w] = full ? kTrNone : pos;
+        t.ccnt[w] = cnt;
+        t.nblk[w] = blocks;
+        t.nros[w] = ros;
+    }
+    return pos;
+}
+
+// mode 0: first pass (burn-in + count), 1: repair pass (count); one wavefront per region
+__global__ void __launch_bounds__(64)
+k_trunk_coop(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const uint64_t *exit_prev, uint64_t *exit_out,
+             uint32_t mode)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_w[kTrunkCoopWin];
+    const uint32_t nreg = (g.nwin + g.rw - 1u) / g.rw, lane = threadIdx.x;
+    CoopCds<kTrunkCoopWin> cw;
+    cw.init(s, c, lds_w);
+    for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
+        const uint32_t w0 = r * g.rw, w1 = w0 + g.rw < g.nwin ? w0 + g.rw : g.nwin;
+        const uint64_t rstart = g.lo + (uint64_t)w0 * g.L, rend = g.lo + (uint64_t)w1 * g.L;
+        uint64_t pos;
+        if (!mode) {
+            pos = rstart > g.start_bit + g.lead ? rstart - g.lead : g.start_bit;
+            if (rend <= g.start_bit || rstart > s.end_bit) pos = kTrNone;
+            while (pos != kTrNone && pos < rstart) {                         // burn-in
+                uint32_t nzc;
+                const uint32_t len = cw.cds(c, pos, 0u, nzc);
+                pos = len ? pos + len : kTrNone;
+            }
+        } else {
+            const uint64_t prev = w0 ? exit_prev[w0 - 1u] : kTrNone;
+            if (prev == kTrNone || prev == t.entry[w0]) {
+                for (uint32_t w = w0 + lane; w < w1; w += 64u) exit_out[w] = exit_prev[w];
+                continue;
+            }
+            pos = prev;
+        }
+        for (uint32_t w = w0; w < w1; w++) pos = coop_trunk_window(cw, c, g, t, w, pos, exit_out);
+    }
 }
 
 // inclusive scan of one 64-bit value per lane over a workgroup of 1024 (16 wavefronts); `total` = sum of all
@@ -496,6 +585,218 @@ k_hyp_walk_mem(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, 
     }
 }
 
+// ---- coalescing hypothesis walks (aec_trunk.h section 2b) ------------------------------------------------
+// Lists the kernels below hand on: walks to be finished from device memory, nodes left to the plain walk.
+struct CoLists {
+    uint2 *queue;              // {node record index, window}
+    uint2 *plain;              // {window, index inside the window}
+    uint32_t *counts;          // [0] queue entries, [1] plain entries (both may run beyond their capacity)
+    uint32_t qcap, pcap;
+    uint32_t over_plain;       // CO_OVER nodes go to the plain walk too (RSIs not much longer than the way to the trunk)
+};
+
+__device__ __forceinline__ void co_push(uint2 *list, uint32_t *count, uint32_t cap, uint2 v)
+{
+    const uint32_t i = atomicAdd(count, 1u);
+    if (i < cap) list[i] = v;
+}
+
+// One workgroup per group of `wpg` windows (persistent: the groups in turn).  The group's stretch of the stream
+// plus a margin is staged in LDS with the trunk marks, and a table of MARKS over its bit positions (one cell per
+// 2^shift bits) that the walks fill as they go; a walk that meets a mark stops and is resolved through the owner
+// after the workgroup's barrier.  Flat loop: one parse per lane and round, a lane that is through takes its next
+// node.  LDS: sw[bits / 32 + 8] | bm[bits / 32] | cells[(bits >> shift) + 1] | wnb[wpg + 1] | wnp[wpg + 1] |
+// recs[cap] (8 bytes each)
+struct CoCells {
+    uint32_t *v;
+    __device__ __forceinline__ uint32_t claim(uint32_t i, uint32_t p) { return atomicCAS(&v[i], 0u, p); }
+    __device__ __forceinline__ uint32_t peek(uint32_t i) const { return v[i]; }
+};
+
+__global__ void __launch_bounds__(256)
+k_hyp_walk_co(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, uint32_t wpg, uint32_t margin,
+              uint32_t ngroups, uint32_t shift, uint32_t tmax, uint32_t cap, const CoLists ls)
+{
+    // ls.over_plain: walks that run over the end of their RSI before they land go to the plain walk as well
+    extern __shared__ __attribute__((aligned(16))) uint32_t co_lds[];
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const TrGlobal mem{s, g, t};
+    for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const uint32_t w0 = grp * wpg;
+        const uint32_t w1 = w0 + wpg < g.ncore ? w0 + wpg : g.ncore;
+        const uint64_t base = g.lo + (uint64_t)w0 * g.L;
+        const uint32_t bits = wpg * g.L + margin, nw = bits / 32u, ncell = (bits >> shift) + 1u;
+        uint32_t *sw = co_lds, *bm = sw + nw + 8u, *cellv = bm + nw, *wnb = cellv + ncell, *wnp = wnb + wpg + 1u;
+        CoRec *recs = reinterpret_cast<CoRec *>(wnp + wpg + 1u + (ncell & 1u));          // (8-byte aligned)
+        __syncthreads();                                      // (the group before is done with the arrays)
+        {
+            const uint64_t bw0 = base >> 5, gw0 = (base - g.lo) >> 5, gwn = (uint64_t)g.nwin * (g.L / 32u);
+            for (uint32_t i = tid; i < nw + 8u; i += nt) sw[i] = tr_word(s, bw0 + i);
+            for (uint32_t i = tid; i < nw; i += nt) bm[i] = gw0 + i < gwn ? t.bitmap[gw0 + i] : 0u;
+            for (uint32_t i = tid; i < ncell; i += nt) cellv[i] = 0u;
+            if (tid <= w1 - w0) wnb[tid] = t.nbase[w0 + tid];
+        }
+        __syncthreads();
+        if (tid <= w1 - w0) wnp[tid] = wnb[tid] - wnb[0];
+        __syncthreads();
+        const uint32_t nnodes = wnp[w1 - w0], nown = nnodes < cap ? nnodes : cap;
+        const TrStaged st{mem, sw, bm, nullptr, base, bits};
+        CoCells cells{cellv};
+        const uint64_t lim = base + bits - 1024u;
+        // ---- the walks: nodes tid, tid + nt, ... of the group
+        uint32_t m = tid, wi = 0;
+        bool run = false;
+        CoWalk h;
+        for (;;) {
+            if (!run && m < nown) {
+                while (m >= wnp[wi + 1u]) wi++;
+                const uint32_t cp = t.cpos[(uint64_t)wnb[wi] + (m - wnp[wi])];
+                tr_co_start(c, h, base + (uint64_t)wi * g.L + cp);
+                run = true;
+            }
+            if (!__any(run)) break;
+            if (run) {
+                uint32_t hit = 0;
+                uint32_t r = tr_co_step(s, c, st, cells, h, m, base, lim, shift, tmax, hit);
+                if (r != CO_RUN) {
+                    uint32_t tt = 0;
+                    if (r == CO_LAND || r == CO_QUEUE) {
+                        if (h.pos - h.c > 0xFFFFFFFFull) r = CO_PLAIN;
+                        tt = (uint32_t)(h.pos - h.c);
+                    } else if (r == CO_LINK) {
+                        tt = hit;
+                    }
+                    recs[m] = CoRec{co_pack(r, h.b, h.b_ros), tt};
+                    m += nt;
+                    run = false;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- every node's links followed inside the group; what it comes to goes into its record
+        wi = 0;
+        for (m = tid; m < nnodes; m += nt) {
+            while (m >= wnp[wi + 1u]) wi++;
+            const uint32_t idx = m - wnp[wi];
+            const uint64_t at = (uint64_t)wnb[wi] + idx;
+            uint64_t z = 0;
+            uint32_t root = 0, b = 0, kind = CO_PLAIN;
+            auto node_pos = [&](uint32_t q) -> uint64_t {
+                uint32_t v = 0;
+                while (q >= wnp[v + 1u]) v++;
+                return base + (uint64_t)v * g.L + t.cpos[(uint64_t)wnb[v] + (q - wnp[v])];
+            };
+            if (m < nown) kind = tr_co_resolve(c, [&](uint32_t q) { return recs[q]; }, node_pos, m, z, root, b, ls.over_plain != 0u);
+            TrRec out{0u, 0u};
+            uint32_t park = 0;
+            const uint64_t mine = base + (uint64_t)wi * g.L + t.cpos[at];
+            if (kind == CO_LAND && z - mine <= 0xFFFFFFFFull) {
+                out.x = (uint32_t)(z - mine);
+                park = kTrParked | b;                          // (a parked hypothesis: k = 0, b blocks done)
+            } else if (kind == CO_QUEUE) {
+                out.x = recs[m].t;
+                park = recs[m].k;
+                co_push(ls.queue, ls.counts, ls.qcap, make_uint2((uint32_t)at, w0 + wi));
+            } else if (kind == CO_DEFER) {
+                // the walk it waits for: its record, the count that one was handed on with, and where its node lies
+                // from here (the distance its landing will be given by is from ITS node)
+                const int64_t delta = (int64_t)node_pos(root) - (int64_t)mine;
+                uint32_t rv = 0;
+                while (root >= wnp[rv + 1u]) rv++;
+                out.x = wnb[rv] + (root - wnp[rv]);
+                out.y = co_bend(recs[root].k) | ((uint32_t)(delta + 0x40000) << 13);
+                park = co_pack(CO_DEFER, b, kCoNoRos);
+                if (delta < -0x40000 || delta >= 0x40000) kind = CO_PLAIN;
+            }
+            if (kind != CO_LAND && kind != CO_QUEUE && kind != CO_DEFER) {
+                out = TrRec{0u, 0u};
+                park = 0;
+                if (kind == CO_PLAIN || (kind == CO_OVER && ls.over_plain))
+                    co_push(ls.plain, ls.counts + 1, ls.pcap, make_uint2(w0 + wi, idx));
+            } else if (kind == CO_LAND && !park) {
+                co_push(ls.plain, ls.counts + 1, ls.pcap, make_uint2(w0 + wi, idx));
+            }
+            t.rec[at] = out;
+            t.park[at] = park;
+        }
+    }
+}
+
+// the walks that were handed on: one lane each, from device memory until they stand on the trunk.  (A wavefront per
+// walk, aec_coop.h, was measured here and lost: 11.3 ms against 3.8 per span of 2 Gbit -- a wavefront's parse is
+// mostly scalar work, the CU's one scalar unit serves all its wavefronts, and there are sixty thousand of these
+// walks; the lanes' time is the longest walk's, ~1500 coded data sets at 2.5 us.)
+constexpr uint32_t kCoopWin = 1024;                  // words of stream (and of trunk marks) a wavefront stages (k_seg_starts)
+__global__ void __launch_bounds__(64)
+k_hyp_walk_rest(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const CoLists ls)
+{
+    const uint32_t n = ls.counts[0] < ls.qcap ? ls.counts[0] : ls.qcap;
+    const TrGlobal mem{s, g, t};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint2 e = ls.queue[i];
+        const uint64_t at = e.x;
+        const uint64_t node = g.lo + (uint64_t)e.y * g.L + t.cpos[at];
+        const uint32_t pk = t.park[at], bh = co_bend(pk);
+        uint32_t dist = 0;
+        const uint32_t res = tr_co_rest(s, c, g, mem, node, node + t.rec[at].x, bh, co_bros(pk), dist);
+        t.rec[at] = TrRec{dist, bh};                           // (y: the count it was handed on with -- k_hyp_defer)
+        t.park[at] = res;
+        const uint32_t rk = co_kind(res);
+        if (rk == CO_PLAIN || (rk == CO_OVER && ls.over_plain))
+            co_push(ls.plain, ls.counts + 1, ls.pcap, make_uint2(e.y, (uint32_t)(at - t.nbase[e.y])));
+    }
+}
+
+// one lane per node: the nodes that waited for a handed-on walk take its landing
+__global__ void __launch_bounds__(256)
+k_hyp_defer(const Cfg c, const TrGeom g, const TrTables t, const CoLists ls)
+{
+    const uint32_t w = blockIdx.x;
+    if (w >= g.ncore) return;
+    const uint32_t n = t.ccnt[w];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t at = t.nbase[w] + i;
+        const uint32_t pk = t.park[at];
+        if ((pk & kTrParked) || !(pk & kCoTag) || co_kind(pk) != CO_DEFER) continue;
+        const TrRec r = t.rec[at];
+        const uint32_t root_pk = t.park[r.x];
+        uint32_t kind;
+        const uint32_t b = co_defer(c, co_bend(pk), r.y & 0x1FFFu, root_pk, kind, ls.over_plain != 0u);
+        const int64_t dist = (int64_t)(r.y >> 13) - 0x40000 + (int64_t)t.rec[r.x].x;
+        if (b && dist > 0 && dist <= 0xFFFFFFFFll) {
+            t.rec[at] = TrRec{(uint32_t)dist, 0u};
+            t.park[at] = kTrParked | b;
+        } else {
+            t.rec[at] = TrRec{0u, 0u};
+            t.park[at] = 0;
+            if (kind == CO_LAND) kind = CO_PLAIN;
+            if (kind == CO_PLAIN || (kind == CO_OVER && ls.over_plain)) co_push(ls.plain, ls.counts + 1, ls.pcap, make_uint2(w, i));
+        }
+    }
+}
+
+// the nodes left to the plain walk (tr_hyp_step: any number of RSIs, the pool of RSI ends), walk and jump
+__global__ void __launch_bounds__(64)
+k_hyp_walk_list(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const CoLists ls)
+{
+    const uint32_t n = ls.counts[1] < ls.pcap ? ls.counts[1] : ls.pcap;
+    const TrGlobal mem{s, g, t};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint2 e = ls.plain[i];
+        TrHyp h;
+        tr_hyp_start(c, h, g.lo + (uint64_t)e.x * g.L + t.cpos[t.nbase[e.x] + e.y]);
+        uint32_t st;
+        while ((st = tr_hyp_step(s, c, g, mem, h)) == TR_RUN) {
+            if (h.pend && !tr_hyp_commit(g, t, h, atomicAdd(t.pool_cnt, 1u))) {
+                st = TR_FAIL;
+                break;
+            }
+        }
+        tr_hyp_finish(g, t, e.x, e.y, h, st);
+        tr_hyp_land(c, g, t, e.x, e.y);
+    }
+}
+
 // one lane per node: the jump of every parked hypothesis
 __global__ void __launch_bounds__(256)
 k_hyp_land(const Cfg c, const TrGeom g, const TrTables t)
@@ -582,12 +883,18 @@ __global__ void k_texpand(const Cfg c, const TwTables t, const TrTables tt, cons
 // that take a lane per segment (aec_dec.hip: launch_decode_bare): seg_bits[r * segs_per_rsi + j] = start bit of
 // segment j of RSI r; entries it cannot give stay as the caller initialised them (~0).  One wavefront per RSI:
 // lane 0 walks from the RSI start until it stands on the trunk, then every lane takes one of the remaining
-// segments -- a search in the block numbering of the trunk each.
+// segments -- a search in the block numbering of the trunk each.  The walk is the wavefront's (aec_coop.h: a few
+// hundred coded data sets, some a few thousand, and the longest one sets the kernel's time).
 __global__ void __launch_bounds__(64)
 k_seg_starts(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const uint64_t *__restrict__ rsi_off,
              const IdxCarry *__restrict__ carry, const DecResult *__restrict__ res, uint64_t *__restrict__ seg_bits,
              uint64_t cap_rsi)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_w[kCoopWin], lds_m[kCoopWin];
+    const TrGlobal mem{s, g, t};
+    CoopCds<kCoopWin> cw;
+    cw.init(s, c, lds_w);
+    cw.with_marks(lds_m, g, t);
     const uint32_t lane = threadIdx.x, S = c.segs_per_rsi;
     const uint64_t r0 = carry->r_prev;
     const bool on = carry->active != 0u;                    // (the walk goes on in the next span: all RSIs whole)
@@ -599,12 +906,34 @@ k_seg_starts(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, co
         uint64_t *out = seg_bits + r * S;
         uint64_t pos = rsi_off[r];
         uint32_t b = 0;
-        int ok = 1;
-        if (lane == 0) ok = tr_seg_walk(s, c, g, t, pos, b, nblocks, [&](uint32_t j, uint64_t q) { out[j] = q; }) ? 1 : 0;
-        ok = __builtin_amdgcn_readfirstlane(ok);
-        pos = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pos >> 32)) << 32) |
-              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pos);
-        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        bool ok = true;
+        if (!cw.usable()) {
+            uint32_t st = 0;
+            if (lane == 0)
+                st = tr_seg_walk(s, c, mem, pos, b, nblocks, ~0ull, [&](uint32_t j, uint64_t q) { out[j] = q; });
+            ok = __builtin_amdgcn_readfirstlane((int)st) == (int)TR_SEG_ON_TRUNK;
+            pos = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pos >> 32)) << 32) |
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pos);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        } else {
+            // (aec_trunk.h tr_seg_walk, the whole wavefront in step)
+            if (lane == 0) out[0] = pos;
+            while (b < nblocks) {
+                cw.prepare(pos);
+                if (b != 0u && cw.marked(pos)) break;
+                const uint32_t ref = (b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u;
+                uint32_t nz;
+                const uint32_t len = cw.cds(c, pos, ref, nz);
+                const uint32_t nb = len ? tr_blocks(c, nz, b) : 0u;
+                if (!nb || nb > nblocks - b || (b % 64u) + nb > 64u) {
+                    ok = false;
+                    break;
+                }
+                pos += len;
+                b += nb;
+                if ((b % 64u) == 0u && b < nblocks && lane == 0) out[b / 64u] = pos;
+            }
+        }
         if (!ok) {
             if (lane == 0) out[0] = ~0ull;                  // (no first segment = the RSI is not taken by segments)
             continue;
@@ -1792,6 +2121,10 @@ struct TrunkPlan {
     uint32_t L, lead, rw, passes, budget, kmax, wpw, wpc, wcap;
     uint32_t staged, margin;  // hypothesis walks: byte table of coded data set lengths or not, margin behind a group (bits)
     size_t lds;               // ... and the LDS of a workgroup
+    // coalescing hypothesis walks (aec_trunk.h section 2b): windows per group, margin, bits per mark cell (log2),
+    // parses before a walk is handed on, walks per group, LDS, list capacities
+    uint32_t co, co_wpg, co_margin, co_shift, co_tmax, co_cap, co_qcap, co_pcap, co_over;
+    size_t co_lds, o_coq, o_cop;
     uint32_t pcap;            // pool of RSI ends inside records
     uint32_t nwin_max;        // windows per span (launch set): core + look-ahead
     uint32_t nlook;           // look-ahead windows behind the core of a span that does not reach the end
@@ -1801,7 +2134,10 @@ struct TrunkPlan {
         o_ros, o_rec, o_park, o_pool, o_wide, o_centry, o_hops, bytes;
 };
 
-constexpr size_t kTrWsWanted = 768u << 20;      // workspace asked for at most (larger inputs take several spans)
+// workspace asked for at most (larger inputs take several spans): 768 MiB, for large streams up to 2.5 times the
+// stream and 3 GiB -- several kernels of a span take as long as the longest serial chain they hold (a trunk region,
+// a walk that was handed on, the walker's hops), whatever the span's size, so fewer and larger spans are cheaper
+constexpr size_t kTrWsWanted = 768u << 20, kTrWsMost = (size_t)3 << 30;
 
 
 size_t trunk_bytes(TrunkPlan &p, uint32_t nwin)
@@ -1830,6 +2166,12 @@ size_t trunk_bytes(TrunkPlan &p, uint32_t nwin)
     p.o_wide = o;   o = up(o + (size_t)nchunk * p.wcap * sizeof(uint4));
     p.o_centry = o; o = up(o + (size_t)nchunk * sizeof(ChunkEntry));
     p.o_hops = o;   o = up(o + ((size_t)nwin * 2 + 16) * sizeof(IdxHop));
+    if (p.co) {
+        p.co_qcap = p.ncap / 4u + 4096u;
+        p.co_pcap = p.ncap / 8u + 4096u;
+        p.o_coq = o; o = up(o + (size_t)p.co_qcap * sizeof(uint2));
+        p.o_cop = o; o = up(o + (size_t)p.co_pcap * sizeof(uint2));
+    }
     return o;
 }
 
@@ -1896,6 +2238,32 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
         // longer node lists per lane -- the walks are bound by memory latency)
         p.wpw = tune("AEC_TR_WPW", 1u);
     }
+    // Coalescing walks where a walk does not complete its RSI before it is back on the trunk (long RSIs: config 3) --
+    // a walk then meets another walk after a dozen parses instead of the trunk after a few hundred.  Groups of up to
+    // 64 kbit (about a thousand nodes at most), marks of 16 bits, 64 parses before a walk is handed on (measured in
+    // tests/emul on the config-3 shape: 15 + 15 parses per node against 280; 16 + 8 with 128 parses).
+    p.co = tune("AEC_TR_CO", (!p.staged && c.rsi >= 8 * cds) ? 1u : 0u);
+    if (p.co) {
+        uint64_t core = 1024 * cds;
+        if (core > 65536) core = 65536;
+        uint32_t wpg = (uint32_t)(core / p.L);
+        if (wpg < 1) wpg = 1;
+        p.co_wpg = tune("AEC_TR_CO_WPG", wpg);
+        p.co_margin = tune("AEC_TR_CO_MARGIN", 32768u) & ~31u;
+        if (p.co_margin < 2048u) p.co_margin = 2048u;
+        p.co_shift = tune("AEC_TR_CO_SHIFT", 4u);
+        if (p.co_shift < 2u || p.co_shift > 4u) p.co_shift = 4u;
+        p.co_tmax = tune("AEC_TR_CO_TMAX", 64u);
+        p.co_cap = tune("AEC_TR_CO_CAP", 1024u);
+        // walks whose count runs over the end of their RSI before they land: with RSIs of 12 and more times the way
+        // back to the trunk those are garbage walks inflated by zero-run codes (one true RSI start in e^12 takes that
+        // long, and is then walked serially); below that they get the plain walk's records of several RSIs
+        p.co_over = tune("AEC_TR_CO_OVER", c.rsi >= 12 * cds ? 0u : 1u);
+        if (p.co_cap > kCoMaxOwners) p.co_cap = kCoMaxOwners;
+        const uint64_t bits = (uint64_t)p.co_wpg * p.L + p.co_margin;
+        p.co_lds = ((bits / 32 + 8) + bits / 32 + ((bits >> p.co_shift) + 2) + 2 * ((size_t)p.co_wpg + 1)) * 4 + (size_t)p.co_cap * 8 + 64;
+        if (bits + 0x1000 >= 0x40000 || p.co_lds > 160 * 1024) p.co = 0;     // (k_hyp_walk_co packs distances inside a group into 19 bits)
+    }
     p.wcap = p.L / 8 < 4096 ? p.L / 8 : 4096;
     uint64_t look = 4 * (rsi_bits_hint ? rsi_bits_hint : (uint64_t)c.rsi * cds) + 8 * sync + 4 * p.L;
     if (look > (1ull << 27)) look = 1ull << 27;
@@ -1912,7 +2280,10 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
         return trunk_bytes(p, (uint32_t)nwin);
     };
     uint64_t nwin = nwin_all;
-    const size_t limit = ws_bytes ? ws_bytes : kTrWsWanted;
+    size_t wanted = (size_t)(total_bits / 8u) * 5u / 2u;
+    if (wanted < kTrWsWanted) wanted = kTrWsWanted;
+    if (wanted > kTrWsMost) wanted = kTrWsMost;
+    const size_t limit = ws_bytes ? ws_bytes : wanted;
     if (bytes_for(nwin) > limit) {
         // as many windows as fit (bytes are linear in nwin up to rounding)
         const size_t per = (bytes_for(4096) - bytes_for(2048)) / 2048 + 1;
@@ -1938,6 +2309,9 @@ void allow_big_lds_walk()
     if (dev < 0 || dev >= 64) dev = 0;
     std::call_once(once[dev], [] {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_hyp_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_hyp_walk_co), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
     });
@@ -1990,11 +2364,21 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
         uint64_t *ex[2] = {reinterpret_cast<uint64_t *>(base + p.o_exit0), reinterpret_cast<uint64_t *>(base + p.o_exit1)};
         const uint32_t nreg = (g.nwin + g.rw - 1) / g.rw;
         t.exit = ex[0];
-        hipLaunchKernelGGL(k_trunk, dim3((nreg + 63) / 64), dim3(64), 0, st, c, s, g, t, (const uint64_t *)nullptr, ex[0], 0u);
+        // (a wavefront per region where a coded data set fits the wavefront's register window, aec_coop.h; else a lane)
+        const bool coop = tune("AEC_TR_COOP", 1u) && c.id_len + 1u + c.bps + c.bs * c.bps + 128u <= 2048u;
+        const uint32_t cgrid = nreg < 256u * 20u ? nreg : 256u * 20u;
+        if (coop)
+            hipLaunchKernelGGL(k_trunk_coop, dim3(cgrid), dim3(64), 0, st, c, s, g, t, (const uint64_t *)nullptr, ex[0], 0u);
+        else
+            hipLaunchKernelGGL(k_trunk, dim3((nreg + 63) / 64), dim3(64), 0, st, c, s, g, t, (const uint64_t *)nullptr, ex[0], 0u);
         uint32_t cur = 0;
         for (uint32_t k = 0; k < p.passes; k++) {
-            hipLaunchKernelGGL(k_trunk, dim3((nreg + 63) / 64), dim3(64), 0, st, c, s, g, t, (const uint64_t *)ex[cur],
-                               ex[cur ^ 1u], 1u);
+            if (coop)
+                hipLaunchKernelGGL(k_trunk_coop, dim3(cgrid), dim3(64), 0, st, c, s, g, t, (const uint64_t *)ex[cur],
+                                   ex[cur ^ 1u], 1u);
+            else
+                hipLaunchKernelGGL(k_trunk, dim3((nreg + 63) / 64), dim3(64), 0, st, c, s, g, t, (const uint64_t *)ex[cur],
+                                   ex[cur ^ 1u], 1u);
             cur ^= 1u;
         }
         t.exit = ex[cur];
@@ -2003,13 +2387,33 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
                            (uint64_t *)nullptr, 2u);
         (void)hipMemsetAsync(t.pool_cnt, 0, 4, st);
         const uint32_t ngroups = (g.ncore + p.wpw - 1) / p.wpw;
-        if (p.staged) {
+        CoLists ls{};
+        if (p.co) {
+            ls.queue = reinterpret_cast<uint2 *>(base + p.o_coq);
+            ls.plain = reinterpret_cast<uint2 *>(base + p.o_cop);
+            ls.counts = reinterpret_cast<uint32_t *>(base + 56);    // (behind the carry record and the pool counter)
+            ls.qcap = p.co_qcap;
+            ls.pcap = p.co_pcap;
+            ls.over_plain = p.co_over;
+            (void)hipMemsetAsync(ls.counts, 0, 8, st);
+            const uint32_t ng = (g.ncore + p.co_wpg - 1) / p.co_wpg;
+            const uint32_t per_cu = (uint32_t)(160 * 1024 / p.co_lds) ? (uint32_t)(160 * 1024 / p.co_lds) : 1u;
+            const uint32_t grid = ng < 256u * per_cu ? ng : 256u * per_cu;
+            hipLaunchKernelGGL(k_hyp_walk_co, dim3(grid), dim3(256), p.co_lds, st, c, s, g, t, p.co_wpg, p.co_margin, ng,
+                               p.co_shift, p.co_tmax, p.co_cap, ls);
+            hipLaunchKernelGGL(k_hyp_walk_rest, dim3((p.co_qcap + 63) / 64 < 16384u ? (p.co_qcap + 63) / 64 : 16384u), dim3(64), 0,
+                               st, c, s, g, t, ls);
+            hipLaunchKernelGGL(k_hyp_defer, dim3(g.ncore), dim3(256), 0, st, c, g, t, ls);
+        } else if (p.staged) {
             const uint32_t grid = ngroups < 256u ? ngroups : 256u;                           // (one workgroup per CU)
             hipLaunchKernelGGL((k_hyp_walk<true>), dim3(grid), dim3(1024), p.lds, st, c, s, g, t, p.wpw, p.margin, ngroups);
         } else {
             hipLaunchKernelGGL(k_hyp_walk_mem, dim3(ngroups), dim3(64), 0, st, c, s, g, t, p.wpw);
         }
         hipLaunchKernelGGL(k_hyp_land, dim3(g.ncore), dim3(256), 0, st, c, g, t);
+        if (p.co)
+            hipLaunchKernelGGL(k_hyp_walk_list, dim3((p.co_pcap + 63) / 64 < 16384u ? (p.co_pcap + 63) / 64 : 16384u), dim3(64), 0,
+                               st, c, s, g, t, ls);
 
         const uint32_t nwin = g.ncore, nchunks = (nwin + p.wpc - 1) / p.wpc;
         TwTables sp;
@@ -2051,9 +2455,13 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
         IdxCarry h{};
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(&h, carry, sizeof(h), hipMemcpyDeviceToHost);
+        uint32_t co_counts[2] = {0, 0};
+        if (p.co) (void)hipMemcpy(co_counts, base + 56, 8, hipMemcpyDeviceToHost);
         fprintf(stderr, "trunk index: L %u lead %u rw %u kmax %u wpw %u nwin/span %u ncap %u | RSIs %llu, walked serially %u, "
-                "table lookups %u\n", p.L, p.lead, p.rw, p.kmax, p.wpw, p.nwin_max, p.ncap, (unsigned long long)h.r,
-                h.n_serial, h.n_lookups);
+                "table lookups %u | coalescing %u (groups of %u windows + %u bits, %u-bit cells, %u parses): last span handed on "
+                "%u walks, left %u nodes to the plain walk\n", p.L, p.lead, p.rw, p.kmax, p.wpw, p.nwin_max, p.ncap,
+                (unsigned long long)h.r, h.n_serial, h.n_lookups, p.co, p.co_wpg, p.co_margin, 1u << p.co_shift, p.co_tmax,
+                co_counts[0], co_counts[1]);
     }
 #endif
 }

