@@ -65,9 +65,11 @@ struct TwTables {
     const uint16_t *cpos;      // [nbase[window] + index]: position inside the window
     uint64_t lo, hi;           // bit range whose nodes have records
     uint32_t core;             // bits per window (multiple of 32)
-    // wide walker: per chunk of wpc windows, what every node of the chunk's first window leads to
+    // wide walker: per chunk of wpc windows, what every node of the chunk's first wfirst windows leads to (index =
+    // the node's number among those: record index - nbase[first window of the chunk])
     const uint4 *wide;         // [chunk * wcap + index]: {exit lo, exit hi, RSIs, 1 = resolved}
-    uint32_t wpc, wcap;
+    uint32_t wpc, wcap, wfirst;
+    uint32_t nrec;             // records there is room for (indices beyond it are never read)
 };
 
 // record of the node at absolute bit p (false: p is not a node)
@@ -129,6 +131,7 @@ struct IdxCarry {          // walker state between the spans of one stream
     uint32_t n_serial, n_lookups;     // statistics: RSIs walked coded data set by coded data set, table hops taken
     uint64_t r_prev;                  // RSIs in front of the span the walker took last (k_seg_starts: its RSIs are
                                       // [r_prev, r) while the walk goes on, [r_prev, what the result record says) else)
+    uint32_t dbg_serial[2];           // statistics: the first two RSIs walked serially (numbers, + 1)
 };
 static_assert(sizeof(IdxCarry) <= 48, "the carry record shares 64 bytes with the pool counter at offset 48");
 
@@ -660,7 +663,7 @@ k_hyp_walk_co(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, u
                 uint32_t r = tr_co_step(s, c, st, cells, h, m, base, lim, shift, tmax, hit);
                 if (r != CO_RUN) {
                     uint32_t tt = 0;
-                    if (r == CO_LAND || r == CO_QUEUE) {
+                    if (r == CO_LAND || r == CO_QUEUE || r == CO_OVER) {
                         if (h.pos - h.c > 0xFFFFFFFFull) r = CO_PLAIN;
                         tt = (uint32_t)(h.pos - h.c);
                     } else if (r == CO_LINK) {
@@ -686,7 +689,7 @@ k_hyp_walk_co(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, u
                 while (q >= wnp[v + 1u]) v++;
                 return base + (uint64_t)v * g.L + t.cpos[(uint64_t)wnb[v] + (q - wnp[v])];
             };
-            if (m < nown) kind = tr_co_resolve(c, [&](uint32_t q) { return recs[q]; }, node_pos, m, z, root, b, ls.over_plain != 0u);
+            if (m < nown) kind = tr_co_resolve(c, [&](uint32_t q) { return recs[q]; }, node_pos, m, z, root, b);
             TrRec out{0u, 0u};
             uint32_t park = 0;
             const uint64_t mine = base + (uint64_t)wi * g.L + t.cpos[at];
@@ -697,6 +700,11 @@ k_hyp_walk_co(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, u
                 out.x = recs[m].t;
                 park = recs[m].k;
                 co_push(ls.queue, ls.counts, ls.qcap, make_uint2((uint32_t)at, w0 + wi));
+            } else if (kind == CO_GOON && z > mine && z - mine <= 0xFFFFFFFFull) {
+                out.x = (uint32_t)(z - mine);                  // (handed on like a root, from where the other walk ran over)
+                park = co_pack(CO_QUEUE, b, kCoNoRos);
+                co_push(ls.queue, ls.counts, ls.qcap, make_uint2((uint32_t)at, w0 + wi));
+                kind = CO_QUEUE;
             } else if (kind == CO_DEFER) {
                 // the walk it waits for: its record, the count that one was handed on with, and where its node lies
                 // from here (the distance its landing will be given by is from ITS node)
@@ -761,7 +769,7 @@ k_hyp_defer(const Cfg c, const TrGeom g, const TrTables t, const CoLists ls)
         const TrRec r = t.rec[at];
         const uint32_t root_pk = t.park[r.x];
         uint32_t kind;
-        const uint32_t b = co_defer(c, co_bend(pk), r.y & 0x1FFFu, root_pk, kind, ls.over_plain != 0u);
+        const uint32_t b = co_defer(c, co_bend(pk), r.y & 0x1FFFu, root_pk, kind);
         const int64_t dist = (int64_t)(r.y >> 13) - 0x40000 + (int64_t)t.rec[r.x].x;
         if (b && dist > 0 && dist <= 0xFFFFFFFFll) {
             t.rec[at] = TrRec{(uint32_t)dist, 0u};
@@ -807,17 +815,29 @@ k_hyp_land(const Cfg c, const TrGeom g, const TrTables t)
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) tr_hyp_land(c, g, t, w, i);
 }
 
-// ---- wide walker: every node of a chunk's first window chases the records through the chunk
+// ---- wide walker: every node of a chunk's first windows chases the records through the chunk.  "First windows":
+// as many as hold an RSI, so that the true chain -- whose RSI starts lie an RSI apart -- has a start among them in
+// every chunk, and the walk needs a few lookups per CHUNK, not one per RSI (RSIs of a megabit: one dependent read
+// each, 3.4 us, 24 ms for the 7000 RSIs of a 7-Gbit span before).
 __global__ void __launch_bounds__(256)
 k_twide(const TwTables t, uint32_t nwin, uint64_t end_bit, uint4 *__restrict__ wide)
 {
     const uint32_t chunk = blockIdx.y;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t first = chunk * t.wpc;
-    if (first >= nwin || i >= t.ccnt[first] || i >= t.wcap) return;
+    if (first >= nwin || i >= t.wcap) return;
+    const uint32_t lastf = first + t.wfirst < nwin ? first + t.wfirst : nwin;
+    const uint32_t at = t.nbase[first] + i;
+    if (at >= t.nbase[lastf]) return;
+    uint32_t w = first, hi = lastf;                     // the node's window: nbase[w] <= at < nbase[w + 1]
+    while (hi - w > 1u) {
+        const uint32_t mid = w + (hi - w) / 2u;
+        if (t.nbase[mid] <= at) w = mid;
+        else hi = mid;
+    }
     const uint32_t last = first + t.wpc < nwin ? first + t.wpc : nwin;      // one past the chunk's windows
     const uint64_t stop = t.lo + (uint64_t)last * t.core;
-    uint64_t pos = t.lo + (uint64_t)first * t.core + t.cpos[t.nbase[first] + i];
+    uint64_t pos = t.lo + (uint64_t)w * t.core + t.cpos[at];
     uint32_t cnt = 0, ok = 1;
     while (pos < stop && pos < end_bit) {
         TrRec rec;
@@ -1686,27 +1706,48 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             // At a chunk's first window ONE lookup in the wide walker's table takes the walk across the whole
             // chunk (k_trewalk fills in what lies inside); else record by record.  No record = not resolved by
             // the tables: that RSI is walked CDS by CDS below.
+            // (a record of one RSI names the node it ends on: the next record is then ONE read, not a search for the node
+            // at a position -- with RSIs of a megabit the walk is a chain of such reads, 2.4 us each before, 1 us now)
+            // (Still one dependent read per RSI, 3.4 us on a table of hundreds of megabytes: the wide table above is
+            // what keeps their number down.  Fetching the records around where the next ones should lie ahead of time
+            // -- the stride between them is an RSI's blocks give or take a few hundred nodes -- was built and changed
+            // nothing.)
+            uint32_t next_at = 0;
             while (sp.bitmap && r < max_rsi && good >= sp.lo && good < sp.hi && good < end_bit) {
                 TrRec rec;
                 uint32_t wv, ix;
-                if (!tw_lookup(sp, good, rec, wv, ix)) break;
+                if (next_at) {
+                    rec = sp.rec[next_at - 1u];
+                    wv = (uint32_t)((good - sp.lo) / sp.core);
+                    ix = next_at - 1u;
+                } else if (!tw_lookup(sp, good, rec, wv, ix)) {
+                    break;
+                } else {
+                    ix += sp.nbase[wv];
+                }
+                // (ix: the node's record index; inside the wide table its number among the nodes of the chunk's first windows)
+                const bool at_front = sp.wide && (wv % sp.wpc) < sp.wfirst;
+                if (at_front) ix -= sp.nbase[wv - wv % sp.wpc];
                 n_lookups++;
-                if (sp.wide && (wv % sp.wpc) == 0u && ix < sp.wcap) {
+                if (at_front && ix < sp.wcap) {
                     const uint4 wd = sp.wide[(uint64_t)(wv / sp.wpc) * sp.wcap + ix];
                     if (wd.w && r + wd.z <= max_rsi) {
                         if (lane == 0) centry[wv / sp.wpc] = ChunkEntry{good, r, 1u, 0u};
                         good = (uint64_t)wd.x | ((uint64_t)wd.y << 32);
                         r += wd.z;
                         hopped = true;
+                        next_at = 0;
                         continue;
                     }
                 }
                 const uint32_t k1 = tr_rec_k(rec.x), b1 = tr_rec_bits(rec.x);
                 if (k1 == 1u) {
                     if (lane == 0) rsi_off[r] = tr_rsi_start(c, good);
+                    next_at = rec.y;
                 } else if (k1 > 1u && r + k1 <= max_rsi && nh < hop_cap) {
                     if (lane == 0) hops[nh] = IdxHop{good, r, k1, 0u};      // (k_texpand writes the starts inside)
                     nh++;
+                    next_at = 0;
                 } else {
                     break;
                 }
@@ -1732,6 +1773,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             }
             if (lane == 0) rsi_off[r] = good;
             cur_start = good;
+            if (lane == 0 && carry && n_serial < 8u) reinterpret_cast<uint32_t *>(carry)[16 + n_serial] = (uint32_t)r + 1u;
             n_serial++;
         }
         // keep the whole next CDS (and the readers' look-ahead) inside the LDS window
@@ -2118,7 +2160,7 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
 // ---- geometry and workspace of the trunk index -------------------------------------------------------
 struct TrunkPlan {
     bool ok;
-    uint32_t L, lead, rw, passes, budget, kmax, wpw, wpc, wcap;
+    uint32_t L, lead, rw, passes, budget, kmax, wpw, wpc, wcap, wfirst;
     uint32_t staged, margin;  // hypothesis walks: byte table of coded data set lengths or not, margin behind a group (bits)
     size_t lds;               // ... and the LDS of a workgroup
     // coalescing hypothesis walks (aec_trunk.h section 2b): windows per group, margin, bits per mark cell (log2),
@@ -2134,10 +2176,10 @@ struct TrunkPlan {
         o_ros, o_rec, o_park, o_pool, o_wide, o_centry, o_hops, bytes;
 };
 
-// workspace asked for at most (larger inputs take several spans): 768 MiB, for large streams up to 2.5 times the
-// stream and 3 GiB -- several kernels of a span take as long as the longest serial chain they hold (a trunk region,
+// workspace asked for at most (larger inputs take several spans): 768 MiB, for large streams up to six times the
+// stream and 4 GiB -- several kernels of a span take as long as the longest serial chain they hold (a trunk region,
 // a walk that was handed on, the walker's hops), whatever the span's size, so fewer and larger spans are cheaper
-constexpr size_t kTrWsWanted = 768u << 20, kTrWsMost = (size_t)3 << 30;
+constexpr size_t kTrWsWanted = 768u << 20, kTrWsMost = (size_t)4 << 30;
 
 
 size_t trunk_bytes(TrunkPlan &p, uint32_t nwin)
@@ -2145,7 +2187,7 @@ size_t trunk_bytes(TrunkPlan &p, uint32_t nwin)
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t words = (size_t)nwin * (p.L / 32);
     const uint32_t nchunk = (nwin + p.wpc - 1) / p.wpc;
-    size_t o = 64;
+    size_t o = 128;                     // (a header: carry record, pool counter, list counters, statistics)
     p.o_bitmap = o; o = up(o + words * 4);
     p.o_pre = o;    o = up(o + words * 2);
     p.o_nbase = o;  o = up(o + ((size_t)nwin + 1) * 4);
@@ -2216,7 +2258,16 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
     }
     const uint64_t budget = (uint64_t)p.kmax * c.rsi;
     p.budget = tune("AEC_TR_BUDGET", (uint32_t)(budget < 65536 ? budget : 65536));
-    p.wpc = tune("AEC_TR_WPC", 64);
+    // wide walker: the first windows of a chunk, whose nodes get a wide entry, hold two average RSIs; a chunk is
+    // eight times that (64 windows at least)
+    {
+        const uint64_t rb = rsi_bits_hint ? rsi_bits_hint : (uint64_t)c.rsi * cds;
+        uint64_t wf = (2 * rb + p.L - 1) / p.L + 1;
+        if (wf > 512) wf = 512;
+        p.wfirst = tune("AEC_TR_WFIRST", (uint32_t)wf);
+        p.wpc = tune("AEC_TR_WPC", p.wfirst * 8u > 64u ? p.wfirst * 8u : 64u);
+        if (p.wfirst > p.wpc) p.wfirst = p.wpc;
+    }
     // The hypothesis walks run on staged stretches of the stream: group + margin.  Short coded data sets get the
     // byte table (1.25 bytes of LDS per bit, stretch 96 kbit); the others stage words and marks only (0.25 bytes
     // per bit, stretch up to 480 kbit).  The margin holds an average walk -- some 150 coded data sets where the
@@ -2264,7 +2315,14 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
         p.co_lds = ((bits / 32 + 8) + bits / 32 + ((bits >> p.co_shift) + 2) + 2 * ((size_t)p.co_wpg + 1)) * 4 + (size_t)p.co_cap * 8 + 64;
         if (bits + 0x1000 >= 0x40000 || p.co_lds > 160 * 1024) p.co = 0;     // (k_hyp_walk_co packs distances inside a group into 19 bits)
     }
-    p.wcap = p.L / 8 < 4096 ? p.L / 8 : 4096;
+    {
+        // (nodes of a chunk's first windows: room for one per 0.4 average coded data sets, as for the node records)
+        uint64_t pn = cds * 2 / 5;
+        if (pn < 8) pn = 8;
+        if (pn > 64) pn = 64;
+        const uint64_t wc = (uint64_t)p.wfirst * p.L / pn;
+        p.wcap = (uint32_t)(wc < (1u << 20) ? wc : (1u << 20));
+    }
     uint64_t look = 4 * (rsi_bits_hint ? rsi_bits_hint : (uint64_t)c.rsi * cds) + 8 * sync + 4 * p.L;
     if (look > (1ull << 27)) look = 1ull << 27;
     p.nlook = (uint32_t)((look + p.L - 1) / p.L);
@@ -2280,7 +2338,7 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
         return trunk_bytes(p, (uint32_t)nwin);
     };
     uint64_t nwin = nwin_all;
-    size_t wanted = (size_t)(total_bits / 8u) * 5u / 2u;
+    size_t wanted = (size_t)(total_bits / 8u) * 6u;
     if (wanted < kTrWsWanted) wanted = kTrWsWanted;
     if (wanted > kTrWsMost) wanted = kTrWsMost;
     const size_t limit = ws_bytes ? ws_bytes : wanted;
@@ -2365,7 +2423,10 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
         const uint32_t nreg = (g.nwin + g.rw - 1) / g.rw;
         t.exit = ex[0];
         // (a wavefront per region where a coded data set fits the wavefront's register window, aec_coop.h; else a lane)
-        const bool coop = tune("AEC_TR_COOP", 1u) && c.id_len + 1u + c.bps + c.bs * c.bps + 128u <= 2048u;
+        // (... and where the regions are few: a wavefront's parse is mostly scalar work, and the one scalar unit of a CU
+        // serves all its wavefronts -- measured on spans of 5167 regions: 4.5 ms against 6.1 for the lanes, whose time
+        // is the latency of ONE region whatever their number)
+        const bool coop = tune("AEC_TR_COOP", nreg <= 6144u ? 1u : 0u) && c.id_len + 1u + c.bps + c.bs * c.bps + 128u <= 2048u;
         const uint32_t cgrid = nreg < 256u * 20u ? nreg : 256u * 20u;
         if (coop)
             hipLaunchKernelGGL(k_trunk_coop, dim3(cgrid), dim3(64), 0, st, c, s, g, t, (const uint64_t *)nullptr, ex[0], 0u);
@@ -2429,6 +2490,8 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
         sp.wide = reinterpret_cast<const uint4 *>(base + p.o_wide);
         sp.wpc = p.wpc;
         sp.wcap = p.wcap;
+        sp.wfirst = p.wfirst;
+        sp.nrec = p.ncap;
         ChunkEntry *centry = reinterpret_cast<ChunkEntry *>(base + p.o_centry);
         IdxHop *hops = reinterpret_cast<IdxHop *>(base + p.o_hops);
         const uint32_t hop_cap = 2 * nwin + 8;
@@ -2462,6 +2525,36 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
                 "%u walks, left %u nodes to the plain walk\n", p.L, p.lead, p.rw, p.kmax, p.wpw, p.nwin_max, p.ncap,
                 (unsigned long long)h.r, h.n_serial, h.n_lookups, p.co, p.co_wpg, p.co_margin, 1u << p.co_shift, p.co_tmax,
                 co_counts[0], co_counts[1]);
+        uint32_t seams = 0;
+        (void)hipMemcpy(&seams, base + p.o_seam + (size_t)((end_bit - lo0) / p.L + 1 < p.nwin_max ? (end_bit - lo0) / p.L + 1 : p.nwin_max) * 4, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "  seams of the last span (seampre behind its last window): %u\n", seams);
+        uint32_t ser[8] = {};
+        (void)hipMemcpy(ser, base + 64, 32, hipMemcpyDeviceToHost);
+        fprintf(stderr, "  RSIs walked serially (number + 1): %u %u %u %u %u %u %u %u\n", ser[0], ser[1], ser[2], ser[3], ser[4], ser[5], ser[6], ser[7]);
+        // (the tables of the LAST span are still there: what do they hold for those RSI starts?)
+        for (int q = 0; q < 8; q++) {
+            if (!ser[q]) continue;
+            uint64_t off = 0;
+            (void)hipMemcpy(&off, d_rsi_off + (ser[q] - 1u), 8, hipMemcpyDeviceToHost);
+            const uint64_t span_lo = lo0 + ((end_bit - lo0) / ((uint64_t)ncore_span * p.L)) * (uint64_t)ncore_span * p.L;
+            if (off < span_lo) { fprintf(stderr, "    RSI %u at bit %llu: not in the last span (from %llu)\n", ser[q] - 1u, (unsigned long long)off, (unsigned long long)span_lo); continue; }
+            const uint64_t i = off - span_lo;
+            uint32_t word = 0, nb = 0, cc = 0; uint16_t pre = 0;
+            (void)hipMemcpy(&word, base + p.o_bitmap + (i >> 5) * 4, 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&pre, base + p.o_pre + (i >> 5) * 2, 2, hipMemcpyDeviceToHost);
+            const uint32_t w = (uint32_t)(i / p.L), sh = (uint32_t)(i & 31u);
+            (void)hipMemcpy(&nb, base + p.o_nbase + (size_t)w * 4, 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&cc, base + p.o_ccnt + (size_t)w * 4, 4, hipMemcpyDeviceToHost);
+            const bool node = (word >> (31u - sh)) & 1u;
+            const uint32_t idx = pre + (sh ? __builtin_popcount(word >> (32u - sh)) : 0);
+            uint32_t rec[2] = {0, 0}, park = 0;
+            if (node) {
+                (void)hipMemcpy(rec, base + p.o_rec + (size_t)(nb + idx) * 8, 8, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&park, base + p.o_park + (size_t)(nb + idx) * 4, 4, hipMemcpyDeviceToHost);
+            }
+            fprintf(stderr, "    RSI %u at bit %llu: window %u (nodes %u) node %d index %u rec x %08x y %08x park %08x\n", ser[q] - 1u,
+                    (unsigned long long)off, w, cc, (int)node, idx, rec[0], rec[1], park);
+        }
     }
 #endif
 }

@@ -77,7 +77,8 @@ struct TrGeom {
 // Record of a node, the layout the walkers read.
 //   x: bits [0,26) = distance to the node the record ends on, [26,32) = RSIs covered; 0 = none
 //   y: records of several RSIs: index + 1 of the pool entry that holds the end of the LAST BUT ONE of them
-//      (each entry links to the one before: the walkers need the starts inside such a record); 0 = none
+//      (each entry links to the one before: the walkers need the starts inside such a record); 0 = none.
+//      Records of ONE RSI: record index + 1 of the node the record ends on (the walker's next record), 0 = unknown
 // Between the walk and the jump a hypothesis is parked: x = distance to the node the walk stands on, and
 // park[node] = kTrParked | RSIs completed << 16 | blocks of the current RSI in front of that node.
 struct TrRec {
@@ -640,6 +641,9 @@ AEC_HD void tr_hyp_finish(const TrGeom &g, const TrTables &t, uint32_t w, uint32
 constexpr uint32_t kCoTag = 0x40000000u;      // park word of a node: a coalescing record, not a parked hypothesis
 constexpr uint32_t kCoNoRos = 0x1FFFu;
 enum : uint32_t { CO_RUN = 0, CO_LAND = 1, CO_LINK = 2, CO_QUEUE = 3, CO_FAIL = 4, CO_PLAIN = 5, CO_DEFER = 6, CO_OVER = 7 };
+// (tr_co_resolve only, never in a record: a guest of a walk that ran over, with room left in its own RSI, goes on
+// from where that walk stopped -- handed on like a root)
+constexpr uint32_t CO_GOON = 8;
 
 AEC_HD uint32_t co_pack(uint32_t kind, uint32_t b_end, uint32_t b_ros)
 {
@@ -735,11 +739,11 @@ AEC_HD uint32_t co_ride(const Cfg &c, uint32_t b, uint32_t bm, uint32_t owner_k)
 // Follows the links of walk n inside the workgroup.  CO_LAND: z = where it lands (absolute), b = its count there;
 // CO_DEFER: root = the walk (local number) it ends up waiting for, b = its count where that one was handed on;
 // CO_QUEUE: n itself is handed on; else CO_PLAIN.
-// strict: a guest of a walk that ran over, with a lower count than the owner's, is CO_PLAIN (it may still land);
-// else it is CO_OVER as well (the caller leaves walks that run over alone: aec_idx.hip trunk_plan).
+// CO_GOON: the way n took ends where another walk ran over the end of ITS RSI; n has b blocks there (fewer) and
+// goes on from z by itself.
 template <class Recs, class NodePos>
 AEC_HD uint32_t tr_co_resolve(const Cfg &c, Recs recs, NodePos node_pos, uint32_t n, uint64_t &z, uint32_t &root,
-                              uint32_t &b, bool strict = true)
+                              uint32_t &b)
 {
     CoRec r = recs(n);
     uint32_t kind = co_kind(r.k), cur = n;
@@ -754,12 +758,14 @@ AEC_HD uint32_t tr_co_resolve(const Cfg &c, Recs recs, NodePos node_pos, uint32_
             return cur == n ? CO_QUEUE : CO_DEFER;
         }
         if (kind == CO_FAIL) return CO_FAIL;
-        // (an owner that ran over: a guest with at least its count runs over no later; one with less may still land)
-        if (kind == CO_OVER) return (!strict || cur == n || b >= co_bend(r.k)) ? CO_OVER : CO_PLAIN;
+        if (kind == CO_OVER) {
+            if (cur == n) return CO_OVER;
+            z = node_pos(cur) + r.t;                        // (a guest with room left: on from where the owner stopped)
+            return CO_GOON;
+        }
         if (kind != CO_LINK) return CO_PLAIN;
         const uint32_t q = co_mark_owner(r.t), bm = co_mark_b(r.t);
         const CoRec o = recs(q);
-        if (co_kind(o.k) == CO_OVER) return (!strict || b >= bm) ? CO_OVER : CO_PLAIN;
         b = co_ride(c, b, bm, o.k);
         if (!b) return CO_OVER;
         // (a way that ends in a coded data set that does not parse fails whoever reaches that point inside its RSI)
@@ -801,11 +807,12 @@ AEC_HD uint32_t tr_co_rest(const TrStream &s, const Cfg &c, const TrGeom &g, con
 
 // A guest that waited for a handed-on walk: its count was b where that walk was handed on with count bh; the
 // walk's final record is root_k.  Its count where the walk landed (0 = not to be had).
-// kind: CO_LAND (with the count), or how it ends instead (CO_FAIL / CO_OVER / CO_PLAIN, as tr_co_resolve)
-AEC_HD uint32_t co_defer(const Cfg &c, uint32_t b, uint32_t bh, uint32_t root_k, uint32_t &kind, bool strict = true)
+// kind: CO_LAND (with the count), or how it ends instead (CO_FAIL / CO_OVER / CO_PLAIN, as tr_co_resolve; a guest
+// with a lower count than a root that ran over is CO_PLAIN: it may still land)
+AEC_HD uint32_t co_defer(const Cfg &c, uint32_t b, uint32_t bh, uint32_t root_k, uint32_t &kind)
 {
     const uint32_t rk = co_kind(root_k);
-    kind = rk == CO_OVER ? ((!strict || b >= bh) ? CO_OVER : CO_PLAIN) : CO_PLAIN;
+    kind = rk == CO_OVER ? (b >= bh ? CO_OVER : CO_PLAIN) : CO_PLAIN;
     if (rk != CO_LAND && rk != CO_FAIL) return 0u;
     const uint32_t out = co_ride(c, b, bh, root_k);
     kind = !out ? CO_OVER : (rk == CO_FAIL ? CO_FAIL : CO_LAND);
@@ -898,11 +905,16 @@ AEC_HD uint64_t tr_G(const TrGeom &g, const TrTables &t, uint32_t w, uint32_t i)
 // (target = c.rsi: where the RSI ends; or a multiple of 64: where a segment starts -- a rest-of-segment run ends on
 // one of those, so it never jumps over the target).
 // kTrNone = unresolved (seam, end of the tables, zero run across the target, dead node on the way).
-AEC_HD uint64_t tr_jump_to(const Cfg &c, const TrGeom &g, const TrTables &t, uint64_t pos, uint32_t b, uint32_t target)
+// end_at (optional): the node's record index (nbase + index inside its window).
+AEC_HD uint64_t tr_jump_to(const Cfg &c, const TrGeom &g, const TrTables &t, uint64_t pos, uint32_t b, uint32_t target,
+                           uint32_t *end_at = nullptr)
 {
     uint32_t w, i;
     if (b > target || !tr_node_at(g, t, pos, w, i)) return kTrNone;
-    if (b == target) return pos;
+    if (b == target) {
+        if (end_at) *end_at = t.nbase[w] + i;
+        return pos;
+    }
     const uint32_t seam0 = t.seampre[w];
     for (uint32_t guard = 0; guard <= c.rsi / 32u + 2u; guard++) {
         const uint32_t n = target - b;
@@ -919,6 +931,7 @@ AEC_HD uint64_t tr_jump_to(const Cfg &c, const TrGeom &g, const TrTables &t, uin
             if (tw >= g.nwin || t.seampre[tw] != seam0) return kTrNone;
             uint32_t ti;
             if (!tr_node_of(g, t, tw, (uint32_t)(G + n - t.gbase[tw]), ti)) return kTrNone;
+            if (end_at) *end_at = t.nbase[tw] + ti;
             return g.lo + (uint64_t)tw * g.L + t.cpos[t.nbase[tw] + ti];
         }
         if (t.seampre[rw] != seam0) return kTrNone;
@@ -933,7 +946,10 @@ AEC_HD uint64_t tr_jump_to(const Cfg &c, const TrGeom &g, const TrTables &t, uin
         if (!tr_node_of(g, t, tw, (uint32_t)(Gn - t.gbase[tw]), ti)) return kTrNone;
         w = tw;
         i = ti;
-        if (b == target) return g.lo + (uint64_t)w * g.L + t.cpos[t.nbase[w] + i];
+        if (b == target) {
+            if (end_at) *end_at = t.nbase[w] + i;
+            return g.lo + (uint64_t)w * g.L + t.cpos[t.nbase[w] + i];
+        }
         if (b > target) return kTrNone;
     }
     return kTrNone;
@@ -997,9 +1013,12 @@ AEC_HD void tr_hyp_land(const Cfg &c, const TrGeom &g, const TrTables &t, uint32
     const uint64_t c0 = g.lo + (uint64_t)w * g.L + t.cpos[at];
     const bool co = !(pk & kTrParked);
     const uint32_t k = co ? 0u : (pk >> 16) & 0x3Fu, b = co ? co_bend(pk) : pk & 0xFFFFu;
-    const uint64_t e = tr_jump(c, g, t, c0 + r.x, b);
+    uint32_t end_at = 0;
+    const uint64_t e = tr_jump_to(c, g, t, c0 + r.x, b, c.rsi, &end_at);
     const uint32_t x = e == kTrNone ? 0u : tr_rec_pack(e - c0, k + 1u);
-    t.rec[at] = TrRec{x, (x && !co) ? r.y : 0u};
+    // y: records of several RSIs -- the list of the RSI ends inside; a record of ONE RSI has no list, and says
+    // instead which node it ends on (record index + 1), so that the walker's next lookup is a single read
+    t.rec[at] = TrRec{x, !x ? 0u : (k == 0u ? end_at + 1u : r.y)};
 }
 
 // The RSI ends inside the record of a node (k RSIs, list head y): out(j, end) for the RSIs j = k - 2 .. 0,

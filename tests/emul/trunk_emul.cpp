@@ -391,8 +391,10 @@ extern "C" int emul_segments(const uint32_t *params, const uint8_t *enc, size_t 
 // walks, 8 parses the plain walks take for the same nodes, 9 nodes whose plain walk does not land (k > 0, failed)
 extern "C" int emul_coalesce(const uint32_t *params, const uint8_t *enc, size_t enc_len, uint32_t L, uint32_t lead,
                              uint32_t rw, uint32_t passes, uint32_t wpg, uint32_t margin, uint32_t shift, uint32_t tmax,
-                             uint64_t *stats)
+                             uint64_t *stats, const uint64_t *offs = nullptr, uint64_t n_offs = 0)
 {
+    // (offs, optional: the true RSI starts -- every one of them that is a node and whose plain walk lands must get its
+    // landing from the coalescing walks as well; those that do not are reported)
     Cfg c;
     if (make_cfg(params[0], params[1], params[2], params[3], 0, false, &c) != RC_OK) return -1;
     std::vector<uint32_t> words((enc_len + 3) / 4 + 1, 0);
@@ -473,7 +475,7 @@ extern "C" int emul_coalesce(const uint32_t *params, const uint8_t *enc, size_t 
             while ((r = tr_co_step(s, c, st, cells, h, m, base, lim, shift, tmax, hit)) == CO_RUN) {}
             stats[6] += h.steps;
             uint32_t tt = 0;
-            if (r == CO_LAND || r == CO_QUEUE) {
+            if (r == CO_LAND || r == CO_QUEUE || r == CO_OVER) {
                 if (h.pos - h.c > 0xFFFFFFFFull) r = CO_PLAIN;
                 tt = (uint32_t)(h.pos - h.c);
             } else if (r == CO_LINK) {
@@ -494,7 +496,13 @@ extern "C" int emul_coalesce(const uint32_t *params, const uint8_t *enc, size_t 
             fin_b[m] = b;
         }
         for (uint32_t m = 0; m < n; m++)
-            if (fin_kind[m] == CO_QUEUE) {
+            if (fin_kind[m] == CO_GOON) {                  // (on from where another walk ran over, as a root of its own)
+                uint32_t dist = 0, parses = 0;
+                root_k[m] = tr_co_rest(s, c, g, mem, npos[m], fin_z[m], fin_b[m], kCoNoRos, dist, &parses);
+                root_dist[m] = dist;
+                stats[7] += parses;
+                fin_kind[m] = CO_QUEUE;
+            } else if (fin_kind[m] == CO_QUEUE) {
                 uint32_t dist = 0;
                 // (count the parses of the rest walk: by the plain parser's counter -- not available; by re-walking)
                 uint32_t parses = 0;
@@ -537,6 +545,12 @@ extern "C" int emul_coalesce(const uint32_t *params, const uint8_t *enc, size_t 
                     b = bb;
                     stats[3]++;
                 }
+            }
+            if (!have && plain_lands && offs) {
+                for (uint64_t q = 0; q < n_offs; q++)
+                    if (offs[q] == npos[m])
+                        fprintf(stderr, "true RSI start %llu (node %llu, group %u local %u): no landing from the coalescing walks: kind %u own %u b %u root %u\n",
+                                (unsigned long long)q, (unsigned long long)npos[m], w0, m, fin_kind[m], co_kind(recs[m].k), fin_b[m], fin_root[m]);
             }
             if (!have) {
                 stats[4]++;
