@@ -391,7 +391,7 @@ extern "C" int emul_segments(const uint32_t *params, const uint8_t *enc, size_t 
 // walks, 8 parses the plain walks take for the same nodes, 9 nodes whose plain walk does not land (k > 0, failed)
 extern "C" int emul_coalesce(const uint32_t *params, const uint8_t *enc, size_t enc_len, uint32_t L, uint32_t lead,
                              uint32_t rw, uint32_t passes, uint32_t wpg, uint32_t margin, uint32_t shift, uint32_t tmax,
-                             uint64_t *stats, const uint64_t *offs = nullptr, uint64_t n_offs = 0)
+                             uint64_t *stats, const uint64_t *offs, uint64_t n_offs)
 {
     // (offs, optional: the true RSI starts -- every one of them that is a node and whose plain walk lands must get its
     // landing from the coalescing walks as well; those that do not are reported)

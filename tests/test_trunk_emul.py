@@ -175,7 +175,7 @@ def _coalesce(emul, enc, bps, bs, rsi, flags, L, lead, rw, wpg, margin, shift, t
     stats = np.zeros(10, dtype=np.uint64)
     rc = emul.emul_coalesce(p, C.c_void_p(enc_a.ctypes.data), C.c_size_t(enc_a.size), C.c_uint32(L), C.c_uint32(lead),
                             C.c_uint32(rw), C.c_uint32(3), C.c_uint32(wpg), C.c_uint32(margin), C.c_uint32(shift),
-                            C.c_uint32(tmax), C.c_void_p(stats.ctypes.data))
+                            C.c_uint32(tmax), C.c_void_p(stats.ctypes.data), C.c_void_p(None), C.c_uint64(0))
     names = "nodes landed roots waited plain mismatches co_parses rest_parses plain_parses plain_not_landing".split()
     d = dict(zip(names, (int(x) for x in stats)))
     assert rc == 0 and d["mismatches"] == 0, (rc, d)
