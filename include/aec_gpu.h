@@ -168,6 +168,15 @@ AEC_GPU_API int aec_gpu_decode_segments_async(aec_gpu_ctx *ctx, const aec_gpu_pa
  * The call may allocate table workspace (up to 768 MiB; larger inputs are indexed span by span).
  */
 AEC_GPU_API void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits);
+/* 1 when the index pass of a stream of in_bytes whose coded RSIs average rsi_bits runs over the window tables
+ * (low-entropy streams, RSIs inside a 64-kbit window): cheap per call also for pieces of a few MiB, so a caller
+ * may decode such a stream piece by piece and overlap one piece's transfers with the next one's kernels. */
+AEC_GPU_API int aec_gpu_index_is_windowed(const aec_gpu_params *p, size_t in_bytes, uint64_t rsi_bits);
+/* The NEXT index pass on ctx (one pass only) is handed a piece of a stream of which the caller holds more: an RSI
+ * that the window tables leave unresolved within stop_near_bits of the end of the piece -- they end there for lack
+ * of look-ahead -- is not walked serially; the pass ends in front of it (n_rsi RSIs, tail_blocks 0, end_bit = its
+ * start) and the caller's next piece starts there. */
+AEC_GPU_API void aec_gpu_set_index_piece(aec_gpu_ctx *ctx, uint64_t stop_near_bits);
 
 /* Release the context's workspaces that are larger than keep_bytes (they are re-allocated on
  * demand); for callers that keep a context around between jobs of very different size. */

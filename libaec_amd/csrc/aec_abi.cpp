@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -88,6 +89,8 @@ constexpr size_t kDecDirectMin = 4096;               // input of at least this s
 constexpr size_t kMinBatchOut = (size_t)4 << 20;     // output a decode batch may produce beyond the room offered
 constexpr size_t kBacklogMax = (size_t)64 << 20;     // undecoded input held on the device before more is accepted
 constexpr size_t kBounce = (size_t)256 << 10;        // pinned bounce buffer: first output bytes ride with the records
+constexpr size_t kPipeOut = (size_t)64 << 20;        // decode: output per batch where batches are pipelined (below)
+constexpr size_t kAsyncMin = (size_t)1 << 20;        // ... and the smallest copy-out that is worth the side stream
 
 }  // namespace
 
@@ -99,6 +102,11 @@ struct internal_state {
     aec_gpu_ctx *ctx;
     hipStream_t stream;
     DevBuf d_in, d_out, d_off, d_res, d_seg;   // (d_seg: segment starts beside the RSI starts, long RSIs only)
+    DevBuf d_out2;                 // decoder: second output buffer (batches alternate while copies are in flight)
+    hipStream_t copy_stream;       // decoder: the copy-out of a batch runs here, beside the kernels of the next one
+    hipEvent_t ev_copied[2];       // ... and this says when the copy out of buffer i has finished
+    bool copy_pending;             // a copy to the caller's buffer is in flight: waited for before the call returns
+    unsigned out_sel;              // which output buffer the next batch writes
     uint8_t *h_res;                // pinned: 256 bytes of records, then kBounce bytes of bounce buffer
 
     std::vector<uint8_t> stage;    // encoder: input not yet coded; decoder: input not yet on the device
@@ -125,6 +133,7 @@ struct internal_state {
     uint64_t delivered;            // samples of that RSI already handed out
     size_t walked_len;             // d_len at the last index pass (anything beyond it is new)
     uint64_t span_mul;             // widening of the batch's input span (coded data sets beyond the encoder's bound)
+    bool span_wide;                // pipelined batches: the tight span did not hold once, the worst case from now on
     bool more;                     // the last batch stopped at its RSI bound: decodable input remains
     bool launched;                 // at least one batch has run
     int sticky_error;
@@ -143,7 +152,9 @@ struct Kit {
     int device = -1;
     aec_gpu_ctx *ctx = nullptr;
     hipStream_t stream = nullptr;
-    DevBuf d_in, d_out, d_off, d_res, d_seg;
+    DevBuf d_in, d_out, d_off, d_res, d_seg, d_out2;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr};
     uint8_t *h_res = nullptr;
     uint8_t *h_stage = nullptr;    // pinned staging of the batch entry points (many chunks, one transfer)
     size_t h_stage_cap = 0;
@@ -161,6 +172,10 @@ void destroy_kit(Kit &k)
     k.d_off.release();
     k.d_res.release();
     k.d_seg.release();
+    k.d_out2.release();
+    if (k.copy_stream) (void)hipStreamDestroy(k.copy_stream);
+    for (hipEvent_t &e : k.ev_copied)
+        if (e) (void)hipEventDestroy(e);
     if (k.h_res) (void)hipHostFree(k.h_res);
     if (k.h_stage) (void)hipHostFree(k.h_stage);
     if (k.stream) (void)hipStreamDestroy(k.stream);
@@ -183,19 +198,19 @@ bool take_kit(int device, Kit *out)
 
 size_t kit_bytes(const Kit &k)
 {
-    return k.d_in.cap + k.d_out.cap + k.d_off.cap + k.d_res.cap + k.d_seg.cap + aec_gpu_held_bytes(k.ctx);
+    return k.d_in.cap + k.d_out.cap + k.d_off.cap + k.d_res.cap + k.d_seg.cap + k.d_out2.cap + aec_gpu_held_bytes(k.ctx);
 }
 
 void park_kit(Kit &k)
 {
     // an error return may have left copies or kernels of this stream object enqueued: nothing of it may still
     // run when the next owner writes the buffers
-    if (hipStreamSynchronize(k.stream) != hipSuccess) {
+    if (hipStreamSynchronize(k.stream) != hipSuccess || (k.copy_stream && hipStreamSynchronize(k.copy_stream) != hipSuccess)) {
         (void)hipGetLastError();
         destroy_kit(k);
         return;
     }
-    for (DevBuf *b : {&k.d_in, &k.d_out, &k.d_off, &k.d_seg})
+    for (DevBuf *b : {&k.d_in, &k.d_out, &k.d_off, &k.d_seg, &k.d_out2})
         if (b->cap > kKeepBytes) b->release();
     if (k.h_stage_cap > kStageKeep) {
         (void)hipHostFree(k.h_stage);
@@ -239,6 +254,10 @@ void free_state(internal_state *s)
     k.d_off = s->d_off;
     k.d_res = s->d_res;
     k.d_seg = s->d_seg;
+    k.d_out2 = s->d_out2;
+    k.copy_stream = s->copy_stream;
+    k.ev_copied[0] = s->ev_copied[0];
+    k.ev_copied[1] = s->ev_copied[1];
     k.h_res = s->h_res;
     if (k.ctx && k.stream && k.h_res && k.d_res.p) park_kit(k);
     else destroy_kit(k);
@@ -274,11 +293,16 @@ int init_common(struct aec_stream *strm, bool enc)
     s->delivered = 0;
     s->walked_len = 0;
     s->span_mul = 1;
+    s->span_wide = false;
     s->more = false;
     s->launched = false;
     s->sticky_error = AEC_OK;
     s->ctx = nullptr;
     s->stream = nullptr;
+    s->copy_stream = nullptr;
+    s->ev_copied[0] = s->ev_copied[1] = nullptr;
+    s->copy_pending = false;
+    s->out_sel = 0;
     s->h_res = nullptr;
     s->device = -1;
     Kit k;
@@ -290,6 +314,10 @@ int init_common(struct aec_stream *strm, bool enc)
         s->d_off = k.d_off;
         s->d_res = k.d_res;
         s->d_seg = k.d_seg;
+        s->d_out2 = k.d_out2;
+        s->copy_stream = k.copy_stream;
+        s->ev_copied[0] = k.ev_copied[0];
+        s->ev_copied[1] = k.ev_copied[1];
         s->h_res = k.h_res;
         aec_gpu_set_index_hint(s->ctx, 0);
     } else if (s->device < 0 || aec_gpu_create(&s->ctx) != RC_OK || hipStreamCreate(&s->stream) != hipSuccess ||
@@ -431,8 +459,22 @@ int decode_run(internal_state *s, struct aec_stream *strm)
     const size_t skip = (size_t)s->delivered * c.bytes;   // bytes of the current RSI already handed out
     const size_t want_out = strm->avail_out;              // (what the caller asks of THIS call)
 
+    // Look-ahead of the speculative index = a small multiple of the average coded RSI: measured on
+    // the previous batch of this stream, else estimated from the room the caller offers for output
+    // (whole-buffer callers offer the decoded size).
+    uint64_t hint = s->rsi_bits_seen;
+    if (!hint && strm->avail_out >= rsi_bytes) {
+        const uint64_t expect = (strm->avail_out + skip + rsi_bytes - 1) / rsi_bytes;
+        hint = ((uint64_t)s->d_len * 8 - rsi_rel) / expect;
+    }
+    // Large outputs of streams whose index pass is cheap per call (the window tables): batches of kPipeOut, the copy
+    // of one batch to the caller's buffer on a side stream beside the index pass and the decode of the next one (one
+    // batch for everything was upload, index, decode, copy one behind the other: 21 GB/s for 256 MiB of config 2
+    // against 42 for the encoder).  The trunk index pays too much per call for that (spans, burn-in): one batch.
+    const bool pipe = strm->avail_out >= kPipeOut + kPipeOut / 2 &&
+                      aec_gpu_index_is_windowed(&s->prm, s->d_len - (size_t)(rsi_rel / 8), hint + hint / 2) != 0;
     // bound of the batch: the room offered (at least kMinBatchOut), and no more than the input can hold
-    const size_t room = (strm->avail_out > kMinBatchOut ? strm->avail_out : kMinBatchOut) + skip;
+    const size_t room = (pipe ? kPipeOut : (strm->avail_out > kMinBatchOut ? strm->avail_out : kMinBatchOut)) + skip;
     uint64_t max_rsi = room / rsi_bytes + 2;
     const uint64_t min_rsi_bits = (uint64_t)c.segs_per_rsi * (c.id_len + 2) + ((c.flags & F_PREPROCESS) ? c.bps : 0);
     const uint64_t avail_bits = (uint64_t)s->d_len * 8 - rsi_rel;
@@ -441,8 +483,29 @@ int decode_run(internal_state *s, struct aec_stream *strm)
     // (worst_rsi_bytes is what an ENCODER makes of an RSI at most; the format allows longer ones: should the
     // walker run out of input inside the span while more is resident, the next batch looks further)
     uint64_t span = walk_rel / 8 + max_rsi * worst_rsi_bytes(c) * s->span_mul + 64;
+    // (pipelined batches: the tables are built over the whole span, so the worst case -- five times the input a
+    // batch of compressible data needs -- would have every batch index most of what is left; twice the measured
+    // average instead, and the worst case again if the walker should run out of input inside it)
+    // (pipelined batches: the tables are built over the whole span, so the worst case -- five times the input a
+    // batch of compressible data needs -- would have every batch index most of what is left.  The span is what the
+    // batch's RSIs need on average plus the index pass's look-ahead; the pass is told that it sees a piece
+    // (aec_gpu_set_index_piece) and stops in front of the RSIs its tables cannot resolve at the end of it -- the next
+    // batch's -- instead of walking them serially.)
+    bool piece = false;
+    if (pipe && hint && s->span_mul == 1 && !s->span_wide) {
+        const uint64_t tight = walk_rel / 8 + (max_rsi * hint + 8 * hint) / 8 + 65536;
+        if (tight < span && tight < s->d_len) {
+            span = tight;
+            piece = true;
+        }
+    }
     const size_t in_bytes = span < s->d_len ? (size_t)span : s->d_len;
-    if (!s->d_off.ensure((max_rsi + 2) * 8) || !s->d_out.ensure(max_rsi * rsi_bytes + blk_bytes + 64))
+    DevBuf &obuf = s->out_sel ? s->d_out2 : s->d_out;
+    if (!s->d_off.ensure((max_rsi + 2) * 8) || !obuf.ensure(max_rsi * rsi_bytes + blk_bytes + 64))
+        return AEC_FAIL(AEC_MEM_ERROR);
+    // (the copy that read this buffer two batches ago must have finished before the decoder writes it again)
+    if (s->ev_copied[s->out_sel] && s->copy_pending &&
+        hipStreamWaitEvent(s->stream, s->ev_copied[s->out_sel], 0) != hipSuccess)
         return AEC_FAIL(AEC_MEM_ERROR);
     // RSIs of eight segments and more: the index pass also leaves the segment starts, and the decoder takes a lane per
     // segment instead of one per RSI (include/aec_gpu.h: aec_gpu_index_segments_async; without the table -- no memory
@@ -452,28 +515,21 @@ int decode_run(internal_state *s, struct aec_stream *strm)
 
     aec_gpu_dec_result *d_idx = static_cast<aec_gpu_dec_result *>(s->d_res.p), *d_dec = d_idx + 1;
     uint64_t *d_off = static_cast<uint64_t *>(s->d_off.p);
-    // Look-ahead of the speculative index = a small multiple of the average coded RSI: measured on
-    // the previous batch of this stream, else estimated from the room the caller offers for output
-    // (whole-buffer callers offer the decoded size).
-    uint64_t hint = s->rsi_bits_seen;
-    if (!hint && strm->avail_out >= rsi_bytes) {
-        const uint64_t expect = (strm->avail_out + skip + rsi_bytes - 1) / rsi_bytes;
-        hint = ((uint64_t)s->d_len * 8 - rsi_rel) / expect;
-    }
     aec_gpu_set_index_hint(s->ctx, hint + hint / 2);
+    if (piece) aec_gpu_set_index_piece(s->ctx, 6 * hint + 8192);
     int rc = d_seg ? aec_gpu_index_segments_async(s->ctx, &s->prm, s->d_in.p, in_bytes, walk_rel, s->walk_blocks, rsi_rel,
                                                   d_off, d_seg, max_rsi, d_idx, s->stream)
                    : aec_gpu_index_resume_async(s->ctx, &s->prm, s->d_in.p, in_bytes, walk_rel, s->walk_blocks, rsi_rel,
                                                 d_off, max_rsi, d_idx, s->stream);
     if (rc != RC_OK) return AEC_FAIL(rc);
     rc = d_seg ? aec_gpu_decode_bare_async(s->ctx, &s->prm, s->d_in.p, in_bytes, d_off, d_seg, max_rsi, 0, d_idx,
-                                           s->d_out.p, d_dec, s->stream)
-               : aec_gpu_decode_indexed_async(s->ctx, &s->prm, s->d_in.p, in_bytes, d_off, max_rsi, d_idx, s->d_out.p,
+                                           obuf.p, d_dec, s->stream)
+               : aec_gpu_decode_indexed_async(s->ctx, &s->prm, s->d_in.p, in_bytes, d_off, max_rsi, d_idx, obuf.p,
                                               d_dec, s->stream);
     if (rc != RC_OK) return AEC_FAIL(rc);
     // records, the start of the trailing partial RSI, and the first output bytes: one synchronisation
     uint8_t *bounce = s->h_res + 256;
-    const uint8_t *d_bytes = static_cast<const uint8_t *>(s->d_out.p) + skip;
+    const uint8_t *d_bytes = static_cast<const uint8_t *>(obuf.p) + skip;
     size_t spec = max_rsi * rsi_bytes - skip;
     if (spec > kBounce) spec = kBounce;
     if (hipMemcpyAsync(s->h_res, d_idx, 2 * sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost, s->stream) !=
@@ -484,6 +540,19 @@ int decode_run(internal_state *s, struct aec_stream *strm)
         return AEC_FAIL(AEC_MEM_ERROR);
     const aec_gpu_dec_result idx = reinterpret_cast<aec_gpu_dec_result *>(s->h_res)[0];
     const aec_gpu_dec_result dec = reinterpret_cast<aec_gpu_dec_result *>(s->h_res)[1];
+    if (getenv("AEC_ABI_TRACE")) {
+        static double t_last = 0;
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+        fprintf(stderr, "libaec (MI355X): [+%.2f ms since the last batch's records] ", t_last ? now - t_last : 0.0);
+        t_last = now;
+    }
+    if (getenv("AEC_ABI_TRACE"))
+        fprintf(stderr, "libaec (MI355X): decode batch: pipelined %d, room for %llu RSIs, span %zu of %zu resident bytes (from byte %llu), "
+                "hint %llu bits per RSI -> %llu RSIs + %llu blocks, walker status %u pad %u\n", (int)pipe, (unsigned long long)max_rsi,
+                in_bytes, s->d_len, (unsigned long long)(walk_rel / 8), (unsigned long long)hint, (unsigned long long)idx.n_rsi,
+                (unsigned long long)idx.tail_blocks, idx.status, idx.pad);
     uint64_t tail_start = 0;
     memcpy(&tail_start, s->h_res + 128, 8);
 
@@ -513,10 +582,27 @@ int decode_run(internal_state *s, struct aec_stream *strm)
         if (direct) {
             const size_t from_bounce = direct < spec ? direct : spec;
             memcpy(strm->next_out, bounce, from_bounce);
-            if (direct > from_bounce &&
-                hipMemcpy(strm->next_out + from_bounce, d_bytes + from_bounce, direct - from_bounce,
-                          hipMemcpyDeviceToHost) != hipSuccess)
-                return AEC_FAIL(AEC_MEM_ERROR);
+            if (direct > from_bounce) {
+                const size_t rest = direct - from_bounce;
+                // a large rest goes on the side stream: the next batch's kernels (the other output buffer) run beside
+                // it, and the call waits for it before it returns (copies_done)
+                bool async = pipe && rest >= kAsyncMin;
+                if (async && !s->copy_stream) async = hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) == hipSuccess;
+                if (async && !s->ev_copied[s->out_sel])
+                    async = hipEventCreateWithFlags(&s->ev_copied[s->out_sel], hipEventDisableTiming) == hipSuccess;
+                if (async) {
+                    if (hipMemcpyAsync(strm->next_out + from_bounce, d_bytes + from_bounce, rest, hipMemcpyDeviceToHost,
+                                       s->copy_stream) != hipSuccess ||
+                        hipEventRecord(s->ev_copied[s->out_sel], s->copy_stream) != hipSuccess)
+                        return AEC_FAIL(AEC_MEM_ERROR);
+                    s->copy_pending = true;
+                    s->out_sel ^= 1u;
+                } else {
+                    (void)hipGetLastError();
+                    if (hipMemcpy(strm->next_out + from_bounce, d_bytes + from_bounce, rest, hipMemcpyDeviceToHost) != hipSuccess)
+                        return AEC_FAIL(AEC_MEM_ERROR);
+                }
+            }
             strm->next_out += direct;
             strm->avail_out -= direct;
         }
@@ -576,8 +662,14 @@ int decode_run(internal_state *s, struct aec_stream *strm)
         s->delivered = (more_behind && dec.status != DEC_OK) ? tail_blocks * c.bs : part;
     }
     s->walked_len = in_bytes;
-    if (idx.pad == 1 && in_bytes < s->d_len) s->span_mul = s->span_mul < (1u << 20) ? s->span_mul * 4 : s->span_mul;
-    else s->span_mul = 1;
+    // (the walker ran out of input inside the span although more is resident: first the worst case instead of the
+    // tight span of the pipelined batches, then wider and wider)
+    if (idx.pad == 1 && in_bytes < s->d_len) {
+        if (piece && !s->span_wide) s->span_wide = true;
+        else s->span_mul = s->span_mul < (1u << 20) ? s->span_mul * 4 : s->span_mul;
+    } else {
+        s->span_mul = 1;
+    }
     // stopped at the bound with input left: the caller's next call (or this one, if it still has
     // room) goes on from here
     s->more = idx.n_rsi >= max_rsi || in_bytes < s->d_len || more_behind;
@@ -710,12 +802,19 @@ int decode_call(struct aec_stream *strm, int flush)
         if (trickle) break;
         const size_t out_before = strm->avail_out, q_before = s->outq.size();
         const uint64_t walk_before = s->walk_bit, span_before = s->span_mul;
+        const bool wide_before = s->span_wide;
         rc = decode_run(s, strm);
         if (rc == AEC_DATA_ERROR) s->sticky_error = rc;
         if (rc != AEC_OK) break;
         const bool progressed = out_before != strm->avail_out || q_before != s->outq.size() ||
-                                walk_before != s->walk_bit || s->span_mul > span_before;   // (a wider span is tried at once)
+                                walk_before != s->walk_bit || s->span_mul > span_before ||
+                                s->span_wide != wide_before;                               // (a wider span is tried at once)
         if (!progressed) break;           // what is here needs more input before anything else comes out
+    }
+    // (copies to the caller's buffer that run on the side stream: the buffer is the caller's again on return)
+    if (s->copy_pending) {
+        s->copy_pending = false;
+        if (hipStreamSynchronize(s->copy_stream) != hipSuccess && rc == AEC_OK) rc = AEC_FAIL(AEC_MEM_ERROR);
     }
     if (rc == AEC_DATA_ERROR) drain(strm, s, bytes);   // the samples in front of the error are delivered
     if (rc != AEC_OK) return rc;          // reference decode.c:818-819 (totals left as they are)
@@ -1295,6 +1394,10 @@ int aec_decode(struct aec_stream *strm, int flush)
         return decode_call(strm, flush);   // (flush is ignored by the reference, decode.c:797; here it only
                                            // says that the caller is not trickling input in)
     } catch (const std::bad_alloc &) {
+        if (strm->state->copy_pending) {       // (nothing of ours may still write the caller's buffer)
+            strm->state->copy_pending = false;
+            (void)hipStreamSynchronize(strm->state->copy_stream);
+        }
         strm->total_in -= strm->avail_in;      // (added on entry, as on every other way out)
         strm->total_out -= strm->avail_out;
         return AEC_MEM_ERROR;

@@ -40,6 +40,7 @@ struct aec_gpu_ctx {
     uint64_t idx_hint;     // caller's estimate of the coded RSI size in bits (0 = derive from max_rsi)
     uint64_t idx_used_hint;  // ... and what the last index pass worked with (sizes the rings of the decode behind it)
     bool seg_filled;       // the last index pass with a segment-start table filled it (it ran over the trunk tables)
+    uint64_t idx_stop_near;  // the next index pass is a piece of a longer stream (aec_gpu_set_index_piece)
     void *dec_ws;          // workspace of the segment-wise decode of bare streams (aec_dec.hip: launch_decode_bare)
     size_t dec_ws_bytes;
     ShardCarry *carry;     // device record: what precedes this context's shard (emit_planned)
@@ -74,6 +75,7 @@ int aec_gpu_create(aec_gpu_ctx **out)
     ctx->idx_hint = 0;
     ctx->idx_used_hint = 0;
     ctx->seg_filled = false;
+    ctx->idx_stop_near = 0;
     ctx->dec_ws = nullptr;
     ctx->dec_ws_bytes = 0;
     ctx->carry = nullptr;
@@ -336,7 +338,8 @@ static int index_common(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d
         return RC_MEM_ERROR;
     ctx->seg_filled = launch_index(c, static_cast<const uint8_t *>(d_in), in_bytes, start_bit, d_rsi_bit_offsets, max_rsi,
                                    reinterpret_cast<DecResult *>(d_result), static_cast<hipStream_t>(stream), ctx->idx_ws,
-                                   ctx->idx_ws_bytes, hint, start_block, rsi_start_bit, tail_slot, d_seg_bits);
+                                   ctx->idx_ws_bytes, hint, start_block, rsi_start_bit, tail_slot, d_seg_bits, ctx->idx_stop_near);
+    ctx->idx_stop_near = 0;
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess && getenv("AEC_ABI_TRACE"))
         fprintf(stderr, "aec_gpu_index_async: %s (in_bytes %zu start %llu max_rsi %llu hint %llu ws %zu)\n",
@@ -434,6 +437,13 @@ int aec_gpu_decode_bare_async(aec_gpu_ctx *ctx, const aec_gpu_params *p, const v
 }
 
 void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits) { ctx->idx_hint = rsi_bits; }
+void aec_gpu_set_index_piece(aec_gpu_ctx *ctx, uint64_t stop_near_bits) { ctx->idx_stop_near = stop_near_bits; }
+
+int aec_gpu_index_is_windowed(const aec_gpu_params *p, size_t in_bytes, uint64_t rsi_bits)
+{
+    Cfg c;
+    return cfg_from(p, 0, false, &c) == RC_OK && index_is_windowed(c, in_bytes, rsi_bits) ? 1 : 0;
+}
 
 void aec_gpu_trim(aec_gpu_ctx *ctx, size_t keep_bytes)
 {

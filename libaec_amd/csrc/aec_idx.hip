@@ -131,7 +131,6 @@ struct IdxCarry {          // walker state between the spans of one stream
     uint32_t n_serial, n_lookups;     // statistics: RSIs walked coded data set by coded data set, table hops taken
     uint64_t r_prev;                  // RSIs in front of the span the walker took last (k_seg_starts: its RSIs are
                                       // [r_prev, r) while the walk goes on, [r_prev, what the result record says) else)
-    uint32_t dbg_serial[2];           // statistics: the first two RSIs walked serially (numbers, + 1)
 };
 static_assert(sizeof(IdxCarry) <= 48, "the carry record shares 64 bytes with the pool counter at offset 48");
 
@@ -1554,8 +1553,11 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         const uint64_t *__restrict__ chunk_off, IdxHop *__restrict__ hops, uint32_t hop_cap, IdxCarry *carry,
         uint32_t first, uint32_t last, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
         const TwTables sp, ChunkEntry *__restrict__ centry, const SparseTables s2,
-        uint32_t *__restrict__ batch_nhops = nullptr)
+        uint32_t *__restrict__ batch_nhops = nullptr, uint64_t stop_near = 0)
 {
+    // stop_near (bits; callers that index a stream piece by piece and have more of it than they hand in): an RSI the
+    // tables do not resolve within this many bits of the end of the input is not walked serially -- the tables end
+    // there for lack of look-ahead, the caller's next piece resolves it -- the pass ends in front of it
     __shared__ __attribute__((aligned(16))) uint32_t win[kIdxWindowWords];
     uint64_t r = 0;
     if (chunk_off) {
@@ -1771,9 +1773,9 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                 good = (good + 7u) & ~7ull;
                 hopped = true;
             }
+            if (stop_near && end_bit - good < stop_near && (hopped || r != 0)) break;   // (status OK, b = 0: ends on an RSI start)
             if (lane == 0) rsi_off[r] = good;
             cur_start = good;
-            if (lane == 0 && carry && n_serial < 8u) reinterpret_cast<uint32_t *>(carry)[16 + n_serial] = (uint32_t)r + 1u;
             n_serial++;
         }
         // keep the whole next CDS (and the readers' look-ahead) inside the LDS window
@@ -2063,7 +2065,8 @@ void side_give(const SideStream &s)
 // events; `st` has waited for everything the side stream did when the last walker is enqueued.
 void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
-                         uint8_t *base, size_t ws_bytes, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot)
+                         uint8_t *base, size_t ws_bytes, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
+                         uint64_t stop_near)
 {
     allow_big_lds2();
     IdxCarry *carry = reinterpret_cast<IdxCarry *>(base);
@@ -2144,7 +2147,7 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
                            const_cast<uint4 *>(t.wide));
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
                            d_res, (const uint64_t *)nullptr, hops, hop_cap, carry, first ? 1u : 0u, last ? 1u : 0u,
-                           start_block, rsi_start, tail_slot, TwTables{}, centry, t);
+                           start_block, rsi_start, tail_slot, TwTables{}, centry, t, (uint32_t *)nullptr, last ? stop_near : 0ull);
         hipLaunchKernelGGL(k_rewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, t, nwin, nchunks, end_bit, centry, rhops,
                            nhops, d_rsi_off);
         hipLaunchKernelGGL(k_expand2, dim3((hop_cap + 255) / 256), dim3(256), 0, st, t, carry, hops,
@@ -2525,41 +2528,17 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
                 "%u walks, left %u nodes to the plain walk\n", p.L, p.lead, p.rw, p.kmax, p.wpw, p.nwin_max, p.ncap,
                 (unsigned long long)h.r, h.n_serial, h.n_lookups, p.co, p.co_wpg, p.co_margin, 1u << p.co_shift, p.co_tmax,
                 co_counts[0], co_counts[1]);
-        uint32_t seams = 0;
-        (void)hipMemcpy(&seams, base + p.o_seam + (size_t)((end_bit - lo0) / p.L + 1 < p.nwin_max ? (end_bit - lo0) / p.L + 1 : p.nwin_max) * 4, 4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "  seams of the last span (seampre behind its last window): %u\n", seams);
-        uint32_t ser[8] = {};
-        (void)hipMemcpy(ser, base + 64, 32, hipMemcpyDeviceToHost);
-        fprintf(stderr, "  RSIs walked serially (number + 1): %u %u %u %u %u %u %u %u\n", ser[0], ser[1], ser[2], ser[3], ser[4], ser[5], ser[6], ser[7]);
-        // (the tables of the LAST span are still there: what do they hold for those RSI starts?)
-        for (int q = 0; q < 8; q++) {
-            if (!ser[q]) continue;
-            uint64_t off = 0;
-            (void)hipMemcpy(&off, d_rsi_off + (ser[q] - 1u), 8, hipMemcpyDeviceToHost);
-            const uint64_t span_lo = lo0 + ((end_bit - lo0) / ((uint64_t)ncore_span * p.L)) * (uint64_t)ncore_span * p.L;
-            if (off < span_lo) { fprintf(stderr, "    RSI %u at bit %llu: not in the last span (from %llu)\n", ser[q] - 1u, (unsigned long long)off, (unsigned long long)span_lo); continue; }
-            const uint64_t i = off - span_lo;
-            uint32_t word = 0, nb = 0, cc = 0; uint16_t pre = 0;
-            (void)hipMemcpy(&word, base + p.o_bitmap + (i >> 5) * 4, 4, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(&pre, base + p.o_pre + (i >> 5) * 2, 2, hipMemcpyDeviceToHost);
-            const uint32_t w = (uint32_t)(i / p.L), sh = (uint32_t)(i & 31u);
-            (void)hipMemcpy(&nb, base + p.o_nbase + (size_t)w * 4, 4, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(&cc, base + p.o_ccnt + (size_t)w * 4, 4, hipMemcpyDeviceToHost);
-            const bool node = (word >> (31u - sh)) & 1u;
-            const uint32_t idx = pre + (sh ? __builtin_popcount(word >> (32u - sh)) : 0);
-            uint32_t rec[2] = {0, 0}, park = 0;
-            if (node) {
-                (void)hipMemcpy(rec, base + p.o_rec + (size_t)(nb + idx) * 8, 8, hipMemcpyDeviceToHost);
-                (void)hipMemcpy(&park, base + p.o_park + (size_t)(nb + idx) * 4, 4, hipMemcpyDeviceToHost);
-            }
-            fprintf(stderr, "    RSI %u at bit %llu: window %u (nodes %u) node %d index %u rec x %08x y %08x park %08x\n", ser[q] - 1u,
-                    (unsigned long long)off, w, cc, (int)node, idx, rec[0], rec[1], park);
-        }
     }
 #endif
 }
 
 }  // namespace
+
+// does the index pass of such a stream run over the window tables (cheap per call, also for small pieces)?
+bool index_is_windowed(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint)
+{
+    return in_bytes && sparse2_plan(c, (uint64_t)in_bytes * 8, rsi_bits_hint).ok;
+}
 
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
 {
@@ -2578,7 +2557,7 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
 bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
                   uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
                   void *d_ws, size_t ws_bytes, uint64_t rsi_bits_hint, uint32_t start_block, uint64_t rsi_start,
-                  uint32_t tail_slot, uint64_t *d_seg_bits)
+                  uint32_t tail_slot, uint64_t *d_seg_bits, uint64_t stop_near)
 {
     const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
     const uint64_t nwords = (in_bytes + 3) / 4, end_bit = (uint64_t)in_bytes * 8;
@@ -2588,7 +2567,7 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
         const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
         if (sp.ok && ws_bytes >= sp.bytes) {
             launch_index_sparse(c, sp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
-                                static_cast<uint8_t *>(d_ws), ws_bytes, start_block, rsi_start, tail_slot);
+                                static_cast<uint8_t *>(d_ws), ws_bytes, start_block, rsi_start, tail_slot, stop_near);
             return false;
         }
     }

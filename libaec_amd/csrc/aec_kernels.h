@@ -149,14 +149,18 @@ bool launch_decode_bare(const Cfg &c, const uint8_t *d_in, size_t in_bytes, cons
 // less than that means more, smaller spans) the walk hops over the trunk tables built by all CUs (aec_idx.hip).
 // rsi_bits_hint: estimate of the coded size of one RSI (0 = unknown); it sizes burn-in, regions and records.
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint);
+bool index_is_windowed(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint);
 // d_seg_bits (optional; (max_rsi + 1) * segs_per_rsi entries, set to ~0 by the caller): where the index runs over
 // the trunk tables it also leaves the start bit of every segment of the RSIs it finds (launch_decode_bare); the
 // return value says whether it did.
+// stop_near (bits, window-table index only): the caller holds more of the stream than it hands in; an RSI that the
+// tables leave unresolved within that many bits of the end of the input is left to the caller's next piece (the pass
+// ends in front of it) instead of being walked serially.
 bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t start_bit,
                   uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t stream,
                   void *d_ws = nullptr, size_t ws_bytes = 0, uint64_t rsi_bits_hint = 0,
                   uint32_t start_block = 0, uint64_t rsi_start = 0, uint32_t tail_slot = 0,
-                  uint64_t *d_seg_bits = nullptr);
+                  uint64_t *d_seg_bits = nullptr, uint64_t stop_near = 0);
 
 // Index pass over many independent streams stored in one buffer (e.g. the chunks of an HDF5
 // dataset): stream s occupies bytes [chunk_off[s], chunk_off[s+1]) (chunk_off 4-byte aligned values,
