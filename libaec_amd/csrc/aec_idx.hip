@@ -749,7 +749,7 @@ k_hyp_walk_rest(const Cfg c, const TrStream s, const TrGeom g, const TrTables t,
         t.rec[at] = TrRec{dist, bh};                           // (y: the count it was handed on with -- k_hyp_defer)
         t.park[at] = res;
         const uint32_t rk = co_kind(res);
-        if (rk == CO_PLAIN || (rk == CO_OVER && ls.over_plain))
+        if (rk == CO_PLAIN || (rk == CO_OVER && (ls.over_plain || co_bend(res))))
             co_push(ls.plain, ls.counts + 1, ls.pcap, make_uint2(e.y, (uint32_t)(at - t.nbase[e.y])));
     }
 }
@@ -782,25 +782,80 @@ k_hyp_defer(const Cfg c, const TrGeom g, const TrTables t, const CoLists ls)
     }
 }
 
-// the nodes left to the plain walk (tr_hyp_step: any number of RSIs, the pool of RSI ends), walk and jump
+// the nodes left to the plain walk (tr_hyp_step: any number of RSIs, the pool of RSI ends), walk and jump.  A
+// WAVEFRONT per node (aec_coop.h): these are few -- the true RSI starts behind which the trunk has not found the
+// true chain again within a whole RSI, and what shares their way -- and their walks are thousands of coded data
+// sets long (a lane each took as long as the serial walker needs for them, 2.5 ms per RSI).
 __global__ void __launch_bounds__(64)
 k_hyp_walk_list(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const CoLists ls)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_w[kCoopWin], lds_m[kCoopWin];
     const uint32_t n = ls.counts[1] < ls.pcap ? ls.counts[1] : ls.pcap;
     const TrGlobal mem{s, g, t};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    CoopCds<kCoopWin> cw;
+    cw.init(s, c, lds_w);
+    cw.with_marks(lds_m, g, t);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint2 e = ls.plain[i];
         TrHyp h;
         tr_hyp_start(c, h, g.lo + (uint64_t)e.x * g.L + t.cpos[t.nbase[e.x] + e.y]);
-        uint32_t st;
-        while ((st = tr_hyp_step(s, c, g, mem, h)) == TR_RUN) {
-            if (h.pend && !tr_hyp_commit(g, t, h, atomicAdd(t.pool_cnt, 1u))) {
+        uint32_t st = TR_RUN;
+        if (!cw.usable()) {
+            if (threadIdx.x == 0) {
+                while ((st = tr_hyp_step(s, c, g, mem, h)) == TR_RUN)
+                    if (h.pend && !tr_hyp_commit(g, t, h, atomicAdd(t.pool_cnt, 1u))) {
+                        st = TR_FAIL;
+                        break;
+                    }
+                tr_hyp_finish(g, t, e.x, e.y, h, st);
+                tr_hyp_land(c, g, t, e.x, e.y);
+            }
+            continue;
+        }
+        // (tr_hyp_step, the whole wavefront in step; every value below is the same in all lanes)
+        while (st == TR_RUN) {
+            const bool first = h.b == 0u;
+            cw.prepare(h.pos);
+            if (!first && cw.marked(h.pos)) {
+                st = TR_LAND;
+                break;
+            }
+            if (h.steps >= g.budget) {
                 st = TR_FAIL;
                 break;
             }
+            const uint32_t ref = (first && (c.flags & F_PREPROCESS)) ? 1u : 0u;
+            uint32_t nz;
+            const uint32_t len = cw.cds(c, h.pos, ref, nz);
+            const uint32_t nb = len ? tr_blocks(c, nz, h.b) : 0u;
+            if (!nb || nb > c.rsi - h.b) {
+                st = TR_FAIL;
+                break;
+            }
+            h.pos += len;
+            h.b += nb;
+            h.steps++;
+            if (h.b == c.rsi) {
+                st = tr_hyp_complete(c, g, h, tr_marked(g, t, h.pos));
+                if (st == TR_RUN && h.pend) {
+                    uint32_t slot = 0;
+                    if (threadIdx.x == 0) slot = atomicAdd(t.pool_cnt, 1u);
+                    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+                    if (slot >= g.pcap) {
+                        st = TR_FAIL;
+                    } else {
+                        if (threadIdx.x == 0) t.pool[slot] = TrPoolEntry{h.pend, h.link};
+                        h.link = slot + 1u;
+                        h.pend = 0;
+                    }
+                }
+            }
         }
-        tr_hyp_finish(g, t, e.x, e.y, h, st);
-        tr_hyp_land(c, g, t, e.x, e.y);
+        if (threadIdx.x == 0) {
+            tr_hyp_finish(g, t, e.x, e.y, h, st);
+            __threadfence();
+            tr_hyp_land(c, g, t, e.x, e.y);
+        }
     }
 }
 
@@ -2476,8 +2531,7 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
         }
         hipLaunchKernelGGL(k_hyp_land, dim3(g.ncore), dim3(256), 0, st, c, g, t);
         if (p.co)
-            hipLaunchKernelGGL(k_hyp_walk_list, dim3((p.co_pcap + 63) / 64 < 16384u ? (p.co_pcap + 63) / 64 : 16384u), dim3(64), 0,
-                               st, c, s, g, t, ls);
+            hipLaunchKernelGGL(k_hyp_walk_list, dim3(p.co_pcap < 2048u ? p.co_pcap : 2048u), dim3(64), 0, st, c, s, g, t, ls);
 
         const uint32_t nwin = g.ncore, nchunks = (nwin + p.wpc - 1) / p.wpc;
         TwTables sp;

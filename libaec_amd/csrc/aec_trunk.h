@@ -783,6 +783,7 @@ template <class Src>
 AEC_HD uint32_t tr_co_rest(const TrStream &s, const Cfg &c, const TrGeom &g, const Src &src, uint64_t node, uint64_t pos,
                            uint32_t b, uint32_t b_ros, uint32_t &dist, uint32_t *parses = nullptr)
 {
+    const uint32_t b0 = b;
     for (uint32_t steps = 0; steps < g.budget; steps++) {
         if (parses) *parses = steps;
         if (src.marked(pos)) {
@@ -796,11 +797,15 @@ AEC_HD uint32_t tr_co_rest(const TrStream &s, const Cfg &c, const TrGeom &g, con
         const uint32_t len = tr_cds(s, c, pos, 0u, nz, W);
         if (!len) return co_pack(CO_FAIL, b, b_ros);
         const uint32_t nb = tr_blocks(c, nz, b);
-        if (!nb || nb > c.rsi - b) return co_pack(CO_OVER, 0u, kCoNoRos);
+        // (a walk that runs over the end of its RSI: b_end = 1 if its block count grew about as its coded data sets
+        // did -- at most half as many blocks again: no zero-run codes inflating it, as on a TRUE chain that the trunk
+        // has not found again for a whole RSI (one RSI in a few thousand at 253 bits per coded data set) -- and 0 for
+        // the garbage walks, which reach the end of their RSI in a quarter of its blocks' worth of coded data sets)
+        if (!nb || nb > c.rsi - b) return co_pack(CO_OVER, (steps + 1u) * 3u >= (b - b0) * 2u ? 1u : 0u, kCoNoRos);
         if (nz == 5u && b_ros == kCoNoRos) b_ros = b;
         pos += len;
         b += nb;
-        if (b == c.rsi) return co_pack(CO_OVER, 0u, kCoNoRos);
+        if (b == c.rsi) return co_pack(CO_OVER, (steps + 1u) * 3u >= (b - b0) * 2u ? 1u : 0u, kCoNoRos);
     }
     return co_pack(CO_PLAIN, 0u, kCoNoRos);
 }
@@ -812,7 +817,8 @@ AEC_HD uint32_t tr_co_rest(const TrStream &s, const Cfg &c, const TrGeom &g, con
 AEC_HD uint32_t co_defer(const Cfg &c, uint32_t b, uint32_t bh, uint32_t root_k, uint32_t &kind)
 {
     const uint32_t rk = co_kind(root_k);
-    kind = rk == CO_OVER ? (b >= bh ? CO_OVER : CO_PLAIN) : CO_PLAIN;
+    // (a root that ran over as a true chain would: its guests get the plain walk, whatever their counts)
+    kind = rk == CO_OVER ? ((b >= bh && !co_bend(root_k)) ? CO_OVER : CO_PLAIN) : CO_PLAIN;
     if (rk != CO_LAND && rk != CO_FAIL) return 0u;
     const uint32_t out = co_ride(c, b, bh, root_k);
     kind = !out ? CO_OVER : (rk == CO_FAIL ? CO_FAIL : CO_LAND);
