@@ -1370,8 +1370,14 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         const bool limited = !cnt && !ua[i] && ub[i] == kS2Limited;
         grec[at] = make_uint2(ua[i], cnt ? ((cnt << 24) | (pos - cpos[i])) : (limited ? 1u : 0u));
         if (limited && blist) {                               // k_bridge's work list
+            // (bit 31: the hypothesis starts with an UNCOMPRESSED coded data set -- what an RSI of incompressible
+            // data does, and one in 2^id_len of the wrong phases that run out of their window on a clean stream:
+            // k_bridge takes those from the first span on, the others once the walker has met enough of their kind)
+            const uint32_t q0 = cpos[i];
+            const uint64_t two = ((uint64_t)win[q0 >> 5] << 32) | win[(q0 >> 5) + 1u];
+            const uint32_t id = (uint32_t)((two << (q0 & 31u)) >> (64u - c.id_len));
             const uint32_t slot = atomicAdd(blist_cnt, 1u);
-            if (slot < kS2BridgeCap) blist[slot] = (uint32_t)at;
+            if (slot < kS2BridgeCap) blist[slot] = (uint32_t)at | (id == (1u << c.id_len) - 1u ? 0x80000000u : 0u);
         }
         gcpos[at] = (uint16_t)(cpos[i] - c0);
     }
@@ -1448,13 +1454,38 @@ struct QuadFetch {
     }
 };
 
+// unc_only: take the hypothesis only if EVERY coded data set of its RSI is an uncompressed one (an RSI of
+// incompressible data): their headers lie a fixed distance apart, so that is a run of independent reads, eight at a
+// time, and a wrong phase on a clean stream is out after the first eight.
 __device__ void bridge_one(const Cfg &c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
-                           const SparseTables &t, uint2 *__restrict__ rec_out, uint32_t at)
+                           const SparseTables &t, uint2 *__restrict__ rec_out, uint32_t at, bool unc_only)
 {
     const uint32_t w = at / t.cap;
     if (t.rec[at].x || t.rec[at].y != 1u) return;
     const uint64_t pos = t.lo + (uint64_t)w * t.core + t.cpos[at];
     if (pos >= end_bit) return;
+    {
+        const uint32_t step = c.id_len + c.bs * c.bps, idmax = (1u << c.id_len) - 1u;
+        const uint64_t len = (uint64_t)c.rsi * step;
+        bool unc = pos + len <= end_bit && len <= 0xFFFFFFFFull;
+        for (uint32_t j0 = 0; j0 < c.rsi && unc; j0 += 8u) {
+            uint32_t ids[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) {
+                const uint64_t q = pos + (uint64_t)(j0 + k < c.rsi ? j0 + k : j0) * step, wi = q >> 5;
+                const uint64_t two = ((uint64_t)bswap32(words[wi < nwords ? wi : nwords - 1u]) << 32) |
+                                     bswap32(words[wi + 1u < nwords ? wi + 1u : nwords - 1u]);
+                ids[k] = (uint32_t)((two << (q & 31u)) >> (64u - c.id_len));
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) unc = unc && ids[k] == idmax;
+        }
+        if (unc) {
+            rec_out[at].x = (uint32_t)len;
+            return;
+        }
+        if (unc_only) return;
+    }
     BitReaderT<QuadFetch> br;
     br.init(QuadFetch{words, nwords}, end_bit, pos);
     const bool pp = c.flags & F_PREPROCESS;
@@ -1478,10 +1509,14 @@ k_bridge(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     // Only for streams that need it: well-behaved streams have a dozen such hypotheses per window too (wrong phases
     // whose zero runs come out long), each a parse of several average RSIs for nothing.  The walker counts the
     // RSIs it had to walk itself; from kS2BridgeAfter of them on the rest of the stream is bridged.
-    if (first_span || carry->n_serial < min_serial) return;
+    // Hypotheses that start with an uncompressed coded data set (bit 31 of their entry) are bridged always: cheap on a
+    // clean stream (few), and what the true start of an incompressible RSI looks like.
+    const bool all = !first_span && carry->n_serial >= min_serial;
     const uint32_t n = *blist_cnt < kS2BridgeCap ? *blist_cnt : kS2BridgeCap;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
-        bridge_one(c, words, nwords, end_bit, t, rec_out, blist[j]);
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const uint32_t e = blist[j];
+        if (all || (e >> 31)) bridge_one(c, words, nwords, end_bit, t, rec_out, e & 0x7FFFFFFFu, !all);
+    }
 }
 
 // ---- wide walker: every candidate of a chunk's first window chases the window chain through the chunk
