@@ -1014,9 +1014,30 @@ k_seg_starts(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, co
         }
         // segments b / 64 + 1 ... : one jump each
         const uint32_t nseg = (nblocks + 63u) / 64u;
+        bool miss = false;
         for (uint32_t j = b / 64u + 1u + lane; j < nseg; j += 64u) {
             const uint64_t e = tr_jump_to(c, g, t, pos, b, j * 64u);
             out[j] = e == kTrNone ? ~0ull : e;
+            miss = miss || e == kTrNone;
+        }
+        // A jump that does not come out (a seam of the trunk on the way: small inputs, whose regions are short): the
+        // walk goes on to the end of the RSI instead and leaves every segment start it passes -- a millisecond, where
+        // the decoder would take the whole RSI with one lane, twenty.
+        if (__any(miss) && cw.usable()) {
+            bool ok2 = true;
+            while (b < nblocks) {
+                uint32_t nz;
+                const uint32_t len = cw.cds(c, pos, 0u, nz);
+                const uint32_t nb = len ? tr_blocks(c, nz, b) : 0u;
+                if (!nb || nb > nblocks - b || (b % 64u) + nb > 64u) {
+                    ok2 = false;
+                    break;
+                }
+                pos += len;
+                b += nb;
+                if ((b % 64u) == 0u && b < nblocks && lane == 0) out[b / 64u] = pos;
+            }
+            if (!ok2 && lane == 0) out[0] = ~0ull;
         }
     }
 }
@@ -2399,10 +2420,11 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
         if (p.co_shift < 2u || p.co_shift > 4u) p.co_shift = 4u;
         p.co_tmax = tune("AEC_TR_CO_TMAX", 64u);
         p.co_cap = tune("AEC_TR_CO_CAP", 1024u);
-        // walks whose count runs over the end of their RSI before they land: with RSIs of 12 and more times the way
-        // back to the trunk those are garbage walks inflated by zero-run codes (one true RSI start in e^12 takes that
-        // long, and is then walked serially); below that they get the plain walk's records of several RSIs
-        p.co_over = tune("AEC_TR_CO_OVER", c.rsi >= 12 * cds ? 0u : 1u);
+        // walks whose count runs over the end of their RSI before they land:
+        // (AEC_TR_CO_OVER=1, measurements: every such walk to the plain walk.  The walks that matter among them -- true
+        // chains the trunk has not found again for a whole RSI -- are told by their counts (aec_trunk.h tr_co_rest) and
+        // get the plain walk in any case; the rest are garbage walks by the thousand, each thousands of parses long.)
+        p.co_over = tune("AEC_TR_CO_OVER", 0u);
         if (p.co_cap > kCoMaxOwners) p.co_cap = kCoMaxOwners;
         const uint64_t bits = (uint64_t)p.co_wpg * p.L + p.co_margin;
         p.co_lds = ((bits / 32 + 8) + bits / 32 + ((bits >> p.co_shift) + 2) + 2 * ((size_t)p.co_wpg + 1)) * 4 + (size_t)p.co_cap * 8 + 64;

@@ -934,6 +934,21 @@ AEC_HD uint64_t tr_jump_to(const Cfg &c, const TrGeom &g, const TrTables &t, uin
             TR_DBG("  target window %u (nwin %u) seam %u/%u want %llu gbase %llu ccnt %u\n", tw, g.nwin,
                    tw < g.nwin ? t.seampre[tw] : 0u, seam0, (unsigned long long)(G + n),
                    (unsigned long long)(tw < g.nwin ? t.gbase[tw] : 0), tw < g.nwin ? t.ccnt[tw] : 0u);
+            if (tw >= g.nwin && G + n == t.gbase[g.nwin]) {
+                // the RSI ends where the trunk does: behind its last coded data set stands a node that covers nothing
+                // (the end of the stream) -- the last RSI of a stream gets its record like any other
+                uint32_t lw = g.nwin;
+                while (lw > w && !t.ccnt[lw - 1u]) lw--;
+                if (lw > w || t.ccnt[w]) {
+                    const uint32_t ew = lw > w ? lw - 1u : w, ei = t.ccnt[ew] - 1u;
+                    const uint32_t ebp = t.bp[t.nbase[ew] + ei];
+                    if ((ebp >> 30) == kTrDead && t.gbase[ew] + (ebp & kTrBpMask) == G + n && t.seampre[ew] == seam0) {
+                        if (end_at) *end_at = t.nbase[ew] + ei;
+                        return g.lo + (uint64_t)ew * g.L + t.cpos[t.nbase[ew] + ei];
+                    }
+                }
+                return kTrNone;
+            }
             if (tw >= g.nwin || t.seampre[tw] != seam0) return kTrNone;
             uint32_t ti;
             if (!tr_node_of(g, t, tw, (uint32_t)(G + n - t.gbase[tw]), ti)) return kTrNone;

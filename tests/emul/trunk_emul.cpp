@@ -275,6 +275,20 @@ extern "C" int emul_trunk(const uint32_t *params, const uint8_t *enc, size_t enc
             if (!okk || !okl) stats[12]++;
         }
     }
+    // the LAST RSI: when it is a whole one its record ends where the stream does (on the node behind the last coded
+    // data set, which covers nothing); a record there must say exactly that
+    if (nk >= 2) {
+        uint32_t w, i;
+        if (tr_node_at(g, t, key[nk - 2], w, i)) {
+            const TrRec rc = t.rec[t.nbase[w] + i];
+            if (rc.x && (tr_rec_k(rc.x) != 1u || key[nk - 2] + tr_rec_bits(rc.x) != key[nk - 1])) {
+                fprintf(stderr, "last RSI: record of %u RSIs over %u bits, the stream ends %llu bits behind its start\n",
+                        tr_rec_k(rc.x), tr_rec_bits(rc.x), (unsigned long long)(key[nk - 1] - key[nk - 2]));
+                stats[12]++;
+            }
+            if (getenv("TR_DEBUG")) fprintf(stderr, "last RSI: %s\n", rc.x ? "resolved" : "no record");
+        }
+    }
     // ---- the walk the serial walker would do: hop over records from start_bit, count fallbacks
     {
         uint64_t r = 0;
