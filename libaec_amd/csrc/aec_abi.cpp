@@ -39,11 +39,16 @@ using namespace aec;
 
 namespace {
 
-// AEC_ABI_TRACE=1 in the environment: say on stderr where a device-side failure was detected
-int fail_at(int code, int line)
+// AEC_ABI_TRACE=1 in the environment (the one variable the product library reads): say on stderr where a
+// device-side failure was detected, and one line per decode batch (span, hint, what the walker brought back)
+bool trace_on()
 {
     static const bool trace = getenv("AEC_ABI_TRACE") != nullptr;
-    if (trace) fprintf(stderr, "libaec (MI355X): error %d raised at aec_abi.cpp:%d (last HIP error: %s)\n", code, line,
+    return trace;
+}
+int fail_at(int code, int line)
+{
+    if (trace_on()) fprintf(stderr, "libaec (MI355X): error %d raised at aec_abi.cpp:%d (last HIP error: %s)\n", code, line,
                        hipGetErrorString(hipPeekAtLastError()));
     return code;
 }
@@ -540,15 +545,7 @@ int decode_run(internal_state *s, struct aec_stream *strm)
         return AEC_FAIL(AEC_MEM_ERROR);
     const aec_gpu_dec_result idx = reinterpret_cast<aec_gpu_dec_result *>(s->h_res)[0];
     const aec_gpu_dec_result dec = reinterpret_cast<aec_gpu_dec_result *>(s->h_res)[1];
-    if (getenv("AEC_ABI_TRACE")) {
-        static double t_last = 0;
-        timespec ts;
-        clock_gettime(CLOCK_MONOTONIC, &ts);
-        const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-        fprintf(stderr, "libaec (MI355X): [+%.2f ms since the last batch's records] ", t_last ? now - t_last : 0.0);
-        t_last = now;
-    }
-    if (getenv("AEC_ABI_TRACE"))
+    if (trace_on())
         fprintf(stderr, "libaec (MI355X): decode batch: pipelined %d, room for %llu RSIs, span %zu of %zu resident bytes (from byte %llu), "
                 "hint %llu bits per RSI -> %llu RSIs + %llu blocks, walker status %u pad %u\n", (int)pipe, (unsigned long long)max_rsi,
                 in_bytes, s->d_len, (unsigned long long)(walk_rel / 8), (unsigned long long)hint, (unsigned long long)idx.n_rsi,
@@ -642,7 +639,7 @@ int decode_run(internal_state *s, struct aec_stream *strm)
         }
     }
     if (corrupt) {
-        if (getenv("AEC_ABI_TRACE"))
+        if (trace_on())
             fprintf(stderr, "libaec (MI355X): AEC_DATA_ERROR: walker status %u after %llu RSIs + %llu blocks (bit %llu), "
                     "decoder status %u at RSI %llu\n", idx.status, (unsigned long long)idx.n_rsi,
                     (unsigned long long)idx.tail_blocks, (unsigned long long)idx.end_bit, dec.status,

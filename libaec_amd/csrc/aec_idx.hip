@@ -492,7 +492,6 @@ k_hyp_walk_mem(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, 
     const uint32_t w0 = blockIdx.x * wpg;
     if (w0 >= g.ncore) return;
     const uint32_t w1 = w0 + wpg < g.ncore ? w0 + wpg : g.ncore;
-    const TrGlobal mem{s, g, t};
     uint32_t pool_cur = 0, pool_end = 0;
     enum : uint32_t { STEP = 0, LONG = 1, ENDRSI = 2, FIN = 3, IDLE = 4 };
     uint32_t w = w0, idx = lane, cls = FIN, fin = 0xFFu;      // (fin 0xFF: nothing to record yet, just take a node)
@@ -2266,6 +2265,27 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
         hipLaunchKernelGGL(k_expand2, dim3((nchunks * p.wpc * 2 + 255) / 256), dim3(256), 0, st, t, carry, rhops, nhops,
                            nchunks, p.wpc * 2, d_rsi_off);
         if (piped) (void)hipEventRecord(side.done[set], st);
+#ifdef AEC_TUNING
+        if (tune_set("AEC_IDX_STATS")) {                   // (diagnostics: synchronises)
+            (void)hipStreamSynchronize(st);
+            std::vector<uint32_t> cc(nwin);
+            (void)hipMemcpy(cc.data(), t.ccnt, (size_t)nwin * 4, hipMemcpyDeviceToHost);
+            uint32_t gave_up = 0, most = 0, nb = 0;
+            uint64_t sum = 0;
+            for (uint32_t v : cc) {
+                gave_up += v == 0;
+                most = v > most ? v : most;
+                sum += v;
+            }
+            IdxCarry h{};
+            (void)hipMemcpy(&h, carry, sizeof(h), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&nb, blist_cnt, 4, hipMemcpyDeviceToHost);
+            fprintf(stderr, "window tables, span %llu: %u windows (%u gave up), candidates per window %.0f on average, %u at "
+                    "most (room for %u) | so far RSIs %llu, walked serially %u, table lookups %u | hypotheses listed for "
+                    "k_bridge %u\n", (unsigned long long)si, nwin, gave_up, nwin ? (double)sum / nwin : 0.0, most,
+                    p.g.cap_core, (unsigned long long)h.r, h.n_serial, h.n_lookups, nb);
+        }
+#endif
     }
     if (piped) side_give(side);
 }

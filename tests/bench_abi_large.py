@@ -27,7 +27,7 @@ def main():
     lib = api.library()
     name, kind, bps, bs, rsi, flags = bench.CONFIGS[args.config]
     n = args.size_mib << 20
-    host_np = bench.generate(kind, n, 0, 8)
+    host_np = bench.typical_tiled(n) if kind < 0 else bench.generate(kind, n, 0, 8)
     pin = (lambda t: t) if args.pageable else (lambda t: t.pin_memory())
     t_host = pin(torch.from_numpy(np.asarray(host_np).view(np.uint8)[:n].copy()))
     t_enc = pin(torch.zeros(n + n // 8 + (1 << 20), dtype=torch.uint8))

@@ -27,6 +27,11 @@ python3 tests/bench_index.py --config c2 --size-mib 1 64 1024 > $OUT/bench_index
 python3 tests/bench_index.py --config c5 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
 python3 tests/bench_index.py --config c3 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
 python3 tests/bench_index.py --config typical --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
+# index + segment starts + decode of the bare stream (the device API the ABI decode and bench decode_bare use)
+for c in c2 c3 c5 typical; do
+  s="64 1024 4096"; [ $c = typical ] && s="64 1024"
+  python3 tests/bench_index.py --config $c --decode --size-mib $s 2>&1 | grep -v amdgpu >> $OUT/bench_index_decode.txt
+done
 # kernel statistics and HBM traffic of the index pass itself (tests/bench_index.py), per configuration
 bash tests/prof_index.sh $1/idx 1024 > /dev/null 2>&1
 for c in c2 c5 c3 typical; do cp $OUT/idx/kernel_stats_index_$c.csv $OUT/kernel_stats_index_$c.csv 2>/dev/null; done
@@ -36,12 +41,18 @@ for c in c2 c5 c3 typical; do cp $OUT/idx/kernel_stats_index_$c.csv $OUT/kernel_
   done; done )
 python3 tests/pmc_summary.py "$OUT/idxpmc_c2_*/runc/*counter_collection.csv" > $OUT/traffic_index_c2_1GiB.txt 2>&1
 python3 tests/pmc_summary.py "$OUT/idxpmc_c3_*/runc/*counter_collection.csv" > $OUT/traffic_index_c3_1GiB.txt 2>&1
+# SQ counters of the index kernels (window tables: C2; trunk + coalescing walks: C3), one counter set per pass
+for c in c2 c3; do
+  bash tests/prof_index_pmc.sh $1/idxsq_$c $c 1024 > /dev/null 2>&1
+  cp $OUT/idxsq_$c/summary_$c.txt $OUT/pmc_sq_index_${c}_1GiB.txt 2>/dev/null
+done
 # phase stamps of the window-table kernel (tuning build: AEC_S2_PROF)
 for c in c2 c5; do
   AEC_AMD_LIB=$R/libaec_amd/lib/tuning/libaec.so.0 AEC_S2_PROF=1 python3 tests/bench_index.py --config $c --size-mib 1024 2>&1 | grep -v amdgpu > $OUT/k_spec2_phases_$c.txt
 done
 python3 tests/bench_index_mixed.py 2>&1 | grep -v amdgpu > $OUT/bench_index_mixed.txt
 python3 tests/bench_abi_small.py > $OUT/bench_abi_small.txt 2>&1
+for c in c2 c3 c5 typical; do python3 tests/bench_abi_large.py --config $c 2>&1 | grep -v amdgpu >> $OUT/bench_abi_large.txt; done
 python3 tests/bench_sz_chunks.py > $OUT/bench_sz_chunks.txt 2>&1
 python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
-rm -rf $OUT/sq_c2 $OUT/stats_* $OUT/traffic_c2 $OUT/traffic_c3 $OUT/traffic_c5 $OUT/traffic_typical $OUT/idx $OUT/idxpmc_*
+rm -rf $OUT/sq_c2 $OUT/stats_* $OUT/traffic_c2 $OUT/traffic_c3 $OUT/traffic_c5 $OUT/traffic_typical $OUT/idx $OUT/idxpmc_* $OUT/idxsq_*
