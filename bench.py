@@ -392,7 +392,7 @@ def main():
         extras["decode_bare"] = {"GBps": round(nbytes / ((ti + td) * 1e-3) / 1e9, 2), "index_ms": round(ti, 3),
                                  "decode_ms": round(td, 3),
                                  "note": "aec_gpu_index_segments_async + aec_gpu_decode_bare_async (a lane per RSI; per "
-                                         "segment where RSIs hold four and more) on the stream alone, median of 3"}
+                                         "segment where RSIs hold eight segments and more) on the stream alone, median of 3"}
         del d_idx, d_sbits
         extras["abi_end_to_end"] = abi_end_to_end(host[: 256 << 20])
     del host

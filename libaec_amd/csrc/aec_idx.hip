@@ -1052,7 +1052,7 @@ constexpr uint32_t kS2BridgeCap = 1u << 18;  // hypotheses per span k_bridge tak
 constexpr uint32_t kS2BridgeAfter = 16;      // RSIs the walker had to walk itself before k_bridge steps in
 
 struct Spec2Geom {
-    uint32_t lead, core, look, stride, burn, cap_lds, cap_core, fast, refill;
+    uint32_t lead, core, look, stride, burn, cap_lds, cap_core, fast, refill, uncrun;
 };
 
 __global__ void __launch_bounds__(1024)
@@ -1196,6 +1196,56 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             const uint32_t len = cds0(q, run);
             ok = len != 0;
             q += len;
+        }
+    }
+    // ---- 1b. runs of uncompressed coded data sets (an RSI of incompressible data).  Their headers -- all ones -- lie a
+    // fixed distance apart, so they are found without a chain that leads there.  A window that begins inside such an
+    // RSI needs that: its own chains start in noise, 24 coded data sets of burn-in are more than its lead-in holds,
+    // and the RSI start BEHIND the run would stay unmarked (the walker then takes that RSI coded data set by coded
+    // data set, and a chunk with one such RSI loses its chunk-level lookup).  Eight headers in a row start a marking
+    // chain; a false alarm on other data marks a few garbage boundaries until it meets the marked chain, which costs
+    // candidates and nothing else.
+    {
+        const uint32_t il = c.id_len, step = il + c.bs * c.bps;
+        // (bit-parallel: for the 32 positions of a word, "id_len ones start here" as a mask; the same for the positions
+        // one, two and three coded data sets further on; their AND leaves next to nothing on other data)
+        // (all words of the four places are read before any is looked at: one LDS round trip per word of the window)
+        auto ones_of = [&](uint32_t a, uint32_t b, uint32_t d, uint32_t sh) -> uint32_t {   // 32 positions from bit sh of a:b:d
+            const uint64_t hi = ((uint64_t)a << 32) | b;
+            const uint64_t y = sh ? (hi << sh) | ((uint64_t)d >> (32u - sh)) : hi;
+            uint64_t m = y;
+            for (uint32_t k = 1; k < il; k++) m &= y << k;
+            return (uint32_t)(m >> 32);
+        };
+        const uint32_t w1 = step >> 5, s1 = step & 31u, w2 = (2u * step) >> 5, s2 = (2u * step) & 31u,
+                       w3 = (3u * step) >> 5, s3 = (3u * step) & 31u;
+        for (uint32_t i = tid; i < nw && g.uncrun; i += nt) {
+            if (i * 32u + 32u + 7u * step + il > s.limit) break;
+            const uint32_t a0 = win[i], b0 = win[i + 1u];
+            const uint32_t a1 = win[i + w1], b1 = win[i + w1 + 1u], d1 = win[i + w1 + 2u];
+            const uint32_t a2 = win[i + w2], b2 = win[i + w2 + 1u], d2 = win[i + w2 + 2u];
+            const uint32_t a3 = win[i + w3], b3 = win[i + w3 + 1u], d3 = win[i + w3 + 2u];
+            uint32_t hits = ones_of(a0, b0, 0u, 0u) & ones_of(a1, b1, d1, s1) & ones_of(a2, b2, d2, s2) & ones_of(a3, b3, d3, s3);
+            // (four in a row still happen on compressible data -- 8-bit samples, 3-bit headers: a hundred per window, each
+            // a chain of garbage boundaries: eight in a row it is, the second four only where the first four hold)
+            for (uint32_t k = 4; k < 8u && hits; k++) {
+                const uint32_t wk = i + ((k * step) >> 5);
+                hits &= ones_of(win[wk], win[wk + 1u], win[wk + 2u], (k * step) & 31u);
+            }
+            while (hits) {
+                const uint32_t j = (uint32_t)__builtin_clz(hits);
+                hits &= ~(0x80000000u >> j);
+                uint32_t q = i * 32u + j;
+                bool ok = true;
+                uint32_t run;
+                while (ok && q < s.limit) {
+                    const uint32_t bit = 1u << (31u - (q & 31u));
+                    if (atomicOr(&marks[q >> 5], bit) & bit) break;
+                    const uint32_t len = cds0(q, run);
+                    ok = len != 0;
+                    q += len;
+                }
+            }
         }
     }
     __syncthreads();
@@ -1474,9 +1524,10 @@ struct QuadFetch {
     }
 };
 
-// unc_only: take the hypothesis only if EVERY coded data set of its RSI is an uncompressed one (an RSI of
-// incompressible data): their headers lie a fixed distance apart, so that is a run of independent reads, eight at a
-// time, and a wrong phase on a clean stream is out after the first eight.
+// unc_only: take the hypothesis only if its RSI looks like incompressible data -- it begins with four uncompressed
+// coded data sets and holds at most eight of another kind (random 16-bit samples: one block in 300 comes out a
+// little shorter as a split).  The headers of a run of uncompressed coded data sets lie a fixed distance apart, so
+// the run is a series of independent reads, eight at a time, and a wrong phase on a clean stream is out after the first.
 __device__ void bridge_one(const Cfg &c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
                            const SparseTables &t, uint2 *__restrict__ rec_out, uint32_t at, bool unc_only)
 {
@@ -1484,41 +1535,48 @@ __device__ void bridge_one(const Cfg &c, const uint32_t *__restrict__ words, uin
     if (t.rec[at].x || t.rec[at].y != 1u) return;
     const uint64_t pos = t.lo + (uint64_t)w * t.core + t.cpos[at];
     if (pos >= end_bit) return;
-    {
-        const uint32_t step = c.id_len + c.bs * c.bps, idmax = (1u << c.id_len) - 1u;
-        const uint64_t len = (uint64_t)c.rsi * step;
-        bool unc = pos + len <= end_bit && len <= 0xFFFFFFFFull;
-        for (uint32_t j0 = 0; j0 < c.rsi && unc; j0 += 8u) {
-            uint32_t ids[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8u; k++) {
-                const uint64_t q = pos + (uint64_t)(j0 + k < c.rsi ? j0 + k : j0) * step, wi = q >> 5;
-                const uint64_t two = ((uint64_t)bswap32(words[wi < nwords ? wi : nwords - 1u]) << 32) |
-                                     bswap32(words[wi + 1u < nwords ? wi + 1u : nwords - 1u]);
-                ids[k] = (uint32_t)((two << (q & 31u)) >> (64u - c.id_len));
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < 8u; k++) unc = unc && ids[k] == idmax;
-        }
-        if (unc) {
-            rec_out[at].x = (uint32_t)len;
-            return;
-        }
-        if (unc_only) return;
-    }
+    const uint32_t step = c.id_len + c.bs * c.bps, idmax = (1u << c.id_len) - 1u;
+    auto id_at = [&](uint64_t q) -> uint32_t {
+        const uint64_t wi = q >> 5;
+        const uint64_t two = ((uint64_t)bswap32(words[wi < nwords ? wi : nwords - 1u]) << 32) |
+                             bswap32(words[wi + 1u < nwords ? wi + 1u : nwords - 1u]);
+        return (uint32_t)((two << (q & 31u)) >> (64u - c.id_len));
+    };
     BitReaderT<QuadFetch> br;
     br.init(QuadFetch{words, nwords}, end_bit, pos);
     const bool pp = c.flags & F_PREPROCESS;
     // (an RSI of the reference encoder is at most all blocks uncompressed; whatever is longer is left to the walker)
-    const uint64_t longest = (uint64_t)c.rsi * (c.id_len + (uint64_t)c.bs * c.bps) + c.bps + 64u;
-    uint32_t b = 0;
+    const uint64_t longest = (uint64_t)c.rsi * step + c.bps + 64u;
+    uint32_t b = 0, slow = 0;
     while (b < c.rsi) {
-        uint32_t nblk = 1;
-        if (skip_cds(br, c, (pp && b == 0) ? 1u : 0u, b, nblk) != DEC_OK) return;
-        b += nblk;
+        if (br.cnt < c.id_len) br.refill();
+        const uint32_t id = (uint32_t)(br.win >> (64u - c.id_len));
+        if (id == idmax) {
+            const uint64_t p = br.pos;
+            const uint32_t left = c.rsi - b;
+            uint32_t ids[7];
+#pragma unroll
+            for (uint32_t k = 0; k < 7u; k++) ids[k] = k + 1u < left ? id_at(p + (uint64_t)(k + 1u) * step) : 0u;
+            uint32_t lead = 1;
+            bool all = true;
+#pragma unroll
+            for (uint32_t k = 0; k < 7u; k++) {
+                all = all && ids[k] == idmax;
+                lead += all ? 1u : 0u;
+            }
+            if (unc_only && b == 0 && lead < (c.rsi < 4u ? c.rsi : 4u)) return;
+            if (p + (uint64_t)lead * step > end_bit) return;
+            br.skip((uint64_t)lead * step);
+            b += lead;
+        } else {
+            if (unc_only && (b == 0 || ++slow > 8u)) return;
+            uint32_t nblk = 1;
+            if (skip_cds(br, c, (pp && b == 0) ? 1u : 0u, b, nblk) != DEC_OK) return;
+            b += nblk;
+        }
         if (br.pos - pos > longest) return;
     }
-    if (b == c.rsi && br.pos <= end_bit) rec_out[at].x = (uint32_t)(br.pos - pos);
+    if (b == c.rsi && br.pos <= end_bit && br.pos - pos <= 0xFFFFFFFFull) rec_out[at].x = (uint32_t)(br.pos - pos);
 }
 
 __global__ void __launch_bounds__(64)
@@ -1641,6 +1699,9 @@ __global__ void k_expand2(const SparseTables t, const IdxCarry *__restrict__ car
 // wave-uniform values), but the stream is served from a 16 KiB LDS window that all 64 lanes refill
 // with coalesced 16-byte loads, so the parser never waits for HBM: a dependent global load per
 // refill of the bit window held the first version at ~5 MB/s of compressed input.
+#ifdef AEC_TUNING
+__device__ int g_dbg_serial = 0;      // (diagnostics, AEC_IDX_STATS=2: k_index names the RSIs it walks itself)
+#endif
 constexpr uint32_t kIdxWindowWords = 4096;
 
 struct LdsWindowFetch {
@@ -1887,6 +1948,9 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             if (lane == 0) rsi_off[r] = good;
             cur_start = good;
             n_serial++;
+#ifdef AEC_TUNING
+            if (lane == 0 && g_dbg_serial && n_serial <= 400u) printf("serial: RSI %llu at bit %llu\n", (unsigned long long)r, (unsigned long long)good);
+#endif
         }
         // keep the whole next CDS (and the readers' look-ahead) inside the LDS window
         if ((good >> 5) + (coop ? 66u : maxw + 2u) > base + kIdxWindowWords) {
@@ -2037,6 +2101,7 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     p.g.burn = tune("AEC_S2_BURN", 24u);
     p.g.fast = tune("AEC_S2_FAST", 1u);
     p.g.refill = tune("AEC_S2_REFILL", 16u);
+    p.g.uncrun = tune("AEC_S2_UNCRUN", 1u);
     const uint32_t W = p.g.lead + p.g.core + p.g.look, nw = W / 32;
     const uint32_t capdiv = tune("AEC_S2_CAPDIV", 8u);
     p.g.cap_lds = (W / (capdiv ? capdiv : 8u) + 63) & ~63u;
@@ -2268,6 +2333,9 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
 #ifdef AEC_TUNING
         if (tune_set("AEC_IDX_STATS")) {                   // (diagnostics: synchronises)
             (void)hipStreamSynchronize(st);
+            const int dbg = tune("AEC_IDX_STATS", 0) >= 2 ? 1 : 0;
+            const hipError_t de = hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_serial), &dbg, sizeof(dbg));
+            if (de != hipSuccess) fprintf(stderr, "g_dbg_serial: %s\n", hipGetErrorString(de));
             std::vector<uint32_t> cc(nwin);
             (void)hipMemcpy(cc.data(), t.ccnt, (size_t)nwin * 4, hipMemcpyDeviceToHost);
             uint32_t gave_up = 0, most = 0, nb = 0;

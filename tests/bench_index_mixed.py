@@ -35,6 +35,8 @@ def main():
         pick = rng.choice(nr, size=nr * pm // 1000, replace=False)
         for r in pick:
             host[r * rsi_bytes:(r + 1) * rsi_bytes] = rng.integers(0, 256, rsi_bytes, dtype=np.uint8)
+        if os.environ.get("MIX_DEBUG"):
+            print("noise RSIs:", " ".join(str(int(r)) for r in sorted(pick)[:3000]))
         codec = gpu.Codec(bps, bs, rsi, flags)
         d_in = torch.from_numpy(host).to(dev)
         d_out, cbytes, bits, _, d_off = codec.encode(d_in)
