@@ -2110,7 +2110,11 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     if (p.lds > 156 * 1024) return p;
     const uint64_t nwin_total = (total_bits + core + core - 1) / core;    // (+ one: the range starts on a core boundary)
     p.nwin_max = (uint32_t)(nwin_total < kS2SuperWindows ? nwin_total : kS2SuperWindows);
-    p.wpc = p.nwin_max >= 2048 ? 256u : (p.nwin_max >= 64 ? p.nwin_max / 8 : p.nwin_max);
+    // (windows per chunk: a lane of k_wide / k_rewalk follows the records through ONE chunk, ~1 us per window, and the
+    // walker takes a lookup per chunk, ~2 us -- chunks of 256 windows made the three of them 0.6 ms of latency per span,
+    // 17 % of the index time of a 64 MiB stream; measured 16 .. 256: 32 is best from 64 MiB to 1 GiB)
+    p.wpc = p.nwin_max >= 512 ? 32u : (p.nwin_max >= 64 ? 16u : p.nwin_max);
+    p.wpc = tune("AEC_S2_WPC", p.wpc);
     if (p.wpc == 0) p.wpc = 1;
     p.nchunk_max = (p.nwin_max + p.wpc - 1) / p.wpc;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
