@@ -2451,7 +2451,10 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
     if (rw < 1) rw = 1;
     if (rw > 8) rw = 8;
     p.rw = tune("AEC_TR_RW", (uint32_t)rw);
-    p.passes = tune("AEC_TR_PASSES", 3);
+    // (a run of k regions whose burn-in did not find the chain takes k repair passes, and a seam that stays costs far
+    // more than a pass: the walks behind it cannot jump across -- 1 GiB of config 3 with one pass too few 36 .. 400 ms
+    // instead of 24.  A pass with nothing to repair is a launch of a few microseconds, so there are two to spare.)
+    p.passes = tune("AEC_TR_PASSES", 5);
     // RSIs per record: a walk meets the trunk inside one RSI with probability about 1 - exp(-rsi bits / sync);
     // enough RSIs that a true start fails once in 1e5
     {
@@ -2501,12 +2504,16 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
     // tests/emul on the config-3 shape: 15 + 15 parses per node against 280; 16 + 8 with 128 parses).
     p.co = tune("AEC_TR_CO", (!p.staged && c.rsi >= 8 * cds) ? 1u : 0u);
     if (p.co) {
+        // (measured on config 3, 1 GiB: what counts is that two or three workgroups fit a CU -- 96 kbit + 16 kbit of margin
+        // 24.0 ms, 64 + 32 kbit 27.0, 128 + 16 kbit 28.0; walks that leave the margin are handed on, which costs little)
         uint64_t core = 1024 * cds;
-        if (core > 65536) core = 65536;
+        if (core > 98304) core = 98304;
         uint32_t wpg = (uint32_t)(core / p.L);
         if (wpg < 1) wpg = 1;
         p.co_wpg = tune("AEC_TR_CO_WPG", wpg);
-        p.co_margin = tune("AEC_TR_CO_MARGIN", 32768u) & ~31u;
+        uint32_t margin = (uint32_t)((64u * cds + 1023u) & ~1023ull);
+        margin = margin < 8192u ? 8192u : (margin > 32768u ? 32768u : margin);
+        p.co_margin = tune("AEC_TR_CO_MARGIN", margin) & ~31u;
         if (p.co_margin < 2048u) p.co_margin = 2048u;
         p.co_shift = tune("AEC_TR_CO_SHIFT", 4u);
         if (p.co_shift < 2u || p.co_shift > 4u) p.co_shift = 4u;
