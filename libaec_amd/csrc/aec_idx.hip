@@ -1049,6 +1049,7 @@ k_seg_starts(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, co
 // Output for the candidates inside the core: the window's part of the global bitmap / prefix table
 // and its records (SparseTables above).
 constexpr uint32_t kS2BridgeCap = 1u << 18;  // hypotheses per span k_bridge takes on (more: left to the walker)
+constexpr uint32_t kS2FlatWindows = 48;     // spans of at most this many windows: no chunk-level walkers
 constexpr uint32_t kS2BridgeAfter = 16;      // RSIs the walker had to walk itself before k_bridge steps in
 
 struct Spec2Geom {
@@ -2315,24 +2316,33 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
             (void)hipEventRecord(side.tab[set], ts);
             (void)hipStreamWaitEvent(st, side.tab[set], 0);
         }
+        // (a few windows only -- a chunk of an HDF5 dataset: the walker takes a lookup per window itself, which costs
+        // what the chunk-level chase alone would, and five launches less)
+        const bool flat = nwin <= kS2FlatWindows;
+        if (flat) t.wide = nullptr;
         // (the chunk-level chase has a few hundred wavefronts: with the walkers, beside the next span's k_spec2)
-        (void)hipMemsetAsync(tb + p.o_wide, 0, (size_t)nchunks * p.g.cap_core * sizeof(uint4), st);
-        (void)hipMemsetAsync(centry, 0, (size_t)nchunks * sizeof(ChunkEntry), st);
+        if (!flat) {
+            (void)hipMemsetAsync(tb + p.o_wide, 0, (size_t)nchunks * p.g.cap_core * sizeof(uint4), st);
+            (void)hipMemsetAsync(centry, 0, (size_t)nchunks * sizeof(ChunkEntry), st);
+        }
         if (tune("AEC_S2_BRIDGE", 1))
             hipLaunchKernelGGL(k_bridge, dim3(1024), dim3(64), 0, st, c, words, nwords, end_bit, t,
                                const_cast<uint2 *>(t.rec), blist, blist_cnt, carry, first ? 1u : 0u,
                                (uint32_t)tune("AEC_S2_BRIDGE_AFTER", kS2BridgeAfter));
-        hipLaunchKernelGGL(k_wide, dim3((p.g.cap_core + 255) / 256, nchunks), dim3(256), 0, st, t, nwin, end_bit,
-                           const_cast<uint4 *>(t.wide));
+        if (!flat)
+            hipLaunchKernelGGL(k_wide, dim3((p.g.cap_core + 255) / 256, nchunks), dim3(256), 0, st, t, nwin, end_bit,
+                               const_cast<uint4 *>(t.wide));
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
                            d_res, (const uint64_t *)nullptr, hops, hop_cap, carry, first ? 1u : 0u, last ? 1u : 0u,
                            start_block, rsi_start, tail_slot, TwTables{}, centry, t, (uint32_t *)nullptr, last ? stop_near : 0ull);
-        hipLaunchKernelGGL(k_rewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, t, nwin, nchunks, end_bit, centry, rhops,
-                           nhops, d_rsi_off);
+        if (!flat)
+            hipLaunchKernelGGL(k_rewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, t, nwin, nchunks, end_bit, centry, rhops,
+                               nhops, d_rsi_off);
         hipLaunchKernelGGL(k_expand2, dim3((hop_cap + 255) / 256), dim3(256), 0, st, t, carry, hops,
                            (const uint32_t *)nullptr, 0u, 0u, d_rsi_off);
-        hipLaunchKernelGGL(k_expand2, dim3((nchunks * p.wpc * 2 + 255) / 256), dim3(256), 0, st, t, carry, rhops, nhops,
-                           nchunks, p.wpc * 2, d_rsi_off);
+        if (!flat)
+            hipLaunchKernelGGL(k_expand2, dim3((nchunks * p.wpc * 2 + 255) / 256), dim3(256), 0, st, t, carry, rhops, nhops,
+                               nchunks, p.wpc * 2, d_rsi_off);
         if (piped) (void)hipEventRecord(side.done[set], st);
 #ifdef AEC_TUNING
         if (tune_set("AEC_IDX_STATS")) {                   // (diagnostics: synchronises)
