@@ -1577,7 +1577,28 @@ __device__ void bridge_one(const Cfg &c, const uint32_t *__restrict__ words, uin
         }
         if (br.pos - pos > longest) return;
     }
-    if (b == c.rsi && br.pos <= end_bit && br.pos - pos <= 0xFFFFFFFFull) rec_out[at].x = (uint32_t)(br.pos - pos);
+    if (b != c.rsi || br.pos > end_bit || br.pos - pos > 0xFFFFFFFFull) return;
+    const uint64_t e1 = br.pos;
+    uint32_t y = 1u;
+    // Is the RSI start behind it a candidate of ITS window?  A window that begins inside a long RSI may have no chain
+    // on the boundaries yet where the RSI ends (burn-in), and the walker would have to take the next RSI coded data
+    // set by coded data set: that RSI goes into the record as well then -- a chain of two, the walker lands on the
+    // third, a whole ordinary RSI further on.
+    if (!(c.flags & F_PAD_RSI) && e1 < t.hi && e1 < end_bit) {
+        uint2 r2;
+        uint32_t wv, ix;
+        if (!sparse_lookup(t, e1, r2, wv, ix)) {
+            b = 0;
+            bool ok = true;
+            while (ok && b < c.rsi) {
+                uint32_t nblk = 1;
+                ok = skip_cds(br, c, (pp && b == 0) ? 1u : 0u, b, nblk) == DEC_OK && br.pos - e1 <= longest;
+                b += nblk;
+            }
+            if (ok && b == c.rsi && br.pos <= end_bit && br.pos - pos < (1ull << 24)) y = (2u << 24) | (uint32_t)(br.pos - pos);
+        }
+    }
+    rec_out[at] = make_uint2((uint32_t)(e1 - pos), y);
 }
 
 __global__ void __launch_bounds__(64)

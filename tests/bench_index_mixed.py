@@ -20,6 +20,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size-mib", type=int, default=1024)
     ap.add_argument("--noise-permille", type=int, nargs="+", default=[0, 1, 10, 50])
+    ap.add_argument("--noise-bits", type=int, default=16,
+                    help="random bits per sample of the sprinkled RSIs (16: incompressible; 13: long but compressible)")
     args = ap.parse_args()
     import torch
     from libaec_amd import gpu
@@ -34,7 +36,7 @@ def main():
         host = base.copy()
         pick = rng.choice(nr, size=nr * pm // 1000, replace=False)
         for r in pick:
-            host[r * rsi_bytes:(r + 1) * rsi_bytes] = rng.integers(0, 256, rsi_bytes, dtype=np.uint8)
+            host[r * rsi_bytes:(r + 1) * rsi_bytes] = rng.integers(0, 1 << args.noise_bits, rsi_bytes // 2, dtype=np.uint16).view(np.uint8)
         if os.environ.get("MIX_DEBUG"):
             print("noise RSIs:", " ".join(str(int(r)) for r in sorted(pick)[:3000]))
         codec = gpu.Codec(bps, bs, rsi, flags)
@@ -51,7 +53,7 @@ def main():
             torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
         ok = bool(torch.equal(d_idx[:nr], d_off[:nr]))
-        print(f"c2 {args.size_mib} MiB, {pm} per mille incompressible RSIs ({len(pick)}): stream {cbytes >> 20} MiB, "
+        print(f"c2 {args.size_mib} MiB, {pm} per mille RSIs of {args.noise_bits} random bits ({len(pick)}): stream {cbytes >> 20} MiB, "
               f"index {best * 1e3:.2f} ms = {n / best / 1e9:.2f} GB/s decoded-equivalent, offsets {'OK' if ok else 'MISMATCH'}")
 
 

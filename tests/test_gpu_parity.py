@@ -744,11 +744,13 @@ def test_uniform_batch_encode_device_api(gpu, bps, bs, rsi, flags, n_rsi, n_chun
         at += len(want)
 
 
-def test_index_bridges_rsis_longer_than_the_look_ahead(gpu):
-    """A low-entropy stream with incompressible RSIs sprinkled in (each several times the average coded RSI, more
-    than the window tables' look-ahead): the RSI starts found from the stream alone must equal the encoder's table,
-    whether the unresolved RSIs are walked by the serial walker (first span) or parsed by k_bridge (from the span
-    behind the 16th such RSI on)."""
+@pytest.mark.parametrize("noise_bits", [16, 13])
+def test_index_bridges_rsis_longer_than_the_look_ahead(gpu, noise_bits):
+    """A low-entropy stream with long RSIs sprinkled in (each several times the average coded RSI, more than the
+    window tables' look-ahead) -- incompressible ones (16 random bits per sample: runs of uncompressed coded data sets
+    with the odd split block, found by their headers and bridged from the first span on) and noisy but compressible
+    ones (13 random bits: split options of k = 11 / 12, bridged once the walker has met sixteen of them, walked by
+    it until then): the RSI starts found from the stream alone must equal the encoder's table either way."""
     import torch
     n = 384 << 20
     free, _ = torch.cuda.mem_get_info()
@@ -760,7 +762,8 @@ def test_index_bridges_rsis_longer_than_the_look_ahead(gpu):
     nr = n // rsi_bytes
     rng = np.random.default_rng(3)
     for r in rng.choice(nr, size=nr // 100, replace=False):
-        data[r * rsi_bytes:(r + 1) * rsi_bytes] = rng.integers(0, 256, rsi_bytes, dtype=np.uint8)
+        noise = rng.integers(0, 1 << noise_bits, rsi_bytes // 2, dtype=np.uint16)
+        data[r * rsi_bytes:(r + 1) * rsi_bytes] = noise.view(np.uint8)
     codec = gpu.Codec(bps, bs, rsi, flags)
     d_in = torch.from_numpy(data).cuda()
     d_out, nbytes, tb, _, d_off = codec.encode(d_in)
