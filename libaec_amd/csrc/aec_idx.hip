@@ -614,12 +614,22 @@ struct CoCells {
     __device__ __forceinline__ uint32_t peek(uint32_t i) const { return v[i]; }
 };
 
+// (walks set aside after `park_at` parses: a workgroup lives as long as its longest walk -- 64 parses where the
+// average walk takes 12 -- and every wavefront held one of the long ones: 4 of 64 lanes busy per instruction.  The
+// long walks are continued densely packed in the first wavefronts, the others go on to the barrier.)
+constexpr uint32_t kCoPark = 256;
+struct CoParked {
+    uint32_t m, c_rel, pos_rel, bb;      // node, its position and the walk's from `base`, b | b_ros << 13
+};
+
 __global__ void __launch_bounds__(256)
 k_hyp_walk_co(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, uint32_t wpg, uint32_t margin,
-              uint32_t ngroups, uint32_t shift, uint32_t tmax, uint32_t cap, const CoLists ls)
+              uint32_t ngroups, uint32_t shift, uint32_t tmax, uint32_t cap, const CoLists ls, uint32_t park_at)
 {
     // ls.over_plain: walks that run over the end of their RSI before they land go to the plain walk as well
     extern __shared__ __attribute__((aligned(16))) uint32_t co_lds[];
+    __shared__ CoParked pk[kCoPark];
+    __shared__ uint32_t sh_npark;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const TrGlobal mem{s, g, t};
     for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -636,6 +646,7 @@ k_hyp_walk_co(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, u
             for (uint32_t i = tid; i < nw; i += nt) bm[i] = gw0 + i < gwn ? t.bitmap[gw0 + i] : 0u;
             for (uint32_t i = tid; i < ncell; i += nt) cellv[i] = 0u;
             if (tid <= w1 - w0) wnb[tid] = t.nbase[w0 + tid];
+            if (tid == 0) sh_npark = 0u;
         }
         __syncthreads();
         if (tid <= w1 - w0) wnp[tid] = wnb[tid] - wnb[0];
@@ -648,6 +659,16 @@ k_hyp_walk_co(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, u
         uint32_t m = tid, wi = 0;
         bool run = false;
         CoWalk h;
+        auto finish = [&](uint32_t node, uint32_t r, uint32_t hit) {
+            uint32_t tt = 0;
+            if (r == CO_LAND || r == CO_QUEUE || r == CO_OVER) {
+                if (h.pos - h.c > 0xFFFFFFFFull) r = CO_PLAIN;
+                tt = (uint32_t)(h.pos - h.c);
+            } else if (r == CO_LINK) {
+                tt = hit;
+            }
+            recs[node] = CoRec{co_pack(r, h.b, h.b_ros), tt};
+        };
         for (;;) {
             if (!run && m < nown) {
                 while (m >= wnp[wi + 1u]) wi++;
@@ -658,18 +679,46 @@ k_hyp_walk_co(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, u
             if (!__any(run)) break;
             if (run) {
                 uint32_t hit = 0;
-                uint32_t r = tr_co_step(s, c, st, cells, h, m, base, lim, shift, tmax, hit);
+                const uint32_t r = tr_co_step(s, c, st, cells, h, m, base, lim, shift, tmax, hit);
                 if (r != CO_RUN) {
-                    uint32_t tt = 0;
-                    if (r == CO_LAND || r == CO_QUEUE || r == CO_OVER) {
-                        if (h.pos - h.c > 0xFFFFFFFFull) r = CO_PLAIN;
-                        tt = (uint32_t)(h.pos - h.c);
-                    } else if (r == CO_LINK) {
-                        tt = hit;
-                    }
-                    recs[m] = CoRec{co_pack(r, h.b, h.b_ros), tt};
+                    finish(m, r, hit);
                     m += nt;
                     run = false;
+                } else if (h.steps == park_at) {
+                    const uint32_t slot = atomicAdd(&sh_npark, 1u);
+                    if (slot < kCoPark) {
+                        pk[slot] = CoParked{m, (uint32_t)(h.c - base), (uint32_t)(h.pos - base), h.b | (h.b_ros << 13)};
+                        m += nt;
+                        run = false;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t np = sh_npark < kCoPark ? sh_npark : kCoPark;
+            uint32_t j = tid, node = 0;
+            run = false;
+            for (;;) {
+                if (!run && j < np) {
+                    const CoParked q = pk[j];
+                    node = q.m;
+                    h.c = base + q.c_rel;
+                    h.pos = base + q.pos_rel;
+                    h.b = q.bb & 0x1FFFu;
+                    h.b_ros = q.bb >> 13;
+                    h.steps = park_at;
+                    j += nt;
+                    run = true;
+                }
+                if (!__any(run)) break;
+                if (run) {
+                    uint32_t hit = 0;
+                    const uint32_t r = tr_co_step(s, c, st, cells, h, node, base, lim, shift, tmax, hit);
+                    if (r != CO_RUN) {
+                        finish(node, r, hit);
+                        run = false;
+                    }
                 }
             }
         }
@@ -2402,7 +2451,7 @@ struct TrunkPlan {
     size_t lds;               // ... and the LDS of a workgroup
     // coalescing hypothesis walks (aec_trunk.h section 2b): windows per group, margin, bits per mark cell (log2),
     // parses before a walk is handed on, walks per group, LDS, list capacities
-    uint32_t co, co_wpg, co_margin, co_shift, co_tmax, co_cap, co_qcap, co_pcap, co_over;
+    uint32_t co, co_wpg, co_margin, co_shift, co_tmax, co_cap, co_qcap, co_pcap, co_over, co_park;
     size_t co_lds, o_coq, o_cop;
     uint32_t pcap;            // pool of RSI ends inside records
     uint32_t nwin_max;        // windows per span (launch set): core + look-ahead
@@ -2549,6 +2598,7 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
         p.co_shift = tune("AEC_TR_CO_SHIFT", 4u);
         if (p.co_shift < 2u || p.co_shift > 4u) p.co_shift = 4u;
         p.co_tmax = tune("AEC_TR_CO_TMAX", 64u);
+        p.co_park = tune("AEC_TR_CO_PARK", 16u);
         p.co_cap = tune("AEC_TR_CO_CAP", 1024u);
         // walks whose count runs over the end of their RSI before they land:
         // (AEC_TR_CO_OVER=1, measurements: every such walk to the plain walk.  The walks that matter among them -- true
@@ -2558,7 +2608,7 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
         if (p.co_cap > kCoMaxOwners) p.co_cap = kCoMaxOwners;
         const uint64_t bits = (uint64_t)p.co_wpg * p.L + p.co_margin;
         p.co_lds = ((bits / 32 + 8) + bits / 32 + ((bits >> p.co_shift) + 2) + 2 * ((size_t)p.co_wpg + 1)) * 4 + (size_t)p.co_cap * 8 + 64;
-        if (bits + 0x1000 >= 0x40000 || p.co_lds > 160 * 1024) p.co = 0;     // (k_hyp_walk_co packs distances inside a group into 19 bits)
+        if (bits + 0x1000 >= 0x40000 || p.co_lds + sizeof(CoParked) * kCoPark + 64 > 160 * 1024) p.co = 0;     // (k_hyp_walk_co packs distances inside a group into 19 bits)
     }
     {
         // (nodes of a chunk's first windows: room for one per 0.4 average coded data sets, as for the node records)
@@ -2703,10 +2753,11 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
             ls.over_plain = p.co_over;
             (void)hipMemsetAsync(ls.counts, 0, 8, st);
             const uint32_t ng = (g.ncore + p.co_wpg - 1) / p.co_wpg;
-            const uint32_t per_cu = (uint32_t)(160 * 1024 / p.co_lds) ? (uint32_t)(160 * 1024 / p.co_lds) : 1u;
+            const size_t lds_wg = p.co_lds + sizeof(CoParked) * kCoPark + 64;          // (dynamic + the kernel's own)
+            const uint32_t per_cu = (uint32_t)(160 * 1024 / lds_wg) ? (uint32_t)(160 * 1024 / lds_wg) : 1u;
             const uint32_t grid = ng < 256u * per_cu ? ng : 256u * per_cu;
             hipLaunchKernelGGL(k_hyp_walk_co, dim3(grid), dim3(256), p.co_lds, st, c, s, g, t, p.co_wpg, p.co_margin, ng,
-                               p.co_shift, p.co_tmax, p.co_cap, ls);
+                               p.co_shift, p.co_tmax, p.co_cap, ls, p.co_park);
             hipLaunchKernelGGL(k_hyp_walk_rest, dim3((p.co_qcap + 63) / 64 < 16384u ? (p.co_qcap + 63) / 64 : 16384u), dim3(64), 0,
                                st, c, s, g, t, ls);
             hipLaunchKernelGGL(k_hyp_defer, dim3(g.ncore), dim3(256), 0, st, c, g, t, ls);

@@ -102,6 +102,12 @@ def run(args):
         cap = data.size * 2 + 4096
         rc_r, enc_r = drive(ref, "encode", data, params, plan, cap)
         rc_p, enc_p = drive(prod, "encode", data, params, plan, cap)
+        # (a flush call BEHIND the one that completed the stream makes the reference write its last byte again,
+        # encode.c:686-695 -- which the driver above does when the reference's output happened to end exactly on the
+        # end of a buffer.  The product hands out in batches and never repeats the byte: the stream proper is compared.)
+        if rc_r == rc_p and enc_r == enc_p + enc_p[-1:] and enc_p:
+            print(f"case {case}: the reference repeated its last byte on a flush call behind the end", flush=True)
+            enc_r = enc_p
         if (rc_r, enc_r) != (rc_p, enc_p):
             why = f"encode: reference rc {rc_r} {len(enc_r)} bytes, product rc {rc_p} {len(enc_p)} bytes"
         else:

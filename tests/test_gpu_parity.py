@@ -12,7 +12,7 @@ from helpers import (AEC_DATA_3BYTE, AEC_DATA_MSB, AEC_DATA_PREPROCESS, AEC_DATA
                      AEC_FLUSH, AEC_MEM_ERROR, AEC_NO_FLUSH, AEC_NOT_ENFORCE, AEC_OK,
                      AEC_RESTRICTED, AEC_STREAM_ERROR, ROOT, bytes_per_sample, have_ref,
                      max_encoded_size, oracle_decode, oracle_encode, pack_samples,
-                     random_walk_samples, ref_decode, ref_encode, unpack_samples, craft_overlong_stream)
+                     random_walk_samples, ref_decode, ref_encode, ref_lib, unpack_samples, craft_overlong_stream)
 
 pytestmark = pytest.mark.gpu
 
@@ -812,6 +812,30 @@ def test_random_sweep_of_the_streaming_calls(api):
     if not have_ref():
         pytest.skip("oracle/_ref not built")
     assert fuzz_stream_gpu.run(argparse.Namespace(cases=40, seed=1, dump="", ref_only=False, big=False)) == 0
+
+
+def test_flush_calls_after_the_stream_is_complete(api):
+    """A caller whose buffer came back FULL from the call that completed the stream calls aec_encode(AEC_FLUSH) once
+    more.  The reference then writes the byte it still holds again (encode.c:686-695 has no guard for a flush that is
+    complete): its stream ends with the last byte twice -- and WHICH calls do that depends on how its output happens
+    to fall onto the caller's buffers.  The product hands output out in batches (include/libaec.h), so it cannot repeat
+    that byte in the same calls and does not repeat it at all: a complete stream stays complete (deliberate deviation,
+    DESIGN.md section 1; found by tests/fuzz_stream_gpu.py --seed 43, case 113)."""
+    import fuzz_stream_gpu
+    if not have_ref():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(113)
+    for bps, bs, rsi, flags in ((8, 64, 128, 0), (16, 16, 16, PP)):
+        vals = random_walk_samples(rng, 12000, bps, flags, scale=3.0, zero_frac=0.2, jump_frac=0.002)
+        data = pack_samples(vals, bps, flags)
+        params = (bps, bs, rsi, flags)
+        rc, whole = fuzz_stream_gpu.drive(ref_lib(), "encode", data, params, [(1 << 30, 1 << 20)], 1 << 20)
+        assert rc == 0
+        plan = [(1 << 30, len(whole))]                     # the whole stream in one buffer that comes back full
+        rc_r, enc_r = fuzz_stream_gpu.drive(ref_lib(), "encode", data, params, plan, 1 << 20)
+        rc_p, enc_p = fuzz_stream_gpu.drive(api.library(), "encode", data, params, plan, 1 << 20)
+        assert enc_r == whole + whole[-1:], "the reference no longer repeats its last byte"
+        assert (rc_p, enc_p) == (0, whole)
 
 
 def test_bare_stream_decodes_by_segments(gpu):
