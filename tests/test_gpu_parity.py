@@ -814,6 +814,39 @@ def test_random_sweep_of_the_streaming_calls(api):
     assert fuzz_stream_gpu.run(argparse.Namespace(cases=40, seed=1, dump="", ref_only=False, big=False)) == 0
 
 
+def test_large_one_shot_decode_of_damaged_streams(api):
+    """aec_buffer_decode of 160 MiB runs as pipelined batches (index pass on a piece of the stream, copy-out of one batch
+    beside the kernels of the next).  Damage in the first, a middle and the last batch, a cut
+    stream and a garbage tail must come out as from the oracle: same return code, and the same bytes where it is
+    AEC_OK (flipped bits can leave a stream that still decodes)."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 4 << 30:
+        pytest.skip("not enough device memory")
+    bps, bs, rsi, flags = 16, 16, 128, PP
+    n = 160 << 20
+    data = gen(0, n)
+    rc, enc = api.aec_buffer_encode(data, bps, bs, rsi, flags)
+    assert rc == AEC_OK
+    rng = np.random.default_rng(160)
+    cases = [("intact", bytes(enc))]
+    for name, where in (("first batch", 0.1), ("middle batch", 0.45), ("last batch", 0.93)):
+        b = bytearray(enc)
+        at = int(len(b) * where)
+        b[at:at + 40] = bytes(rng.integers(0, 256, 40, dtype=np.uint8).tolist())
+        cases.append((f"40 bytes overwritten in the {name}", bytes(b)))
+    cases.append(("cut + garbage", bytes(enc[: int(len(enc) * 0.6)]) + bytes(rng.integers(0, 256, 50, dtype=np.uint8).tolist())))
+    cases.append(("garbage tail", bytes(enc) + bytes(rng.integers(0, 256, 200, dtype=np.uint8).tolist())))
+    for name, stream in cases:
+        rc_o, dec_o = ref_decode(stream, bps, bs, rsi, flags, n) if have_ref() else oracle_decode(stream, bps, bs, rsi, flags, n)[:2]
+        rc_p, dec_p = api.aec_buffer_decode(stream, bps, bs, rsi, flags, n)
+        assert rc_p == rc_o, (name, rc_p, rc_o)
+        if rc_o == AEC_OK:
+            assert dec_p == dec_o, name
+        if name in ("intact", "garbage tail"):
+            assert rc_p == AEC_OK and np.array_equal(np.frombuffer(dec_p, dtype=np.uint8), data), name
+
+
 def test_flush_calls_after_the_stream_is_complete(api):
     """A caller whose buffer came back FULL from the call that completed the stream calls aec_encode(AEC_FLUSH) once
     more.  The reference then writes the byte it still holds again (encode.c:686-695 has no guard for a flush that is
