@@ -2802,7 +2802,8 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
         if (d_seg_bits) {
             // (at most one RSI per minimal coded RSI of the span; a wavefront each, the rest in turn)
             const uint64_t most = (uint64_t)g.ncore * g.L / ((uint64_t)c.segs_per_rsi * (c.id_len + 2u)) + 2u;
-            const uint32_t grid = (uint32_t)(most < 4096u ? most : 4096u);
+            const uint32_t gmax = tune("AEC_TR_SEG_GRID", 4096u);
+            const uint32_t grid = (uint32_t)(most < gmax ? most : gmax);
             hipLaunchKernelGGL(k_seg_starts, dim3(grid), dim3(64), 0, st, c, s, g, t, d_rsi_off, carry, d_res, d_seg_bits,
                                max_rsi + 1u);
         }

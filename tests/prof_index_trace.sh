@@ -1,10 +1,10 @@
 #!/bin/bash
 # per-dispatch kernel durations of one index pass (tests/bench_index.py), in launch order.
-#   tests/prof_index_trace.sh <outdir-under-gpurun_out> <config> [size-mib]
-OUT=$PWD/gpurun_out/$1; CFG=$2; SZ=${3:-1024}; R=$PWD
+#   tests/prof_index_trace.sh <outdir-under-gpurun_out> <config> [size-mib] [--decode]
+OUT=$PWD/gpurun_out/$1; CFG=$2; SZ=${3:-1024}; EXTRA=$4; R=$PWD
 mkdir -p $OUT
 ( cd /tmp && export TMPDIR=/tmp
-  timeout -s KILL 500 rocprofv3 --kernel-trace --output-format csv -d $OUT/tr_$CFG -- python3 $R/tests/bench_index.py --config $CFG --size-mib $SZ > $OUT/bench_index_$CFG.txt 2>&1 )
+  timeout -s KILL 500 rocprofv3 --kernel-trace --output-format csv -d $OUT/tr_$CFG -- python3 $R/tests/bench_index.py --config $CFG --size-mib $SZ $EXTRA > $OUT/bench_index_$CFG.txt 2>&1 )
 f=$(find $OUT/tr_$CFG -name "*kernel_trace.csv" | head -1)
 python3 - "$f" > $OUT/trace_$CFG.txt <<'PY'
 import csv, re, sys
