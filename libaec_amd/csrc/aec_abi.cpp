@@ -34,6 +34,7 @@
 #include "../../include/aec_gpu.h"
 #include "../../include/libaec.h"
 #include "aec_cfg.h"
+#include "aec_pool.h"
 
 using namespace aec;
 
@@ -925,22 +926,16 @@ int run_parts(size_t n, size_t total_bytes, Part part)
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return AEC_FAIL(AEC_MEM_ERROR);
     std::vector<int> rcs(parts, AEC_OK);
-    auto work = [&](size_t t) {
+    // (the threads are kept between calls: aec_pool.h)
+    WorkerPool::run(parts, [&](size_t t) {
         (void)hipSetDevice(device);
+        const bool outer = !t_in_part;
         t_in_part = true;
         try { rcs[t] = part(n * t / parts, n * (t + 1) / parts); }
         catch (const std::bad_alloc &) { rcs[t] = AEC_MEM_ERROR; }
-        t_in_part = false;
-    };
-    std::vector<std::thread> th;
-    size_t started = 1;
-    try {
-        for (; started < parts; started++) th.emplace_back(work, started);
-    } catch (...) {                      // (no more threads: this one does the rest of the parts in turn)
-    }
-    work(0);
-    for (size_t t = started; t < parts; t++) work(t);
-    for (std::thread &x : th) x.join();
+        catch (...) { rcs[t] = AEC_MEM_ERROR; }
+        if (outer) t_in_part = false;
+    });
     int rc = AEC_OK;
     for (size_t t = 0; t < parts; t++)
         if (rcs[t] != AEC_OK) rc = rcs[t];

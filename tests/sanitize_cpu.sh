@@ -16,3 +16,6 @@ g++ $SAN -std=c++17 -Wno-unknown-pragmas -o tests/emul/_build/libtrunk_emul.so t
 gcc $SAN -o oracle/_build/libaec_oracle.so oracle/aec_oracle.c
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 \
     python3 -m pytest tests/test_lane_emul.py tests/test_trunk_emul.py tests/test_oracle.py -q -x
+# the host threads of the batch entry points (libaec_amd/csrc/aec_pool.h) under ThreadSanitizer
+g++ -O1 -g -fsanitize=thread -std=c++17 -pthread tests/c/pool_test.cpp -o $T/pool_test_tsan
+TSAN_OPTIONS=die_after_fork=0 $T/pool_test_tsan

@@ -92,3 +92,15 @@ def test_fails_loudly_without_gpu(lib):
     from libaec_amd import gpu
     with pytest.raises(RuntimeError):
         gpu.Codec(16, 16, 128, 8)
+
+
+def test_worker_pool_of_the_batch_entry_points(tmp_path):
+    """libaec_amd/csrc/aec_pool.h (host only): the threads that drive the parts of a batch are kept between calls.
+    tests/c/pool_test.cpp: every task of every job exactly once, two callers at a time, more tasks than workers, a
+    forked child with a pool of its own (tests/sanitize_cpu.sh runs the same under ThreadSanitizer)."""
+    import subprocess
+    exe = tmp_path / "pool_test"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "c", "pool_test.cpp"), "-o", str(exe)],
+                   check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
