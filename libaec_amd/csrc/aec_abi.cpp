@@ -1090,9 +1090,32 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
     int worst = AEC_OK;
     // the outputs: through pinned staging in pieces of whole slots (one transfer per piece, then copies to the
     // callers' buffers on a few threads), or chunk by chunk where there is no staging to be had
+    // (pieces of about 4 MiB through the two halves of the staging buffer: the transfer of piece p + 1 runs beside the
+    // host's copies of piece p -- one transfer of a whole part and then its copies were the two largest items of a
+    // batch of 64 x 1 MiB behind the index kernels)
     const size_t slot_out = (size_t)rpc * rsi_bytes;
-    const size_t per_piece = slot_out && slot_out <= kStagePiece ? kStagePiece / slot_out : 0;
-    const bool staged = n >= 4 && per_piece && stage_ensure(k, (n < per_piece ? n : per_piece) * slot_out);
+    constexpr size_t kOutPiece = (size_t)4 << 20;
+    const size_t per_piece = !slot_out ? 0 : (slot_out <= kOutPiece ? kOutPiece / slot_out : (slot_out <= kStagePiece / 2 ? 1 : 0));
+    const size_t npieces = per_piece ? (n + per_piece - 1) / per_piece : 0;
+    const size_t half_bytes = per_piece * slot_out;
+    bool staged = n >= 4 && per_piece && stage_ensure(k, (npieces > 1 ? 2 : 1) * (n < per_piece ? n : per_piece) * slot_out);
+    for (int e = 0; e < 2 && staged; e++)
+        if (!k.ev_copied[e]) staged = hipEventCreateWithFlags(&k.ev_copied[e], hipEventDisableTiming) == hipSuccess;
+    auto fetch = [&](size_t piece) -> bool {         // the transfer of a piece into half (piece & 1)
+        const size_t first = piece * per_piece, cnt = n - first < per_piece ? n - first : per_piece;
+        return hipMemcpyAsync(k.h_stage + (piece & 1) * half_bytes, static_cast<uint8_t *>(k.d_out.p) + first * slot_out,
+                              cnt * slot_out, hipMemcpyDeviceToHost, k.stream) == hipSuccess &&
+               hipEventRecord(k.ev_copied[piece & 1], k.stream) == hipSuccess;
+    };
+    auto landed = [&](size_t piece) -> bool {
+        if (!t_in_part) return hipEventSynchronize(k.ev_copied[piece & 1]) == hipSuccess;
+        for (;;) {                                   // (polling, as batch_sync does)
+            const hipError_t e = hipEventQuery(k.ev_copied[piece & 1]);
+            if (e != hipErrorNotReady) return e == hipSuccess;
+            std::this_thread::yield();
+        }
+    };
+    if (staged && !fetch(0)) return AEC_FAIL(AEC_MEM_ERROR);
     std::vector<CopyJob> jobs;
     for (size_t i = 0; i < n; i++) {
         const uint64_t blocks = res[i].n_rsi * c.rsi + res[i].tail_blocks;
@@ -1101,16 +1124,12 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
         int st = res[i].status == DEC_DATA_ERROR ? AEC_DATA_ERROR : AEC_OK;
         if (!grouped && res[n].status != DEC_OK && res[n].bad_rsi / rpc == i) st = AEC_DATA_ERROR;
         if (staged) {
-            const size_t first = i - i % per_piece;
-            if (i == first) {                            // a new piece: bring its slots over
-                const size_t cnt = n - first < per_piece ? n - first : per_piece;
-                if (hipMemcpyAsync(k.h_stage, static_cast<uint8_t *>(k.d_out.p) + first * slot_out, cnt * slot_out,
-                                   hipMemcpyDeviceToHost, k.stream) != hipSuccess ||
-                    batch_sync(k.stream) != hipSuccess)
-                    return AEC_FAIL(AEC_MEM_ERROR);
+            const size_t piece = i / per_piece, first = piece * per_piece;
+            if (i == first) {                            // a new piece: the next one sets out, this one has to be here
+                if ((piece + 1 < npieces && !fetch(piece + 1)) || !landed(piece)) return AEC_FAIL(AEC_MEM_ERROR);
                 jobs.clear();
             }
-            jobs.push_back(CopyJob{dst[i], k.h_stage + (i - first) * slot_out, produced});
+            jobs.push_back(CopyJob{dst[i], k.h_stage + (piece & 1) * half_bytes + (i - first) * slot_out, produced});
             if (i + 1 == n || (i + 1) % per_piece == 0) copy_all(jobs);
         } else if (produced && hipMemcpyAsync(dst[i], static_cast<uint8_t *>(k.d_out.p) + i * slot_out, produced,
                                               hipMemcpyDeviceToHost, k.stream) != hipSuccess) {
