@@ -62,7 +62,15 @@ private:
         static std::mutex *m = new std::mutex;           // (never destroyed)
         return *m;
     }
-    static void forget_in_child() { slot() = nullptr; }  // (the child has none of the threads; the old object leaks)
+    // fork: the child has none of the threads (the old object leaks there); the lock that guards the pointer is held
+    // across the fork so that the child does not inherit it locked by a thread it does not have
+    static void fork_prepare() { slot_mu().lock(); }
+    static void fork_parent() { slot_mu().unlock(); }
+    static void fork_child()
+    {
+        slot() = nullptr;
+        slot_mu().unlock();
+    }
     static WorkerPool *instance()
     {
         std::lock_guard<std::mutex> lk(slot_mu());
@@ -70,7 +78,7 @@ private:
             static bool hooked = false;
             if (!hooked) {
                 hooked = true;
-                (void)pthread_atfork(nullptr, nullptr, forget_in_child);
+                (void)pthread_atfork(fork_prepare, fork_parent, fork_child);
             }
             slot() = new (std::nothrow) WorkerPool;
         }
