@@ -233,7 +233,13 @@ k_trunk_coop(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, co
             }
             pos = prev;
         }
-        for (uint32_t w = w0; w < w1; w++) pos = coop_trunk_window(cw, c, g, t, w, pos, exit_out);
+        for (uint32_t w = w0; w < w1; w++) {
+            if (mode && w > w0 && pos == t.entry[w]) {       // (back on the chain the region held before: tr_trunk_region)
+                for (uint32_t u = w + lane; u < w1; u += 64u) exit_out[u] = exit_prev[u];
+                break;
+            }
+            pos = coop_trunk_window(cw, c, g, t, w, pos, exit_out);
+        }
     }
 }
 

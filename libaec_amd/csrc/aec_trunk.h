@@ -379,7 +379,14 @@ AEC_HD void tr_trunk_region(const TrStream &s, const Cfg &c, const TrGeom &g, co
         }
         pos = prev;
     }
-    for (uint32_t w = w0; w < w1; w++) pos = tr_trunk_window(s, c, g, t, w, pos, exit_out, mode);
+    for (uint32_t w = w0; w < w1; w++) {
+        // (a repair that is back on the chain the region held before: the windows from here on stand as they are)
+        if (exit_prev && mode == TR_COUNT && w > w0 && pos == t.entry[w]) {
+            for (uint32_t u = w; u < w1; u++) exit_out[u] = exit_prev[u];
+            return;
+        }
+        pos = tr_trunk_window(s, c, g, t, w, pos, exit_out, mode);
+    }
 }
 
 // scan over the windows (serial form; the kernel does the same with a workgroup scan)
