@@ -2178,7 +2178,9 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     p.g.burn = tune("AEC_S2_BURN", 24u);
     p.g.fast = tune("AEC_S2_FAST", 1u);
     p.g.refill = tune("AEC_S2_REFILL", 16u);
-    p.g.uncrun = tune("AEC_S2_UNCRUN", 1u);
+    // (headers of one or two bits -- AEC_RESTRICTED with at most 4 bits per sample -- are no pattern to go by: eight
+    // in a row happen by chance all the time there)
+    p.g.uncrun = tune("AEC_S2_UNCRUN", c.id_len >= 3u ? 1u : 0u);
     const uint32_t W = p.g.lead + p.g.core + p.g.look, nw = W / 32;
     const uint32_t capdiv = tune("AEC_S2_CAPDIV", 8u);
     p.g.cap_lds = (W / (capdiv ? capdiv : 8u) + 63) & ~63u;

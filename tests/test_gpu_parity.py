@@ -575,6 +575,12 @@ def test_pad_rsi_and_restricted_through_abi(api):
         vals = rng.integers(0, 1 << bps, size=5000)
         vals[1000:3000] = vals[1000]
         check_roundtrip(api, f"restricted-{bps}", bps, 16, 10, fl, pack_samples(vals, bps, fl))
+    # (the same with streams of megabytes: headers of one or two bits through the window tables of the index pass)
+    for bps, rsi in ((2, 64), (4, 128)):
+        fl = PP | AEC_RESTRICTED
+        vals = np.clip(np.cumsum(rng.integers(-1, 2, size=3_000_000)) + (1 << (bps - 1)), 0, (1 << bps) - 1)
+        vals[rng.random(vals.size) < 0.3] = 0
+        check_roundtrip(api, f"restricted-{bps}-3M", bps, 16, rsi, fl, pack_samples(vals, bps, fl))
 
 
 def _check_truncated(dec, dec_o, plain, bs, nb, what):
