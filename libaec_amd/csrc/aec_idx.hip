@@ -1503,7 +1503,8 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             const uint64_t two = ((uint64_t)win[q0 >> 5] << 32) | win[(q0 >> 5) + 1u];
             const uint32_t id = (uint32_t)((two << (q0 & 31u)) >> (64u - c.id_len));
             const uint32_t slot = atomicAdd(blist_cnt, 1u);
-            if (slot < kS2BridgeCap) blist[slot] = (uint32_t)at | (id == (1u << c.id_len) - 1u ? 0x80000000u : 0u);
+            // (bits 26 .. 30: the header itself)
+            if (slot < kS2BridgeCap) blist[slot] = (uint32_t)at | (id << 26) | (id == (1u << c.id_len) - 1u ? 0x80000000u : 0u);
         }
         gcpos[at] = (uint16_t)(cpos[i] - c0);
     }
@@ -1670,7 +1671,7 @@ k_bridge(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
     const uint32_t n = *blist_cnt < kS2BridgeCap ? *blist_cnt : kS2BridgeCap;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
         const uint32_t e = blist[j];
-        if (all || (e >> 31)) bridge_one(c, words, nwords, end_bit, t, rec_out, e & 0x7FFFFFFFu, !all);
+        if (all || (e >> 31)) bridge_one(c, words, nwords, end_bit, t, rec_out, e & 0x03FFFFFFu, !all);
     }
 }
 
@@ -2440,6 +2441,16 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
             IdxCarry h{};
             (void)hipMemcpy(&h, carry, sizeof(h), hipMemcpyDeviceToHost);
             (void)hipMemcpy(&nb, blist_cnt, 4, hipMemcpyDeviceToHost);
+            {
+                const uint32_t m = nb < kS2BridgeCap ? nb : kS2BridgeCap;
+                std::vector<uint32_t> bl(m);
+                if (m) (void)hipMemcpy(bl.data(), blist, (size_t)m * 4, hipMemcpyDeviceToHost);
+                uint32_t hist[32] = {0};
+                for (uint32_t v : bl) hist[(v >> 26) & 31u]++;
+                fprintf(stderr, "  headers of the listed hypotheses:");
+                for (uint32_t q = 0; q < (1u << c.id_len); q++) fprintf(stderr, " %u:%u", q, hist[q]);
+                fprintf(stderr, "\n");
+            }
             fprintf(stderr, "window tables, span %llu: %u windows (%u gave up), candidates per window %.0f on average, %u at "
                     "most (room for %u) | so far RSIs %llu, walked serially %u, table lookups %u | hypotheses listed for "
                     "k_bridge %u\n", (unsigned long long)si, nwin, gave_up, nwin ? (double)sum / nwin : 0.0, most,
