@@ -25,8 +25,8 @@ cp $OUT/sq_c2/summary.txt $OUT/pmc_sq_c2_4GiB.txt 2>/dev/null
 [ -x build/store_pattern ] && timeout 120 build/store_pattern > $OUT/store_pattern.txt 2>&1
 python3 tests/bench_index.py --config c2 --size-mib 1 64 1024 > $OUT/bench_index.txt 2>&1
 python3 tests/bench_index.py --config c5 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
-python3 tests/bench_index.py --config c3 --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
-python3 tests/bench_index.py --config typical --size-mib 64 1024 >> $OUT/bench_index.txt 2>&1
+python3 tests/bench_index.py --config c3 --size-mib 1 8 64 1024 >> $OUT/bench_index.txt 2>&1
+python3 tests/bench_index.py --config typical --size-mib 1 8 64 1024 >> $OUT/bench_index.txt 2>&1
 # index + segment starts + decode of the bare stream (the device API the ABI decode and bench decode_bare use)
 for c in c2 c3 c5 typical; do
   s="64 1024 4096"; [ $c = typical ] && s="64 1024"
