@@ -1802,8 +1802,10 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         const uint64_t *__restrict__ chunk_off, IdxHop *__restrict__ hops, uint32_t hop_cap, IdxCarry *carry,
         uint32_t first, uint32_t last, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
         const TwTables sp, ChunkEntry *__restrict__ centry, const SparseTables s2,
-        uint32_t *__restrict__ batch_nhops = nullptr, uint64_t stop_near = 0)
+        uint32_t *__restrict__ batch_nhops = nullptr, uint64_t stop_near = 0,
+        const uint32_t *__restrict__ skip_if = nullptr)
 {
+    if (skip_if && *skip_if) return;                 // (the phase-locked chains have delivered everything: launch_index_locked)
     // stop_near (bits; callers that index a stream piece by piece and have more of it than they hand in): an RSI the
     // tables do not resolve within this many bits of the end of the input is not walked serially -- the tables end
     // there for lack of look-ahead, the caller's next piece resolves it -- the pass ends in front of it
@@ -2857,10 +2859,376 @@ bool index_is_windowed(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint)
     return in_bytes && sparse2_plan(c, (uint64_t)in_bytes * 8, rsi_bits_hint).ok;
 }
 
+// ======== short RSIs: phase-locked chains =================================================================
+// Both table schemes follow chains that parse WITHOUT reference samples and try RSI starts as hypotheses on them.
+// That needs RSIs much longer than the distance such a chain takes to find the true one again behind an RSI start
+// (a hundred coded data sets): with RSIs of 1 .. 32 blocks -- narrow SZIP scan lines -- no chain is ever on the true
+// one, every RSI fell to the serial walker, and 16 MiB took 0.7 s (one host core with the reference: 0.03 s).
+// Short RSIs allow something simpler: a chain that keeps the RSI's bookkeeping itself (a reference sample every `rsi`
+// blocks, zero runs by the block count) is the TRUE chain for good once it stands on an RSI start with its count at
+// zero -- it locks, after about (bits per coded data set) x rsi steps from anywhere.  So: the stream in regions;
+// per region a wavefront of 64 such chains from 64 places in front of it, the state most of them agree on where the
+// region begins is the guess for its entry; one lane walks the region from there (count); regions whose entry is
+// not where the region in front of them ended are walked again from there (repair passes, as for the trunk; the
+// first region starts from the caller's exact state); a scan numbers the RSIs; a last walk writes their starts.
+// If the regions do not all agree in the end, or a coded data set of the agreed chain does not parse, nothing is
+// delivered and the serial walker behind takes the stream as before: results never rest on the guesses.
+struct LkState {
+    uint64_t pos;
+    uint32_t b, st;        // blocks of the current RSI done; st: 0 walking, 1 no coded data set ends inside the input, 2 refused
+};
+struct LockTables {
+    LkState *entry, *exit0, *exit1;
+    uint32_t *cnt;         // RSI starts met in the region
+    uint64_t *base;        // ... in front of the region
+    uint32_t *flags;       // [0] done (k_index behind returns at once), [1] inconsistent
+    uint32_t nreg, region_bits, lead;
+    uint64_t lo;           // bit position where region 0 begins (the caller's start)
+};
+
+__device__ __forceinline__ void lk_step(const TrStream &s, const Cfg &c, LkState &x)
+{
+    const uint32_t ref = (x.b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u;
+    uint32_t nz;
+    const uint32_t len = tr_cds(s, c, x.pos, ref, nz);
+    if (!len) {
+        x.st = 1u;
+        return;
+    }
+    const uint32_t nb = tr_blocks(c, nz, x.b);
+    if (!nb) {
+        x.st = 2u;
+        return;
+    }
+    x.pos += len;
+    x.b += nb;
+    if (x.b >= c.rsi) x.b = 0u;
+}
+
+// the guess for the entry of every region but the first: 64 chains from 64 places in front of it
+__global__ void __launch_bounds__(64)
+k_lock_guess(const Cfg c, const TrStream s, const LockTables t)
+{
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t r = 1u + blockIdx.x; r < t.nreg; r += gridDim.x) {
+        const uint64_t rstart = t.lo + (uint64_t)r * t.region_bits;
+        uint64_t from = rstart > t.lo + t.lead ? rstart - t.lead : t.lo;
+        LkState x{from + (uint64_t)lane * 37u, 0u, 0u};
+        // (a chain that cannot go on starts again one bit further: it is a guess either way)
+        uint32_t steps = 0;
+        const uint32_t most = 4u * (t.lead / (c.id_len + 1u) + 64u);
+        while (x.pos < rstart && steps++ < most) {
+            const uint32_t b_was = x.b;
+            lk_step(s, c, x);
+            if (x.st) {
+                if (x.st == 1u) break;
+                // (a zero run that does not fit the RSI by this chain's count: the count is wrong -- an RSI may start here;
+                // refused with the count at zero as well: one bit on)
+                if (b_was == 0u) x.pos++;
+                x.b = 0u;
+                x.st = 0u;
+            }
+        }
+        const bool have = x.st == 0u && x.pos >= rstart;
+        // the state most lanes stand on
+        uint64_t left = __ballot(have);
+        LkState best{rstart, 0u, 0u};
+        uint32_t best_n = 0;
+        for (uint32_t round = 0; round < 8u && left; round++) {
+            const uint32_t l0 = (uint32_t)__builtin_ctzll(left);
+            const uint64_t p0 = __shfl(x.pos, (int)l0);
+            const uint32_t b0 = (uint32_t)__shfl((int)x.b, (int)l0);
+            const uint64_t same = __ballot(have && x.pos == p0 && x.b == b0);
+            const uint32_t n = (uint32_t)__popcll(same);
+            if (n > best_n) {
+                best_n = n;
+                best = LkState{p0, b0, 0u};
+            }
+            left &= ~same;
+        }
+        if (lane == 0) t.entry[r] = best;
+    }
+}
+
+// mode 0: count from the guessed entries; 1: repair (regions whose entry is not the exit of the region in front)
+__global__ void __launch_bounds__(64)
+k_lock_walk(const Cfg c, const TrStream s, const LockTables t, const LkState *exit_prev, LkState *exit_out, uint32_t mode,
+            uint64_t start_bit, uint32_t start_block)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= t.nreg) return;
+    LkState x;
+    if (r == 0u) {
+        if (mode) {
+            exit_out[0] = exit_prev[0];
+            return;
+        }
+        x = LkState{start_bit, start_block, 0u};
+        t.entry[0] = x;
+    } else if (!mode) {
+        x = t.entry[r];
+    } else {
+        const LkState prev = exit_prev[r - 1u], mine = t.entry[r];
+        if (prev.st || (prev.pos == mine.pos && prev.b == mine.b)) {
+            exit_out[r] = exit_prev[r];
+            return;
+        }
+        x = LkState{prev.pos, prev.b, 0u};
+        t.entry[r] = x;
+    }
+    // (the last region has no end: its walk stops where the input does)
+    const uint64_t rend = r + 1u == t.nreg ? ~0ull : t.lo + (uint64_t)(r + 1u) * t.region_bits;
+    uint32_t n = 0;
+    while (x.pos < rend) {
+        n += x.b == 0u ? 1u : 0u;
+        lk_step(s, c, x);
+        if (x.st) break;
+    }
+    t.cnt[r] = n;
+    exit_out[r] = x;
+}
+
+// one workgroup: the first region in which the walk ended (those behind it are dead: nobody confirmed their
+// guesses), do the live regions agree, RSI starts in front of every region
+__global__ void __launch_bounds__(1024)
+k_lock_scan(const LockTables t, const LkState *exit_last)
+{
+    __shared__ uint64_t sh[1024];
+    __shared__ uint32_t bad, first_end;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) {
+        bad = 0u;
+        first_end = t.nreg - 1u;
+    }
+    __syncthreads();
+    const uint32_t per = (t.nreg + nt - 1u) / nt, lo = tid * per, hi = lo + per < t.nreg ? lo + per : t.nreg;
+    for (uint32_t r = lo; r < hi; r++)
+        if (exit_last[r].st) {
+            atomicMin(&first_end, r);
+            break;
+        }
+    __syncthreads();
+    const uint32_t fe = first_end;
+    uint64_t sum = 0;
+    uint32_t wrong = 0;
+    for (uint32_t r = lo; r < hi; r++) {
+        const bool live = r <= fe;
+        if (live && r) {
+            const LkState prev = exit_last[r - 1u], mine = t.entry[r];
+            if (prev.pos != mine.pos || prev.b != mine.b) wrong = 1u;
+        }
+        if (!live) t.cnt[r] = 0u;
+        sum += live ? t.cnt[r] : 0u;
+    }
+    sh[tid] = sum;
+    if (wrong) atomicOr(&bad, 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t acc = 0;
+        for (uint32_t i = 0; i < nt; i++) {
+            const uint64_t v = sh[i];
+            sh[i] = acc;
+            acc += v;
+        }
+    }
+    __syncthreads();
+    uint64_t acc = sh[tid];
+    for (uint32_t r = lo; r < hi; r++) {
+        t.base[r] = acc;
+        acc += t.cnt[r];
+    }
+    if (tid == 0) {
+        t.flags[1] = bad;
+        t.flags[2] = fe;
+    }
+}
+
+// the RSI starts, and the result record; the first region in which the walk ended writes the record
+__global__ void __launch_bounds__(64)
+k_lock_fill(const Cfg c, const TrStream s, const LockTables t, const LkState *exit_last, const uint32_t *__restrict__ words,
+            uint64_t nwords, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res, uint32_t tail_slot,
+            uint64_t rsi_start_in)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= t.nreg || t.flags[1] || r > t.flags[2]) return;      // (not agreed, or behind the region that ended the walk)
+    const uint64_t rend = r + 1u == t.nreg ? ~0ull : t.lo + (uint64_t)(r + 1u) * t.region_bits;
+    LkState x = t.entry[r];
+    uint64_t idx = t.base[r];
+    // the last RSI start in front of this region (the RSI the walk is in when it enters): found by walking the nearest
+    // region in front that met one -- only the lane that ends the walk asks
+    auto start_in_front = [&]() -> uint64_t {
+        for (uint32_t q = r; q-- > 0u;) {
+            if (!t.cnt[q]) continue;
+            LkState y = t.entry[q];
+            const uint64_t qend = t.lo + (uint64_t)(q + 1u) * t.region_bits;
+            uint64_t last = rsi_start_in;
+            while (y.pos < qend) {
+                if (y.b == 0u) last = y.pos;
+                lk_step(s, c, y);
+                if (y.st) break;
+            }
+            return last;
+        }
+        return rsi_start_in;
+    };
+    uint64_t cur = 0;                                    // start of the RSI the walk is in, if it began in this region
+    bool met = false, clipped = false;
+    while (x.pos < rend) {
+        if (x.b == 0u) {
+            if (idx >= max_rsi) {                        // the caller's bound: ends on this RSI start
+                clipped = true;
+                break;
+            }
+            rsi_off[idx] = x.pos;
+            cur = x.pos;
+            met = true;
+            idx++;
+        }
+        lk_step(s, c, x);
+        if (x.st) break;
+    }
+    if (!clipped && !x.st) return;                       // the walk goes on in the next region
+    if (clipped) {
+        // (only the region that holds RSI number max_rsi gets here with idx == max_rsi at an RSI start)
+        res->n_rsi = max_rsi;
+        res->tail_blocks = 0;
+        res->end_bit = x.pos;
+        res->status = DEC_OK;                            // (the whole record: the walker behind does not start it then)
+        res->pad = 0u;
+        res->bad_rsi = ~0ull;
+        if (tail_slot) rsi_off[max_rsi] = met ? cur : start_in_front();
+        __threadfence();
+        t.flags[0] = 1u;
+        return;
+    }
+    // the walk ended here: only "the input ends inside this coded data set", confirmed by the sequential reader, is
+    // delivered; anything else is the serial walker's to report
+    if (x.st != 1u) return;
+    {
+        BitReaderT<QuadFetch> br;
+        br.init(QuadFetch{words, nwords}, s.end_bit, x.pos);
+        uint32_t nblk = 1;
+        if (skip_cds(br, c, (x.b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u, x.b, nblk) != DEC_NEED_INPUT) return;
+    }
+    // RSI starts met = idx; the last of them began an RSI that is not complete (or nothing at all behind it)
+    if (idx == 0) return;                                // (cannot happen: the first state is an RSI start)
+    res->n_rsi = idx - 1u;
+    res->tail_blocks = x.b;
+    res->end_bit = x.pos;
+    res->status = DEC_OK;
+    res->pad = 1u;
+    res->bad_rsi = ~0ull;
+    if (tail_slot) rsi_off[max_rsi] = met ? cur : start_in_front();
+    __threadfence();
+    t.flags[0] = 1u;
+}
+
+struct LockPlan {
+    bool ok;
+    uint32_t nreg, region_bits, lead;
+    size_t o_entry, o_exit0, o_exit1, o_cnt, o_base, o_flags, bytes;
+};
+
+LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, uint32_t start_block)
+{
+    LockPlan p{};
+    // (a walk that resumes inside an RSI -- streaming callers -- numbers its RSIs from the one it is in: the walker's)
+    // (without the preprocessor no coded data set holds a reference sample: nothing a chain could lock its count on)
+    if (!tune("AEC_IDX_LOCK", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS) || c.rsi > 32u || start_block != 0u) return p;
+    if (total_bits < (1u << 18)) return p;               // (a few thousand coded data sets: the serial walker is as fast)
+    uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 3;
+    if (cds < 8) cds = 8;
+    // lock distance ~ cds x rsi steps of cds bits; most of 64 chains are to be locked where the region begins
+    uint64_t lead = 4 * cds * cds * c.rsi;
+    if (lead < 8192) lead = 8192;
+    if (lead > (1u << 22)) return p;                     // (long coded data sets: too far to lock)
+    uint64_t region = lead < 16384 ? 16384 : lead;
+    region = (region + 1023) & ~1023ull;
+    const uint64_t nreg = (total_bits + region - 1) / region;
+    if (nreg > (1u << 24)) return p;
+    p.nreg = (uint32_t)nreg;
+    p.region_bits = (uint32_t)region;
+    p.lead = (uint32_t)lead;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t o = 0;
+    p.o_flags = o;  o = up(o + 64);
+    p.o_entry = o;  o = up(o + nreg * sizeof(LkState));
+    p.o_exit0 = o;  o = up(o + nreg * sizeof(LkState));
+    p.o_exit1 = o;  o = up(o + nreg * sizeof(LkState));
+    p.o_cnt = o;    o = up(o + nreg * 4);
+    p.o_base = o;   o = up(o + (nreg + 1) * 8);
+    p.bytes = o;
+    p.ok = true;
+    return p;
+}
+
+void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
+                         uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
+                         uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot)
+{
+    const TrStream s{words, nwords, end_bit};
+    LockTables t{};
+    t.flags = reinterpret_cast<uint32_t *>(base + p.o_flags);
+    t.entry = reinterpret_cast<LkState *>(base + p.o_entry);
+    t.exit0 = reinterpret_cast<LkState *>(base + p.o_exit0);
+    t.exit1 = reinterpret_cast<LkState *>(base + p.o_exit1);
+    t.cnt = reinterpret_cast<uint32_t *>(base + p.o_cnt);
+    t.base = reinterpret_cast<uint64_t *>(base + p.o_base);
+    t.nreg = p.nreg;
+    t.region_bits = p.region_bits;
+    t.lead = p.lead;
+    t.lo = start_bit;
+    (void)hipMemsetAsync(t.flags, 0, 64, st);
+    if (p.nreg > 1)
+        hipLaunchKernelGGL(k_lock_guess, dim3(p.nreg - 1 < 65536u ? p.nreg - 1 : 65536u), dim3(64), 0, st, c, s, t);
+    const uint32_t wgrid = (p.nreg + 63) / 64;
+    LkState *ex[2] = {t.exit0, t.exit1};
+    hipLaunchKernelGGL(k_lock_walk, dim3(wgrid), dim3(64), 0, st, c, s, t, (const LkState *)nullptr, ex[0], 0u, start_bit,
+                       start_block);
+    uint32_t cur = 0;
+    // (a stretch of k regions with wrong guesses -- incompressible data, where a chain needs far longer to lock -- takes
+    // k passes; a pass with nothing to repair is a few microseconds)
+    const uint32_t passes = tune("AEC_IDX_LOCK_PASSES", 48);
+    for (uint32_t k = 0; k < passes; k++) {
+        hipLaunchKernelGGL(k_lock_walk, dim3(wgrid), dim3(64), 0, st, c, s, t, (const LkState *)ex[cur], ex[cur ^ 1u], 1u,
+                           start_bit, start_block);
+        cur ^= 1u;
+    }
+    hipLaunchKernelGGL(k_lock_scan, dim3(1), dim3(1024), 0, st, t, (const LkState *)ex[cur]);
+    hipLaunchKernelGGL(k_lock_fill, dim3(wgrid), dim3(64), 0, st, c, s, t, (const LkState *)ex[cur], words, nwords, d_rsi_off,
+                       max_rsi, d_res, tail_slot, rsi_start);
+#ifdef AEC_TUNING
+    if (tune_set("AEC_IDX_STATS")) {                       // (diagnostics: synchronises)
+        (void)hipStreamSynchronize(st);
+        uint32_t fl[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(fl, t.flags, 16, hipMemcpyDeviceToHost);
+        std::vector<LkState> en(p.nreg), exs(p.nreg);
+        (void)hipMemcpy(en.data(), t.entry, p.nreg * sizeof(LkState), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(exs.data(), ex[cur], p.nreg * sizeof(LkState), hipMemcpyDeviceToHost);
+        uint32_t mism = 0, ended = 0, refused = 0;
+        for (uint32_t r = 1; r < p.nreg; r++) mism += exs[r - 1].st == 0 && (exs[r - 1].pos != en[r].pos || exs[r - 1].b != en[r].b);
+        for (uint32_t r = 0; r < p.nreg; r++) {
+            ended += exs[r].st == 1;
+            refused += exs[r].st == 2;
+        }
+        fprintf(stderr, "locked chains: %u regions of %u bits, lead %u | delivered %u, inconsistent %u, walk ended in region %u | "
+                "entries that are not the exit in front: %u, regions ended %u, refused %u\n", p.nreg, p.region_bits, p.lead, fl[0],
+                fl[1], fl[2], mism, ended, refused);
+    }
+#endif
+    // whatever was not delivered: the serial walker, which returns at once otherwise
+    hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res,
+                       (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start,
+                       tail_slot, TwTables{}, (ChunkEntry *)nullptr, SparseTables{}, (uint32_t *)nullptr, (uint64_t)0,
+                       (const uint32_t *)t.flags);
+}
+
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
 {
     const uint64_t end_bit = (uint64_t)in_bytes * 8;
     if (start_bit >= end_bit) return 0;
+    const LockPlan lp = lock_plan(c, end_bit - start_bit, rsi_bits_hint, 0u);
+    if (lp.ok) return lp.bytes;
     const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
     if (sp.ok) {
         // (many spans of windows: two sets of tables, so that the spans can be pipelined -- launch_index_sparse)
@@ -2880,6 +3248,14 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
     const uint64_t nwords = (in_bytes + 3) / 4, end_bit = (uint64_t)in_bytes * 8;
     // Low-entropy streams whose RSIs fit a window: candidates and RSI hypotheses per window (k_spec2); everything
     // else: the trunk.
+    if (d_ws && ws_bytes && start_bit < end_bit && !d_seg_bits) {
+        const LockPlan lp = lock_plan(c, end_bit - start_bit, rsi_bits_hint, start_block);
+        if (lp.ok && ws_bytes >= lp.bytes) {
+            launch_index_locked(c, lp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
+                                static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot);
+            return false;
+        }
+    }
     if (d_ws && ws_bytes && start_bit < end_bit) {
         const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
         if (sp.ok && ws_bytes >= sp.bytes) {

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=-1, help="run this case alone (the others only draw their random numbers)")
+    ap.add_argument("--time", action="store_true", help="time a second index pass per case and list the slowest shapes")
     return run(ap.parse_args())
 
 
@@ -30,6 +31,7 @@ def run(args):
     from libaec_amd import gpu
     rng = np.random.default_rng(args.seed)
     bad = 0
+    slow = []
     for case in range(args.cases):
         bps = int(rng.choice([8, 10, 12, 16, 16, 16, 24, 32]))
         bs = int(rng.choice([8, 16, 16, 32, 64]))
@@ -91,10 +93,24 @@ def run(args):
                 rc2, dec_o, _ = oracle_decode(enc, bps, bs, rsi, flags, nblk * bs * nb)
                 if status != 0 or d_dec.cpu().numpy().tobytes() != dec_o:
                     ok, why = False, f"decode differs from the oracle's (status {status})"
+        ms = 0.0
+        if args.time and ok:                     # (a second, warm index pass: which shapes are slow?)
+            import time
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            codec.index_async(d_out, nbytes, 0, d_idx, nr, d_res)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+            slow.append((data.size / ms / 1e6, f"case {case}: bps {bps} bs {bs} rsi {rsi} flags {flags} {data.size >> 20} MiB scale {scale} "
+                                                 f"ratio {data.size / nbytes:.2f}: index {ms:.2f} ms = {data.size / ms / 1e6:.2f} GB/s"))
         print(f"case {case}: bps {bps} bs {bs} rsi {rsi} flags {flags} n {n} scale {scale} ratio "
               f"{data.size / nbytes:.2f}: {'ok' if ok else 'MISMATCH ' + why}", flush=True)
         bad += 0 if ok else 1
         del d_in, d_out, d_off, d_idx
+    if args.time:
+        print("slowest index passes (decoded bytes per second of index time):")
+        for _, line in sorted(slow)[:25]:
+            print("  " + line)
     print("mismatches:", bad)
     return 1 if bad else 0
 

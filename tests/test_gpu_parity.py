@@ -792,7 +792,7 @@ def test_random_sweep_of_the_bare_stream_path(gpu):
     against the oracle's."""
     import argparse
     import fuzz_index_gpu
-    assert fuzz_index_gpu.run(argparse.Namespace(cases=30, seed=5, only=-1)) == 0
+    assert fuzz_index_gpu.run(argparse.Namespace(cases=30, seed=5, only=-1, time=False)) == 0
 
 
 def test_random_sweep_of_corrupted_streams(api):
