@@ -820,6 +820,46 @@ def test_random_sweep_of_the_streaming_calls(api):
     assert fuzz_stream_gpu.run(argparse.Namespace(cases=40, seed=1, dump="", ref_only=False, big=False)) == 0
 
 
+def test_streams_with_short_rsis(api, gpu):
+    """RSIs of 1 .. 32 blocks (narrow SZIP scan lines): no table scheme of the index pass applies -- its chains parse
+    without reference samples and every few coded data sets hold one -- and until round 4 every RSI fell to the serial
+    walker (16 MiB of 8-bit data with rsi 1: 3.2 s; the reference on one core: 0.05 s).  Now phase-locked chains find
+    the RSI starts (aec_idx.hip: launch_index_locked).  Offsets against the encoder's table, decoded bytes against the
+    oracle for whole, cut and garbage-tailed streams, and a loose bound on the time."""
+    import time
+    import torch
+    rng = np.random.default_rng(32)
+    for bps, bs, rsi, kind in ((8, 8, 1, 2), (8, 8, 5, 2), (16, 16, 3, 0), (16, 16, 16, 0), (16, 32, 32, 0), (8, 16, 8, 2)):
+        n = 6 << 20
+        data = gen(kind, n)
+        flags = PP
+        codec = gpu.Codec(bps, bs, rsi, flags)
+        d_in = torch.from_numpy(data).cuda()
+        d_out, nbytes, tb, _, d_off = codec.encode(d_in)
+        nr = codec.rsi_count(n)
+        d_idx = torch.zeros(nr + 2, dtype=torch.int64, device="cuda")
+        d_res = torch.zeros(40, dtype=torch.uint8, device="cuda")
+        codec.index_async(d_out, nbytes, 0, d_idx, nr, d_res)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        codec.index_async(d_out, nbytes, 0, d_idx, nr, d_res)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.uint64)
+        whole = codec.block_count(n) // rsi              # (a short last RSI counts as the trailing incomplete one)
+        assert int(res[0]) in (nr, whole) and torch.equal(d_idx[:whole], d_off[:whole]), (bps, bs, rsi)
+        assert dt < 0.25, f"index pass of {n >> 20} MiB with rsi {rsi} took {dt * 1e3:.0f} ms: the serial walker again?"
+        enc = d_out[:nbytes].cpu().numpy().tobytes()
+        for name, stream in (("whole", enc), ("cut", enc[: int(len(enc) * 0.61)]),
+                             ("cut + garbage", enc[: len(enc) // 3] + bytes(rng.integers(0, 256, 300, dtype=np.uint8).tolist())),
+                             ("garbage tail", enc + bytes(rng.integers(0, 256, 100, dtype=np.uint8).tolist()))):
+            rc_o, dec_o, _ = oracle_decode(stream, bps, bs, rsi, flags, n)
+            rc_p, dec_p = api.aec_buffer_decode(stream, bps, bs, rsi, flags, n)
+            assert rc_p == rc_o, (bps, bs, rsi, name, rc_p, rc_o)
+            if rc_o == AEC_OK:
+                assert dec_p == dec_o, (bps, bs, rsi, name)
+
+
 def test_large_one_shot_decode_of_damaged_streams(api):
     """aec_buffer_decode of 160 MiB runs as pipelined batches (index pass on a piece of the stream, copy-out of one batch
     beside the kernels of the next).  Damage in the first, a middle and the last batch, a cut
