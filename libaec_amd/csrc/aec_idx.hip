@@ -3135,14 +3135,16 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     // (a walk that resumes inside an RSI -- streaming callers -- numbers its RSIs from the one it is in: the walker's)
     // (without the preprocessor no coded data set holds a reference sample: nothing a chain could lock its count on)
     if (!tune("AEC_IDX_LOCK", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS) || c.rsi > 32u || start_block != 0u) return p;
-    if (total_bits < (1u << 18)) return p;               // (a few thousand coded data sets: the serial walker is as fast)
+    if (total_bits < (1u << 16)) return p;               // (a thousand coded data sets: the serial walker is as fast)
     uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 3;
     if (cds < 8) cds = 8;
     // lock distance ~ cds x rsi steps of cds bits; most of 64 chains are to be locked where the region begins
     uint64_t lead = 4 * cds * cds * c.rsi;
     if (lead < 8192) lead = 8192;
     if (lead > (1u << 22)) return p;                     // (long coded data sets: too far to lock)
-    uint64_t region = lead < 16384 ? 16384 : lead;
+    // (small streams: short regions -- the pass is as long as one lane's walk of a region, three times over)
+    const uint64_t rmin = total_bits < (1u << 22) ? 4096 : 16384;
+    uint64_t region = lead < rmin ? rmin : lead;
     region = (region + 1023) & ~1023ull;
     const uint64_t nreg = (total_bits + region - 1) / region;
     if (nreg > (1u << 24)) return p;
@@ -3288,6 +3290,9 @@ static uint32_t batch_hop_cap(const Sparse2Plan &p, size_t max_chunk_bytes)
 size_t index_batch_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t n_chunks, size_t max_chunk_bytes,
                                    uint64_t rsi_bits_hint)
 {
+    // (short RSIs: the window tables resolve none of them -- chunk by chunk through launch_index, whose phase-locked
+    // chains do)
+    if (c.rsi <= 32u && (c.flags & F_PREPROCESS) && !(c.flags & F_PAD_RSI)) return 0;
     const Sparse2Plan p = sparse2_plan(c, (uint64_t)in_bytes * 8, rsi_bits_hint);
     if (!p.ok || n_chunks == 0) return 0;
     const uint64_t nwin = ((uint64_t)in_bytes * 8 + p.g.core - 1) / p.g.core;

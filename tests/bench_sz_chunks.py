@@ -19,9 +19,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     run(64, 1 << 20)
     run(1024, 64 << 10)
+    if "--narrow" in sys.argv:                  # (scan lines of 32 pixels: RSIs of 4 blocks)
+        run(64, 1 << 20, 32)
+        run(1024, 64 << 10, 32)
 
 
-def run(n, chunk):
+def run(n, chunk, scanline=1024):
     import torch  # noqa: F401
     from helpers import REF_SO, have_ref
     from libaec_amd import szip
@@ -30,7 +33,9 @@ def run(n, chunk):
     data = gen(2, n * chunk)
     chunks = [data[i * chunk:(i + 1) * chunk] for i in range(n)]
     lib = szip.library()
-    prm = szip.SZ_com_t(opts, 8, 8, 1024)
+    prm = szip.SZ_com_t(opts, 8, 8, scanline)
+    if scanline != 1024:
+        print(f"scan lines of {scanline} pixels:")
 
     def one_by_one(lib_, name, srcs, cap):
         """n calls of SZ_BufftoBuff*: returns (seconds of the calls, outputs)"""
