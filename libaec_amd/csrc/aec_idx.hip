@@ -2540,14 +2540,13 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
     // windows: 128 to 256 coded data sets (measured at 253 bits per coded data set: 81 ms per GiB with windows of
     // 32768 or 16384 bits, 91 with 65536, 212 with 8192), fewer bits for small inputs so that the lanes still fill
     // the chip
-    // (... but never below 64 coded data sets, 32768 bits at most: smaller windows for small inputs were the rule of round 3,
-    // and with the sample shape -- 720 bits per coded data set -- windows of 8192 bits leave two thirds of the RSIs to the
-    // serial walker: 20 MiB took 83 ms where windows of 32768 bits take 8, 3 MiB 18 against 6; config 3 below 50 MiB
-    // 8 - 11 ms against 4 - 6)
-    uint32_t L = 2048, Lmin = 2048;
-    while (L < 65536u && L < 128 * cds) L *= 2;
-    while (Lmin < 32768u && Lmin < 64 * cds) Lmin *= 2;
-    while (L > Lmin && total_bits / L < 8192) L /= 2;
+    // (never below 32768 bits, whatever the size of the input: smaller windows for small inputs -- and for short coded
+    // data sets -- were the rule of round 3, and they leave most RSIs to the serial walker on many shapes: with the
+    // sample shape (720 bits per coded data set) windows of 8192 bits made 20 MiB take 83 ms where 32768 take 8; 16 MiB
+    // of 16-bit data at 8 bits per sample (rsi 128) 134 ms with 8192, 64 with 16384, 4.2 with 32768; 12-bit, rsi 64:
+    // 150 / 150 / 4.7 ms.  Found by sweeping sizes and shapes the benches do not have: tests/fuzz_index_gpu.py --time.)
+    uint32_t L = 32768;
+    if (total_bits >= (1ull << 28) && 128 * cds > 32768) L = 65536;      // (sample shape: 32768 is better below ~100 MiB)
     p.L = tune("AEC_TR_L", L);
     uint64_t lead = 4 * sync;
     if (lead < 4096) lead = 4096;
