@@ -53,6 +53,8 @@ done
 python3 tests/bench_index_mixed.py 2>&1 | grep -v amdgpu > $OUT/bench_index_mixed.txt
 python3 tests/bench_abi_small.py > $OUT/bench_abi_small.txt 2>&1
 for c in c2 c3 c5 typical; do python3 tests/bench_abi_large.py --config $c 2>&1 | grep -v amdgpu >> $OUT/bench_abi_large.txt; done
-python3 tests/bench_sz_chunks.py > $OUT/bench_sz_chunks.txt 2>&1
+python3 tests/bench_sz_chunks.py --narrow > $OUT/bench_sz_chunks.txt 2>&1
+python3 tests/bench_short_rsi.py 2>&1 | grep -v amdgpu > $OUT/bench_short_rsi.txt
+timeout 600 python3 tests/fuzz_index_gpu.py --cases 150 --seed 123 --time 2>&1 | grep -A25 "slowest" > $OUT/fuzz_index_slowest_shapes.txt
 python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
 rm -rf $OUT/sq_c2 $OUT/stats_* $OUT/traffic_c2 $OUT/traffic_c3 $OUT/traffic_c5 $OUT/traffic_typical $OUT/idx $OUT/idxpmc_* $OUT/idxsq_*
