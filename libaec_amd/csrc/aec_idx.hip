@@ -2559,7 +2559,11 @@ TrunkPlan trunk_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, 
     // (a run of k regions whose burn-in did not find the chain takes k repair passes, and a seam that stays costs far
     // more than a pass: the walks behind it cannot jump across -- 1 GiB of config 3 with one pass too few 36 .. 400 ms
     // instead of 24.  A pass with nothing to repair is a launch of a few microseconds, so there are two to spare.)
-    p.passes = tune("AEC_TR_PASSES", 5);
+    // (Sixteen: on raw samples without the preprocessor -- every block uncompressed, the same bits at the same place in
+    // every sample -- a chain off the true one does not find it again at all, whole runs of regions start wrong, and
+    // every pass repairs one more of a run: 16 MiB 85 / 63 / 122 ms with five passes, 77 / 42 / 109 with sixteen; still
+    // mostly serial, an open item.)
+    p.passes = tune("AEC_TR_PASSES", 16);
     // RSIs per record: a walk meets the trunk inside one RSI with probability about 1 - exp(-rsi bits / sync);
     // enough RSIs that a true start fails once in 1e5
     {
@@ -2838,6 +2842,8 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
     if (tune_set("AEC_IDX_STATS")) {                       // (diagnostics: synchronises)
         IdxCarry h{};
         (void)hipStreamSynchronize(st);
+        const int dbg = tune("AEC_IDX_STATS", 0) >= 2 ? 1 : 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_serial), &dbg, sizeof(dbg));
         (void)hipMemcpy(&h, carry, sizeof(h), hipMemcpyDeviceToHost);
         uint32_t co_counts[2] = {0, 0};
         if (p.co) (void)hipMemcpy(co_counts, base + 56, 8, hipMemcpyDeviceToHost);
