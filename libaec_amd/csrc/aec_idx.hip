@@ -220,6 +220,10 @@ k_trunk_coop(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, co
         if (!mode) {
             pos = rstart > g.start_bit + g.lead ? rstart - g.lead : g.start_bit;
             if (rend <= g.start_bit || rstart > s.end_bit) pos = kTrNone;
+            if (pos != kTrNone && pos != g.start_bit) {                      // (tr_trunk_region: a run of uncompressed headers)
+                const uint64_t q = tr_unc_run(s, c, g.start_bit, rstart);
+                if (q != kTrNone) pos = q;
+            }
             while (pos != kTrNone && pos < rstart) {                         // burn-in
                 uint32_t nzc;
                 const uint32_t len = cw.cds(c, pos, 0u, nzc);

@@ -352,6 +352,31 @@ AEC_HD uint64_t tr_trunk_window(const TrStream &s, const Cfg &c, const TrGeom &g
     return pos;
 }
 
+// A run of uncompressed coded data sets right in front of `upto`: the first of eight headers -- all ones -- a fixed
+// distance apart, or kTrNone.  Such a run is the true chain wherever it is met (chance aside, and the repair passes
+// check every region's entry anyway), and on raw samples without the preprocessor -- every block uncompressed, the
+// same bits at the same place in every sample -- it is the ONLY way onto it: a chain that is off there stays off.
+AEC_HD uint64_t tr_unc_run(const TrStream &s, const Cfg &c, uint64_t start_bit, uint64_t upto)
+{
+    const uint32_t step = c.id_len + c.bs * c.bps, idmax = (1u << c.id_len) - 1u;
+    const uint64_t span = 9ull * step;
+    if (upto < start_bit + span || upto > s.end_bit) return kTrNone;
+    const uint64_t from = upto - span;
+    auto id_at = [&](uint64_t q) -> uint32_t {
+        const uint64_t wi = q >> 5;
+        const uint64_t two = ((uint64_t)tr_word(s, wi) << 32) | tr_word(s, wi + 1u);
+        return (uint32_t)((two << (q & 31u)) >> (64u - c.id_len));
+    };
+    for (uint32_t k = 0; k < step; k++) {
+        const uint64_t q = from + k;
+        if (id_at(q) != idmax) continue;
+        bool run = true;
+        for (uint32_t j = 1; j < 8u && run; j++) run = id_at(q + (uint64_t)j * step) == idmax;
+        if (run) return q;
+    }
+    return kTrNone;
+}
+
 // One trunk lane: region r = windows [r * rw, ...).  exit_prev == nullptr: the first pass (burn-in from `lead`
 // bits in front of the region); else a repair pass: a region whose first window does not begin where the
 // window in front of it ended (exit_prev, the result of the pass before) is walked again from there.
@@ -366,6 +391,10 @@ AEC_HD void tr_trunk_region(const TrStream &s, const Cfg &c, const TrGeom &g, co
     } else if (!exit_prev) {
         pos = rstart > g.start_bit + g.lead ? rstart - g.lead : g.start_bit;
         if (rend <= g.start_bit || rstart > s.end_bit) pos = kTrNone;
+        if (pos != kTrNone && pos != g.start_bit) {
+            const uint64_t q = tr_unc_run(s, c, g.start_bit, rstart);
+            if (q != kTrNone) pos = q;                                   // (nine steps of burn-in instead of thousands)
+        }
         while (pos != kTrNone && pos < rstart) {                         // burn-in
             uint32_t nzc;
             const uint32_t len = tr_cds(s, c, pos, 0u, nzc);
