@@ -3148,9 +3148,12 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 3;
     if (cds < 8) cds = 8;
     // lock distance ~ cds x rsi steps of cds bits; most of 64 chains are to be locked where the region begins
-    uint64_t lead = 4 * cds * cds * c.rsi;
+    // (measured with factors 4 / 2 / 1: 16-bit, rsi 16: 20 / 13 / 10 ms per 16 MiB; 32-bit, block 32, rsi 5: 67 / 38 / 24 ms per
+    // 48 MiB; a guess that is wrong only costs a repair pass)
+    uint64_t lead = (uint64_t)tune("AEC_IDX_LOCK_LEAD", 2) * cds * cds * c.rsi;
     if (lead < 8192) lead = 8192;
-    if (lead > (1u << 22)) return p;                     // (long coded data sets: too far to lock)
+    // (long coded data sets: too far to lock, unless the stream is long enough for a number of such regions)
+    if (lead > (1u << 24) || (lead > (1u << 22) && total_bits < 4 * lead)) return p;
     // (small streams: short regions -- the pass is as long as one lane's walk of a region, three times over)
     const uint64_t rmin = total_bits < (1u << 22) ? 4096 : 16384;
     uint64_t region = lead < rmin ? rmin : lead;
