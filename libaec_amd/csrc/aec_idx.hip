@@ -3063,6 +3063,9 @@ k_lock_fill(const Cfg c, const TrStream s, const LockTables t, const LkState *ex
     const uint64_t rend = r + 1u == t.nreg ? ~0ull : t.lo + (uint64_t)(r + 1u) * t.region_bits;
     LkState x = t.entry[r];
     uint64_t idx = t.base[r];
+    // (regions behind the caller's bound have nothing to deliver: the ONE region in which RSI number max_rsi starts
+    // writes the record -- every region behind it would meet "idx >= max_rsi" at its first RSI start as well)
+    if (idx > max_rsi) return;
     // the last RSI start in front of this region (the RSI the walk is in when it enters): found by walking the nearest
     // region in front that met one -- only the lane that ends the walk asks
     auto start_in_front = [&]() -> uint64_t {
@@ -3084,7 +3087,7 @@ k_lock_fill(const Cfg c, const TrStream s, const LockTables t, const LkState *ex
     bool met = false, clipped = false;
     while (x.pos < rend) {
         if (x.b == 0u) {
-            if (idx >= max_rsi) {                        // the caller's bound: ends on this RSI start
+            if (idx == max_rsi) {                        // the caller's bound: ends on this RSI start
                 clipped = true;
                 break;
             }

@@ -849,7 +849,30 @@ def test_streams_with_short_rsis(api, gpu):
         whole = codec.block_count(n) // rsi              # (a short last RSI counts as the trailing incomplete one)
         assert int(res[0]) in (nr, whole) and torch.equal(d_idx[:whole], d_off[:whole]), (bps, bs, rsi)
         assert dt < 0.25, f"index pass of {n >> 20} MiB with rsi {rsi} took {dt * 1e3:.0f} ms: the serial walker again?"
+        # a caller's bound in the middle of the stream (what every batch but the last of a large decode asks for): ends
+        # on the start of RSI number `bound`, which ONE region delivers (every region behind it is past the bound too)
+        bound = whole // 3 + 1
+        d_idx.zero_()
+        codec.index_async(d_out, nbytes, 0, d_idx, bound, d_res)
+        torch.cuda.synchronize()
+        res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.uint64)
+        assert int(res[0]) == bound and int(res[1]) == 0 and int(res[2]) == int(d_off[bound]), (bps, bs, rsi, res[:3])
+        assert torch.equal(d_idx[:bound], d_off[:bound]), (bps, bs, rsi)
         enc = d_out[:nbytes].cpu().numpy().tobytes()
+        # ... and the streaming calls with little room per call: several batches, each resuming where the last ended
+        from libaec_amd.api import Decoder
+        d = Decoder(bps, bs, rsi, flags)
+        got = bytearray()
+        rc, used, out = d.call(enc, 1 << 20, AEC_NO_FLUSH)
+        got += out
+        while rc == AEC_OK and len(got) < n:
+            rc, used2, out = d.call(enc[used:] if used < len(enc) else b"", 1 << 20, AEC_NO_FLUSH)
+            used += used2
+            got += out
+            if not out and not used2:
+                break
+        assert d.end() == AEC_OK
+        assert rc == AEC_OK and bytes(got) == data.tobytes(), (bps, bs, rsi, len(got))
         for name, stream in (("whole", enc), ("cut", enc[: int(len(enc) * 0.61)]),
                              ("cut + garbage", enc[: len(enc) // 3] + bytes(rng.integers(0, 256, 300, dtype=np.uint8).tolist())),
                              ("garbage tail", enc + bytes(rng.integers(0, 256, 100, dtype=np.uint8).tolist()))):
