@@ -860,19 +860,9 @@ def test_streams_with_short_rsis(api, gpu):
         assert torch.equal(d_idx[:bound], d_off[:bound]), (bps, bs, rsi)
         enc = d_out[:nbytes].cpu().numpy().tobytes()
         # ... and the streaming calls with little room per call: several batches, each resuming where the last ended
-        from libaec_amd.api import Decoder
-        d = Decoder(bps, bs, rsi, flags)
-        got = bytearray()
-        rc, used, out = d.call(enc, 1 << 20, AEC_NO_FLUSH)
-        got += out
-        while rc == AEC_OK and len(got) < n:
-            rc, used2, out = d.call(enc[used:] if used < len(enc) else b"", 1 << 20, AEC_NO_FLUSH)
-            used += used2
-            got += out
-            if not out and not used2:
-                break
-        assert d.end() == AEC_OK
-        assert rc == AEC_OK and bytes(got) == data.tobytes(), (bps, bs, rsi, len(got))
+        import fuzz_stream_gpu
+        rc, got = fuzz_stream_gpu.drive(api.library(), "decode", enc, (bps, bs, rsi, flags), [(1 << 30, 1 << 20)], n)
+        assert rc == AEC_OK and got == data.tobytes(), (bps, bs, rsi, len(got))
         for name, stream in (("whole", enc), ("cut", enc[: int(len(enc) * 0.61)]),
                              ("cut + garbage", enc[: len(enc) // 3] + bytes(rng.integers(0, 256, 300, dtype=np.uint8).tolist())),
                              ("garbage tail", enc + bytes(rng.integers(0, 256, 100, dtype=np.uint8).tolist()))):
