@@ -173,6 +173,10 @@ AEC_GPU_API void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits);
  * (low-entropy streams, RSIs inside a 64-kbit window): cheap per call also for pieces of a few MiB, so a caller
  * may decode such a stream piece by piece and overlap one piece's transfers with the next one's kernels. */
 AEC_GPU_API int aec_gpu_index_is_windowed(const aec_gpu_params *p, size_t in_bytes, uint64_t rsi_bits);
+/* Which scheme the index pass of such a stream takes, given the workspace it asks for: 0 = the serial walk alone,
+ * 1 = phase-locked chains (RSIs of at most 32 blocks), 2 = window tables, 3 = the trunk.  start_block != 0: a walk that
+ * resumes inside an RSI (aec_gpu_index_resume_async).  Host arithmetic only; tests assert the path instead of a time. */
+AEC_GPU_API int aec_gpu_index_scheme(const aec_gpu_params *p, size_t in_bytes, uint64_t rsi_bits, unsigned int start_block);
 /* The NEXT index pass on ctx (one pass only) is handed a piece of a stream of which the caller holds more: an RSI
  * that the window tables leave unresolved within stop_near_bits of the end of the piece -- they end there for lack
  * of look-ahead -- is not walked serially; the pass ends in front of it (n_rsi RSIs, tail_blocks 0, end_bit = its

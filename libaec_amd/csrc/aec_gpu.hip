@@ -445,6 +445,13 @@ int aec_gpu_index_is_windowed(const aec_gpu_params *p, size_t in_bytes, uint64_t
     return cfg_from(p, 0, false, &c) == RC_OK && index_is_windowed(c, in_bytes, rsi_bits) ? 1 : 0;
 }
 
+int aec_gpu_index_scheme(const aec_gpu_params *p, size_t in_bytes, uint64_t rsi_bits, unsigned int start_block)
+{
+    Cfg c;
+    if (cfg_from(p, 0, false, &c) != RC_OK) return 0;
+    return index_scheme(c, in_bytes, rsi_bits, start_block);
+}
+
 void aec_gpu_trim(aec_gpu_ctx *ctx, size_t keep_bytes)
 {
     if (ctx->ws && ctx->ws_bytes > keep_bytes) {

@@ -1113,6 +1113,7 @@ constexpr uint32_t kS2BridgeAfter = 16;      // RSIs the walker had to walk itse
 
 struct Spec2Geom {
     uint32_t lead, core, look, stride, burn, cap_lds, cap_core, fast, refill, uncrun;
+    uint32_t v4;          // k_spec4 (a table of every position's coded data set) instead of k_spec2
 };
 
 __global__ void __launch_bounds__(1024)
@@ -1518,6 +1519,432 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     }
     if (tid == 0) gccnt[blockIdx.x] = ncore;
     stamp(6);
+}
+
+// ---- the same tables from a table of EVERY position's coded data set (round 5) --------------------------------
+// k_spec2 parses a coded data set wherever a walk stands (~100 vector instructions per parse, spec_cds_fast): the sync
+// chains alone take 27 000 parses per window, the catch-up of the RSI hypotheses 15 000 more, and the two phases were
+// 220 k of the window's 320 k cycles.  Here the length of the coded data set that would begin at a bit is tabulated for
+// ALL bits of the window first -- F[q], the nxt[] entry format of aec_spec.h -- which costs ~30 instructions per bit and
+// no divergence, because the end of a unary part is ONE lookup once the positions of the window's 1-bits lie in a
+// table: the n-th 1-bit behind q1 is ones[rank(q1) + n - 1].  (The table of ones is built tile by tile in the space
+// the candidate arrays take later; rank is a prefix count per word + one popcount.)  Every step of a chain or of a
+// catch-up walk is then one LDS read.  Everything else -- marks, candidates, hop tables, hypotheses, records -- is
+// k_spec2's, in the same order and with the same results: the tables a span gets are bit for bit the ones k_spec2
+// writes (tests: AEC_S2_V4=0/1 in the tuning build give identical index results; k_spec_verify on both).
+// LDS: win | marks | rank | sel | mpre | [cpos cnxt ua ub] (the ones tile while F is filled) | F[W] (later chop4
+// chop16 csucc).  W = 48 kbit fits the 160 KB of a CU.
+__global__ void __launch_bounds__(1024)
+k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
+        uint64_t start_bit, const Spec2Geom g, uint32_t *__restrict__ gbitmap, uint16_t *__restrict__ gpre,
+        uint2 *__restrict__ grec, uint16_t *__restrict__ gcpos, uint32_t *__restrict__ gccnt,
+        unsigned long long *__restrict__ prof, const uint64_t *__restrict__ starts = nullptr, uint32_t nstarts = 0,
+        uint32_t *__restrict__ blist = nullptr, uint32_t *__restrict__ blist_cnt = nullptr)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
+    __shared__ uint32_t sh_total, sh_next[2], sh_part[16];
+    auto stamp = [&](int k) {
+        if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    const uint32_t W = g.lead + g.core + g.look, nw = W / 32u, cap = g.cap_lds;
+    uint32_t *win = spec_lds;
+    uint32_t *marks = win + nw + 4;
+    uint16_t *rank = reinterpret_cast<uint16_t *>(marks + nw);
+    uint16_t *sel = rank + nw + 2;
+    uint16_t *mpre = sel + nw + 2;
+    uint16_t *cpos = mpre + nw + 2;
+    uint16_t *cnxt = cpos + cap;
+    uint16_t *ua = cnxt + cap;
+    uint16_t *ub = ua + cap;
+    uint16_t *F = ub + cap;                           // W entries; dead once the catch-up walks are through
+    uint16_t *chop4 = F;
+    uint16_t *chop16 = chop4 + cap;
+    uint16_t *csucc = chop16 + cap;
+    uint16_t *ones = cpos;                            // 4 * cap entries, while F is filled
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint64_t core_abs = tab_lo + (uint64_t)blockIdx.x * g.core;
+    const uint64_t gw0 = ((uint64_t)blockIdx.x * g.core) >> 5;
+    const uint32_t cw = g.core / 32u;
+    auto give_up = [&]() {
+        for (uint32_t i = tid; i < cw; i += nt) {
+            gbitmap[gw0 + i] = 0u;
+            gpre[gw0 + i] = 0;
+        }
+        if (tid == 0) gccnt[blockIdx.x] = 0u;
+    };
+    if (core_abs >= end_bit) {
+        give_up();
+        return;
+    }
+    const uint64_t wstart = core_abs >= g.lead ? core_abs - g.lead : 0;
+    const uint32_t c0 = (uint32_t)(core_abs - wstart), c1 = c0 + g.core;
+    const uint64_t w0 = wstart >> 5;
+    for (uint32_t i = tid; i < nw + 4; i += nt) {
+        const uint64_t idx = w0 + i;
+        win[i] = idx < nwords ? bswap32(words[idx]) : 0u;
+        if (i < nw) marks[i] = 0u;
+    }
+    __syncthreads();
+    auto prefix16 = [&](const uint32_t *src, uint16_t *dst) {
+        const uint32_t nwv = nt >> 6, wv = tid >> 6, ln = tid & 63u;
+        const uint32_t per = ((nw + nwv - 1u) / nwv + 63u) & ~63u;
+        const uint32_t lo = wv * per, hi = lo + per < nw ? lo + per : nw;
+        uint32_t carry = 0;
+        for (uint32_t base = lo; base < hi; base += 64) {
+            const uint32_t i = base + ln;
+            const uint32_t pc = i < hi ? (uint32_t)__popc(src[i]) : 0u;
+            const uint32_t incl = wave_incl_sum_dpp(pc);
+            if (i < hi) dst[i + 1] = (uint16_t)(carry + incl);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (ln == 0) sh_part[wv] = carry;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t v = 0; v < nwv; v++) {
+            const uint32_t t = sh_part[v];
+            before += v < wv ? t : 0u;
+            all += t;
+        }
+        for (uint32_t i = lo + ln; i < hi; i += 64) dst[i + 1] = (uint16_t)(dst[i + 1] + before);
+        if (tid == 0) {
+            dst[0] = 0;
+            sh_total = all;
+        }
+        __syncthreads();
+    };
+    prefix16(win, rank);
+    __syncthreads();
+    for (uint32_t i = tid; i < nw; i += nt) {
+        const uint32_t lo = rank[i], hi = rank[i + 1], m = (lo + 31u) >> 5;
+        if (32u * m + 1u > lo && 32u * m + 1u <= hi) sel[m] = (uint16_t)i;
+    }
+    __syncthreads();
+    const uint64_t left = end_bit - wstart;
+    const SpecWin s{win, rank, sel, nw, left < W ? (uint32_t)left : W};
+    stamp(1);
+    // ---- 0. F[q] for every bit of the window
+    {
+        const uint32_t il = c.id_len, idmax = (1u << il) - 1u, unc_len = il + c.bs * c.bps;
+        // a tile: `T` positions whose entries are computed + `look` bits behind them, in which any coded data set of a
+        // reference encoder ends (longer ones -- a foreign encoder's -- take the search over the rank table)
+        const uint32_t tcap = 4u * cap;
+        uint32_t look = (il + 1u + c.bs * c.bps + 63u) & ~31u;
+        if (look > tcap / 2u) look = (tcap / 2u) & ~31u;
+        const uint32_t T = (tcap - look) & ~31u;
+        for (uint32_t t0 = 0; t0 < s.limit; t0 += T) {
+            const uint32_t wlo = t0 >> 5, whi = (t0 + T + look) >> 5 < nw ? (t0 + T + look) >> 5 : nw;
+            const uint32_t r0 = rank[wlo], tcnt = (uint32_t)rank[whi] - r0;
+            // positions just behind the 1-bits of words [wlo, whi), one lane per byte
+            for (uint32_t j = tid; j < (whi - wlo) * 4u; j += nt) {
+                const uint32_t wi = wlo + (j >> 2), k = j & 3u, word = win[wi];
+                uint32_t at = (uint32_t)rank[wi] - r0 + (k ? (uint32_t)__popc(word >> (32u - 8u * k)) : 0u);
+                uint32_t bits = (word << (8u * k)) & 0xFF000000u;
+                const uint32_t base = wi * 32u + 8u * k + 1u;
+                while (bits) {
+                    const uint32_t z = (uint32_t)__builtin_clz(bits);
+                    bits &= ~(0x80000000u >> z);
+                    ones[at++] = (uint16_t)(base + z);
+                }
+            }
+            __syncthreads();
+            const uint32_t t1 = t0 + T < s.limit ? t0 + T : s.limit;
+            for (uint32_t q = t0 + tid; q < t1; q += nt) {
+                const uint32_t w = q >> 5, sh = q & 31u;
+                const uint32_t a = win[w], b = win[w + 1u];
+                const uint32_t h = spec_shl_hi(a, b, sh);
+                const uint32_t id = h >> (32u - il);
+                const bool unc = id == idmax, low = id == 0u;
+                const uint32_t selbit = (h >> (31u - il)) & 1u;
+                const uint32_t off1 = il + (low ? 1u : 0u);
+                const uint32_t n = low ? (selbit ? c.bs / 2u : 1u) : c.bs;
+                const uint32_t add = low ? 0u : n * (id - 1u);
+                const uint32_t q1 = q + off1, sh1 = q1 & 31u;
+                const uint32_t w1 = (q1 >> 5) == w ? a : b;
+                const uint32_t r1 = (uint32_t)rank[q1 >> 5] + (sh1 ? (uint32_t)__popc(w1 >> (32u - sh1)) : 0u);
+                const uint32_t k = r1 + n - 1u - r0;                       // index of the 1-bit that ends the unary part
+                uint32_t e = k < tcnt ? (uint32_t)ones[k] : 0u;
+                const bool in = q + il + 1u <= s.limit;
+                if (in && !unc && q1 < s.limit && k >= tcnt) e = spec_select(s, r1 + n);   // (beyond the tile: rare)
+                const uint32_t end = unc ? q + unc_len : e + add;
+                const bool ok = in && (unc || (q1 < s.limit && e != 0u && e != kSpecInvalid)) && end <= s.limit && end - q < 4096u;
+                F[q] = ok ? (uint16_t)((end - q) | ((low && !selbit) ? kNxtZero : kNxtBlock)) : (uint16_t)0;
+            }
+            __syncthreads();
+        }
+    }
+    stamp(2);
+    const bool use_fast = g.fast != 0;
+    auto near_end = [&](uint32_t pos) { return pos + 4096u > s.limit; };
+    auto cds1 = [&](uint32_t q, uint32_t &run) -> uint32_t {
+        if (!use_fast) return spec_cds(s, c, q, 1u, run);
+        uint32_t len = spec_cds_fast<1>(win, s.limit, c, q, run);
+        if (len == kSpecUnresolved) len = spec_cds(s, c, q, 1u, run);
+        return len;
+    };
+    // (q < s.limit; `run` != 0: a zero-block coded data set, the callers take its code from the length)
+    auto cds0 = [&](uint32_t q, uint32_t &run) -> uint32_t {
+        const uint32_t e = F[q];
+        run = e & kNxtZero;
+        return e & 0xFFFu;
+    };
+
+    // ---- 1. sync chains: burn in, then mark until a marked boundary is met
+    if (tid == 0 && start_bit >= wstart && start_bit - wstart < s.limit) {
+        const uint32_t q = (uint32_t)(start_bit - wstart);
+        atomicOr(&marks[q >> 5], 1u << (31u - (q & 31u)));
+    }
+    if (starts && tid == 0) {
+        uint32_t lo = 0, hi = nstarts;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            if (starts[mid] * 8u < wstart) lo = mid + 1u;
+            else hi = mid;
+        }
+        for (; lo < nstarts && starts[lo] * 8u - wstart < s.limit; lo++) {
+            const uint32_t q = (uint32_t)(starts[lo] * 8u - wstart);
+            atomicOr(&marks[q >> 5], 1u << (31u - (q & 31u)));
+        }
+    }
+    for (uint32_t q0 = tid * g.stride; q0 < s.limit; q0 += nt * g.stride) {
+        uint32_t q = q0;
+        bool ok = true;
+        for (uint32_t k = 0; k < g.burn && ok; k++) {
+            const uint32_t len = q < s.limit ? (uint32_t)F[q] & 0xFFFu : 0u;
+            ok = len != 0;
+            q += len;
+        }
+        while (ok && q < s.limit) {
+            const uint32_t bit = 1u << (31u - (q & 31u));
+            if (atomicOr(&marks[q >> 5], bit) & bit) break;
+            const uint32_t len = (uint32_t)F[q] & 0xFFFu;
+            ok = len != 0;
+            q += len;
+        }
+    }
+    // ---- 1b. runs of uncompressed coded data sets (k_spec2, step 1b)
+    {
+        const uint32_t il = c.id_len, step = il + c.bs * c.bps;
+        auto ones_of = [&](uint32_t a, uint32_t b, uint32_t d, uint32_t sh) -> uint32_t {
+            const uint64_t hi = ((uint64_t)a << 32) | b;
+            const uint64_t y = sh ? (hi << sh) | ((uint64_t)d >> (32u - sh)) : hi;
+            uint64_t m = y;
+            for (uint32_t k = 1; k < il; k++) m &= y << k;
+            return (uint32_t)(m >> 32);
+        };
+        const uint32_t w1 = step >> 5, s1 = step & 31u, w2 = (2u * step) >> 5, s2 = (2u * step) & 31u,
+                       w3 = (3u * step) >> 5, s3 = (3u * step) & 31u;
+        for (uint32_t i = tid; i < nw && g.uncrun; i += nt) {
+            if (i * 32u + 32u + 7u * step + il > s.limit) break;
+            const uint32_t a0 = win[i], b0 = win[i + 1u];
+            const uint32_t a1 = win[i + w1], b1 = win[i + w1 + 1u], d1 = win[i + w1 + 2u];
+            const uint32_t a2 = win[i + w2], b2 = win[i + w2 + 1u], d2 = win[i + w2 + 2u];
+            const uint32_t a3 = win[i + w3], b3 = win[i + w3 + 1u], d3 = win[i + w3 + 2u];
+            uint32_t hits = ones_of(a0, b0, 0u, 0u) & ones_of(a1, b1, d1, s1) & ones_of(a2, b2, d2, s2) & ones_of(a3, b3, d3, s3);
+            for (uint32_t k = 4; k < 8u && hits; k++) {
+                const uint32_t wk = i + ((k * step) >> 5);
+                hits &= ones_of(win[wk], win[wk + 1u], win[wk + 2u], (k * step) & 31u);
+            }
+            while (hits) {
+                const uint32_t j = (uint32_t)__builtin_clz(hits);
+                hits &= ~(0x80000000u >> j);
+                uint32_t q = i * 32u + j;
+                bool ok = true;
+                while (ok && q < s.limit) {
+                    const uint32_t bit = 1u << (31u - (q & 31u));
+                    if (atomicOr(&marks[q >> 5], bit) & bit) break;
+                    const uint32_t len = (uint32_t)F[q] & 0xFFFu;
+                    ok = len != 0;
+                    q += len;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    stamp(3);
+    prefix16(marks, mpre);
+    __syncthreads();
+    const uint32_t ncand = sh_total;
+    if (ncand > cap) {
+        give_up();
+        return;
+    }
+    // ---- 2. the candidates' positions and coded data sets
+    for (uint32_t i = tid; i < nw; i += nt) {
+        uint32_t m = marks[i], idx = mpre[i];
+        while (m) {
+            const uint32_t b = (uint32_t)__builtin_clz(m);
+            m &= ~(0x80000000u >> b);
+            const uint32_t q = i * 32u + b;
+            cpos[idx] = (uint16_t)q;
+            cnxt[idx] = q < s.limit ? F[q] : (uint16_t)0;
+            idx++;
+        }
+    }
+    __syncthreads();
+    // ---- 3. the RSI hypothesis at every candidate of the core
+    const uint32_t i0 = mpre[c0 >> 5], i1 = mpre[c1 >> 5 < nw ? c1 >> 5 : nw];
+    const uint32_t ncore = i1 - i0;
+    if (tid == 0) sh_next[0] = sh_next[1] = i0;
+    // A0. the first coded data set of every hypothesis (with the reference sample)
+    {
+        const uint32_t ref_first = (c.flags & F_PREPROCESS) ? 1u : 0u, bend = c.rsi;
+        for (uint32_t i = i0 + tid; i < i1; i += nt) {
+            const uint32_t p0 = cpos[i];
+            uint32_t delta = 0, bb = near_end(p0) ? kS2Limited : 0u;
+            if (p0 < s.limit) {
+                uint32_t run;
+                const uint32_t len = ref_first ? cds1(p0, run) : cds0(p0, run);
+                bool fail = len == 0u;
+                uint32_t n = 1;
+                if (!fail && run) {
+                    n = spec_run_blocks(c, len - c.id_len - 1u - (ref_first ? c.bps : 0u), 0u);
+                    fail = !n || n > bend;
+                    if (fail) bb = 0;
+                }
+                if (!fail) {
+                    const uint32_t pos = p0 + len;
+                    bb = pos >= s.limit ? kS2Limited : 0u;
+                    if (n >= bend || (pos < s.limit && s2_marked(marks, pos))) {
+                        delta = len;
+                        bb = n;
+                    } else if (pos < s.limit) {
+                        delta = len;
+                        bb = n | 0x8000u;
+                    }
+                }
+            }
+            ua[i] = (uint16_t)delta;
+            ub[i] = (uint16_t)bb;
+        }
+    }
+    __syncthreads();
+    // A1. catch-up: table steps (no reference sample) until the walk stands on a marked boundary
+    {
+        const uint32_t bend = c.rsi;
+        uint32_t i = 0, p0 = 0, pos = 0, b = 0;
+        bool have = false, out = false;
+        while (true) {
+            const uint64_t idle = __ballot(!have && !out), busy = __ballot(have);
+            if (!(idle | busy)) break;
+            if (idle && ((uint32_t)__popcll(idle) >= g.refill || !busy)) {
+                if (!have && !out) {
+                    i = atomicAdd(&sh_next[0], 1u);
+                    if (i >= i1) {
+                        out = true;
+                    } else {
+                        const uint32_t bb = ub[i], d0 = ua[i];
+                        if ((bb & 0x8000u) && d0) {
+                            p0 = cpos[i];
+                            pos = p0 + d0;
+                            b = bb & 0x7FFFu;
+                            have = true;
+                        }
+                    }
+                }
+            }
+            if (!have) continue;
+            uint32_t run;
+            const uint32_t len = cds0(pos, run);
+            bool fail = len == 0u, done = false;
+            uint32_t n = 1;
+            if (!fail && run) {
+                n = spec_run_blocks(c, len - c.id_len - 1u, b);
+                fail = !n || n > bend - b;
+            }
+            if (!fail) {
+                pos += len;
+                b += n;
+                if (b >= bend || (pos < s.limit && s2_marked(marks, pos))) done = true;
+                else if (pos >= s.limit) fail = true;
+            }
+            if (done && pos - p0 > 0xFFFFu) fail = true;
+            if (fail || done) {
+                ua[i] = fail ? (uint16_t)0 : (uint16_t)(pos - p0);
+                ub[i] = fail ? (uint16_t)((near_end(pos) || done) ? kS2Limited : 0u) : (uint16_t)b;
+                have = false;
+            }
+        }
+    }
+    __syncthreads();
+    stamp(4);
+    // ---- (F is dead: the hop tables take its place)
+    S2Win w{s, marks, mpre, cnxt, csucc, chop4, chop16, cpos, ncand};
+    for (uint32_t i = tid; i < ncand; i += nt) csucc[i] = s2_succ(w, i);
+    __syncthreads();
+    for (uint32_t i = tid; i < ncand; i += nt) chop4[i] = s2_hop4(w, c, i);
+    __syncthreads();
+    for (uint32_t i = tid; i < ncand; i += nt) chop16[i] = s2_hop16(w, i);
+    __syncthreads();
+    stamp(5);
+    // B. table steps from where pass A left the walk
+    {
+        const uint32_t bend = c.rsi;
+        uint32_t i = 0, idx = 0, b = 0;
+        bool have = false, out = false;
+        while (true) {
+            const uint64_t idle = __ballot(!have && !out), busy = __ballot(have);
+            if (!(idle | busy)) break;
+            if (idle && ((uint32_t)__popcll(idle) >= g.refill || !busy)) {
+                if (!have && !out) {
+                    i = atomicAdd(&sh_next[1], 1u);
+                    if (i >= i1) {
+                        out = true;
+                    } else {
+                        const uint32_t d = ua[i];
+                        b = ub[i];
+                        if (d && b < bend) {
+                            idx = s2_index(w, (uint32_t)cpos[i] + d);
+                            if (idx == kS2NoIndex) { ua[i] = 0; ub[i] = 0; }
+                            else have = true;
+                        }
+                    }
+                }
+            }
+            if (!have) continue;
+            uint32_t end = 0;
+            const uint32_t st = s2_table_step(w, c, idx, b, bend, end);
+            if (st != 1u) {
+                const uint32_t a = st == 2u ? end - cpos[i] : 0u;
+                ua[i] = a > 0xFFFFu ? (uint16_t)0 : (uint16_t)a;
+                ub[i] = (st == 0u || (st == 2u && a > 0xFFFFu)) ? (uint16_t)kS2Limited : (uint16_t)0;
+                have = false;
+            }
+        }
+    }
+    __syncthreads();
+    stamp(6);
+    if (ncore > g.cap_core) {
+        give_up();
+        return;
+    }
+    // ---- 4. chains out of the core, records, this window's part of the bitmap
+    for (uint32_t i = i0 + tid; i < i1; i += nt) {
+        uint32_t pos = cpos[i], cnt = 0;
+        while (pos < c1 && pos < s.limit && cnt < 255u) {
+            const uint32_t j = s2_index(w, pos);
+            if (j == kS2NoIndex || !ua[j]) break;
+            pos += ua[j];
+            cnt++;
+        }
+        const uint64_t at = (uint64_t)blockIdx.x * g.cap_core + (i - i0);
+        const bool limited = !cnt && !ua[i] && ub[i] == kS2Limited;
+        grec[at] = make_uint2(ua[i], cnt ? ((cnt << 24) | (pos - cpos[i])) : (limited ? 1u : 0u));
+        if (limited && blist) {
+            const uint32_t q0 = cpos[i];
+            const uint64_t two = ((uint64_t)win[q0 >> 5] << 32) | win[(q0 >> 5) + 1u];
+            const uint32_t id = (uint32_t)((two << (q0 & 31u)) >> (64u - c.id_len));
+            const uint32_t slot = atomicAdd(blist_cnt, 1u);
+            if (slot < kS2BridgeCap) blist[slot] = (uint32_t)at | (id << 26) | (id == (1u << c.id_len) - 1u ? 0x80000000u : 0u);
+        }
+        gcpos[at] = (uint16_t)(cpos[i] - c0);
+    }
+    for (uint32_t i = tid; i < cw; i += nt) {
+        gbitmap[gw0 + i] = marks[(c0 >> 5) + i];
+        gpre[gw0 + i] = (uint16_t)(mpre[(c0 >> 5) + i] - i0);
+    }
+    if (tid == 0) gccnt[blockIdx.x] = ncore;
+    stamp(7);
 }
 
 #ifdef AEC_TUNING
@@ -2153,6 +2580,7 @@ struct Sparse2Plan {
 };
 
 constexpr uint32_t kS2WindowBits = 65536;      // lead-in + core + look-ahead (16-bit positions in LDS)
+constexpr uint32_t kS4WindowBits = 49152;      // k_spec4: + 2 bytes per bit for the table of coded data set lengths
 constexpr uint32_t kS2Lead = 4096;
 constexpr uint32_t kS2SuperWindows = 4096;     // windows per launch: bounds the table workspace (~60 KB each)
 
@@ -2174,6 +2602,11 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     if (wbits < 16384 || wbits > kS2WindowBits) wbits = kS2WindowBits;
     if (look + kS2Lead + 8192 > wbits) wbits = kS2WindowBits;            // long RSIs: the largest window
     if (look > kS2WindowBits - kS2Lead - 16384) return p;
+    // k_spec4: the table of every position's coded data set wants 2 bytes per bit of the window, so the window is 48
+    // kbit; candidates have room for one per 12 bits (coded data sets of 16 bits and more on average)
+    const bool v4 = tune("AEC_S2_V4", 0) != 0 && look + kS2Lead + 8192 <= kS4WindowBits &&
+                    rsi_bits_hint >= (uint64_t)c.rsi * 16u && !tune_set("AEC_S2_WINDOW");
+    if (v4) wbits = kS4WindowBits;
     uint64_t core = (wbits - kS2Lead - look) & ~1023ull;
     // small inputs: about one window per CU
     const uint64_t want = ((total_bits / 256 + 1023) & ~1023ull);
@@ -2189,10 +2622,16 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     // in a row happen by chance all the time there)
     p.g.uncrun = tune("AEC_S2_UNCRUN", c.id_len >= 3u ? 1u : 0u);
     const uint32_t W = p.g.lead + p.g.core + p.g.look, nw = W / 32;
-    const uint32_t capdiv = tune("AEC_S2_CAPDIV", 8u);
+    const uint32_t capdiv = tune("AEC_S2_CAPDIV", v4 ? 12u : 8u);
     p.g.cap_lds = (W / (capdiv ? capdiv : 8u) + 63) & ~63u;
     p.g.cap_core = (p.g.core / 8 + 63) & ~63u;
+    p.g.v4 = v4 ? 1u : 0u;
     p.lds = (size_t)(nw + 4) * 4 + (size_t)nw * 4 + (size_t)(nw + 2) * 2 * 3 + (size_t)p.g.cap_lds * 2 * 7 + 64;
+    if (v4) {
+        if (p.g.cap_core > p.g.cap_lds) p.g.cap_core = p.g.cap_lds;
+        const size_t tab = (size_t)W * 2 > (size_t)p.g.cap_lds * 2 * 3 ? (size_t)W * 2 : (size_t)p.g.cap_lds * 2 * 3;
+        p.lds = (size_t)(nw + 4) * 4 + (size_t)nw * 4 + (size_t)(nw + 2) * 2 * 3 + (size_t)p.g.cap_lds * 2 * 4 + tab + 64;
+    }
     if (p.lds > 156 * 1024) return p;
     const uint64_t nwin_total = (total_bits + core + core - 1) / core;    // (+ one: the range starts on a core boundary)
     p.nwin_max = (uint32_t)(nwin_total < kS2SuperWindows ? nwin_total : kS2SuperWindows);
@@ -2234,7 +2673,7 @@ unsigned long long *spec2_prof_buffer(uint32_t nwin, bool reset = true)
     return buf;
 }
 
-void spec2_prof_report(uint32_t nwin, hipStream_t st)
+void spec2_prof_report(uint32_t nwin, hipStream_t st, bool v4 = false)
 {
     unsigned long long *buf = spec2_prof_buffer(nwin, false);
     if (!buf) return;
@@ -2243,6 +2682,20 @@ void spec2_prof_report(uint32_t nwin, hipStream_t st)
     (void)hipStreamSynchronize(st);
     std::vector<unsigned long long> h((size_t)nwin * 8);
     (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
+    if (v4) {                                   // k_spec4: stamps 0 .. 7 in the order of the phases
+        double e[7] = {0, 0, 0, 0, 0, 0, 0};
+        uint32_t m = 0;
+        for (uint32_t w = 0; w + 1 < nwin; w++) {
+            if (!h[(size_t)w * 8 + 7]) continue;
+            for (int k = 0; k < 7; k++) e[k] += (double)(h[(size_t)w * 8 + k + 1] - h[(size_t)w * 8 + k]);
+            m++;
+        }
+        if (!m) m = 1;
+        fprintf(stderr, "k_spec4 phases (shader-clock ticks per window, %u windows): load+rank %.0f | table %.0f | chains %.0f | "
+                "candidates+first+catch-up %.0f | hop tables %.0f | table steps %.0f | chain+write %.0f\n", m, e[0] / m,
+                e[1] / m, e[2] / m, e[3] / m, e[4] / m, e[5] / m, e[6] / m);
+        return;
+    }
     double d[6] = {0, 0, 0, 0, 0, 0};
     uint32_t n = 0;
     for (uint32_t w = 0; w + 1 < nwin; w++) {
@@ -2266,6 +2719,9 @@ void allow_big_lds2()
     if (dev < 0 || dev >= 64) dev = 0;
     std::call_once(once[dev], [] {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_spec2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                156 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_spec4), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 156 * 1024) != hipSuccess)
             (void)hipGetLastError();
 
@@ -2377,11 +2833,17 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
         if (piped && si >= 2) (void)hipStreamWaitEvent(ts, side.done[set], 0);      // the walkers of span si - 2 are through
         uint32_t *blist = reinterpret_cast<uint32_t *>(tb + p.o_blist), *blist_cnt = reinterpret_cast<uint32_t *>(tb + 56);
         (void)hipMemsetAsync(blist_cnt, 0, 4, ts);
-        hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, ts, c, words, nwords, end_bit, lo, start_bit, p.g,
-                           const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
-                           const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin),
-                           (const uint64_t *)nullptr, 0u, blist, blist_cnt);
-        spec2_prof_report(nwin, ts);
+        if (p.g.v4)
+            hipLaunchKernelGGL(k_spec4, dim3(nwin), dim3(1024), p.lds, ts, c, words, nwords, end_bit, lo, start_bit, p.g,
+                               const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
+                               const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin),
+                               (const uint64_t *)nullptr, 0u, blist, blist_cnt);
+        else
+            hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, ts, c, words, nwords, end_bit, lo, start_bit, p.g,
+                               const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
+                               const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin),
+                               (const uint64_t *)nullptr, 0u, blist, blist_cnt);
+        spec2_prof_report(nwin, ts, p.g.v4 != 0);
 #ifdef AEC_TUNING
         if (tune_set("AEC_S2_VERIFY")) {
             static uint32_t *d_bad = nullptr;
@@ -2868,6 +3330,8 @@ bool index_is_windowed(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint)
     return in_bytes && sparse2_plan(c, (uint64_t)in_bytes * 8, rsi_bits_hint).ok;
 }
 
+namespace {
+
 // ======== short RSIs: phase-locked chains =================================================================
 // Both table schemes follow chains that parse WITHOUT reference samples and try RSI starts as hypotheses on them.
 // That needs RSIs much longer than the distance such a chain takes to find the true one again behind an RSI start
@@ -3056,13 +3520,17 @@ k_lock_scan(const LockTables t, const LkState *exit_last)
 __global__ void __launch_bounds__(64)
 k_lock_fill(const Cfg c, const TrStream s, const LockTables t, const LkState *exit_last, const uint32_t *__restrict__ words,
             uint64_t nwords, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res, uint32_t tail_slot,
-            uint64_t rsi_start_in)
+            uint64_t rsi_start_in, uint32_t start_block)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= t.nreg || t.flags[1] || r > t.flags[2]) return;      // (not agreed, or behind the region that ended the walk)
     const uint64_t rend = r + 1u == t.nreg ? ~0ull : t.lo + (uint64_t)(r + 1u) * t.region_bits;
     LkState x = t.entry[r];
-    uint64_t idx = t.base[r];
+    // A walk that resumes INSIDE an RSI (streaming callers: start_block blocks of it lie in front of the input): that
+    // RSI is number 0 and began at rsi_start_in, the first RSI start the chains meet is number 1 (as k_index counts).
+    const uint64_t off = start_block ? 1u : 0u;
+    uint64_t idx = t.base[r] + off;
+    if (off && r == 0u && max_rsi) rsi_off[0] = rsi_start_in;
     // (regions behind the caller's bound have nothing to deliver: the ONE region in which RSI number max_rsi starts
     // writes the record -- every region behind it would meet "idx >= max_rsi" at its first RSI start as well)
     if (idx > max_rsi) return;
@@ -3144,9 +3612,10 @@ struct LockPlan {
 LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, uint32_t start_block)
 {
     LockPlan p{};
-    // (a walk that resumes inside an RSI -- streaming callers -- numbers its RSIs from the one it is in: the walker's)
     // (without the preprocessor no coded data set holds a reference sample: nothing a chain could lock its count on)
-    if (!tune("AEC_IDX_LOCK", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS) || c.rsi > 32u || start_block != 0u) return p;
+    // (a walk that resumes inside an RSI numbers that RSI 0 and the first RSI start it meets 1: k_lock_fill)
+    (void)start_block;
+    if (!tune("AEC_IDX_LOCK", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS) || c.rsi > 32u) return p;
     if (total_bits < (1u << 16)) return p;               // (a thousand coded data sets: the serial walker is as fast)
     uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 3;
     if (cds < 8) cds = 8;
@@ -3213,7 +3682,7 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
     }
     hipLaunchKernelGGL(k_lock_scan, dim3(1), dim3(1024), 0, st, t, (const LkState *)ex[cur]);
     hipLaunchKernelGGL(k_lock_fill, dim3(wgrid), dim3(64), 0, st, c, s, t, (const LkState *)ex[cur], words, nwords, d_rsi_off,
-                       max_rsi, d_res, tail_slot, rsi_start);
+                       max_rsi, d_res, tail_slot, rsi_start, start_block);
 #ifdef AEC_TUNING
     if (tune_set("AEC_IDX_STATS")) {                       // (diagnostics: synchronises)
         (void)hipStreamSynchronize(st);
@@ -3238,6 +3707,17 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
                        (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start,
                        tail_slot, TwTables{}, (ChunkEntry *)nullptr, SparseTables{}, (uint32_t *)nullptr, (uint64_t)0,
                        (const uint32_t *)t.flags);
+}
+
+}  // namespace
+
+int index_scheme(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint, uint32_t start_block)
+{
+    const uint64_t bits = (uint64_t)in_bytes * 8;
+    if (!bits) return 0;
+    if (lock_plan(c, bits, rsi_bits_hint, start_block).ok) return 1;
+    if (sparse2_plan(c, bits, rsi_bits_hint).ok) return 2;
+    return trunk_plan(c, bits, rsi_bits_hint, 0).ok ? 3 : 0;
 }
 
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
@@ -3353,10 +3833,16 @@ void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, cons
     IdxHop *hops = reinterpret_cast<IdxHop *>(base + p.bytes);
     uint32_t *nhops = reinterpret_cast<uint32_t *>(base + p.bytes +
                                                    (((size_t)n_chunks * hop_cap * sizeof(IdxHop) + 255) & ~(size_t)255));
-    hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, st, c, words, nwords, end_bit, (uint64_t)0, (uint64_t)0, p.g,
-                       const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
-                       const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), (unsigned long long *)nullptr,
-                       d_chunk_off, (uint32_t)n_chunks);
+    if (p.g.v4)
+        hipLaunchKernelGGL(k_spec4, dim3(nwin), dim3(1024), p.lds, st, c, words, nwords, end_bit, (uint64_t)0, (uint64_t)0, p.g,
+                           const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
+                           const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), (unsigned long long *)nullptr,
+                           d_chunk_off, (uint32_t)n_chunks);
+    else
+        hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, st, c, words, nwords, end_bit, (uint64_t)0, (uint64_t)0, p.g,
+                           const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
+                           const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), (unsigned long long *)nullptr,
+                           d_chunk_off, (uint32_t)n_chunks);
     hipLaunchKernelGGL(k_index, dim3((uint32_t)n_chunks), dim3(64), 0, st, c, words, nwords, end_bit, (uint64_t)0, d_rsi_off,
                        rsi_per_chunk, d_res, d_chunk_off, hops, hop_cap, (IdxCarry *)nullptr, 1u, 1u, 0u, (uint64_t)0, 0u,
                        TwTables{}, (ChunkEntry *)nullptr, t, nhops);

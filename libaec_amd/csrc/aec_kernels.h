@@ -150,6 +150,9 @@ bool launch_decode_bare(const Cfg &c, const uint8_t *d_in, size_t in_bytes, cons
 // rsi_bits_hint: estimate of the coded size of one RSI (0 = unknown); it sizes burn-in, regions and records.
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint);
 bool index_is_windowed(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint);
+// the scheme launch_index takes with the workspace index_workspace_bytes asks for: 0 serial walk, 1 phase-locked
+// chains, 2 window tables, 3 trunk
+int index_scheme(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint, uint32_t start_block);
 // d_seg_bits (optional; (max_rsi + 1) * segs_per_rsi entries, set to ~0 by the caller): where the index runs over
 // the trunk tables it also leaves the start bit of every segment of the RSIs it finds (launch_decode_bare); the
 // return value says whether it did.

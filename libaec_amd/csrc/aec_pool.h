@@ -35,6 +35,17 @@ public:
             f(0);
             return;
         }
+        // a job started from inside a task (of the pool or of run_on_new_threads): in turn on this thread -- the
+        // pool's lock may be held by this very thread (try_lock on a mutex its owner holds is undefined), and a
+        // worker that waited for other workers could wait for itself
+        if (inside()) {
+            for (size_t i = 0; i < count; i++) f(i);
+            return;
+        }
+        struct Mark {
+            Mark() { inside() = true; }
+            ~Mark() { inside() = false; }
+        } mark;
         WorkerPool *p = instance();
         if (!p || !p->busy_.try_lock()) {
             run_on_new_threads(count, f);
@@ -52,6 +63,11 @@ private:
     const std::function<void(size_t)> *fn_ = nullptr;
     size_t n_ = 0, next_ = 0, finished_ = 0, workers_ = 0;
 
+    static bool &inside()                    // this thread is running a task of some job (or waiting for one's tasks)
+    {
+        static thread_local bool in = false;
+        return in;
+    }
     static WorkerPool *&slot()
     {
         static WorkerPool *p = nullptr;
@@ -93,6 +109,7 @@ private:
             const size_t i = next_++;
             const std::function<void(size_t)> *f = fn_;
             lk.unlock();
+            inside() = true;
             (*f)(i);
             lk.lock();
             if (++finished_ == n_) done_.notify_all();
@@ -138,7 +155,11 @@ private:
         std::vector<std::thread> th;
         size_t started = 1;
         try {
-            for (; started < count; started++) th.emplace_back(f, started);
+            for (; started < count; started++)
+                th.emplace_back([&f](size_t i) {
+                    inside() = true;
+                    f(i);
+                }, started);
         } catch (...) {                      // (no more threads: this one does the rest in turn)
         }
         f(0);

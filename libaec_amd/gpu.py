@@ -78,6 +78,8 @@ def _lib():
         lib.aec_gpu_segments_per_rsi.argtypes = [pp]
         lib.aec_gpu_index_segments_async.restype = C.c_int
         lib.aec_gpu_index_segments_async.argtypes = [vp, pp, vp, sz, u64, C.c_uint, u64, vp, vp, u64, vp, vp]
+        lib.aec_gpu_index_scheme.restype = C.c_int
+        lib.aec_gpu_index_scheme.argtypes = [pp, sz, u64, C.c_uint]
         lib.aec_gpu_decode_bare_async.restype = C.c_int
         lib.aec_gpu_decode_bare_async.argtypes = [vp, pp, vp, sz, vp, vp, u64, u64, vp, vp, vp, vp]
         _bound = True
@@ -95,6 +97,15 @@ def stitch_async(d_gathered, slot, d_plans, world, d_stream, d_total=None, strea
                                   C.c_void_p(d_total.data_ptr()) if d_total is not None else None, st)
     if rc != 0:
         raise RuntimeError(f"aec_gpu_stitch_async failed ({rc})")
+
+
+INDEX_SCHEMES = ("serial walk", "phase-locked chains", "window tables", "trunk")
+
+
+def index_scheme(bits_per_sample, block_size, rsi, flags, in_bytes, rsi_bits=0, start_block=0):
+    """aec_gpu_index_scheme: which scheme the index pass of such a stream takes (index into INDEX_SCHEMES)."""
+    p = Params(bits_per_sample, block_size, rsi, flags)
+    return _lib().aec_gpu_index_scheme(C.byref(p), in_bytes, rsi_bits, start_block)
 
 
 class Codec:

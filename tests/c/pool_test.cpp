@@ -30,9 +30,26 @@ static int one_caller(unsigned seed, int jobs)
     return bad;
 }
 
+// a job started from inside a task: runs in turn on the task's thread, every task once
+static int nested(int jobs)
+{
+    int bad = 0;
+    for (int j = 0; j < jobs; j++) {
+        const size_t outer = 2 + j % 5, inner = 1 + j % 7;
+        std::vector<std::atomic<int>> hits(outer * inner);
+        for (auto &h : hits) h = 0;
+        aec::WorkerPool::run(outer, [&](size_t i) {
+            aec::WorkerPool::run(inner, [&](size_t k) { hits[i * inner + k]++; });
+        });
+        for (auto &h : hits) bad += h != 1;
+    }
+    return bad;
+}
+
 int main()
 {
     int bad = one_caller(1, 300);
+    bad += nested(200);
     std::atomic<int> bad2{0};
     std::thread a([&] { bad2 += one_caller(2, 400); }), b([&] { bad2 += one_caller(3, 400); });
     a.join();
