@@ -14,11 +14,13 @@
 //   (the index pass for streams that arrive without an offset table lives in aec_idx.hip)
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
 #include "aec_kernels.h"
 #include "aec_lane.h"
+#include "aec_spec.h"
 #include "aec_tune.h"
 
 namespace aec {
@@ -751,6 +753,498 @@ k_decode_redo(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, 
     }
 }
 
+// ---- small and medium streams: ONE WAVEFRONT PER RSI, ONE LANE PER BLOCK (round 5) -------------------------------
+// k_decode gives an RSI to a lane: its 128 blocks are a chain of ~1.5 us each when nothing else hides the latency, so a
+// 64 KiB chunk, a 1 MiB chunk and a 16 MiB stream all took the same 197 us while 99 % of the chip idled.  Here a
+// wavefront owns the RSI.  Two phases per round of up to 64 blocks:
+//   walk    the coded data sets are LOCATED one behind the other (their lengths only: reference src/decode.c:402-421 has
+//           no other way in).  A wave-cooperative parse per coded data set (the index walker's: masked popcounts, DPP
+//           prefix sum, ballot, rank select) costs ~0.8 us each -- cross-lane round trips one behind the other -- and
+//           made this kernel 105 us for an RSI of 128 blocks.  So the 64 lanes parse the coded data sets that WOULD
+//           begin at the next 64 BITS, one each: ~45 vector instructions and no dependence between the lanes, because
+//           the end of a unary part is one lookup once the positions of the 1-bits of a piece of the stream (4096
+//           bits) lie in a table (n-th 1-bit behind q = ones[rank(q) + n - 1]).  The chain through those 64 bits is
+//           then one lane read per coded data set.  (The same lengths in an LDS table for a whole piece, then one LDS
+//           read per step: 320 cycles per coded data set against ~180, and 8 KB more per wavefront.)  Only the first
+//           coded data set of the RSI (the one with the reference sample), zero runs and whatever the table does not
+//           resolve take the cooperative parse.  The start of block i stays in lane i's register.
+//   decode  every lane decodes ITS block (decode_block, the same code k_decode runs per lane); the inverse predictor,
+//           a serial chain over the samples in the reference (decode.c:96-134), runs per block from a GUESSED
+//           predecessor -- the running sum of the steps, exact whenever nothing clips at the ends of the range -- and
+//           the guesses are checked: lane i's input must be lane i-1's output; the first lane where it is not takes
+//           the true value, the lanes behind it shift, and the blocks are computed again until all agree (one pass on
+//           data that stays inside the range, one more per clipping block otherwise: exactness never rests on the guess)
+//   store   a lane's block lies behind its neighbour's: whole lines per store instruction, no staging
+// Items, tables, result record and error reporting as k_decode<SEG = false> (no list mode); coded data sets longer than
+// the wave's window of the stream raise kDecRedo like a lane's ring does.  Chosen by launch_decode_any for few, long
+// enough RSIs (dec_wave_wanted).
+constexpr uint32_t kDwWin = 1024;          // words of the stream a wavefront stages in LDS
+constexpr uint32_t kDwPad = 72;            // zero words behind them (register window, peeks of decode_block)
+constexpr uint32_t kDwPiece = 4096;        // bits whose coded-data-set lengths are tabulated at a time
+// words of LDS per wavefront: window | rank per word of (piece + look-ahead) | positions of the 1-bits of (piece +
+// look-ahead) (u16 each)
+__host__ __device__ inline uint32_t dw_look_words(const Cfg &c) { return (c.id_len + 1u + c.bs * c.bps + 31u) / 32u + 2u; }
+__host__ __device__ inline uint32_t dw_wave_words(const Cfg &c)
+{
+    const uint32_t pw = kDwPiece / 32u + dw_look_words(c);
+    return kDwWin + kDwPad + (pw + 2u + 1u) / 2u + pw * 16u;
+}
+
+struct WaveSrc {
+    const uint32_t *win;
+    uint32_t limit;        // words that hold stream (relative index); reads at or beyond it starve
+    uint32_t starve;
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return win[i < kDwWin + kDwPad - 1u ? i : kDwWin + kDwPad - 1u]; }
+    __device__ __forceinline__ uint32_t word(uint32_t i)
+    {
+        starve |= (i >= limit) ? 1u : 0u;
+        return at(i);
+    }
+    __device__ __forceinline__ void word2(uint32_t i, uint32_t &w0, uint32_t &w1)
+    {
+        starve |= (i + 1 >= limit) ? 1u : 0u;
+        w0 = at(i);
+        w1 = at(i + 1u);
+    }
+    __device__ __forceinline__ void word3(uint32_t i, uint32_t &w0, uint32_t &w1, uint32_t &w2)
+    {
+        starve |= (i + 2 >= limit) ? 1u : 0u;
+        w0 = at(i);
+        w1 = at(i + 1u);
+        w2 = at(i + 2u);
+    }
+    __device__ __forceinline__ bool starved() const { return starve != 0; }
+};
+
+struct WaveWinFetch {      // word source of the sequential reader (coded data sets beyond the register window)
+    const uint32_t *win;
+    uint64_t base;         // stream word index of win[0]
+    __device__ __forceinline__ uint32_t operator()(uint64_t idx) const
+    {
+        const uint64_t rel = idx - base;
+        return rel < kDwWin + kDwPad ? win[rel] : 0u;
+    }
+};
+
+#ifdef AEC_TUNING
+__device__ unsigned long long g_dw_prof[8];      // (diagnostics, AEC_DW_PROF=1: shader-clock ticks of RSI 0's phases)
+#define DW_T0() const unsigned long long dw_t0 = __builtin_amdgcn_s_memtime()
+#define DW_T1(k) do { if (r == 0 && lane == 0) g_dw_prof[k] += __builtin_amdgcn_s_memtime() - dw_t0; } while (0)
+#else
+#define DW_T0() do { } while (0)
+#define DW_T1(k) do { } while (0)
+#endif
+
+template <int BS, int BYTES>
+__global__ void __launch_bounds__(256)
+k_decode_wave(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
+              const uint64_t *__restrict__ rsi_off, uint64_t n_rsi, uint64_t total_blocks, uint8_t *__restrict__ out,
+              DecResult *res, uint8_t *__restrict__ dump, const DecResult *__restrict__ idx,
+              const DecResult *__restrict__ batch, uint32_t rsi_per_chunk)
+{
+    static_assert(BS == 8 || BS == 16 || BS == 32 || BS == 64, "templated block sizes");
+    if (idx) {
+        const uint64_t whole = idx->n_rsi, tail = idx->tail_blocks;
+        n_rsi = whole + (tail ? 1u : 0u);
+        total_blocks = whole * c.rsi + tail;
+    }
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *win = smem + (size_t)wave * dw_wave_words(c);
+    const uint32_t pwords = kDwPiece / 32u + dw_look_words(c);            // words of a piece + its look-ahead
+    uint16_t *prank = reinterpret_cast<uint16_t *>(win + kDwWin + kDwPad);  // [pwords + 1]: 1-bits in front of a word
+    uint16_t *ones = reinterpret_cast<uint16_t *>(win + kDwWin + kDwPad + (pwords + 2u + 1u) / 2u);   // [pwords * 32]
+    const uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= n_rsi) return;
+    const bool pp = c.flags & F_PREPROCESS, sgn = c.flags & F_SIGNED;
+    uint32_t nb;
+    uint64_t start;
+    if (batch) {
+        const uint64_t sidx = r / rsi_per_chunk;
+        const uint32_t rin = (uint32_t)(r - sidx * rsi_per_chunk);
+        const uint64_t whole = batch[sidx].n_rsi, tail = batch[sidx].tail_blocks;
+        nb = rin < whole ? c.rsi : (rin == whole ? (uint32_t)tail : 0u);
+        start = nb ? rsi_off[r] : 0;
+    } else {
+        const uint64_t left = total_blocks - r * c.rsi;
+        nb = left > c.rsi ? c.rsi : (uint32_t)left;
+        start = rsi_off[r];
+    }
+    const uint64_t first_blk = r * c.rsi;
+    constexpr uint32_t BLK = (uint32_t)BS * (uint32_t)BYTES;
+    uint8_t *dst = out + (size_t)first_blk * BLK;
+    const uint32_t maxbits = c.id_len + 1u + c.bps + c.bs * c.bps, idmax = (1u << c.id_len) - 1u;
+    const bool coop = maxbits + 128u <= 2048u;
+
+    // ---- the wave's window of the stream
+    uint32_t pc0 = 0xFFFFFFFFu;        // first bit (window-relative) of the tabulated piece; none yet
+    uint64_t base = 0;                 // stream word of win[0]
+    uint32_t have = 0;                 // words of it that hold stream (the rest: zeros)
+    bool to_end = false;               // the window reaches the end of the stream
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto refill = [&](uint64_t from_word) {
+        DW_T0();
+        base = from_word & ~3ull;
+        wave_sync();
+        for (uint32_t i = lane * 4u; i < kDwWin; i += 64u * 4u) {
+            const uint64_t at = base + i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (at + 4u <= nwords) {
+                v = *reinterpret_cast<const uint4 *>(words + at);
+            } else {
+                if (at < nwords) v.x = words[at];
+                if (at + 1u < nwords) v.y = words[at + 1u];
+                if (at + 2u < nwords) v.z = words[at + 2u];
+            }
+            *reinterpret_cast<uint4 *>(&win[i]) = make_uint4(bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w));
+        }
+        for (uint32_t i = lane; i < kDwPad; i += 64u) win[kDwWin + i] = 0u;
+        wave_sync();
+        const uint64_t left = nwords > base ? nwords - base : 0u;
+        have = left < kDwWin ? (uint32_t)left : kDwWin;
+        to_end = left <= kDwWin;
+        pc0 = 0xFFFFFFFFu;                 // (the table of a piece goes with the window it was made from)
+        DW_T1(0);
+    };
+    // ---- the register window: lane l holds word wb + l of the LDS window
+    uint32_t wb = 0, W = 0;
+    bool loaded = false;
+    auto load_regs = [&](uint32_t first) {
+        wb = first;
+        W = win[first + lane < kDwWin + kDwPad ? first + lane : kDwWin + kDwPad - 1u];
+        loaded = true;
+    };
+    auto rdlane = [&](uint32_t v, uint32_t l) {
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)l));
+    };
+    auto peek = [&](uint32_t rel) {                                      // 32 bits at register-window bit offset rel
+        const uint32_t w = rel >> 5, sh = rel & 31u;
+        const uint64_t two = ((uint64_t)rdlane(W, w) << 32) | rdlane(W, (w + 1u) & 63u);
+        return (uint32_t)((two << sh) >> 32);
+    };
+    auto skip_ones = [&](uint32_t rel, uint32_t n) -> uint32_t {         // offset just behind the n-th 1-bit from rel on
+        const uint32_t w = rel >> 5, sh = rel & 31u;
+        const uint32_t m = lane < w ? 0u : (lane == w ? W & (0xFFFFFFFFu >> sh) : W);
+        const uint32_t pc = (uint32_t)__builtin_popcount(m);
+        const uint32_t S = wave_incl_sum_dpp(pc);
+        const uint64_t enough = __ballot(S >= n);
+        if (enough == 0) return 0xFFFFFFFFu;
+        const uint32_t L = (uint32_t)__builtin_ctzll(enough);
+        const uint32_t need = n - (rdlane(S, L) - rdlane(pc, L));
+        const uint32_t word = rdlane(m, L);
+        const uint32_t j = lane & 31u;
+        const uint32_t bit = (word >> (31u - j)) & 1u;
+        const uint32_t rank = j ? (uint32_t)__builtin_popcount(word >> (32u - j)) : 0u;
+        const uint64_t hit = __ballot(lane < 32u && bit && rank + 1u == need);
+        return L * 32u + (uint32_t)__builtin_ctzll(hit) + 1u;
+    };
+    // length of the coded data set at window bit `rel` (0 = not found inside the window), nz = zero-run code or 0
+    auto cds_len = [&](uint32_t rel, uint32_t ref, uint32_t &nz) -> uint32_t {
+        nz = 0;
+        if (coop) {
+            if (!loaded || rel < wb * 32u || rel - wb * 32u + maxbits + 64u > 2048u) load_regs(rel >> 5);
+            const uint32_t q0 = rel - wb * 32u;
+            const uint32_t h = peek(q0);
+            const uint32_t id = h >> (32u - c.id_len);
+            uint32_t q = q0 + c.id_len;
+            if (id == 0u) {
+                const uint32_t selb = (h >> (31u - c.id_len)) & 1u;
+                q += 1u + ref * c.bps;
+                if (selb) {
+                    q = skip_ones(q, c.bs / 2u);
+                } else {
+                    const uint32_t e = skip_ones(q, 1u);
+                    if (e != 0xFFFFFFFFu) nz = e - q;
+                    q = e;
+                }
+            } else if (id == idmax) {
+                q += c.bs * c.bps;
+            } else {
+                q += ref * c.bps;
+                q = skip_ones(q, c.bs - ref);
+                if (q != 0xFFFFFFFFu) q += (c.bs - ref) * (id - 1u);
+            }
+            if (q != 0xFFFFFFFFu) return q - q0;
+            nz = 0;
+        }
+        // large blocks, or a unary part that leaves the register window: the sequential reader over the LDS window
+        // (every lane the same walk)
+        BitReaderT<WaveWinFetch> br;
+        br.init(WaveWinFetch{win, base}, ((uint64_t)base + kDwWin + kDwPad) * 32u, base * 32u + rel);
+        const uint32_t il = c.id_len;
+        const uint32_t id = br.get(il);
+        if (id == 0u) {
+            const uint32_t selb = br.get(1);
+            if (ref) br.skip(c.bps);
+            if (selb) {
+                if (!br.skip_unary(c.bs / 2u)) return 0u;
+            } else {
+                uint32_t fs;
+                if (!br.unary(fs)) return 0u;
+                nz = fs + 1u;
+            }
+        } else if (id == idmax) {
+            br.skip((uint64_t)c.bs * c.bps);
+        } else {
+            if (ref) br.skip(c.bps);
+            if (!br.skip_unary(c.bs - ref)) return 0u;
+            br.skip((uint64_t)(c.bs - ref) * (id - 1u));
+        }
+        const uint64_t len = br.pos - (base * 32u + rel);
+        return len < 0x7FFFFFFFull ? (uint32_t)len : 0u;
+    };
+
+    // ---- rank and positions of the 1-bits of a piece: window bits [pc0, pc0 + kDwPiece + look-ahead), pc0 a multiple of 32
+    uint32_t tcnt = 0, plim = 0;       // 1-bits of the piece; bits of the window that are stream
+    auto build_piece = [&](uint32_t from_bit) {
+        DW_T0();
+        pc0 = from_bit & ~31u;
+        const uint32_t w0 = pc0 >> 5;
+        plim = to_end ? (uint32_t)(end_bit - base * 32u < (uint64_t)(kDwWin + kDwPad) * 32u ? end_bit - base * 32u
+                                                                                              : (uint64_t)(kDwWin + kDwPad) * 32u)
+                      : have * 32u;
+        wave_sync();
+        uint32_t carry = 0;
+        for (uint32_t i0 = 0; i0 < pwords; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            const uint32_t wi = w0 + i;
+            const uint32_t word = (i < pwords && wi < kDwWin + kDwPad) ? win[wi] : 0u;
+            const uint32_t pc = (uint32_t)__builtin_popcount(word);
+            const uint32_t incl = wave_incl_sum_dpp(pc);
+            if (i < pwords) prank[i + 1u] = (uint16_t)(carry + incl);
+            uint32_t at = carry + incl - pc, bits = word;             // positions just behind the 1-bits of this word
+            const uint32_t bbase = wi * 32u + 1u;
+            while (bits) {
+                const uint32_t z = (uint32_t)__builtin_clz(bits);
+                bits &= ~(0x80000000u >> z);
+                ones[at++] = (uint16_t)(bbase + z);
+            }
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) prank[0] = 0;
+        tcnt = carry;
+        wave_sync();
+        DW_T1(1);
+    };
+    // the coded data set that would begin at window bit q (pc0 <= q < pc0 + kDwPiece), WITHOUT a reference sample: its
+    // entry in the nxt[] format of aec_spec.h -- length | kind, 0 = not resolved here.  One code path for all options:
+    // the end of the unary part is the n-th 1-bit behind the header, ones[rank(q1) + n - 1].
+    auto fentry = [&](uint32_t q) -> uint32_t {
+        const uint32_t il = c.id_len, w = q >> 5, sh = q & 31u;
+        const uint32_t wa = w < kDwWin + kDwPad - 1u ? w : kDwWin + kDwPad - 2u;
+        const uint32_t a = win[wa], bw = win[wa + 1u];
+        const uint32_t h = (uint32_t)(((((uint64_t)a) << 32) | bw) << sh >> 32);
+        const uint32_t id = h >> (32u - il);
+        const bool unc = id == idmax, low = id == 0u;
+        const uint32_t selb = (h >> (31u - il)) & 1u;
+        const uint32_t off1 = il + (low ? 1u : 0u);
+        const uint32_t n = low ? (selb ? c.bs / 2u : 1u) : c.bs;
+        const uint32_t rq = (uint32_t)prank[w - (pc0 >> 5)] + (sh ? (uint32_t)__builtin_popcount(a >> (32u - sh)) : 0u);
+        const uint32_t k = rq + (uint32_t)__builtin_popcount(h >> (32u - off1)) + n - 1u;
+        const uint32_t e = k < tcnt ? (uint32_t)ones[k] : 0u;
+        const uint32_t add = low ? 0u : c.bs * (id - 1u);
+        const uint32_t end = unc ? q + il + c.bs * c.bps : e + add;
+        const bool ok = (unc || e != 0u) && end <= plim && end - q < 4096u;
+        return ok ? ((end - q) | ((low && !selb) ? kNxtZero : kNxtBlock)) : 0u;
+    };
+
+    uint64_t pos = start;              // absolute bit of the next coded data set
+    uint32_t b = 0;                    // blocks of the RSI located so far
+    uint32_t zpend = 0;                // blocks of a zero run that the round in front could not hold
+    uint32_t xcarry = 0;               // predictor state behind the blocks stored so far
+    uint32_t done_blocks = 0;
+    bool stop = false;
+    refill(pos >> 5);
+    while (done_blocks < nb && !stop) {
+        // ---- walk: up to 64 blocks
+        DW_T0();
+        uint32_t cnt = 0, mypos = 0, myblk = 0;
+        bool myparse = false;
+        uint32_t fail_lane = 64u;      // the lane whose coded data set the walk could not take: its decode says why
+        if (zpend) {                   // the rest of a zero run: blocks of zeros, nothing to parse
+            const uint32_t take = zpend < 64u ? zpend : 64u;
+            if (lane < take) myblk = done_blocks + lane;
+            cnt = take;
+            zpend -= take;
+        }
+        while (cnt < 64u && b < nb && !zpend) {
+            uint32_t rel = (uint32_t)(pos - base * 32u);
+            // The common steps in a loop of their own: the 64 lanes parse the coded data sets that WOULD begin at the
+            // next 64 bits (one each, no dependence between them), then the chain through those 64 bits is a lane read per
+            // coded data set -- ~3 of them per round at 23 bits each.  Taken while the coded data sets have one block and
+            // an entry; everything else below (reference sample, zero runs, the next piece, the next window, failures).
+            if (pc0 != 0xFFFFFFFFu && b != 0u) {
+                uint32_t fr = rel, fc = cnt, fb = b;
+                bool plain = true;
+                while (plain && fr >= pc0 && fr + 64u <= pc0 + kDwPiece) {
+                    const uint32_t E = fentry(fr + lane);
+                    uint32_t l = 0;
+                    do {
+                        const uint32_t e = rdlane(E, l);
+                        if ((e >> 12) != (kNxtBlock >> 12)) {
+                            plain = false;
+                            break;
+                        }
+                        const bool mine = lane == fc;
+                        mypos = mine ? fr + l : mypos;
+                        myparse = myparse || mine;
+                        l += e & 0xFFFu;
+                        fc++;
+                        fb++;
+                    } while (l < 64u && fc < 64u && fb < nb);
+                    fr += l;
+                    if (fc == 64u || fb == nb) break;
+                }
+                pos += fr - rel;
+                cnt = fc;
+                b = fb;
+                rel = fr;
+                if (cnt == 64u || b == nb) break;
+            }
+            // (the whole coded data set inside the window -- or the window reaches the end of the stream)
+            if (!to_end && rel + maxbits + 64u > have * 32u) {
+                if (cnt) break;                                   // decode what the round holds, refill behind it
+                refill(pos >> 5);
+                loaded = false;
+                rel = (uint32_t)(pos - base * 32u);
+            }
+            const uint32_t ref = (pp && b == 0u) ? 1u : 0u;
+            uint32_t nz = 0, len = 0;
+            if (!ref) {
+                // (the piece must have its look-ahead inside the window's stream, or the window reach the stream's end)
+                if (pc0 == 0xFFFFFFFFu || rel < pc0 || rel >= pc0 + kDwPiece) {
+                    const uint32_t from = rel & ~31u;
+                    if (!to_end && from + kDwPiece + dw_look_words(c) * 32u > have * 32u && from > 4096u) {
+                        if (cnt) break;                           // (a fresh window for a fresh piece)
+                        refill(pos >> 5);
+                        loaded = false;
+                        rel = (uint32_t)(pos - base * 32u);
+                    }
+                    build_piece(rel);
+                }
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)fentry(rel));
+                len = e & 0xFFFu;
+                nz = (e & kNxtZero) ? len - c.id_len - 1u : 0u;
+            }
+            if (!len) len = cds_len(rel, ref, nz);                // (reference sample, or beyond the table's look-ahead)
+            const uint32_t nblk = len ? (nz ? spec_run_blocks(c, nz, b) : 1u) : 0u;
+            const bool inside = len != 0u && (to_end ? base * 32u + rel + len <= end_bit : rel + len <= have * 32u);
+            if (!inside || !nblk) {
+                // A coded data set that does not end inside a freshly filled window is longer than any an encoder of
+                // the reference writes -- or the stream is cut or damaged here.  The lane's decode gives the verdict
+                // (status, or kDecRedo when it ran out of the window) exactly as a lane of k_decode would.
+                if (!to_end && cnt) break;
+                if (lane == cnt) {
+                    mypos = rel;
+                    myblk = b;
+                    myparse = true;
+                }
+                fail_lane = cnt;
+                cnt++;
+                stop = true;
+                break;
+            }
+            uint32_t take = nblk;
+            if (take > nb - b) take = nb - b;                     // (a caller's block count may cut a run)
+            const uint32_t room = 64u - cnt;
+            const uint32_t now = take < room ? take : room;
+            if (lane >= cnt && lane < cnt + now) {
+                mypos = rel;
+                myblk = b + (lane - cnt);
+                myparse = lane == cnt;
+            }
+            zpend = take - now;
+            cnt += now;
+            pos += len;
+            b += take;
+        }
+        DW_T1(2);                      // (includes the refills and pieces inside the walk)
+        myblk = done_blocks + lane;    // (the blocks of a round are consecutive)
+        // ---- decode: lane i, block done_blocks + i
+        uint32_t d[BS];
+        const bool live = lane < cnt;
+        const uint32_t ref_l = (pp && live && myparse && myblk == 0u) ? 1u : 0u;
+        WaveSrc src{win, to_end ? 0xFFFFFFFFu : have, 0u};
+        uint32_t p = mypos, nzl = 0;
+        const uint64_t left_bits = end_bit - base * 32u;
+        const uint32_t end_p = left_bits > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)left_bits;
+        uint32_t st = decode_block<BS>(src, p, end_p, d, c, ref_l, myblk, live && myparse, nzl);
+        if (!(live && myparse)) {
+#pragma unroll
+            for (int i = 0; i < BS; i++) d[i] = 0u;
+            st = DEC_OK;
+        }
+        const bool over = live && myparse && !to_end && (((p + 31u) >> 5) > have || (st != DEC_OK && src.starved()));
+        DW_T1(3);                      // (walk + decode)
+        const uint64_t bad = __ballot((live && myparse && st != DEC_OK) || over);
+        uint32_t good = cnt;           // blocks of this round that are delivered
+        if (bad) {
+            const uint32_t f = (uint32_t)__builtin_ctzll(bad);
+            good = f;
+            stop = true;
+            if (lane == f) {
+                if (over) {
+                    atomicOr(&res->pad, kDecRedo);
+                } else {
+                    report(res, st, r, first_blk + done_blocks + f);
+                    if (batch && st == DEC_DATA_ERROR)
+                        atomicMax(&const_cast<DecResult *>(batch)[r / rsi_per_chunk].status, (uint32_t)DEC_DATA_ERROR);
+                }
+            }
+        } else if (fail_lane < 64u) {
+            // (the walk could not take a coded data set that the decode accepts: cannot happen -- both read the same
+            // bits -- but must not go unnoticed: the batch is decoded again by the sequential path)
+            if (lane == 0) atomicOr(&res->pad, kDecRedo);
+            good = fail_lane;
+            stop = true;
+        }
+        // ---- inverse predictor + store
+        const bool act = lane < good;
+        uint8_t *q = act ? dst + (size_t)(done_blocks + lane) * BLK : dump + (size_t)lane * BLK;
+        uint32_t x = 0;
+        if (!pp) {
+            store_block<BS, BYTES>(q, d, c, false, x);
+        } else {
+            // the running sum of the steps (reference decode.c:96-134: +d/2 or -(d+1)/2 while nothing clips)
+            uint32_t ssum = 0;
+#pragma unroll
+            for (int i = 0; i < BS; i++) {
+                const uint32_t v = (i == 0 && ref_l) ? 0u : d[i];
+                ssum += (v >> 1) ^ (0u - (v & 1u));
+            }
+            if (!act) ssum = 0;
+            const uint32_t incl = wave_incl_sum_dpp(ssum);
+            const uint32_t has_ref = (uint32_t)__builtin_amdgcn_readlane((int)ref_l, 0);
+            const uint32_t refv = (uint32_t)__builtin_amdgcn_readlane((int)d[0], 0);
+            const uint32_t xb = has_ref ? (sgn ? sign_extend(refv, c.bps) : refv) : xcarry;
+            uint32_t xin = xb + incl - ssum;
+            uint32_t xout;
+            for (;;) {
+                xout = xin;
+                store_block<BS, BYTES>(q, d, c, ref_l != 0u, xout);
+                const uint32_t prev = (uint32_t)__shfl_up((int)xout, 1);        // lane l - 1's output (lane 0: its own)
+                const uint64_t wrong = __ballot(act && lane != 0u && !ref_l && prev != xin);
+                if (!wrong) break;
+                const uint32_t f = (uint32_t)__builtin_ctzll(wrong);
+                const uint32_t delta = rdlane(prev - xin, f);
+                if (lane >= f) xin += delta;
+            }
+            if (good) xcarry = rdlane(xout, good - 1u);
+            x = xcarry;
+        }
+        done_blocks += good;
+        DW_T1(4);                      // (walk + decode + predictor + store)
+        if (bad || fail_lane < 64u) break;
+    }
+    // the predictor state behind the LAST item of the batch (k_decode_partial continues from it)
+    if (lane == 0 && r + 1 == n_rsi) res->end_bit = pp ? xcarry : 0u;
+}
+
 // ---- the coded data set the input ends in ------------------------------------------------------------
 // The reference's resumable readers release every sample whose bits have arrived, also from a coded
 // data set that is cut by the end of the input (reference src/decode.c:342-400 bits_ask / fs_ask,
@@ -962,6 +1456,16 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
 
 }  // namespace
 
+// Few RSIs, each long enough to keep a wavefront's lanes busy: a wavefront per RSI (k_decode_wave) instead of a lane.
+// A lane per RSI needs ~260 000 RSIs to fill the chip and takes as long as ONE RSI's serial chain however few there
+// are; a wavefront per RSI costs ~7 times the instructions per RSI, which only matters once the chip is full.
+static bool dec_wave_wanted(const Cfg &c, uint64_t n_items)
+{
+    if (c.bs != 8u && c.bs != 16u && c.bs != 32u && c.bs != 64u) return false;
+    const uint32_t most = tune("AEC_DEC_WAVE_MAX", 16384u), least = tune("AEC_DEC_WAVE_RSI", 16u);
+    return c.rsi >= least && n_items <= most;
+}
+
 template <bool SEG>
 static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes, const uint64_t *d_rsi_off,
                               const SegEntry *d_seg, uint64_t n_items, uint64_t total_blocks, uint8_t *d_out,
@@ -979,6 +1483,48 @@ static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
     // vector stores need 16-byte aligned blocks
     const bool vec_ok = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
     const uint32_t bs = vec_ok ? c.bs : 0;
+    if (!SEG && bs && dec_wave_wanted(c, n_items)) {
+        const uint32_t waves = 2;                            // (~24 KB of LDS per wavefront: six of them on a CU)
+        const dim3 grid((uint32_t)((n_items + waves - 1) / waves)), block(64 * waves);
+        const size_t lds = (size_t)waves * dw_wave_words(c) * 4;
+#define AEC_WV2(BSV, B)                                                                                              \
+    hipLaunchKernelGGL((k_decode_wave<BSV, B>), grid, block, lds, st, c, words, nwords, end_bit, d_rsi_off, n_items, \
+                       total_blocks, d_out, d_res, dump, d_idx, d_batch, rpc)
+#define AEC_WV(BSV)                                                                                                  \
+    switch (c.bytes) {                                                                                               \
+    case 1: AEC_WV2(BSV, 1); break;                                                                                  \
+    case 2: AEC_WV2(BSV, 2); break;                                                                                  \
+    case 3: AEC_WV2(BSV, 3); break;                                                                                  \
+    default: AEC_WV2(BSV, 4); break;                                                                                 \
+    }
+#ifdef AEC_TUNING
+        static const bool dw_prof = tune("AEC_DW_PROF", 0) != 0;
+        if (dw_prof) {
+            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dw_prof), z, sizeof(z), 0, hipMemcpyHostToDevice, st);
+        }
+#endif
+        switch (bs) {
+        case 8: AEC_WV(8); break;
+        case 16: AEC_WV(16); break;
+        case 32: AEC_WV(32); break;
+        default: AEC_WV(64); break;
+        }
+#undef AEC_WV
+#undef AEC_WV2
+#ifdef AEC_TUNING
+        if (dw_prof) {
+            static int reports = 0;
+            if (reports++ < 6) {
+                unsigned long long h[8];
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dw_prof), sizeof(h));
+                fprintf(stderr, "k_decode_wave, RSI 0 (shader-clock ticks, 100 MHz): refills %llu | pieces %llu | walk incl. those %llu | "
+                        "+ decode %llu | + predictor, store %llu\n", h[0], h[1], h[2], h[3], h[4]);
+            }
+        }
+#endif
+    } else
     switch (bs) {
     case 8: launch_decode_bytes<8, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc); break;
     case 16: launch_decode_bytes<16, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc); break;

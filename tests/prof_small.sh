@@ -15,7 +15,7 @@ for i, r in enumerate(rows):
 # print a window of kernels around each of the first few k_decode launches following a k_index
 cnt = 0
 for i, (s, e, n, g, w) in enumerate(out):
-    if n.startswith("k_decode<") and cnt < 40:
+    if (n.startswith("k_decode<") or n.startswith("k_decode_wave<")) and cnt < 40:
         cnt += 1
         if cnt in (5, 25, 38):
             j0 = max(0, i - 9)
