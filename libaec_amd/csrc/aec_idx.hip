@@ -35,6 +35,7 @@
 #include "aec_spec2.h"
 #include "aec_trunk.h"
 #include "aec_coop.h"
+#include "aec_stretch.h"
 #include "aec_tune.h"
 
 namespace aec {
@@ -2210,8 +2211,11 @@ __global__ void k_expand2(const SparseTables t, const IdxCarry *__restrict__ car
 // refill of the bit window held the first version at ~5 MB/s of compressed input.
 #ifdef AEC_TUNING
 __device__ int g_dbg_serial = 0;      // (diagnostics, AEC_IDX_STATS=2: k_index names the RSIs it walks itself)
+__device__ int g_idx_no_stretch = 0;  // (A/B: AEC_IDX_STRETCH=0 gives the serial walk of round 4)
 #endif
 constexpr uint32_t kIdxWindowWords = 4096;
+constexpr uint32_t kIdxPiece = 4096;                                   // bits of a piece
+constexpr uint32_t kIdxPieceWords = kIdxPiece / 32 + 68;               // + the longest coded data set of an encoder (2118 bits)
 
 struct LdsWindowFetch {
     const uint32_t *lds;    // window of kIdxWindowWords words (host order)
@@ -2241,6 +2245,12 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     // tables do not resolve within this many bits of the end of the input is not walked serially -- the tables end
     // there for lack of look-ahead, the caller's next piece resolves it -- the pass ends in front of it
     __shared__ __attribute__((aligned(16))) uint32_t win[kIdxWindowWords];
+    // (round 5) rank and positions of the 1-bits of a PIECE of the window (kIdxPiece bits + the look-ahead of one coded
+    // data set): with them "the coded data set that would begin at bit q" is ~50 vector instructions without a
+    // dependence between lanes, so the 64 lanes parse the coded data sets that WOULD begin at the next 64 bits at once
+    // and the walk through those bits is a lane read per coded data set (see the serial walk below)
+    __shared__ uint16_t prank[kIdxPieceWords + 2];
+    __shared__ uint16_t ones[kIdxPieceWords * 32];
     uint64_t r = 0;
     if (chunk_off) {
         start_bit = chunk_off[blockIdx.x] * 8u;
@@ -2331,9 +2341,72 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         return L * 32u + (uint32_t)__builtin_ctzll(hit) + 1u;
     };
 
+    // ---- the piece tables and the parse of a position from them
+    const uint32_t look_words = (maxbits + 31u) / 32u + 2u;
+    const uint32_t pwords = kIdxPiece / 32u + (look_words < 68u ? look_words : 68u);
+#ifdef AEC_TUNING
+    const bool stretch = g_idx_no_stretch == 0 && maxbits <= 2118u;      // (AEC_IDX_STRETCH=0: the walk as it was)
+#else
+    const bool stretch = maxbits <= 2118u;
+#endif
+    uint64_t piece_base = ~0ull;       // LDS window the piece was made from
+    uint32_t pc0 = 0, tcnt = 0, plim = 0;
+    auto build_piece = [&](uint32_t from_bit) {
+        pc0 = from_bit & ~31u;
+        piece_base = base;
+        const uint32_t w0 = pc0 >> 5;
+        const uint64_t wbits = (uint64_t)kIdxWindowWords * 32u;
+        const uint64_t sbits = end_bit > base * 32u ? end_bit - base * 32u : 0u;
+        plim = (uint32_t)(sbits < wbits ? sbits : wbits);                 // bits of the window that are stream
+        __syncthreads();
+        uint32_t carry = 0;
+        for (uint32_t i0 = 0; i0 < pwords; i0 += 64u) {
+            const uint32_t i = i0 + lane, wi = w0 + i;
+            const uint32_t word = (i < pwords && wi < kIdxWindowWords) ? win[wi] : 0u;
+            const uint32_t pc = (uint32_t)__builtin_popcount(word);
+            const uint32_t incl = wave_incl_sum_dpp(pc);
+            if (i < pwords) prank[i + 1u] = (uint16_t)(carry + incl);
+            uint32_t at = carry + incl - pc, bits = word;
+            const uint32_t bbase = wi * 32u + 1u;
+            while (bits) {
+                const uint32_t z = (uint32_t)__builtin_clz(bits);
+                bits &= ~(0x80000000u >> z);
+                ones[at++] = (uint16_t)(bbase + z);
+            }
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) prank[0] = 0;
+        tcnt = carry;
+        __syncthreads();
+    };
+    // entry (aec_spec.h nxt[] format: length | kind, 0 = not resolved here) of the coded data set that would begin at
+    // window bit q, pc0 <= q < pc0 + kIdxPiece; ref: with a reference sample behind its header
+    auto fentry = [&](uint32_t q, uint32_t ref) -> uint32_t {
+        const uint32_t il = c.id_len, w = q >> 5, sh = q & 31u;
+        const uint32_t wa = w < kIdxWindowWords - 1u ? w : kIdxWindowWords - 2u;
+        const uint32_t a = win[wa], bw = win[wa + 1u];
+        const uint32_t h = (uint32_t)(((((uint64_t)a) << 32) | bw) << sh >> 32);
+        const uint32_t id = h >> (32u - il);
+        const bool unc = id == idmax, low = id == 0u;
+        const uint32_t selb = (h >> (31u - il)) & 1u;
+        const uint32_t q1 = q + il + (low ? 1u : 0u) + ((ref && !unc) ? c.bps : 0u);
+        const uint32_t n = low ? (selb ? c.bs / 2u : 1u) : c.bs - ref;
+        const uint32_t w1 = q1 >> 5, sh1 = q1 & 31u;
+        const uint32_t w1c = w1 < kIdxWindowWords ? w1 : kIdxWindowWords - 1u;
+        const uint32_t pi = w1 - (pc0 >> 5);
+        const uint32_t r1 = (uint32_t)prank[pi < kIdxPieceWords ? pi : kIdxPieceWords] + (sh1 ? (uint32_t)__builtin_popcount(win[w1c] >> (32u - sh1)) : 0u);
+        const uint32_t k = r1 + n - 1u;
+        const uint32_t e = (k < tcnt && n != 0u) ? (uint32_t)ones[k] : 0u;
+        const uint32_t add = low ? 0u : n * (id - 1u);
+        const uint32_t end = unc ? q + il + c.bs * c.bps : e + add;
+        const bool ok = (unc || e != 0u) && q1 < plim && end <= plim && end - q < 4096u;
+        return ok ? ((end - q) | ((low && !selb) ? kNxtZero : kNxtBlock)) : 0u;
+    };
+
     BitReaderT<LdsWindowFetch> br;
     br.init(LdsWindowFetch{win, base}, end_bit, start_bit);
     uint64_t good = start_bit;
+    bool hopped_far = false;           // `good` moved without the sequential reader: it starts from there again
     uint32_t b = 0, status = DEC_OK, nh = 0;
     uint32_t n_serial = (carry && !first) ? carry->n_serial : 0u, n_lookups = (carry && !first) ? carry->n_lookups : 0u;
     // Resumed walk (streaming callers): start_bit is a CDS boundary inside an RSI that began at
@@ -2472,9 +2545,60 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         } else if (hopped) {
             br.init(LdsWindowFetch{win, base}, end_bit, good);
         }
+        // ---- the coded data sets that begin in the next 64 bits, parsed by the 64 lanes at once; the chain through them
+        // a lane read each (the cooperative parse below: ~1 us per coded data set, cross-lane round trips one behind
+        // the other; this: ~0.5 us per 64 bits + 0.05 us per coded data set).  Ends on the RSI's last block (the RSI
+        // start behind it is the outer loop's: tables, padding, the caller's bound), on a coded data set the piece
+        // tables do not resolve, or on a zero run that does not fit (both: the parse below gives the verdict).
+        if (stretch) {
+            uint32_t rel0 = (uint32_t)(good - base * 32u);
+            if (piece_base != base || rel0 < pc0 || rel0 + 64u > pc0 + kIdxPiece) {
+                // (a piece whose look-ahead leaves the window while the stream goes on: a fresh window first)
+                if ((rel0 & ~31u) + pwords * 32u > kIdxWindowWords * 32u && base + kIdxWindowWords < nwords && rel0 >= 2048u) {
+                    __syncthreads();
+                    refill(good >> 5);
+                    br.init(LdsWindowFetch{win, base}, end_bit, good);
+                    if (coop) load_regs(good >> 5);
+                    rel0 = (uint32_t)(good - base * 32u);
+                }
+                build_piece(rel0);
+            }
+            const uint32_t E0 = fentry(rel0 + lane, 0u);
+            const uint32_t E1 = pp ? fentry(rel0 + lane, 1u) : E0;
+            uint32_t l = 0;
+            bool moved = false;
+            while (l < 64u) {
+                const uint32_t rf = (pp && b == 0) ? 1u : 0u;
+                const uint32_t e = rdlane(rf ? E1 : E0, l);
+                const uint32_t len = e & 0xFFFu;
+                if (!(e >> 12)) break;
+                uint32_t nb1 = 1;
+                if (e & kNxtZero) {
+                    nb1 = spec_run_blocks(c, len - c.id_len - 1u - rf * c.bps, b);
+                    if (!nb1) break;
+                }
+                l += len;
+                good += len;
+                b += nb1;
+                moved = true;
+                if (b >= c.rsi) {
+                    b = 0;
+                    r++;
+                    break;
+                }
+            }
+            if (moved) {
+                hopped_far = true;                         // (the readers below start from `good` again)
+                continue;
+            }
+        }
         const uint32_t ref = (pp && b == 0) ? 1u : 0u;
         uint32_t nblk = 1;
         bool done = false;
+        if (hopped_far) {
+            br.init(LdsWindowFetch{win, base}, end_bit, good);
+            hopped_far = false;
+        }
         if (coop) {
             uint32_t rel = (uint32_t)(good - wbase * 32u);
             if (good < wbase * 32u || rel + maxbits + 64u > 2048u) {     // slide the register window
@@ -3607,6 +3731,350 @@ k_lock_fill(const Cfg c, const TrStream s, const LockTables t, const LkState *ex
     t.flags[0] = 1u;
 }
 
+// ---- the same three walks, a WAVEFRONT per region (round 5; aec_stretch.h) ---------------------------------------
+// A lane that follows a chain through device memory takes 2.5 us per coded data set, and the pass was three such walks
+// of a region one behind the other (guess, count, fill) plus a repair pass per wrong guess: 2.1 ms for a 64 KiB chunk
+// with scan lines of 32 pixels, 29 ms for 16 MiB of 16-bit data with rsi 32 -- as long as the reference takes on one
+// core.  Here a wavefront owns the region: the 64 lanes parse the coded data sets that would begin at the next 64 bits,
+// with and without a reference sample, and the chain with the RSI's bookkeeping is a lane read per coded data set.  The
+// guess keeps its 64 chains per region, one per lane, but they parse out of the wavefront's LDS tables (they stand
+// within a few kbit of each other) instead of device memory.  Same states, same tables, same results as the kernels
+// above (tune AEC_IDX_LOCK_WAVE=0 runs those).
+
+// one step of the bookkeeping from an entry; false = the entry does not resolve it (lk_step from memory then)
+__device__ __forceinline__ bool lk_apply(const Cfg &c, LkState &x, uint32_t e, uint32_t rf)
+{
+    if (!(e >> 12)) return false;
+    const uint32_t len = e & 0xFFFu;
+    uint32_t nb = 1;
+    if (e & kNxtZero) {
+        nb = spec_run_blocks(c, len - c.id_len - 1u - rf * c.bps, x.b);
+        if (!nb) {
+            x.st = 2u;
+            return true;
+        }
+    }
+    x.pos += len;
+    x.b += nb;
+    if (x.b >= c.rsi) x.b = 0u;
+    return true;
+}
+
+// The chain from x (wave-uniform) until x.pos >= rend or x.st != 0; at_start(x) is called once at every step that
+// begins an RSI (x.b == 0), before the step; it returns false to end the walk there.
+template <class F>
+__device__ __forceinline__ void lk_walk_wave(WaveStream &ws, const TrStream &s, const Cfg &c, LkState &x, uint64_t rend,
+                                             F at_start)
+{
+    const bool pp = c.flags & F_PREPROCESS;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t handled = ~0ull;
+    while (x.pos < rend && !x.st) {
+        const uint32_t rel = ws.ensure(x.pos, 64u);
+        // (the entries with a reference sample only where an RSI starts inside these 64 bits)
+        uint32_t E0 = 0, E1 = 0;
+        bool have0 = false, have1 = false;
+        const uint64_t p0 = x.pos;
+        bool moved = false;
+        while (x.pos < rend && x.pos - p0 < 64u) {
+            if (x.b == 0u && handled != x.pos) {
+                handled = x.pos;
+                if (!at_start(x)) return;
+            }
+            const uint32_t rf = (pp && x.b == 0u) ? 1u : 0u;
+            if (rf && !have1) {
+                E1 = ws.entry(c, rel + lane, 1u);
+                have1 = true;
+            } else if (!rf && !have0) {
+                E0 = ws.entry(c, rel + lane, 0u);
+                have0 = true;
+            }
+            const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x.pos - p0));
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)(rf ? E1 : E0), (int)l);
+            if (!lk_apply(c, x, e, rf)) break;
+            moved = true;
+            if (x.st) return;
+        }
+        if (!moved && x.pos < rend) {                   // (not resolved by the tables: from memory, as before)
+            if (x.b == 0u && handled != x.pos) {
+                handled = x.pos;
+                if (!at_start(x)) return;
+            }
+            lk_step(s, c, x);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_lock_guess_w(const Cfg c, const TrStream s, const LockTables t)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WaveStream ws;
+    ws.init(lk_lds + (size_t)wave * kSwWaveWords, s, c);
+    const bool pp = c.flags & F_PREPROCESS;
+    const uint32_t r = 1u + blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= t.nreg) return;
+    const uint64_t rstart = t.lo + (uint64_t)r * t.region_bits;
+    const uint64_t from = rstart > t.lo + t.lead ? rstart - t.lead : t.lo;
+    LkState x{from + (uint64_t)lane * 37u, 0u, 0u};
+    uint32_t steps = 0;
+    const uint32_t most = 4u * (t.lead / (c.id_len + 1u) + 64u);
+    bool ended = false;                                 // (no coded data set ends inside the input from here: out)
+    for (;;) {
+        const bool run = !ended && x.pos < rstart && steps < most;
+        if (!__any(run)) break;
+        // the chains that lag furthest: window and piece go where they stand, the others wait
+        uint64_t lo = run ? x.pos : ~0ull;
+        for (int off = 32; off; off >>= 1) {
+            const uint64_t o = __shfl_xor(lo, off);
+            lo = o < lo ? o : lo;
+        }
+        const uint32_t rel0 = ws.ensure(lo, kSwPiece / 2u);
+        const uint64_t pend = ws.base * 32u + ws.pc0 + kSwPiece, pbeg = ws.base * 32u + ws.pc0;
+        (void)rel0;
+        // (a lane outside the piece waits; every round moves the laggards at least half a piece on)
+        for (uint32_t it = 0; it < 4096u; it++) {
+            const bool go = !ended && x.pos < rstart && steps < most && x.pos >= pbeg && x.pos < pend &&
+                            x.pos < lo + kSwPiece / 2u;
+            if (!__any(go)) break;
+            if (go) {
+                steps++;
+                const uint32_t b_was = x.b;
+                const uint32_t rf = (pp && x.b == 0u) ? 1u : 0u;
+                const uint32_t e = ws.entry(c, (uint32_t)(x.pos - ws.base * 32u), rf);
+                if (!lk_apply(c, x, e, rf)) lk_step(s, c, x);
+                if (x.st) {
+                    if (x.st == 1u) {
+                        ended = true;
+                    } else {
+                        if (b_was == 0u) x.pos++;
+                        x.b = 0u;
+                        x.st = 0u;
+                    }
+                }
+            }
+        }
+    }
+    const bool have = !ended && x.st == 0u && x.pos >= rstart;
+    uint64_t left = __ballot(have);
+    LkState best{rstart, 0u, 0u};
+    uint32_t best_n = 0;
+    for (uint32_t round = 0; round < 8u && left; round++) {
+        const uint32_t l0 = (uint32_t)__builtin_ctzll(left);
+        const uint64_t p0 = __shfl(x.pos, (int)l0);
+        const uint32_t b0 = (uint32_t)__shfl((int)x.b, (int)l0);
+        const uint64_t same = __ballot(have && x.pos == p0 && x.b == b0);
+        const uint32_t n = (uint32_t)__popcll(same);
+        if (n > best_n) {
+            best_n = n;
+            best = LkState{p0, b0, 0u};
+        }
+        left &= ~same;
+    }
+    if (lane == 0) t.entry[r] = best;
+}
+
+__global__ void __launch_bounds__(256)
+k_lock_walk_w(const Cfg c, const TrStream s, const LockTables t, const LkState *exit_prev, LkState *exit_out, uint32_t mode,
+              uint64_t start_bit, uint32_t start_block)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t r = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= t.nreg) return;
+    LkState x;
+    if (r == 0u) {
+        if (mode) {
+            if (lane == 0) exit_out[0] = exit_prev[0];
+            return;
+        }
+        x = LkState{start_bit, start_block, 0u};
+        if (lane == 0) t.entry[0] = x;
+    } else if (!mode) {
+        x = t.entry[r];
+    } else {
+        const LkState prev = exit_prev[r - 1u], mine = t.entry[r];
+        if (prev.st || (prev.pos == mine.pos && prev.b == mine.b)) {
+            if (lane == 0) exit_out[r] = exit_prev[r];
+            return;
+        }
+        x = LkState{prev.pos, prev.b, 0u};
+        if (lane == 0) t.entry[r] = x;
+    }
+    const uint64_t rend = r + 1u == t.nreg ? ~0ull : t.lo + (uint64_t)(r + 1u) * t.region_bits;
+    WaveStream ws;
+    ws.init(lk_lds + (size_t)wave * kSwWaveWords, s, c);
+    uint32_t n = 0;
+    if (ws.usable()) {
+        lk_walk_wave(ws, s, c, x, rend, [&](const LkState &) {
+            n++;
+            return true;
+        });
+    } else {
+        while (x.pos < rend) {
+            n += x.b == 0u ? 1u : 0u;
+            lk_step(s, c, x);
+            if (x.st) break;
+        }
+    }
+    if (lane == 0) {
+        t.cnt[r] = n;
+        exit_out[r] = x;
+    }
+}
+
+// What the parallel repair passes left: ONE wavefront goes through the regions in order and, wherever a region's entry is
+// not the exit of the region in front, walks on from that exit -- region after region, entries, counts and exits
+// rewritten -- until the walk stands on a stored entry again (from there on the stored walks hold).  A repair pass mends
+// one region of a run of wrong guesses per launch; this mends a run at the speed of the walk, and only the runs.
+__global__ void __launch_bounds__(64)
+k_lock_fix_w(const Cfg c, const TrStream s, const LockTables t, LkState *ex)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
+    const uint32_t lane = threadIdx.x & 63u;
+    WaveStream ws;
+    ws.init(lk_lds, s, c);
+    const bool fast = ws.usable();
+    uint32_t r = 1;
+    while (r < t.nreg) {
+        const uint32_t q0 = r + lane;
+        bool mis = false, dead = false;
+        if (q0 < t.nreg) {
+            const LkState prev = ex[q0 - 1u], mine = t.entry[q0];
+            dead = prev.st != 0u;
+            mis = !dead && (prev.pos != mine.pos || prev.b != mine.b);
+        }
+        const uint64_t mm = __ballot(mis), dd = __ballot(dead);
+        const uint32_t fm = mm ? (uint32_t)__builtin_ctzll(mm) : 64u, fd = dd ? (uint32_t)__builtin_ctzll(dd) : 64u;
+        if (fd < fm) return;                              // (the walk ended in front of it: nothing behind lives)
+        if (fm == 64u) {
+            r += 64u;
+            continue;
+        }
+        uint32_t q = r + fm;
+        LkState x = ex[q - 1u];
+        for (;;) {
+            if (lane == 0) t.entry[q] = x;
+            const uint64_t rend = q + 1u == t.nreg ? ~0ull : t.lo + (uint64_t)(q + 1u) * t.region_bits;
+            uint32_t n = 0;
+            if (fast) {
+                lk_walk_wave(ws, s, c, x, rend, [&](const LkState &) {
+                    n++;
+                    return true;
+                });
+            } else {
+                while (x.pos < rend) {
+                    n += x.b == 0u ? 1u : 0u;
+                    lk_step(s, c, x);
+                    if (x.st) break;
+                }
+            }
+            if (lane == 0) {
+                t.cnt[q] = n;
+                ex[q] = x;
+            }
+            if (x.st) return;
+            q++;
+            if (q >= t.nreg) return;
+            const LkState nx = t.entry[q];
+            if (nx.pos == x.pos && nx.b == x.b) break;    // on a stored entry again
+        }
+        __threadfence_block();
+        r = q;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_lock_fill_w(const Cfg c, const TrStream s, const LockTables t, const LkState *exit_last, const uint32_t *__restrict__ words,
+              uint64_t nwords, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res, uint32_t tail_slot,
+              uint64_t rsi_start_in, uint32_t start_block)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t r = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= t.nreg || t.flags[1] || r > t.flags[2]) return;
+    const uint64_t rend = r + 1u == t.nreg ? ~0ull : t.lo + (uint64_t)(r + 1u) * t.region_bits;
+    LkState x = t.entry[r];
+    const uint64_t off = start_block ? 1u : 0u;          // (k_lock_fill: a walk that resumes inside an RSI)
+    uint64_t idx = t.base[r] + off;
+    if (off && r == 0u && max_rsi && lane == 0) rsi_off[0] = rsi_start_in;
+    if (idx > max_rsi) return;
+    auto start_in_front = [&]() -> uint64_t {
+        for (uint32_t q = r; q-- > 0u;) {
+            if (!t.cnt[q]) continue;
+            LkState y = t.entry[q];
+            const uint64_t qend = t.lo + (uint64_t)(q + 1u) * t.region_bits;
+            uint64_t last = rsi_start_in;
+            while (y.pos < qend) {
+                if (y.b == 0u) last = y.pos;
+                lk_step(s, c, y);
+                if (y.st) break;
+            }
+            return last;
+        }
+        return rsi_start_in;
+    };
+    uint64_t cur = 0;
+    bool met = false, clipped = false;
+    WaveStream ws;
+    ws.init(lk_lds + (size_t)wave * kSwWaveWords, s, c);
+    auto at_start = [&](const LkState &y) {
+        if (idx == max_rsi) {
+            clipped = true;
+            return false;
+        }
+        if (lane == 0) rsi_off[idx] = y.pos;
+        cur = y.pos;
+        met = true;
+        idx++;
+        return true;
+    };
+    if (ws.usable()) {
+        lk_walk_wave(ws, s, c, x, rend, at_start);
+    } else {
+        while (x.pos < rend) {
+            if (x.b == 0u && !at_start(x)) break;
+            lk_step(s, c, x);
+            if (x.st) break;
+        }
+    }
+    if (!clipped && !x.st) return;
+    if (lane != 0) return;
+    if (clipped) {
+        res->n_rsi = max_rsi;
+        res->tail_blocks = 0;
+        res->end_bit = x.pos;
+        res->status = DEC_OK;
+        res->pad = 0u;
+        res->bad_rsi = ~0ull;
+        if (tail_slot) rsi_off[max_rsi] = met ? cur : start_in_front();
+        __threadfence();
+        t.flags[0] = 1u;
+        return;
+    }
+    if (x.st != 1u) return;
+    {
+        BitReaderT<QuadFetch> br;
+        br.init(QuadFetch{words, nwords}, s.end_bit, x.pos);
+        uint32_t nblk = 1;
+        if (skip_cds(br, c, (x.b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u, x.b, nblk) != DEC_NEED_INPUT) return;
+    }
+    if (idx == 0) return;
+    res->n_rsi = idx - 1u;
+    res->tail_blocks = x.b;
+    res->end_bit = x.pos;
+    res->status = DEC_OK;
+    res->pad = 1u;
+    res->bad_rsi = ~0ull;
+    if (tail_slot) rsi_off[max_rsi] = met ? cur : start_in_front();
+    __threadfence();
+    t.flags[0] = 1u;
+}
+
 struct LockPlan {
     bool ok;
     uint32_t nreg, region_bits, lead;
@@ -3626,13 +4094,21 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     // lock distance ~ cds x rsi steps of cds bits; most of 64 chains are to be locked where the region begins
     // (measured with factors 4 / 2 / 1: 16-bit, rsi 16: 20 / 13 / 10 ms per 16 MiB; 32-bit, block 32, rsi 5: 67 / 38 / 24 ms per
     // 48 MiB; a guess that is wrong only costs a repair pass)
+    // (round 5, a wavefront per region: swept again with factors 2 / 1 and regions of 1/1 .. 1/16 of the lead-in.  Factor 1
+    // halves the guesses' cost and is faster where it locks -- 16 MiB of 16-bit data, rsi 32: 8.8 against 10.6 ms -- but
+    // its guesses are wrong in longer runs, and it moves streams of long coded data sets from the trunk to this scheme
+    // with lead-ins of megabits: 16 MiB of 24-bit data in blocks of 64, rsi 16: 380 ms instead of 6.  2 it stays.)
     uint64_t lead = (uint64_t)tune("AEC_IDX_LOCK_LEAD", 2) * cds * cds * c.rsi;
-    if (lead < 8192) lead = 8192;
+    const uint64_t lmin = tune("AEC_IDX_LOCK_LMIN", 4096);
+    if (lead < lmin) lead = lmin;
     // (long coded data sets: too far to lock, unless the stream is long enough for a number of such regions)
     if (lead > (1u << 24) || (lead > (1u << 22) && total_bits < 4 * lead)) return p;
     // (small streams: short regions -- the pass is as long as one lane's walk of a region, three times over)
-    const uint64_t rmin = total_bits < (1u << 22) ? 4096 : 16384;
-    uint64_t region = lead < rmin ? rmin : lead;
+    const uint64_t rmin = total_bits < (1u << 22) ? tune("AEC_IDX_LOCK_RMIN", 1024) : 16384;
+    // (a region per wavefront now: regions a fraction of the lead-in, so that the walks -- one behind the other: count,
+    // repairs, fill -- are short and the chip has wavefronts to run; the guesses cost the lead-in per region either way)
+    const uint64_t rdiv = tune("AEC_IDX_LOCK_DIV", 16);
+    uint64_t region = lead / (rdiv ? rdiv : 1) < rmin ? rmin : lead / (rdiv ? rdiv : 1);
     region = (region + 1023) & ~1023ull;
     const uint64_t nreg = (total_bits + region - 1) / region;
     if (nreg > (1u << 24)) return p;
@@ -3669,6 +4145,39 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
     t.lead = p.lead;
     t.lo = start_bit;
     (void)hipMemsetAsync(t.flags, 0, 64, st);
+    // a wavefront per region (k_lock_*_w) -- unless the parameters are beyond its tables' look-ahead
+    const bool wave = tune("AEC_IDX_LOCK_WAVE", 1) != 0 && c.id_len + 1u + c.bps + c.bs * c.bps <= (kSwLookWords - 2u) * 32u;
+    const uint32_t wpw = 4;                                             // wavefronts per workgroup
+    const size_t wlds = (size_t)wpw * kSwWaveWords * 4;
+    if (wave) {
+        LkState *ex[2] = {t.exit0, t.exit1};
+        if (p.nreg > 1)
+            hipLaunchKernelGGL(k_lock_guess_w, dim3((p.nreg - 1 + wpw - 1) / wpw), dim3(64 * wpw), wlds, st, c, s, t);
+        const uint32_t wg = (p.nreg + wpw - 1) / wpw;
+        hipLaunchKernelGGL(k_lock_walk_w, dim3(wg), dim3(64 * wpw), wlds, st, c, s, t, (const LkState *)nullptr, ex[0], 0u,
+                           start_bit, start_block);
+        uint32_t cur = 0;
+        // (small streams: a dozen passes -- an idle pass is a launch of 5 us, 48 of them were a quarter of a millisecond
+        // on a 64 KiB chunk; a run of wrong guesses longer than that leaves the stream to the serial walker)
+        // a few parallel repair passes (each mends one region of every run of wrong guesses; an idle one is a launch of
+        // 5 us, and 48 of them were a quarter of a millisecond on a 64 KiB chunk), then one wavefront mends what is left
+        // run by run at the speed of the walk
+        const uint32_t passes = tune("AEC_IDX_LOCK_PASSES", 16u);
+        for (uint32_t k = 0; k < passes; k++) {
+            hipLaunchKernelGGL(k_lock_walk_w, dim3(wg), dim3(64 * wpw), wlds, st, c, s, t, (const LkState *)ex[cur], ex[cur ^ 1u],
+                               1u, start_bit, start_block);
+            cur ^= 1u;
+        }
+        hipLaunchKernelGGL(k_lock_fix_w, dim3(1), dim3(64), (size_t)kSwWaveWords * 4, st, c, s, t, ex[cur]);
+        hipLaunchKernelGGL(k_lock_scan, dim3(1), dim3(1024), 0, st, t, (const LkState *)ex[cur]);
+        hipLaunchKernelGGL(k_lock_fill_w, dim3(wg), dim3(64 * wpw), wlds, st, c, s, t, (const LkState *)ex[cur], words, nwords,
+                           d_rsi_off, max_rsi, d_res, tail_slot, rsi_start, start_block);
+        hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res,
+                           (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start,
+                           tail_slot, TwTables{}, (ChunkEntry *)nullptr, SparseTables{}, (uint32_t *)nullptr, (uint64_t)0,
+                           (const uint32_t *)t.flags);
+        return;
+    }
     if (p.nreg > 1)
         hipLaunchKernelGGL(k_lock_guess, dim3(p.nreg - 1 < 65536u ? p.nreg - 1 : 65536u), dim3(64), 0, st, c, s, t);
     const uint32_t wgrid = (p.nreg + 63) / 64;
@@ -3715,6 +4224,19 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
 
 }  // namespace
 
+// (tuning build: the A/B switches that live in device globals)
+static void idx_tuning_sync()
+{
+#ifdef AEC_TUNING
+    static const int no_stretch = tune("AEC_IDX_STRETCH", 1) == 0 ? 1 : 0;
+    static std::once_flag once[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    std::call_once(once[dev], [] { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_idx_no_stretch), &no_stretch, sizeof(int)); });
+#endif
+}
+
 int index_scheme(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint, uint32_t start_block)
 {
     const uint64_t bits = (uint64_t)in_bytes * 8;
@@ -3747,6 +4269,7 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
 {
     const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
     const uint64_t nwords = (in_bytes + 3) / 4, end_bit = (uint64_t)in_bytes * 8;
+    idx_tuning_sync();
     // Low-entropy streams whose RSIs fit a window: candidates and RSI hypotheses per window (k_spec2); everything
     // else: the trunk.
     if (d_ws && ws_bytes && start_bit < end_bit && !d_seg_bits) {
@@ -3808,6 +4331,7 @@ void launch_index_batch(const Cfg &c, const uint8_t *d_in, size_t in_bytes, cons
                         hipStream_t st, void *d_ws, size_t ws_bytes, size_t max_chunk_bytes, uint64_t rsi_bits_hint)
 {
     if (n_chunks == 0) return;
+    idx_tuning_sync();
     const uint32_t *words = reinterpret_cast<const uint32_t *>(d_in);
     const uint64_t nwords = (in_bytes + 3) / 4, end_bit = (uint64_t)in_bytes * 8;
     const size_t need = d_ws ? index_batch_workspace_bytes(c, in_bytes, n_chunks, max_chunk_bytes, rsi_bits_hint) : 0;

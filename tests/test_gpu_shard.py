@@ -165,6 +165,14 @@ def test_bench_sharded_path_with_ranks_sharing_one_gpu(world):
     out = json.loads(line)
     assert out["n_gpus"] == world and out["value"] > 0
     assert "one bit-exact stream" in out["config"]["parallelism"]
+    # the line proves its own N: what the process group says, every rank's device, the size of
+    # the all-gather, and a checksum of the stitched stream that all ranks agreed on
+    comm = out["comm"]
+    assert comm["backend"] == "gloo" and comm["world_size"] == world and len(comm["devices"]) == world
+    assert sorted(d["rank"] for d in comm["devices"]) == list(range(world))
+    assert len({d["pid"] for d in comm["devices"]}) == world and comm["distinct_devices"] == 1      # (--share-gpu)
+    assert comm["allgather_bytes"] > 0 and comm["plan_exchange_bytes"] == 24 * world
+    assert comm["stitched"]["bytes"] > 0 and "sha16" in comm["stitched"]
 
 
 def test_bench_starts_its_ranks_itself():
