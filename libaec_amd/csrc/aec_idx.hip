@@ -2719,7 +2719,14 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     const bool off = tune("AEC_IDX_NO_SPARSE", 0) != 0;                  // A/B switch for measurements
     if (off || (c.flags & F_PAD_RSI) || !rsi_bits_hint || total_bits < 16384) return p;
     const uint64_t samples = (uint64_t)c.rsi * c.bs;
-    if (rsi_bits_hint * 2 > samples * 9) return p;                       // more than 4.5 bits per sample
+    // more than 4.5 bits per sample -- unless the coded data sets are still short (small blocks): what the lead-in must
+    // cover is the distance a chain needs to fall onto the true one, ~2 cds^2 bits, whatever the bits per sample
+    // (round 5: 8-sample blocks at up to ~9 bits per sample came over the trunk and paid its fixed phases, 17 - 50 ms
+    // for 1 - 4 MiB: tests/fuzz_index_gpu.py --time)
+    const uint64_t cds_max = tune("AEC_S2_CDS_MAX", 80);
+    // (with the preprocessor only: raw samples repeat the same bits at the same place, a chain that is off the true one
+    // does not find it again, and every RSI fell to the serial walker -- 16 MiB of 8-bit data, ratio 1.19: 1.4 s)
+    if (rsi_bits_hint * 2 > samples * 9 && (rsi_bits_hint > (uint64_t)c.rsi * cds_max || !(c.flags & F_PREPROCESS))) return p;
     uint64_t look = (2 * rsi_bits_hint + 1024 + 31) & ~31ull;
     if (look < 4096) look = 4096;
     uint32_t wbits = tune("AEC_S2_WINDOW", kS2WindowBits);
