@@ -103,6 +103,20 @@ struct SparseTables {
     uint32_t wpc;
 };
 
+// The DENSE tables (launch_index_sparse: windows with room for a candidate per four bits, built only where a window of
+// the ordinary tables gave up): a window that was not built has a count of 0 and its part of the bitmap is not written.
+__device__ __forceinline__ bool dense_lookup(const SparseTables &t, uint64_t p, uint2 &rec)
+{
+    const uint64_t i = p - t.lo;
+    const uint32_t window = (uint32_t)(i / t.core);
+    if (!t.ccnt[window]) return false;
+    const uint32_t word = t.bitmap[i >> 5], sh = (uint32_t)(i & 31u);
+    if (!((word >> (31u - sh)) & 1u)) return false;
+    const uint32_t index = (uint32_t)t.pre[i >> 5] + (sh ? (uint32_t)__popc(word >> (32u - sh)) : 0u);
+    rec = t.rec[(uint64_t)window * t.cap + index];
+    return true;
+}
+
 // record of the candidate at absolute bit p (false: p is not a candidate)
 __device__ __forceinline__ bool sparse_lookup(const SparseTables &t, uint64_t p, uint2 &rec, uint32_t &window,
                                               uint32_t &index)
@@ -1540,7 +1554,8 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         uint64_t start_bit, const Spec2Geom g, uint32_t *__restrict__ gbitmap, uint16_t *__restrict__ gpre,
         uint2 *__restrict__ grec, uint16_t *__restrict__ gcpos, uint32_t *__restrict__ gccnt,
         unsigned long long *__restrict__ prof, const uint64_t *__restrict__ starts = nullptr, uint32_t nstarts = 0,
-        uint32_t *__restrict__ blist = nullptr, uint32_t *__restrict__ blist_cnt = nullptr)
+        uint32_t *__restrict__ blist = nullptr, uint32_t *__restrict__ blist_cnt = nullptr,
+        const uint32_t *__restrict__ only_where_zero = nullptr, uint32_t other_core = 0, uint32_t other_nwin = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
     __shared__ uint32_t sh_total, sh_next[2], sh_part[16];
@@ -1548,6 +1563,18 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
+    // dense mode: this window is built only if a window of the ordinary tables that covers part of its core gave up
+    // (its count is 0) -- a launch over all dense windows of which nearly all return here
+    if (only_where_zero) {
+        const uint64_t a = (uint64_t)blockIdx.x * g.core, b = a + g.core - 1u;
+        uint32_t j0 = (uint32_t)(a / other_core), j1 = (uint32_t)(b / other_core);
+        bool any = false;
+        for (uint32_t j = j0; j <= j1 && j < other_nwin; j++) any = any || only_where_zero[j] == 0u;
+        if (!any) {
+            if (threadIdx.x == 0) gccnt[blockIdx.x] = 0u;
+            return;
+        }
+    }
     const uint32_t W = g.lead + g.core + g.look, nw = W / 32u, cap = g.cap_lds;
     uint32_t *win = spec_lds;
     uint32_t *marks = win + nw + 4;
@@ -1650,10 +1677,13 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             }
             __syncthreads();
             const uint32_t t1 = t0 + T < s.limit ? t0 + T : s.limit;
+            // (one position per lane and round: consecutive lanes read and write consecutive LDS addresses.  Half a word --
+            // 16 positions -- per lane with the rank carried along bit by bit was measured SLOWER, 66 k against 59 k cycles
+            // per window: the lanes' table reads and stores then lie 32 bytes apart, eight to a bank)
             for (uint32_t q = t0 + tid; q < t1; q += nt) {
                 const uint32_t w = q >> 5, sh = q & 31u;
                 const uint32_t a = win[w], b = win[w + 1u];
-                const uint32_t h = spec_shl_hi(a, b, sh);
+                const uint32_t h = sh ? __builtin_amdgcn_alignbit(a, b, 32u - sh) : a;
                 const uint32_t id = h >> (32u - il);
                 const bool unc = id == idmax, low = id == 0u;
                 const uint32_t selbit = (h >> (31u - il)) & 1u;
@@ -1844,26 +1874,33 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                     }
                 }
             }
-            if (!have) continue;
-            uint32_t run;
-            const uint32_t len = cds0(pos, run);
-            bool fail = len == 0u, done = false;
-            uint32_t n = 1;
-            if (!fail && run) {
-                n = spec_run_blocks(c, len - c.id_len - 1u, b);
-                fail = !n || n > bend - b;
-            }
-            if (!fail) {
-                pos += len;
-                b += n;
-                if (b >= bend || (pos < s.limit && s2_marked(marks, pos))) done = true;
-                else if (pos >= s.limit) fail = true;
-            }
-            if (done && pos - p0 > 0xFFFFu) fail = true;
-            if (fail || done) {
-                ua[i] = fail ? (uint16_t)0 : (uint16_t)(pos - p0);
-                ub[i] = fail ? (uint16_t)((near_end(pos) || done) ? kS2Limited : 0u) : (uint16_t)b;
-                have = false;
+            // (up to eight steps before the queue is looked at again: a step is a table read and a dozen instructions,
+            // the ballots and the refill logic around it cost four times that per round)
+#pragma unroll 1
+            for (uint32_t t = 0; t < 8u; t++) {
+                if (have) {
+                    uint32_t run;
+                    const uint32_t len = cds0(pos, run);
+                    bool fail = len == 0u, done = false;
+                    uint32_t n = 1;
+                    if (!fail && run) {
+                        n = spec_run_blocks(c, len - c.id_len - 1u, b);
+                        fail = !n || n > bend - b;
+                    }
+                    if (!fail) {
+                        pos += len;
+                        b += n;
+                        if (b >= bend || (pos < s.limit && s2_marked(marks, pos))) done = true;
+                        else if (pos >= s.limit) fail = true;
+                    }
+                    if (done && pos - p0 > 0xFFFFu) fail = true;
+                    if (fail || done) {
+                        ua[i] = fail ? (uint16_t)0 : (uint16_t)(pos - p0);
+                        ub[i] = fail ? (uint16_t)((near_end(pos) || done) ? kS2Limited : 0u) : (uint16_t)b;
+                        have = false;
+                    }
+                }
+                if (!__any(have)) break;
             }
         }
     }
@@ -1902,14 +1939,19 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                     }
                 }
             }
-            if (!have) continue;
-            uint32_t end = 0;
-            const uint32_t st = s2_table_step(w, c, idx, b, bend, end);
-            if (st != 1u) {
-                const uint32_t a = st == 2u ? end - cpos[i] : 0u;
-                ua[i] = a > 0xFFFFu ? (uint16_t)0 : (uint16_t)a;
-                ub[i] = (st == 0u || (st == 2u && a > 0xFFFFu)) ? (uint16_t)kS2Limited : (uint16_t)0;
-                have = false;
+#pragma unroll 1
+            for (uint32_t t = 0; t < 4u; t++) {
+                if (have) {
+                    uint32_t end = 0;
+                    const uint32_t st = s2_table_step(w, c, idx, b, bend, end);
+                    if (st != 1u) {
+                        const uint32_t a = st == 2u ? end - cpos[i] : 0u;
+                        ua[i] = a > 0xFFFFu ? (uint16_t)0 : (uint16_t)a;
+                        ub[i] = (st == 0u || (st == 2u && a > 0xFFFFu)) ? (uint16_t)kS2Limited : (uint16_t)0;
+                        have = false;
+                    }
+                }
+                if (!__any(have)) break;
             }
         }
     }
@@ -2238,7 +2280,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         uint32_t first, uint32_t last, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
         const TwTables sp, ChunkEntry *__restrict__ centry, const SparseTables s2,
         uint32_t *__restrict__ batch_nhops = nullptr, uint64_t stop_near = 0,
-        const uint32_t *__restrict__ skip_if = nullptr)
+        const uint32_t *__restrict__ skip_if = nullptr, const SparseTables s2d = SparseTables{})
 {
     if (skip_if && *skip_if) return;                 // (the phase-locked chains have delivered everything: launch_index_locked)
     // stop_near (bits; callers that index a stream piece by piece and have more of it than they hand in): an RSI the
@@ -2432,7 +2474,24 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             while (s2.bitmap && r < max_rsi && good >= s2.lo && good < s2.hi && good < end_bit) {
                 uint2 rec;
                 uint32_t wv, ix;
-                if (!sparse_lookup(s2, good, rec, wv, ix)) break;
+                // (the dense tables, built where a window of the ordinary ones gave up: this RSI alone)
+                auto dense_hop = [&]() -> bool {
+                    uint2 rd;
+                    if (!s2d.bitmap || good < s2d.lo || good >= s2d.hi || !dense_lookup(s2d, good, rd)) return false;
+                    if (!rd.x || good + rd.x > end_bit) return false;
+                    if (lane == 0) rsi_off[r] = good;
+                    good += rd.x;
+                    r++;
+                    n_lookups++;
+                    return true;
+                };
+                if (!sparse_lookup(s2, good, rec, wv, ix)) {
+                    if (dense_hop()) {
+                        hopped = true;
+                        continue;
+                    }
+                    break;
+                }
                 if (s2.wide && (wv % s2.wpc) == 0u) {
                     const uint4 wd = s2.wide[(uint64_t)(wv / s2.wpc) * s2.cap + ix];
                     if (wd.w && r + wd.z <= max_rsi) {
@@ -2453,7 +2512,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                     if (lane == 0) rsi_off[r] = good;
                     good += t;
                     r++;
-                } else {
+                } else if (!dense_hop()) {
                     break;
                 }
                 hopped = true;
@@ -2696,6 +2755,13 @@ struct Sparse2Plan {
     bool ok;
     Spec2Geom g;
     size_t lds;
+    // the dense fallback (k_spec4 in windows of 32 kbit with room for a candidate per four bits): geometry, windows per
+    // span, offsets of its tables behind the ordinary ones
+    bool dense;
+    Spec2Geom dg;
+    size_t dlds;
+    uint32_t dnwin_max;
+    size_t od_bitmap, od_pre, od_rec, od_cpos, od_ccnt;
     uint32_t nwin_max;        // windows per super-chunk (one k_spec2 launch)
     uint32_t wpc;             // windows per chunk of the wide walker
     uint32_t nchunk_max;
@@ -2791,6 +2857,36 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
     p.o_rhops = o;  o = up(o + (size_t)p.nchunk_max * p.wpc * 2 * sizeof(IdxHop));
     p.o_nhops = o;  o = up(o + (size_t)p.nchunk_max * 4);
     p.o_blist = o;  o = up(o + (size_t)kS2BridgeCap * 4);
+    // Dense fallback.  A stream whose coded data sets repeat -- a ramp, a gradient: every block the same residuals -- is
+    // periodic, chains from different places fall into different cycles and never meet, and the candidates of all of
+    // them exceed a window's room: every window gave up and ONE wavefront walked the stream (64 MiB of a 16-bit ramp:
+    // 2 s, the reference 0.1 s).  Windows half the size with four times the room per bit resolve those; they are built
+    // only where an ordinary window gave up, and the walker takes their records RSI by RSI.
+    p.dense = false;
+    if (tune("AEC_S2_DENSE", 1) && look + kS2Lead + 4096 <= 32768) {
+        p.dg = p.g;
+        p.dg.lead = kS2Lead;
+        p.dg.look = (uint32_t)look;
+        p.dg.core = (32768u - kS2Lead - (uint32_t)look) & ~1023u;
+        if (p.dg.core > p.g.core) p.dg.core = p.g.core;
+        p.dg.cap_lds = 8192;
+        p.dg.cap_core = p.dg.core / 4;
+        p.dg.v4 = 1;
+        const uint32_t dW = p.dg.lead + p.dg.core + p.dg.look, dnw = dW / 32;
+        const size_t tab = (size_t)dW * 2 > (size_t)p.dg.cap_lds * 2 * 3 ? (size_t)dW * 2 : (size_t)p.dg.cap_lds * 2 * 3;
+        p.dlds = (size_t)(dnw + 4) * 4 + (size_t)dnw * 4 + (size_t)(dnw + 2) * 2 * 3 + (size_t)p.dg.cap_lds * 2 * 4 + tab + 64;
+        const uint64_t dn = ((uint64_t)p.nwin_max * p.g.core + p.dg.core - 1) / p.dg.core + 1;
+        if (p.dlds <= 156 * 1024 && dn < (1u << 24)) {
+            p.dnwin_max = (uint32_t)dn;
+            const size_t dwords = (size_t)p.dnwin_max * (p.dg.core / 32);
+            p.od_bitmap = o; o = up(o + dwords * 4);
+            p.od_pre = o;    o = up(o + dwords * 2);
+            p.od_rec = o;    o = up(o + (size_t)p.dnwin_max * p.dg.cap_core * sizeof(uint2));
+            p.od_cpos = o;   o = up(o + (size_t)p.dnwin_max * p.dg.cap_core * 2);
+            p.od_ccnt = o;   o = up(o + (size_t)p.dnwin_max * 4);
+            p.dense = true;
+        }
+    }
     p.bytes = o;
     p.ok = true;
     return p;
@@ -2979,6 +3075,25 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
                                const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin),
                                (const uint64_t *)nullptr, 0u, blist, blist_cnt);
         spec2_prof_report(nwin, ts, p.g.v4 != 0);
+        SparseTables td{};
+        if (p.dense) {
+            const uint32_t dnwin = (uint32_t)(((uint64_t)nwin * p.g.core + p.dg.core - 1) / p.dg.core);
+            td.bitmap = reinterpret_cast<const uint32_t *>(tb + p.od_bitmap);
+            td.pre = reinterpret_cast<const uint16_t *>(tb + p.od_pre);
+            td.rec = reinterpret_cast<const uint2 *>(tb + p.od_rec);
+            td.cpos = reinterpret_cast<const uint16_t *>(tb + p.od_cpos);
+            td.ccnt = reinterpret_cast<const uint32_t *>(tb + p.od_ccnt);
+            td.lo = lo;
+            td.hi = lo + (uint64_t)dnwin * p.dg.core < t.hi ? lo + (uint64_t)dnwin * p.dg.core : t.hi;
+            td.core = p.dg.core;
+            td.cap = p.dg.cap_core;
+            td.wide = nullptr;
+            td.wpc = 1;
+            hipLaunchKernelGGL(k_spec4, dim3(dnwin), dim3(1024), p.dlds, ts, c, words, nwords, end_bit, lo, start_bit, p.dg,
+                               const_cast<uint32_t *>(td.bitmap), const_cast<uint16_t *>(td.pre), const_cast<uint2 *>(td.rec),
+                               const_cast<uint16_t *>(td.cpos), const_cast<uint32_t *>(td.ccnt), (unsigned long long *)nullptr,
+                               (const uint64_t *)nullptr, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, t.ccnt, p.g.core, nwin);
+        }
 #ifdef AEC_TUNING
         if (tune_set("AEC_S2_VERIFY")) {
             static uint32_t *d_bad = nullptr;
@@ -3016,7 +3131,8 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
                                const_cast<uint4 *>(t.wide));
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
                            d_res, (const uint64_t *)nullptr, hops, hop_cap, carry, first ? 1u : 0u, last ? 1u : 0u,
-                           start_block, rsi_start, tail_slot, TwTables{}, centry, t, (uint32_t *)nullptr, last ? stop_near : 0ull);
+                           start_block, rsi_start, tail_slot, TwTables{}, centry, t, (uint32_t *)nullptr, last ? stop_near : 0ull,
+                           (const uint32_t *)nullptr, td);
         if (!flat)
             hipLaunchKernelGGL(k_rewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, t, nwin, nchunks, end_bit, centry, rhops,
                                nhops, d_rsi_off);
@@ -4094,7 +4210,11 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     // (without the preprocessor no coded data set holds a reference sample: nothing a chain could lock its count on)
     // (a walk that resumes inside an RSI numbers that RSI 0 and the first RSI start it meets 1: k_lock_fill)
     (void)start_block;
-    if (!tune("AEC_IDX_LOCK", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS) || c.rsi > 32u) return p;
+    // RSIs of at most 32 blocks -- or of any number of blocks that code to next to nothing: constant data, fill values
+    // (an RSI of 128 zero blocks is two coded data sets, 26 bits; as many candidates per window as the tables of neither
+    // kind have room for, and the serial walk took 64 ms for 64 MiB of a constant)
+    const bool tiny = rsi_bits_hint != 0 && rsi_bits_hint <= tune("AEC_IDX_LOCK_TINY", 256u);
+    if (!tune("AEC_IDX_LOCK", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS) || (c.rsi > 32u && !tiny)) return p;
     if (total_bits < (1u << 16)) return p;               // (a thousand coded data sets: the serial walker is as fast)
     uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 3;
     if (cds < 8) cds = 8;
