@@ -781,6 +781,13 @@ int decode_call(struct aec_stream *strm, int flush)
             size_t n = strm->avail_in < backlog_max ? strm->avail_in : backlog_max;
             if (n >= kDecDirectMin && s->stage.empty()) {
                 rc = upload(s, strm->next_in, n);
+                // (a one-shot caller's whole stream did not fit beside its output and the index workspace: in pieces
+                // of the ordinary backlog, as before round 4 -- only then AEC_MEM_ERROR)
+                if (rc == AEC_MEM_ERROR && n > kBacklogMax) {
+                    (void)hipGetLastError();
+                    n = kBacklogMax;
+                    rc = upload(s, strm->next_in, n);
+                }
                 if (rc != AEC_OK) break;
             } else {
                 s->stage.insert(s->stage.end(), strm->next_in, strm->next_in + n);

@@ -1462,7 +1462,9 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
 static bool dec_wave_wanted(const Cfg &c, uint64_t n_items)
 {
     if (c.bs != 8u && c.bs != 16u && c.bs != 32u && c.bs != 64u) return false;
-    const uint32_t most = tune("AEC_DEC_WAVE_MAX", 16384u), least = tune("AEC_DEC_WAVE_RSI", 16u);
+    // (a wavefront takes ~40 us for an RSI of 128 blocks and ~1500 of them run at a time: from ~8000 RSIs on the lane
+    // per RSI, 205 us whatever the number, is through first -- 16 MiB of the 8-bit shape: 1.53 against 1.57 ms per call)
+    const uint32_t most = tune("AEC_DEC_WAVE_MAX", 4096u), least = tune("AEC_DEC_WAVE_RSI", 16u);
     return c.rsi >= least && n_items <= most;
 }
 

@@ -1142,7 +1142,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     __shared__ uint32_t sh_total, sh_next[2], sh_part[16];
     // (diagnostic builds of the host pass `prof`: shader-clock stamps at the phase boundaries)
     auto stamp = [&](int k) {
-        if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 16 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     const uint32_t W = g.lead + g.core + g.look, nw = W / 32u, cap = g.cap_lds;
@@ -1560,7 +1560,7 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
     __shared__ uint32_t sh_total, sh_next[2], sh_part[16];
     auto stamp = [&](int k) {
-        if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 16 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     // dense mode: this window is built only if a window of the ordinary tables that covers part of its core gave up
@@ -1813,6 +1813,7 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         }
     }
     __syncthreads();
+    stamp(8);
     // ---- 3. the RSI hypothesis at every candidate of the core
     const uint32_t i0 = mpre[c0 >> 5], i1 = mpre[c1 >> 5 < nw ? c1 >> 5 : nw];
     const uint32_t ncore = i1 - i0;
@@ -1850,6 +1851,7 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         }
     }
     __syncthreads();
+    stamp(9);
     // A1. catch-up: table steps (no reference sample) until the walk stands on a marked boundary
     {
         const uint32_t bend = c.rsi;
@@ -1859,8 +1861,13 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             const uint64_t idle = __ballot(!have && !out), busy = __ballot(have);
             if (!(idle | busy)) break;
             if (idle && ((uint32_t)__popcll(idle) >= g.refill || !busy)) {
+                // (ONE atomic per wavefront: 1400 of them on one LDS word, lane by lane, were a third of this pass)
+                const uint32_t nreq = (uint32_t)__popcll(idle);
+                uint32_t base_i = 0;
+                if ((tid & 63u) == (uint32_t)__builtin_ctzll(idle)) base_i = atomicAdd(&sh_next[0], nreq);
+                base_i = (uint32_t)__builtin_amdgcn_readlane((int)base_i, (int)__builtin_ctzll(idle));
                 if (!have && !out) {
-                    i = atomicAdd(&sh_next[0], 1u);
+                    i = base_i + (uint32_t)__popcll(idle & ((1ull << (tid & 63u)) - 1ull));
                     if (i >= i1) {
                         out = true;
                     } else {
@@ -1874,24 +1881,42 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                     }
                 }
             }
-            // (up to eight steps before the queue is looked at again: a step is a table read and a dozen instructions,
-            // the ballots and the refill logic around it cost four times that per round)
+            // A step is one read of the table; the marks are looked at once per group of four plain steps (coded data sets
+            // of one block): a walk that has reached the marked chain stays on it, so it may hand over a few boundaries
+            // further on -- the table steps behind get to the same end.  Zero runs and failures one at a time.
 #pragma unroll 1
-            for (uint32_t t = 0; t < 8u; t++) {
+            for (uint32_t t = 0; t < 4u; t++) {
                 if (have) {
-                    uint32_t run;
-                    const uint32_t len = cds0(pos, run);
-                    bool fail = len == 0u, done = false;
-                    uint32_t n = 1;
-                    if (!fail && run) {
-                        n = spec_run_blocks(c, len - c.id_len - 1u, b);
-                        fail = !n || n > bend - b;
+                    uint32_t e = F[pos];
+#pragma unroll 1
+                    for (uint32_t u = 0; u < 4u && (e >> 12) == (kNxtBlock >> 12); u++) {
+                        pos += e & 0xFFFu;
+                        b++;
+                        if (b >= bend || pos >= s.limit) break;
+                        if (u < 3u) e = F[pos];
                     }
-                    if (!fail) {
-                        pos += len;
-                        b += n;
-                        if (b >= bend || (pos < s.limit && s2_marked(marks, pos))) done = true;
-                        else if (pos >= s.limit) fail = true;
+                    bool fail = false, done = false;
+                    if (b >= bend) {
+                        done = true;
+                    } else if (pos >= s.limit) {
+                        fail = true;
+                    } else if (s2_marked(marks, pos)) {
+                        done = true;
+                    } else {
+                        e = F[pos];
+                        if ((e >> 12) != (kNxtBlock >> 12)) {                 // a zero run, or no coded data set from here
+                            const uint32_t len = e & 0xFFFu;
+                            uint32_t n = 0;
+                            if (len) n = spec_run_blocks(c, len - c.id_len - 1u, b);
+                            if (!len || !n || n > bend - b) {
+                                fail = true;
+                            } else {
+                                pos += len;
+                                b += n;
+                                if (b >= bend || (pos < s.limit && s2_marked(marks, pos))) done = true;
+                                else if (pos >= s.limit) fail = true;
+                            }
+                        }
                     }
                     if (done && pos - p0 > 0xFFFFu) fail = true;
                     if (fail || done) {
@@ -1924,8 +1949,12 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             const uint64_t idle = __ballot(!have && !out), busy = __ballot(have);
             if (!(idle | busy)) break;
             if (idle && ((uint32_t)__popcll(idle) >= g.refill || !busy)) {
+                const uint32_t nreq = (uint32_t)__popcll(idle);
+                uint32_t base_i = 0;
+                if ((tid & 63u) == (uint32_t)__builtin_ctzll(idle)) base_i = atomicAdd(&sh_next[1], nreq);
+                base_i = (uint32_t)__builtin_amdgcn_readlane((int)base_i, (int)__builtin_ctzll(idle));
                 if (!have && !out) {
-                    i = atomicAdd(&sh_next[1], 1u);
+                    i = base_i + (uint32_t)__popcll(idle & ((1ull << (tid & 63u)) - 1ull));
                     if (i >= i1) {
                         out = true;
                     } else {
@@ -2898,8 +2927,8 @@ unsigned long long *spec2_prof_buffer(uint32_t nwin, bool reset = true)
     static const bool on = tune("AEC_S2_PROF", 0) != 0;
     static unsigned long long *buf = nullptr;
     if (!on) return nullptr;
-    if (!buf) (void)hipMalloc(reinterpret_cast<void **>(&buf), (size_t)kS2SuperWindows * 8 * sizeof(unsigned long long));
-    if (reset) (void)hipMemset(buf, 0, (size_t)kS2SuperWindows * 8 * sizeof(unsigned long long));
+    if (!buf) (void)hipMalloc(reinterpret_cast<void **>(&buf), (size_t)kS2SuperWindows * 16 * sizeof(unsigned long long));
+    if (reset) (void)hipMemset(buf, 0, (size_t)kS2SuperWindows * 16 * sizeof(unsigned long long));
     (void)nwin;
     return buf;
 }
@@ -2911,32 +2940,38 @@ void spec2_prof_report(uint32_t nwin, hipStream_t st, bool v4 = false)
     static int reports = 0;
     if (reports++ >= 2) return;
     (void)hipStreamSynchronize(st);
-    std::vector<unsigned long long> h((size_t)nwin * 8);
+    std::vector<unsigned long long> h((size_t)nwin * 16);
     (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
     if (v4) {                                   // k_spec4: stamps 0 .. 7 in the order of the phases
         double e[7] = {0, 0, 0, 0, 0, 0, 0};
         uint32_t m = 0;
         for (uint32_t w = 0; w + 1 < nwin; w++) {
-            if (!h[(size_t)w * 8 + 7]) continue;
-            for (int k = 0; k < 7; k++) e[k] += (double)(h[(size_t)w * 8 + k + 1] - h[(size_t)w * 8 + k]);
+            if (!h[(size_t)w * 16 + 7]) continue;
+            for (int k = 0; k < 7; k++) e[k] += (double)(h[(size_t)w * 16 + k + 1] - h[(size_t)w * 16 + k]);
             m++;
         }
         if (!m) m = 1;
+        double f1 = 0, f2 = 0;
+        for (uint32_t w = 0; w + 1 < nwin; w++) {
+            if (!h[(size_t)w * 16 + 7]) continue;
+            f1 += (double)(h[(size_t)w * 16 + 8] - h[(size_t)w * 16 + 3]);
+            f2 += (double)(h[(size_t)w * 16 + 9] - h[(size_t)w * 16 + 8]);
+        }
         fprintf(stderr, "k_spec4 phases (shader-clock ticks per window, %u windows): load+rank %.0f | table %.0f | chains %.0f | "
-                "candidates+first+catch-up %.0f | hop tables %.0f | table steps %.0f | chain+write %.0f\n", m, e[0] / m,
-                e[1] / m, e[2] / m, e[3] / m, e[4] / m, e[5] / m, e[6] / m);
+                "candidates+first+catch-up %.0f (candidates %.0f, first coded data sets %.0f) | hop tables %.0f | table steps %.0f | chain+write %.0f\n", m, e[0] / m,
+                e[1] / m, e[2] / m, e[3] / m, f1 / m, f2 / m, e[4] / m, e[5] / m, e[6] / m);
         return;
     }
     double d[6] = {0, 0, 0, 0, 0, 0};
     uint32_t n = 0;
     for (uint32_t w = 0; w + 1 < nwin; w++) {
-        if (!h[(size_t)w * 8 + 6]) continue;
-        for (int k = 0; k < 6; k++) d[k] += (double)(h[(size_t)w * 8 + k + 1] - h[(size_t)w * 8 + k]);
+        if (!h[(size_t)w * 16 + 6]) continue;
+        for (int k = 0; k < 6; k++) d[k] += (double)(h[(size_t)w * 16 + k + 1] - h[(size_t)w * 16 + k]);
         n++;
     }
     double pa = 0;
     for (uint32_t w = 0; w + 1 < nwin; w++)
-        if (h[(size_t)w * 8 + 6]) pa += (double)(h[(size_t)w * 8 + 7] - h[(size_t)w * 8 + 4]);
+        if (h[(size_t)w * 16 + 6]) pa += (double)(h[(size_t)w * 16 + 7] - h[(size_t)w * 16 + 4]);
     fprintf(stderr, "k_spec2 phases (shader-clock ticks per window, %u windows): load+rank %.0f | chains %.0f | "
             "prefix+cand nxt %.0f | hop4+hop16 %.0f | units %.0f (parses %.0f) | chain+write %.0f\n", n, d[0] / n,
             d[1] / n, d[2] / n, d[3] / n, d[4] / n, pa / n, d[5] / n);

@@ -53,8 +53,16 @@ done
 python3 tests/bench_index_mixed.py 2>&1 | grep -v amdgpu > $OUT/bench_index_mixed.txt
 python3 tests/bench_abi_small.py > $OUT/bench_abi_small.txt 2>&1
 for c in c2 c3 c5 typical; do python3 tests/bench_abi_large.py --config $c 2>&1 | grep -v amdgpu >> $OUT/bench_abi_large.txt; done
-python3 tests/bench_sz_chunks.py --narrow > $OUT/bench_sz_chunks.txt 2>&1
+python3 tests/bench_sz_chunks.py 2>&1 | grep -v amdgpu > $OUT/bench_sz_chunks.txt
+python3 tests/bench_sz_chunks.py --narrow 2>&1 | grep -v amdgpu >> $OUT/bench_sz_chunks.txt
 python3 tests/bench_short_rsi.py 2>&1 | grep -v amdgpu > $OUT/bench_short_rsi.txt
-timeout 600 python3 tests/fuzz_index_gpu.py --cases 150 --seed 123 --time 2>&1 | grep -A25 "slowest" > $OUT/fuzz_index_slowest_shapes.txt
+python3 tests/bench_degenerate.py --size-mib 64 2>&1 | grep -v amdgpu > $OUT/bench_degenerate.txt
+# kernel trace of small one-shot decodes (which kernels a 64 KiB call is made of) and the wave-per-RSI decoder's phases
+bash tests/prof_small.sh $1/small > /dev/null 2>&1
+python3 tests/trace_windows.py $(find $OUT/small -name "*kernel_trace.csv" | head -1) 5 25 > $OUT/small_call_kernels_c5.txt 2>&1
+AEC_AMD_LIB=$R/libaec_amd/lib/tuning/libaec.so.0 AEC_DW_PROF=1 python3 tests/bench_abi_small.py --chunk-kib 64 --reps 3 2>&1 | grep -v amdgpu > $OUT/k_decode_wave_phases_c5.txt
+bash tests/prof_short_rsi.sh $1/shortrsi 16 > /dev/null 2>&1
+cp $OUT/shortrsi/kernel_stats_short_rsi.csv $OUT/kernel_stats_short_rsi.csv 2>/dev/null
+timeout 600 python3 tests/fuzz_index_gpu.py --cases 300 --seed 5001 --time 2>&1 | grep -A25 "slowest" > $OUT/fuzz_index_slowest_shapes.txt
 python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
-rm -rf $OUT/sq_c2 $OUT/stats_* $OUT/traffic_c2 $OUT/traffic_c3 $OUT/traffic_c5 $OUT/traffic_typical $OUT/idx $OUT/idxpmc_* $OUT/idxsq_*
+rm -rf $OUT/small $OUT/shortrsi $OUT/sq_c2 $OUT/stats_* $OUT/traffic_c2 $OUT/traffic_c3 $OUT/traffic_c5 $OUT/traffic_typical $OUT/idx $OUT/idxpmc_* $OUT/idxsq_*
