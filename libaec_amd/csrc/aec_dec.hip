@@ -1463,8 +1463,10 @@ static bool dec_wave_wanted(const Cfg &c, uint64_t n_items)
 {
     if (c.bs != 8u && c.bs != 16u && c.bs != 32u && c.bs != 64u) return false;
     // (a wavefront takes ~40 us for an RSI of 128 blocks and ~1500 of them run at a time: from ~8000 RSIs on the lane
-    // per RSI, 205 us whatever the number, is through first -- 16 MiB of the 8-bit shape: 1.53 against 1.57 ms per call)
-    const uint32_t most = tune("AEC_DEC_WAVE_MAX", 4096u), least = tune("AEC_DEC_WAVE_RSI", 16u);
+    // per RSI, 205 us whatever the number, is through first -- 16 MiB of the 8-bit shape: 1.53 against 1.57 ms per call.
+    // n_items is the MOST the index pass can have found where the counts come from its record: the streaming ABI asks
+    // for room / RSI size + 2 of at least 4 MiB of room, 4098 for the 8-bit shape whatever the call holds)
+    const uint32_t most = tune("AEC_DEC_WAVE_MAX", 8192u), least = tune("AEC_DEC_WAVE_RSI", 16u);
     return c.rsi >= least && n_items <= most;
 }
 
@@ -1521,7 +1523,7 @@ static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
                 unsigned long long h[8];
                 (void)hipStreamSynchronize(st);
                 (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dw_prof), sizeof(h));
-                fprintf(stderr, "k_decode_wave, RSI 0 (shader-clock ticks, 100 MHz): refills %llu | pieces %llu | walk incl. those %llu | "
+                fprintf(stderr, "k_decode_wave, RSI 0 (s_memtime ticks): refills %llu | pieces %llu | walk incl. those %llu | "
                         "+ decode %llu | + predictor, store %llu\n", h[0], h[1], h[2], h[3], h[4]);
             }
         }

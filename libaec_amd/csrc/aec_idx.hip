@@ -1549,32 +1549,19 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
 // writes (tests: AEC_S2_V4=0/1 in the tuning build give identical index results; k_spec_verify on both).
 // LDS: win | marks | rank | sel | mpre | [cpos cnxt ua ub] (the ones tile while F is filled) | F[W] (later chop4
 // chop16 csucc).  W = 48 kbit fits the 160 KB of a CU.
-__global__ void __launch_bounds__(1024)
-k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
-        uint64_t start_bit, const Spec2Geom g, uint32_t *__restrict__ gbitmap, uint16_t *__restrict__ gpre,
-        uint2 *__restrict__ grec, uint16_t *__restrict__ gcpos, uint32_t *__restrict__ gccnt,
-        unsigned long long *__restrict__ prof, const uint64_t *__restrict__ starts = nullptr, uint32_t nstarts = 0,
-        uint32_t *__restrict__ blist = nullptr, uint32_t *__restrict__ blist_cnt = nullptr,
-        const uint32_t *__restrict__ only_where_zero = nullptr, uint32_t other_core = 0, uint32_t other_nwin = 0)
+__device__ __forceinline__ void
+spec4_window(const uint32_t wid, const Cfg &c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit,
+             uint64_t tab_lo, uint64_t start_bit, const Spec2Geom &g, uint32_t *__restrict__ gbitmap,
+             uint16_t *__restrict__ gpre, uint2 *__restrict__ grec, uint16_t *__restrict__ gcpos,
+             uint32_t *__restrict__ gccnt, unsigned long long *__restrict__ prof, const uint64_t *__restrict__ starts,
+             uint32_t nstarts, uint32_t *__restrict__ blist, uint32_t *__restrict__ blist_cnt)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
     __shared__ uint32_t sh_total, sh_next[2], sh_part[16];
     auto stamp = [&](int k) {
-        if (prof && threadIdx.x == 0) prof[(size_t)blockIdx.x * 16 + k] = __builtin_amdgcn_s_memtime();
+        if (prof && threadIdx.x == 0) prof[(size_t)wid * 16 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
-    // dense mode: this window is built only if a window of the ordinary tables that covers part of its core gave up
-    // (its count is 0) -- a launch over all dense windows of which nearly all return here
-    if (only_where_zero) {
-        const uint64_t a = (uint64_t)blockIdx.x * g.core, b = a + g.core - 1u;
-        uint32_t j0 = (uint32_t)(a / other_core), j1 = (uint32_t)(b / other_core);
-        bool any = false;
-        for (uint32_t j = j0; j <= j1 && j < other_nwin; j++) any = any || only_where_zero[j] == 0u;
-        if (!any) {
-            if (threadIdx.x == 0) gccnt[blockIdx.x] = 0u;
-            return;
-        }
-    }
     const uint32_t W = g.lead + g.core + g.look, nw = W / 32u, cap = g.cap_lds;
     uint32_t *win = spec_lds;
     uint32_t *marks = win + nw + 4;
@@ -1591,15 +1578,15 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     uint16_t *csucc = chop16 + cap;
     uint16_t *ones = cpos;                            // 4 * cap entries, while F is filled
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint64_t core_abs = tab_lo + (uint64_t)blockIdx.x * g.core;
-    const uint64_t gw0 = ((uint64_t)blockIdx.x * g.core) >> 5;
+    const uint64_t core_abs = tab_lo + (uint64_t)wid * g.core;
+    const uint64_t gw0 = ((uint64_t)wid * g.core) >> 5;
     const uint32_t cw = g.core / 32u;
     auto give_up = [&]() {
         for (uint32_t i = tid; i < cw; i += nt) {
             gbitmap[gw0 + i] = 0u;
             gpre[gw0 + i] = 0;
         }
-        if (tid == 0) gccnt[blockIdx.x] = 0u;
+        if (tid == 0) gccnt[wid] = 0u;
     };
     if (core_abs >= end_bit) {
         give_up();
@@ -1999,7 +1986,7 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             pos += ua[j];
             cnt++;
         }
-        const uint64_t at = (uint64_t)blockIdx.x * g.cap_core + (i - i0);
+        const uint64_t at = (uint64_t)wid * g.cap_core + (i - i0);
         const bool limited = !cnt && !ua[i] && ub[i] == kS2Limited;
         grec[at] = make_uint2(ua[i], cnt ? ((cnt << 24) | (pos - cpos[i])) : (limited ? 1u : 0u));
         if (limited && blist) {
@@ -2015,8 +2002,59 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         gbitmap[gw0 + i] = marks[(c0 >> 5) + i];
         gpre[gw0 + i] = (uint16_t)(mpre[(c0 >> 5) + i] - i0);
     }
-    if (tid == 0) gccnt[blockIdx.x] = ncore;
+    if (tid == 0) gccnt[wid] = ncore;
     stamp(7);
+}
+
+__global__ void __launch_bounds__(1024)
+k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64_t end_bit, uint64_t tab_lo,
+        uint64_t start_bit, const Spec2Geom g, uint32_t *__restrict__ gbitmap, uint16_t *__restrict__ gpre,
+        uint2 *__restrict__ grec, uint16_t *__restrict__ gcpos, uint32_t *__restrict__ gccnt,
+        unsigned long long *__restrict__ prof, const uint64_t *__restrict__ starts = nullptr, uint32_t nstarts = 0,
+        uint32_t *__restrict__ blist = nullptr, uint32_t *__restrict__ blist_cnt = nullptr,
+        const uint32_t *__restrict__ wlist = nullptr, const uint32_t *__restrict__ wcount = nullptr,
+        const uint32_t *__restrict__ only_where_zero = nullptr, uint32_t other_core = 0, uint32_t other_nwin = 0)
+{
+    // dense mode of a few windows (small inputs): every window looks itself whether an ordinary window over its core
+    // gave up -- one launch instead of the list's two
+    if (only_where_zero) {
+        const uint64_t a = (uint64_t)blockIdx.x * g.core, b = a + g.core - 1u;
+        const uint32_t j0 = (uint32_t)(a / other_core), j1 = (uint32_t)(b / other_core);
+        bool any = false;
+        for (uint32_t j = j0; j <= j1 && j < other_nwin; j++) any = any || only_where_zero[j] == 0u;
+        if (!any) {
+            if (threadIdx.x == 0) gccnt[blockIdx.x] = 0u;
+            return;
+        }
+    }
+    if (!wlist) {
+        spec4_window(blockIdx.x, c, words, nwords, end_bit, tab_lo, start_bit, g, gbitmap, gpre, grec, gcpos, gccnt, prof, starts,
+                     nstarts, blist, blist_cnt);
+        return;
+    }
+    // dense mode: the windows on the list k_dense_pick left (those over an ordinary window that gave up), a few per
+    // workgroup -- on nearly every stream the list is empty and the launch is a few hundred workgroups that return
+    const uint32_t n = *wcount;
+    for (uint32_t li = blockIdx.x; li < n; li += gridDim.x) {
+        spec4_window(wlist[li], c, words, nwords, end_bit, tab_lo, start_bit, g, gbitmap, gpre, grec, gcpos, gccnt, prof, starts,
+                     nstarts, blist, blist_cnt);
+        __syncthreads();
+    }
+}
+
+// which windows of the dense tables are to be built: those whose core lies over an ordinary window with a count of 0
+__global__ void __launch_bounds__(256)
+k_dense_pick(const uint32_t *__restrict__ sparse_ccnt, uint32_t sparse_core, uint32_t sparse_nwin, uint32_t dcore, uint32_t dnwin,
+             uint32_t *__restrict__ dccnt, uint32_t *__restrict__ wlist, uint32_t *__restrict__ wcount)
+{
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= dnwin) return;
+    const uint64_t a = (uint64_t)w * dcore, b = a + dcore - 1u;
+    const uint32_t j0 = (uint32_t)(a / sparse_core), j1 = (uint32_t)(b / sparse_core);
+    bool any = false;
+    for (uint32_t j = j0; j <= j1 && j < sparse_nwin; j++) any = any || sparse_ccnt[j] == 0u;
+    if (any) wlist[atomicAdd(wcount, 1u)] = w;
+    else dccnt[w] = 0u;
 }
 
 #ifdef AEC_TUNING
@@ -2790,7 +2828,7 @@ struct Sparse2Plan {
     Spec2Geom dg;
     size_t dlds;
     uint32_t dnwin_max;
-    size_t od_bitmap, od_pre, od_rec, od_cpos, od_ccnt;
+    size_t od_bitmap, od_pre, od_rec, od_cpos, od_ccnt, od_list;
     uint32_t nwin_max;        // windows per super-chunk (one k_spec2 launch)
     uint32_t wpc;             // windows per chunk of the wide walker
     uint32_t nchunk_max;
@@ -2913,6 +2951,7 @@ Sparse2Plan sparse2_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hi
             p.od_rec = o;    o = up(o + (size_t)p.dnwin_max * p.dg.cap_core * sizeof(uint2));
             p.od_cpos = o;   o = up(o + (size_t)p.dnwin_max * p.dg.cap_core * 2);
             p.od_ccnt = o;   o = up(o + (size_t)p.dnwin_max * 4);
+            p.od_list = o;   o = up(o + (size_t)p.dnwin_max * 4);
             p.dense = true;
         }
     }
@@ -3098,7 +3137,7 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
         const uint32_t hop_cap = 2 * nwin + 8;
         if (piped && si >= 2) (void)hipStreamWaitEvent(ts, side.done[set], 0);      // the walkers of span si - 2 are through
         uint32_t *blist = reinterpret_cast<uint32_t *>(tb + p.o_blist), *blist_cnt = reinterpret_cast<uint32_t *>(tb + 56);
-        (void)hipMemsetAsync(blist_cnt, 0, 4, ts);
+        (void)hipMemsetAsync(blist_cnt, 0, 8, ts);                  // (+ the count of the dense windows' list at offset 60)
         if (p.g.v4)
             hipLaunchKernelGGL(k_spec4, dim3(nwin), dim3(1024), p.lds, ts, c, words, nwords, end_bit, lo, start_bit, p.g,
                                const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
@@ -3124,10 +3163,22 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
             td.cap = p.dg.cap_core;
             td.wide = nullptr;
             td.wpc = 1;
-            hipLaunchKernelGGL(k_spec4, dim3(dnwin), dim3(1024), p.dlds, ts, c, words, nwords, end_bit, lo, start_bit, p.dg,
-                               const_cast<uint32_t *>(td.bitmap), const_cast<uint16_t *>(td.pre), const_cast<uint2 *>(td.rec),
-                               const_cast<uint16_t *>(td.cpos), const_cast<uint32_t *>(td.ccnt), (unsigned long long *)nullptr,
-                               (const uint64_t *)nullptr, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, t.ccnt, p.g.core, nwin);
+            uint32_t *dlist = reinterpret_cast<uint32_t *>(tb + p.od_list), *dcount = reinterpret_cast<uint32_t *>(tb + 60);
+            if (dnwin <= 1024u)
+                hipLaunchKernelGGL(k_spec4, dim3(dnwin), dim3(1024), p.dlds, ts, c, words, nwords, end_bit, lo, start_bit, p.dg,
+                                   const_cast<uint32_t *>(td.bitmap), const_cast<uint16_t *>(td.pre), const_cast<uint2 *>(td.rec),
+                                   const_cast<uint16_t *>(td.cpos), const_cast<uint32_t *>(td.ccnt), (unsigned long long *)nullptr,
+                                   (const uint64_t *)nullptr, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                   (const uint32_t *)nullptr, t.ccnt, p.g.core, nwin);
+            else {
+            hipLaunchKernelGGL(k_dense_pick, dim3((dnwin + 255) / 256), dim3(256), 0, ts, t.ccnt, p.g.core, nwin, p.dg.core, dnwin,
+                               const_cast<uint32_t *>(td.ccnt), dlist, dcount);
+            hipLaunchKernelGGL(k_spec4, dim3(dnwin < 512u ? dnwin : 512u), dim3(1024), p.dlds, ts, c, words, nwords, end_bit, lo,
+                               start_bit, p.dg, const_cast<uint32_t *>(td.bitmap), const_cast<uint16_t *>(td.pre),
+                               const_cast<uint2 *>(td.rec), const_cast<uint16_t *>(td.cpos), const_cast<uint32_t *>(td.ccnt),
+                               (unsigned long long *)nullptr, (const uint64_t *)nullptr, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                               (const uint32_t *)dlist, (const uint32_t *)dcount);
+            }
         }
 #ifdef AEC_TUNING
         if (tune_set("AEC_S2_VERIFY")) {

@@ -962,6 +962,96 @@ def test_flush_calls_after_the_stream_is_complete(api):
         assert (rc_p, enc_p) == (0, whole)
 
 
+def test_wave_per_rsi_decoder_edges(api, gpu):
+    """k_decode_wave (a wavefront per RSI, a lane per block; chosen for at most 4096 RSIs of at least 16 blocks) against the
+    ORACLE's bytes on what its three phases can get wrong: the walk -- zero runs longer than a round of 64 blocks, rest-of-
+    segment codes, blocks of 64 32-bit samples (coded data sets beyond the 2048-bit register window: the sequential reader),
+    RSIs longer than the wavefront's window of the stream (4096 blocks); the predictor -- data that clips at both ends of the
+    range in most blocks (the lane-against-lane check has to iterate), signed samples, no preprocessor; the store -- 3-byte
+    containers, a short last RSI; and the device API with the encoder's offset table as well as the ABI."""
+    import torch
+    rng = np.random.default_rng(55)
+
+    def clipping(n, bps, signed):
+        lo, hi = (-(1 << (bps - 1)), (1 << (bps - 1)) - 1) if signed else (0, (1 << bps) - 1)
+        v = np.cumsum(rng.integers(-3, 4, n) * max(1, (hi - lo) // 40))
+        return np.clip(v - v.min() // 2 + lo, lo, hi)
+
+    def zero_runs(n, bps):
+        v = np.cumsum(rng.integers(-2, 3, n)) + (1 << (bps - 1))
+        for _ in range(12):
+            a = int(rng.integers(0, n - 5000))
+            v[a:a + int(rng.integers(200, 5000))] = v[a]                    # constant stretches: zero runs, ROS codes
+        return np.clip(v, 0, (1 << bps) - 1)
+
+    cases = [
+        ("clip u16", 16, 16, 128, PP, pack_samples(clipping(16 * 128 * 9 + 37, 16, False), 16, PP)),
+        ("clip s8", 8, 8, 64, PP | SGN, pack_samples(clipping(8 * 64 * 40 + 3, 8, True), 8, PP | SGN)),
+        ("clip s32 msb", 32, 32, 96, PP | SGN | MSB, pack_samples(clipping(32 * 96 * 7, 32, True), 32, PP | SGN | MSB)),
+        ("zero runs", 16, 16, 300, PP, pack_samples(zero_runs(16 * 300 * 11 + 100, 16), 16, PP)),
+        ("zero runs 8", 8, 8, 1000, PP, pack_samples(zero_runs(8 * 1000 * 6, 8), 8, PP)),
+        ("all zero", 16, 16, 128, PP, np.zeros(16 * 128 * 2 * 5, dtype=np.uint8)),
+        ("block 64 x 32 bit", 32, 64, 64, PP, gen(1, 64 * 64 * 4 * 6 + 64 * 4 * 3)),
+        ("rsi 4096", 16, 16, 4096, PP, gen(0, 16 * 4096 * 2 * 3 + 16 * 2 * 100)),
+        ("rsi 4096 noise", 16, 32, 4096, PP, rng.integers(0, 256, 32 * 4096 * 2 * 2, dtype=np.uint8)),
+        ("24 bit 3 byte", 24, 16, 128, PP | AEC_DATA_3BYTE, rng.integers(0, 40, 16 * 128 * 3 * 7, dtype=np.uint8)),
+        ("no preprocessor", 16, 16, 128, 0, gen(0, 16 * 128 * 2 * 9)),
+        ("ramp", 16, 16, 128, PP, pack_samples(np.arange(16 * 128 * 30) % 65536, 16, PP)),
+    ]
+    for name, bps, bs, rsi, flags, data in cases:
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        nb = bytes_per_sample(bps, flags)
+        data = data[: data.size - data.size % nb]
+        rc, enc, _, offs, bits = oracle_encode(data, bps, bs, rsi, flags)
+        assert rc == AEC_OK, name
+        nblk = (data.size // nb + bs - 1) // bs
+        rc_o, dec_o, _ = oracle_decode(enc, bps, bs, rsi, flags, nblk * bs * nb)
+        assert rc_o == AEC_OK, name
+        # the ABI (index pass + decode)
+        rc, dec = api.aec_buffer_decode(enc, bps, bs, rsi, flags, nblk * bs * nb)
+        assert rc == AEC_OK and dec == dec_o, (name, "ABI")
+        # the device API with the oracle's offsets (the decoder alone)
+        codec = gpu.Codec(bps, bs, rsi, flags)
+        d_enc = torch.from_numpy(np.frombuffer(enc + b"\0" * 64, dtype=np.uint8).copy()).cuda()
+        nrsi = (nblk + rsi - 1) // rsi
+        d_off = torch.from_numpy(np.concatenate([np.asarray(offs, dtype=np.uint64), np.array([bits], dtype=np.uint64)])
+                                 .astype(np.int64)).cuda()
+        d_dec, st = codec.decode(d_enc, len(enc), d_off, nrsi, nblk)
+        assert st == 0 and d_dec[: nblk * bs * nb].cpu().numpy().tobytes() == dec_o, (name, "device API")
+        # ... and cut inside a coded data set: what the reference releases of it (decode.c:423-460)
+        cut = enc[: max(1, int(len(enc) * 0.77))]
+        rc_o, dec_c, _ = oracle_decode(cut, bps, bs, rsi, flags, nblk * bs * nb)
+        rc, dec = api.aec_buffer_decode(cut, bps, bs, rsi, flags, nblk * bs * nb)
+        assert rc == rc_o and dec == dec_c, (name, "cut", rc, rc_o, len(dec), len(dec_c))
+
+
+def test_degenerate_inputs(api):
+    """Streams whose coded data sets are as short or as regular as the format allows (tests/bench_degenerate.py): all
+    zeros and constants (an RSI of 128 blocks is two coded data sets: the phase-locked index), ramps (every coded data set
+    the same: a periodic stream on which chains from different places never meet; the dense fallback tables), a sawtooth,
+    noise in the low bits -- 8 MiB each through aec_buffer_encode / aec_buffer_decode against the oracle."""
+    n = 8 << 20
+    rng = np.random.default_rng(9)
+    for bps, bs, rsi in ((16, 16, 128), (8, 8, 128), (16, 32, 64)):
+        dt = np.dtype("<u2") if bps == 16 else np.dtype(np.uint8)
+        m = n // dt.itemsize
+        shapes = {
+            "zeros": np.zeros(m, dtype=dt),
+            "constant": np.full(m, 1000 if bps == 16 else 100, dtype=dt),
+            "ramp": (np.arange(m) % (1 << bps)).astype(dt),
+            "ramp by 3": ((3 * np.arange(m)) % (1 << bps)).astype(dt),
+            "sawtooth": (np.arange(m) % 37).astype(dt),
+            "noise in 2 low bits": (rng.integers(0, 4, m, dtype=np.uint64) + (1 << (bps - 1))).astype(dt),
+        }
+        for name, arr in shapes.items():
+            data = arr.view(np.uint8)
+            rc, enc = api.aec_buffer_encode(data, bps, bs, rsi, PP)
+            rc_o, enc_o, *_ = oracle_encode(data, bps, bs, rsi, PP)
+            assert rc == AEC_OK and enc == enc_o, (name, bps, bs, rsi)
+            rc, dec = api.aec_buffer_decode(enc, bps, bs, rsi, PP, n)
+            assert rc == AEC_OK and dec == data.tobytes(), (name, bps, bs, rsi)
+
+
 def test_bare_stream_decodes_by_segments(gpu):
     """A bare stream with long RSIs (BASELINE config 3 shape: 64 segments per RSI): the index pass leaves the segment
     starts beside the RSI starts (aec_gpu_index_segments_async; the reference has no entry points inside an RSI,
