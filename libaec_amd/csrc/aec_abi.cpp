@@ -902,15 +902,8 @@ void copy_all(const std::vector<CopyJob> &jobs)
         work(0);
         return;
     }
-    std::vector<std::thread> th;
-    try {
-        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
-    } catch (...) {                      // (no more threads: the ones that started do their share, this one the rest)
-        const unsigned started = (unsigned)th.size() + 1;
-        for (unsigned t = started; t < nt; t++) work(t);
-    }
-    work(0);
-    for (std::thread &x : th) x.join();
+    // (the pool's threads, kept between calls -- round 5; until then a thread per share was created and joined per call)
+    WorkerPool::run(nt, [&](size_t t) { work((unsigned)t); });
 }
 
 // A large batch as several parts side by side: every part is a batch of its own on its own kit (HIP stream,

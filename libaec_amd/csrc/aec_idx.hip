@@ -71,6 +71,7 @@ struct TwTables {
     const uint4 *wide;         // [chunk * wcap + index]: {exit lo, exit hi, RSIs, 1 = resolved}
     uint32_t wpc, wcap, wfirst;
     uint32_t nrec;             // records there is room for (indices beyond it are never read)
+    const uint32_t *skip_if;   // non-null and *skip_if != 0: another scheme has delivered the index, the kernels return
 };
 
 // record of the node at absolute bit p (false: p is not a node)
@@ -155,6 +156,7 @@ __global__ void __launch_bounds__(64)
 k_trunk(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const uint64_t *exit_prev, uint64_t *exit_out,
         uint32_t mode)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (mode == 2u) {
         if (i < g.nwin) tr_trunk_window(s, c, g, t, i, t.entry[i], nullptr, TR_FILL);
@@ -224,6 +226,7 @@ __global__ void __launch_bounds__(64)
 k_trunk_coop(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const uint64_t *exit_prev, uint64_t *exit_out,
              uint32_t mode)
 {
+    if (t.skip_if && *t.skip_if) return;
     __shared__ __attribute__((aligned(16))) uint32_t lds_w[kTrunkCoopWin];
     const uint32_t nreg = (g.nwin + g.rw - 1u) / g.rw, lane = threadIdx.x;
     CoopCds<kTrunkCoopWin> cw;
@@ -291,6 +294,7 @@ __device__ __forceinline__ uint64_t block_incl_scan64(uint64_t v, uint64_t *sh16
 __global__ void __launch_bounds__(1024)
 k_trunk_scan(const TrGeom g, const TrTables t)
 {
+    if (t.skip_if && *t.skip_if) return;
     __shared__ uint64_t sh16[16];
     uint64_t c_nod = 0, c_blk = 0, c_sr = 0;             // carried over the rounds (the same in every lane)
     const uint32_t tid = threadIdx.x;
@@ -377,6 +381,7 @@ __global__ void __launch_bounds__(1024)
 k_hyp_walk(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, uint32_t wpg, uint32_t margin,
            uint32_t ngroups)
 {
+    if (t.skip_if && *t.skip_if) return;
     extern __shared__ __attribute__((aligned(16))) uint32_t hyp_lds[];
     const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u;
     const TrGlobal mem{s, g, t};
@@ -513,6 +518,7 @@ k_hyp_walk(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, uint
 __global__ void __launch_bounds__(64)
 k_hyp_walk_mem(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, uint32_t wpg)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t w0 = blockIdx.x * wpg;
     if (w0 >= g.ncore) return;
@@ -651,6 +657,7 @@ __global__ void __launch_bounds__(256)
 k_hyp_walk_co(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, uint32_t wpg, uint32_t margin,
               uint32_t ngroups, uint32_t shift, uint32_t tmax, uint32_t cap, const CoLists ls, uint32_t park_at)
 {
+    if (t.skip_if && *t.skip_if) return;
     // ls.over_plain: walks that run over the end of their RSI before they land go to the plain walk as well
     extern __shared__ __attribute__((aligned(16))) uint32_t co_lds[];
     __shared__ CoParked pk[kCoPark];
@@ -810,6 +817,7 @@ constexpr uint32_t kCoopWin = 1024;                  // words of stream (and of 
 __global__ void __launch_bounds__(64)
 k_hyp_walk_rest(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const CoLists ls)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t n = ls.counts[0] < ls.qcap ? ls.counts[0] : ls.qcap;
     const TrGlobal mem{s, g, t};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -831,6 +839,7 @@ k_hyp_walk_rest(const Cfg c, const TrStream s, const TrGeom g, const TrTables t,
 __global__ void __launch_bounds__(256)
 k_hyp_defer(const Cfg c, const TrGeom g, const TrTables t, const CoLists ls)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t w = blockIdx.x;
     if (w >= g.ncore) return;
     const uint32_t n = t.ccnt[w];
@@ -862,6 +871,7 @@ k_hyp_defer(const Cfg c, const TrGeom g, const TrTables t, const CoLists ls)
 __global__ void __launch_bounds__(64)
 k_hyp_walk_list(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, const CoLists ls)
 {
+    if (t.skip_if && *t.skip_if) return;
     __shared__ __attribute__((aligned(16))) uint32_t lds_w[kCoopWin], lds_m[kCoopWin];
     const uint32_t n = ls.counts[1] < ls.pcap ? ls.counts[1] : ls.pcap;
     const TrGlobal mem{s, g, t};
@@ -936,6 +946,7 @@ k_hyp_walk_list(const Cfg c, const TrStream s, const TrGeom g, const TrTables t,
 __global__ void __launch_bounds__(256)
 k_hyp_land(const Cfg c, const TrGeom g, const TrTables t)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t w = blockIdx.x;
     if (w >= g.ncore) return;
     const uint32_t n = t.ccnt[w];
@@ -949,6 +960,7 @@ k_hyp_land(const Cfg c, const TrGeom g, const TrTables t)
 __global__ void __launch_bounds__(256)
 k_twide(const TwTables t, uint32_t nwin, uint64_t end_bit, uint4 *__restrict__ wide)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t chunk = blockIdx.y;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t first = chunk * t.wpc;
@@ -997,6 +1009,7 @@ __global__ void __launch_bounds__(64)
 k_trewalk(const Cfg c, const TwTables t, const TrTables tt, uint32_t nwin, uint32_t nchunks, uint64_t end_bit,
          const ChunkEntry *__restrict__ entry, uint64_t *__restrict__ rsi_off)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= nchunks || !entry[chunk].valid) return;
     const uint32_t first = chunk * t.wpc;
@@ -1017,6 +1030,7 @@ k_trewalk(const Cfg c, const TwTables t, const TrTables tt, uint32_t nwin, uint3
 __global__ void k_texpand(const Cfg c, const TwTables t, const TrTables tt, const IdxCarry *__restrict__ carry,
                          const IdxHop *__restrict__ hops, uint64_t *__restrict__ rsi_off)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= carry->n_hops) return;
     const IdxHop h = hops[i];
@@ -1037,6 +1051,7 @@ k_seg_starts(const Cfg c, const TrStream s, const TrGeom g, const TrTables t, co
              const IdxCarry *__restrict__ carry, const DecResult *__restrict__ res, uint64_t *__restrict__ seg_bits,
              uint64_t cap_rsi)
 {
+    if (t.skip_if && *t.skip_if) return;
     __shared__ __attribute__((aligned(16))) uint32_t lds_w[kCoopWin], lds_m[kCoopWin];
     const TrGlobal mem{s, g, t};
     CoopCds<kCoopWin> cw;
@@ -3504,7 +3519,8 @@ void allow_big_lds_walk()
 
 void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                         uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
-                        uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot, uint64_t *d_seg_bits)
+                        uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot, uint64_t *d_seg_bits,
+                        const uint32_t *skip_if = nullptr)
 {
     IdxCarry *carry = reinterpret_cast<IdxCarry *>(base);
     const TrStream s{words, nwords, end_bit};
@@ -3546,6 +3562,7 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
         t.park = reinterpret_cast<uint32_t *>(base + p.o_park);
         t.pool = reinterpret_cast<TrPoolEntry *>(base + p.o_pool);
         t.pool_cnt = reinterpret_cast<uint32_t *>(base + 48);       // (behind the carry record)
+        t.skip_if = skip_if;
         uint64_t *ex[2] = {reinterpret_cast<uint64_t *>(base + p.o_exit0), reinterpret_cast<uint64_t *>(base + p.o_exit1)};
         const uint32_t nreg = (g.nwin + g.rw - 1) / g.rw;
         t.exit = ex[0];
@@ -3619,6 +3636,7 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
         sp.wcap = p.wcap;
         sp.wfirst = p.wfirst;
         sp.nrec = p.ncap;
+        sp.skip_if = skip_if;
         ChunkEntry *centry = reinterpret_cast<ChunkEntry *>(base + p.o_centry);
         IdxHop *hops = reinterpret_cast<IdxHop *>(base + p.o_hops);
         const uint32_t hop_cap = 2 * nwin + 8;
@@ -3627,7 +3645,8 @@ void launch_index_trunk(const Cfg &c, TrunkPlan p, const uint32_t *words, uint64
                            const_cast<uint4 *>(sp.wide));
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
                            d_res, (const uint64_t *)nullptr, hops, hop_cap, carry, first ? 1u : 0u, last ? 1u : 0u,
-                           start_block, rsi_start, tail_slot, sp, centry, SparseTables{});
+                           start_block, rsi_start, tail_slot, sp, centry, SparseTables{}, (uint32_t *)nullptr, (uint64_t)0,
+                           skip_if);
         hipLaunchKernelGGL(k_trewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, c, sp, t, nwin, nchunks, end_bit, centry,
                            d_rsi_off);
         hipLaunchKernelGGL(k_texpand, dim3((hop_cap + 255) / 256), dim3(256), 0, st, c, sp, t, carry, hops, d_rsi_off);
@@ -3691,8 +3710,10 @@ struct LockTables {
     LkState *entry, *exit0, *exit1;
     uint32_t *cnt;         // RSI starts met in the region
     uint64_t *base;        // ... in front of the region
-    uint32_t *flags;       // [0] done (k_index behind returns at once), [1] inconsistent
+    uint32_t *flags;       // [0] done (k_index behind returns at once), [1] inconsistent, [2] region that ended the walk,
+                           // [3] abandoned (plausibility guesses: too many did not hold; the trunk takes the stream)
     uint32_t nreg, region_bits, lead;
+    uint32_t coop;         // long coded data sets: the walks parse one at a time (lk_walk_coop) instead of 64 bits at a time
     uint64_t lo;           // bit position where region 0 begins (the caller's start)
 };
 
@@ -3971,8 +3992,8 @@ __device__ __forceinline__ bool lk_apply(const Cfg &c, LkState &x, uint32_t e, u
 
 // The chain from x (wave-uniform) until x.pos >= rend or x.st != 0; at_start(x) is called once at every step that
 // begins an RSI (x.b == 0), before the step; it returns false to end the walk there.
-template <class F>
-__device__ __forceinline__ void lk_walk_wave(WaveStream &ws, const TrStream &s, const Cfg &c, LkState &x, uint64_t rend,
+template <class WS, class F>
+__device__ __forceinline__ void lk_walk_wave(WS &ws, const TrStream &s, const Cfg &c, LkState &x, uint64_t rend,
                                              F at_start)
 {
     const bool pp = c.flags & F_PREPROCESS;
@@ -4012,6 +4033,36 @@ __device__ __forceinline__ void lk_walk_wave(WaveStream &ws, const TrStream &s, 
             lk_step(s, c, x);
         }
     }
+}
+
+// The same walk where coded data sets are long (hundreds of bits: one boundary in ten such steps): one coded data set at
+// a time, parsed by the wavefront out of the window alone (aec_stretch.h: coop_half) -- 0.25 us each, where the piece
+// tables cost 7 us per 2048 bits to look up the three boundaries in them.
+template <class WS, class F>
+__device__ __forceinline__ void lk_walk_coop(WS &ws, const TrStream &s, const Cfg &c, LkState &x, uint64_t rend,
+                                             F at_start)
+{
+    const bool pp = c.flags & F_PREPROCESS;
+    uint64_t handled = ~0ull;
+    while (x.pos < rend && !x.st) {
+        if (x.b == 0u && handled != x.pos) {
+            handled = x.pos;
+            if (!at_start(x)) return;
+        }
+        const uint32_t rf = (pp && x.b == 0u) ? 1u : 0u;
+        const uint32_t rel = ws.ensure_win(x.pos, 64u);
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)ws.coop_half(c, rel, rf));
+        if (!lk_apply(c, x, e, rf)) lk_step(s, c, x);
+    }
+}
+template <class WS, class F>
+__device__ __forceinline__ void lk_walk_any(bool coop, WS &ws, const TrStream &s, const Cfg &c, LkState &x, uint64_t rend,
+                                            F at_start)
+{
+    if (coop)
+        lk_walk_coop(ws, s, c, x, rend, at_start);
+    else
+        lk_walk_wave(ws, s, c, x, rend, at_start);
 }
 
 __global__ void __launch_bounds__(256)
@@ -4086,39 +4137,54 @@ k_lock_guess_w(const Cfg c, const TrStream s, const LockTables t)
 }
 
 __global__ void __launch_bounds__(256)
-k_lock_walk_w(const Cfg c, const TrStream s, const LockTables t, const LkState *exit_prev, LkState *exit_out, uint32_t mode,
-              uint64_t start_bit, uint32_t start_block)
+k_lock_walk_w(const Cfg c, const TrStream s, const LockTables t, const LkState *exit_prev, LkState *exit_out, LkState *entry_out,
+              uint32_t mode, uint64_t start_bit, uint32_t start_block)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t r = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (r >= t.nreg) return;
+    if (r >= t.nreg || t.flags[3]) return;
     LkState x;
     if (r == 0u) {
         if (mode) {
-            if (lane == 0) exit_out[0] = exit_prev[0];
+            if (lane == 0) {
+                exit_out[0] = exit_prev[0];
+                entry_out[0] = t.entry[0];
+            }
             return;
         }
         x = LkState{start_bit, start_block, 0u};
-        if (lane == 0) t.entry[0] = x;
+        if (lane == 0) entry_out[0] = x;
     } else if (!mode) {
         x = t.entry[r];
     } else {
+        // A region whose entry is not the exit in front is walked again from that exit -- if the region in front is not
+        // in doubt itself: the exit of a walk from a wrong entry is wrong too (the position finds the true chain again,
+        // the count of blocks does not), and walking on from it would throw a right guess after a wrong one, region by
+        // region down the stream.  The first region of a run in doubt always has an undoubted one in front.
         const LkState prev = exit_prev[r - 1u], mine = t.entry[r];
-        if (prev.st || (prev.pos == mine.pos && prev.b == mine.b)) {
+        bool idle = prev.st || (prev.pos == mine.pos && prev.b == mine.b);
+        // (Where 64 chains lock onto the phase -- short RSIs -- a walk from a wrong entry locks as well and its exit is
+        // mostly right: there every region in doubt is walked again at once.)
+        if (!idle && r >= 2u && t.coop) {
+            const LkState pp = exit_prev[r - 2u], pe = t.entry[r - 1u];
+            idle = !pp.st && (pp.pos != pe.pos || pp.b != pe.b);
+        }
+        // (the wavefront of region r + 1 reads this region's entry in the same pass: entries have a twin like the exits)
+        if (lane == 0) entry_out[r] = idle ? mine : LkState{prev.pos, prev.b, 0u};
+        if (idle) {
             if (lane == 0) exit_out[r] = exit_prev[r];
             return;
         }
         x = LkState{prev.pos, prev.b, 0u};
-        if (lane == 0) t.entry[r] = x;
     }
     const uint64_t rend = r + 1u == t.nreg ? ~0ull : t.lo + (uint64_t)(r + 1u) * t.region_bits;
     WaveStream ws;
     ws.init(lk_lds + (size_t)wave * kSwWaveWords, s, c);
     uint32_t n = 0;
     if (ws.usable()) {
-        lk_walk_wave(ws, s, c, x, rend, [&](const LkState &) {
+        lk_walk_any(t.coop != 0u, ws, s, c, x, rend, [&](const LkState &) {
             n++;
             return true;
         });
@@ -4135,6 +4201,289 @@ k_lock_walk_w(const Cfg c, const TrStream s, const LockTables t, const LkState *
     }
 }
 
+// ---- entries by PLAUSIBILITY (round 5): streams of long coded data sets in RSIs too short for any chain ---------------
+// The reference's own sample shape (16-bit, blocks of 64, rsi 256): coded data sets of 720 bits, so a chain needs ~2 cds^2 =
+// 1 Mbit to fall onto the true one -- and an RSI is 184 kbit: between two reference samples no chain that parses without
+// them ever gets there.  The trunk is mostly off the true chain (17 % of the RSI starts are nodes), its hypotheses walk
+// 1500 coded data sets each, and the index ran at 9.7 GB/s; the phase-locked chains would need lead-ins of 265 Mbit.
+// What such a stream does have: consecutive blocks of real data take NEIGHBOURING code options, while a parse from a wrong
+// bit reads its option out of payload bits -- random.  So the entry of a region is GUESSED from that:
+//   1. every bit of a stretch as long as the longest coded data set (one of them is a boundary) starts a chain of 12
+//      coded data sets without reference samples, a lane each; the chain most of whose options lie within one of their
+//      predecessor's stands on true boundaries (a wrong one that scores as well has met the true chain on its way);
+//   2. from there a wavefront walks on, 64 bits per step as everywhere in this scheme, until an option does NOT fit its
+//      predecessor: the coded data set in front of it was parsed without the reference sample it has -- an RSI starts
+//      there -- if the parse WITH one is followed by plausible coded data sets again (else the data jumped: on it goes);
+//   3. from that RSI start the walk with the RSI's bookkeeping is exact up to the region's start: the entry.
+// Nothing rests on the guess: entries are checked against the exits of the regions in front, repaired and mended by the
+// kernels of the phase-locked scheme; k_lock_judge counts the guesses that did not hold after the first walk and, if they
+// are many (data whose options say nothing: noise in every block, periodic streams), hands the stream to the trunk.
+constexpr uint32_t kLpSteps = 16;          // coded data sets per scoring chain
+constexpr uint32_t kLpAccept = 8;          // options within 1 of their predecessor's (of kLpSteps - 1) that make a chain the true one
+constexpr uint32_t kLpConfirm = 8;         // coded data sets looked at where the walk doubts ...
+constexpr uint32_t kLpConfirmOk = 6;       // ... and how many of their options must lie within 2 of their predecessor's
+constexpr uint32_t kLpLost = 3;            // fewer than this along the plain chain: the walk has lost the true one
+constexpr uint32_t kLpSpan = 10240;        // bits of the window in front of the walk (a confirmation's coded data sets)
+// (tests/emul-style check on the reference's sample file, 120 region starts: 116 entries right, 2 without an anchor in a
+// noisy stretch, 2 lost next to the start of the stream; with 12 steps, options within 1 and all of 5 confirmations: 22 of 31)
+
+__device__ __forceinline__ uint32_t lp_id(const TrStream &s, const Cfg &c, uint64_t q)
+{
+    return (uint32_t)(tr_peek64(s, q) >> (64u - c.id_len));
+}
+
+#ifdef AEC_TUNING
+__device__ unsigned long long g_lp_prof[16];       // (diagnostics, AEC_IDX_STATS=1: shader-clock ticks and counts of the guesses, summed)
+#define LP_ADD(k, v) do { if (lane == 0) atomicAdd(&g_lp_prof[k], (unsigned long long)(v)); } while (0)
+#define LP_MAX(k, v) do { if (lane == 0) atomicMax(&g_lp_prof[k], (unsigned long long)(v)); } while (0)
+#define LP_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define LP_MAX(k, v) do { } while (0)
+#define LP_ADD(k, v) do { } while (0)
+#define LP_NOW() 0ull
+#endif
+constexpr uint32_t kLpPiece = 16384;       // the guess's piece of the stream: 16 coded data sets of a scoring chain fit it
+
+__global__ void __launch_bounds__(64)
+k_lock_guess_p(const Cfg c, const TrStream s, const LockTables t, uint32_t back_bits)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t r = 1u + blockIdx.x;
+    if (r >= t.nreg) return;
+    typedef WaveStreamT<kLpPiece> WS;
+    WS ws;
+    ws.init(lk_lds, s, c);
+    const bool fast = ws.usable();
+    const bool pp = c.flags & F_PREPROCESS;
+    const uint64_t rstart = t.lo + (uint64_t)r * t.region_bits;
+    const uint64_t A = rstart > t.lo + back_bits ? rstart - back_bits : t.lo;
+    const uint32_t maxbits = c.id_len + 1u + c.bps + c.bs * c.bps;
+    auto near1 = [](uint32_t a, uint32_t b) { return (a > b ? a - b : b - a) <= 1u; };
+    auto near2 = [](uint32_t a, uint32_t b) { return (a > b ? a - b : b - a) <= 2u; };
+    // ---- 1. a position on the true chain: every bit of a stretch as long as the longest coded data set starts a chain,
+    // a lane each; returns where the best one stands after three coded data sets (0: none is convincing)
+    // (the lanes parse at their own positions out of the wavefront's LDS tables -- the piece holds the 16 coded data sets
+    // of a chain; from device memory where a chain leaves it: 2.5 us instead of 0.3 per coded data set)
+    auto find_anchor = [&](uint64_t from) -> uint64_t {
+        uint32_t best_sc = 0;
+        uint64_t best_at = 0;
+        uint64_t pbeg = 0, pend = 0;
+        if (fast) {
+            (void)ws.ensure(from, WS::kPiece / 2u);
+            pbeg = ws.base * 32u + ws.pc0;
+            pend = pbeg + WS::kPiece;
+        }
+        for (uint64_t q0 = from; q0 < from + maxbits + 64u; q0 += 64u) {
+            uint64_t q = q0 + lane, at3 = 0;
+            uint32_t sc = 0, prev = 0;
+            bool ok = true;
+            for (uint32_t i = 0; i < kLpSteps && ok; i++) {
+                uint32_t nz, len = 0, id;
+                if (q >= pbeg && q < pend) {
+                    const uint32_t rel = (uint32_t)(q - ws.base * 32u);
+                    len = ws.entry(c, rel, 0u) & 0xFFFu;
+                    id = ws.option(c, rel);
+                } else {
+                    id = lp_id(s, c, q);
+                }
+                if (!len) len = tr_cds(s, c, q, 0u, nz);
+                ok = len != 0u;
+                if (i && near1(id, prev)) sc++;
+                prev = id;
+                if (i == 3u) at3 = q;
+                q += len;
+            }
+            if (!ok) sc = 0;
+            if (sc > best_sc) {
+                best_sc = sc;
+                best_at = at3;
+            }
+        }
+        uint32_t top = best_sc;
+        for (int off = 32; off; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)top, off);
+            top = o > top ? o : top;
+        }
+        const uint64_t who = __ballot(best_sc == top);
+        const uint64_t at = __shfl(best_at, (int)__builtin_ctzll(who));
+        return top >= kLpAccept ? at : 0ull;
+    };
+    // the coded data set that would begin at v, parsed by the lane's half of the wavefront out of the window (v and ref
+    // are the same in the 32 lanes of a half; aec_stretch.h: coop_half); from device memory what that does not resolve
+    uint64_t wbeg = 0, wend = 0;
+    const uint32_t myref = pp ? (lane >> 5) : 0u;      // (the half of the wavefront that parses with a reference sample)
+    auto cover = [&](uint64_t q, uint32_t span) {
+        if (!fast) return;
+        (void)ws.ensure_win(q, span);
+        wbeg = ws.base * 32u;
+        wend = wbeg + kSwWin * 32u;
+    };
+    auto parse = [&](uint64_t v, uint32_t ref, uint32_t &nz) -> uint32_t {
+        uint32_t len = 0;
+        nz = 0;
+        if (fast) {
+            const uint32_t rel = (v >= wbeg && v < wbeg + ws.wlim) ? (uint32_t)(v - wbeg) : 0x7FFFFF00u;
+            const uint32_t e = ws.coop_half(c, rel, ref);
+            len = e & 0xFFFu;
+            if (e & kNxtZero) nz = len - c.id_len - 1u - ref * c.bps;
+        }
+#ifdef AEC_TUNING
+        if (!len) atomicAdd(&g_lp_prof[7], 1ull);
+#endif
+        if (!len) len = tr_cds(s, c, v, ref, nz);
+        return len;
+    };
+    auto opt = [&](uint64_t v) -> uint32_t {
+        return (v >= wbeg && v + 64u < wend) ? ws.option(c, (uint32_t)(v - wbeg)) : lp_id(s, c, v);
+    };
+    // Two chains of up to kLpConfirm coded data sets from q0 on, one per half of the wavefront: the plain one (lanes 0..)
+    // and the one whose first coded data set has a reference sample (lanes 32..), scored by the options that lie within
+    // 2 of their predecessor's; where one does not fit, the coded data set in front is tried WITH a reference sample (a
+    // true chain may pass an RSI start and still scores).  Verdict: 1 an RSI starts at q0 (the chain with the reference
+    // sample is plausible, and more so than the plain one), 2 neither is plausible (the walk has lost the true chain),
+    // 0 on with the plain one -- as soon as it is certain, or the plain chain is two ahead.
+    auto confirm = [&](uint64_t q0, bool with_ref) -> uint32_t {
+        const uint32_t n = kLpConfirm;
+        uint32_t sc = 0, idp = opt(q0), so = 0, sr = 0;
+        uint64_t v = q0;
+        bool ok = true;
+        for (uint32_t k = 0; k < n; k++) {
+            uint32_t nz, len = parse(v, k == 0u ? myref : 0u, nz);
+            ok = ok && len != 0u;
+            uint32_t idk = ok ? opt(v + len) : ~0u;
+            const bool doubt = ok && k && pp && !near2(idk, idp);
+            if (__any(doubt)) {
+                uint32_t nz1;
+                const uint32_t l1 = parse(v, 1u, nz1);
+                const uint32_t id1 = l1 ? opt(v + l1) : ~0u;
+                if (doubt && l1 && near2(id1, idp)) {
+                    len = l1;
+                    idk = id1;
+                }
+            }
+            if (ok) {
+                v += len;
+                sc += near2(idk, idp) ? 1u : 0u;
+                idp = idk;
+            }
+            so = (uint32_t)__builtin_amdgcn_readlane((int)sc, 0);
+            sr = with_ref ? (uint32_t)__builtin_amdgcn_readlane((int)sc, 32) : 0u;
+            const uint32_t done = k + 1u;
+            if (so >= sr + 2u && so >= 2u) return 0u;
+            if (done - sr > n - kLpConfirmOk && (so >= kLpLost || done - so > n - kLpLost)) break;
+        }
+        if (sr >= kLpConfirmOk && sr > so) return 1u;
+        return so < kLpLost ? 2u : 0u;
+    };
+    LkState guess{rstart, 0u, 0u};                      // (no guess: a wrong one, repaired or judged later)
+    const unsigned long long lp_t0 = LP_NOW();
+    uint64_t q = find_anchor(A);
+    LP_ADD(0, LP_NOW() - lp_t0);
+    LP_ADD(1, 1);
+    // ---- 2. along the chain WITHOUT reference samples, looking one coded data set ahead BOTH ways at every step (one half
+    // of the wavefront parses without a reference sample, the other with one): as long as the option behind the plain parse fits and the one
+    // behind the other does not, on it goes.  Anything else is decided by kLpConfirm coded data sets either way: an RSI
+    // starts here if the chain WITH a reference sample is plausible and more so than the plain one (found); the plain
+    // one if it is plausible (the data jumped); neither: the walk has lost the true chain and looks for it again.
+    // The walk notes where it passes the region's start and counts the blocks from there: RSIs start every rsi blocks,
+    // so the first RSI start behind the region's start gives the count at the entry.
+    uint64_t cross = 0, S = 0;
+    uint32_t steps = 0, nb_since = 0, reanch = 0;
+    bool crossed = false, found = false, cnt_ok = true;
+    const uint32_t most = 2u * c.rsi + 64u;
+    while (q && steps++ < most) {
+        if (!crossed && q >= rstart) {
+            crossed = true;
+            cross = q;
+            nb_since = 0;
+        }
+        // (an RSI start is passed unseen where the plain parse of its first coded data set finds the true chain again at
+        // once -- both ways look the same then, one in six on the sample file; the count of blocks mostly survives it,
+        // and the next RSI start gives the same answer modulo rsi)
+        cover(q, kLpSpan);
+        uint32_t nzl;
+        const uint32_t ll = parse(q, myref, nzl);
+        const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)opt(q));
+        const uint32_t idn = ll ? opt(q + ll) : ~0u;
+        const uint32_t l0 = (uint32_t)__builtin_amdgcn_readlane((int)ll, 0);
+        const uint32_t nz0 = (uint32_t)__builtin_amdgcn_readlane((int)nzl, 0);
+        const uint32_t l1 = pp ? (uint32_t)__builtin_amdgcn_readlane((int)ll, 32) : 0u;
+        if (!l0) break;
+        const bool nf = near1((uint32_t)__builtin_amdgcn_readlane((int)idn, 0), id);
+        const bool ng = l1 && near1((uint32_t)__builtin_amdgcn_readlane((int)idn, 32), id);
+        if (!(nf && !ng)) {
+            const unsigned long long lp_t2 = LP_NOW();
+            const uint32_t verdict = confirm(q, l1 != 0u);
+            LP_ADD(2, LP_NOW() - lp_t2);
+            LP_ADD(3, 1);
+            if (verdict == 1u) {
+                found = true;
+                S = q;
+                break;
+            }
+            if (verdict == 2u) {
+                LP_ADD(14, 1);
+                if (crossed || ++reanch > 3u) break;
+                const unsigned long long lp_t4 = LP_NOW();
+                q = find_anchor(q);
+                LP_ADD(0, LP_NOW() - lp_t4);
+                LP_ADD(1, 1);
+                continue;
+            }
+        }
+        q += l0;
+        if (crossed) {
+            if (nz0 == 5u) cnt_ok = false;              // (a rest-of-segment run: its blocks depend on the count)
+            nb_since += nz0 ? (nz0 > 5u ? nz0 - 1u : nz0) : 1u;
+        }
+    }
+    LP_ADD(4, LP_NOW() - lp_t0);
+    LP_MAX(13, LP_NOW() - lp_t0);
+    LP_ADD(5, steps);
+    LP_ADD(8, found ? 1 : 0);
+    LP_ADD(9, (found && !crossed) ? 1 : 0);
+    // ---- 3. the entry
+    if (found && !crossed) {                            // exact from the RSI start on to the region's start
+        LkState x{S, 0u, 0u};
+        if (fast) {
+            lk_walk_coop(ws, s, c, x, rstart, [](const LkState &) { return true; });
+        } else {
+            while (x.pos < rstart && !x.st) lk_step(s, c, x);
+        }
+        if (!x.st && x.pos >= rstart) guess = x;
+    } else if (found && cnt_ok) {                       // back from the RSI start: rsi less the blocks since the entry
+        guess = LkState{cross, (c.rsi - nb_since % c.rsi) % c.rsi, 0u};
+    }
+    LP_ADD(6, LP_NOW() - lp_t0);
+    LP_MAX(10, LP_NOW() - lp_t0);
+    LP_MAX(11, steps);
+    LP_MAX(12, reanch);
+    if (lane == 0) t.entry[r] = guess;
+}
+
+// after the first walk: how many guesses did not hold?  Many: the options of this data say nothing; the stream is the
+// trunk's (flags[3]; the kernels of this scheme return, the trunk's are no longer skipped -- flags[0] stays 0).
+__global__ void __launch_bounds__(1024)
+k_lock_judge(const LockTables t, const LkState *exit_last)
+{
+    __shared__ uint32_t wrong;
+    if (threadIdx.x == 0) wrong = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t r = 1u + threadIdx.x; r < t.nreg; r += blockDim.x) {
+        const LkState prev = exit_last[r - 1u], en = t.entry[r];
+        // (a walk from a wrong entry mostly ends refused -- a run of zero blocks that does not fit the RSI by its count)
+        if (prev.st != 0u || prev.pos != en.pos || prev.b != en.b) mine++;
+    }
+    if (mine) atomicAdd(&wrong, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t.flags[4] = wrong;                              // (statistics)
+        if (t.nreg >= 8u && wrong * 4u > t.nreg) t.flags[3] = 1u;
+    }
+}
+
 // What the parallel repair passes left: ONE wavefront goes through the regions in order and, wherever a region's entry is
 // not the exit of the region in front, walks on from that exit -- region after region, entries, counts and exits
 // rewritten -- until the walk stands on a stored entry again (from there on the stored walks hold).  A repair pass mends
@@ -4144,6 +4493,7 @@ k_lock_fix_w(const Cfg c, const TrStream s, const LockTables t, LkState *ex)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
     const uint32_t lane = threadIdx.x & 63u;
+    if (t.flags[3]) return;
     WaveStream ws;
     ws.init(lk_lds, s, c);
     const bool fast = ws.usable();
@@ -4170,7 +4520,7 @@ k_lock_fix_w(const Cfg c, const TrStream s, const LockTables t, LkState *ex)
             const uint64_t rend = q + 1u == t.nreg ? ~0ull : t.lo + (uint64_t)(q + 1u) * t.region_bits;
             uint32_t n = 0;
             if (fast) {
-                lk_walk_wave(ws, s, c, x, rend, [&](const LkState &) {
+                lk_walk_any(t.coop != 0u, ws, s, c, x, rend, [&](const LkState &) {
                     n++;
                     return true;
                 });
@@ -4205,7 +4555,7 @@ k_lock_fill_w(const Cfg c, const TrStream s, const LockTables t, const LkState *
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t r = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (r >= t.nreg || t.flags[1] || r > t.flags[2]) return;
+    if (r >= t.nreg || t.flags[1] || t.flags[3] || r > t.flags[2]) return;
     const uint64_t rend = r + 1u == t.nreg ? ~0ull : t.lo + (uint64_t)(r + 1u) * t.region_bits;
     LkState x = t.entry[r];
     const uint64_t off = start_block ? 1u : 0u;          // (k_lock_fill: a walk that resumes inside an RSI)
@@ -4243,7 +4593,7 @@ k_lock_fill_w(const Cfg c, const TrStream s, const LockTables t, const LkState *
         return true;
     };
     if (ws.usable()) {
-        lk_walk_wave(ws, s, c, x, rend, at_start);
+        lk_walk_any(t.coop != 0u, ws, s, c, x, rend, at_start);
     } else {
         while (x.pos < rend) {
             if (x.b == 0u && !at_start(x)) break;
@@ -4286,9 +4636,58 @@ k_lock_fill_w(const Cfg c, const TrStream s, const LockTables t, const LkState *
 
 struct LockPlan {
     bool ok;
+    uint32_t mode;            // 0: entries by 64 chains that agree (short RSIs); 1: by plausibility (k_lock_guess_p)
+    uint32_t back;            // mode 1: how far in front of a region its guess begins (bits)
     uint32_t nreg, region_bits, lead;
-    size_t o_entry, o_exit0, o_exit1, o_cnt, o_base, o_flags, bytes;
+    size_t o_entry, o_entry1, o_exit0, o_exit1, o_cnt, o_base, o_flags, bytes;
 };
+
+// the tables of either mode
+static void lock_layout(LockPlan &p, uint64_t nreg)
+{
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t o = 0;
+    p.o_flags = o;  o = up(o + 64);
+    p.o_entry = o;  o = up(o + nreg * sizeof(LkState));
+    p.o_entry1 = o; o = up(o + nreg * sizeof(LkState));
+    p.o_exit0 = o;  o = up(o + nreg * sizeof(LkState));
+    p.o_exit1 = o;  o = up(o + nreg * sizeof(LkState));
+    p.o_cnt = o;    o = up(o + nreg * 4);
+    p.o_base = o;   o = up(o + (nreg + 1) * 8);
+    p.bytes = o;
+}
+
+// Mode 1 (k_lock_guess_p): long coded data sets in RSIs that are short against the distance a chain needs to find the
+// true one (2 cds^2 bits) -- rsi < 8 cds, where the trunk's hypotheses walk for RSIs on end; with the preprocessor (the
+// guess looks for the coded data set that has a reference sample), fewer than 8 segments per RSI (no segment starts come
+// out of this scheme), a stream of at least a few RSIs.
+static LockPlan lock_plan_p(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint)
+{
+    LockPlan p{};
+    if (!tune("AEC_IDX_LOCK_P", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS) || !rsi_bits_hint) return p;
+    const uint64_t cds = rsi_bits_hint / c.rsi;
+    if (cds < 96 || c.rsi >= 8 * cds || c.segs_per_rsi >= 8u || total_bits < 4 * rsi_bits_hint) return p;
+    if (c.id_len + 1u + c.bps + c.bs * c.bps > (kSwLookWords - 2u) * 32u) return p;
+    // regions of 1 .. 8 RSIs: large streams pay the guess (two RSIs walked per region) less often, small ones get
+    // wavefronts to run
+    uint64_t region = (total_bits / 2048 + 1023) & ~1023ull;
+    if (region < rsi_bits_hint) region = rsi_bits_hint;
+    if (region > 8 * rsi_bits_hint) region = 8 * rsi_bits_hint;
+    region = (region + 1023) & ~1023ull;
+    const uint64_t nreg = (total_bits + region - 1) / region;
+    if (nreg > (1u << 24) || region > 0xFFFFFFFFull) return p;
+    p.mode = 1;
+    p.nreg = (uint32_t)nreg;
+    p.region_bits = (uint32_t)region;
+    p.lead = 0;
+    // (the scoring chains start in a stretch as long as the longest coded data set and stand three coded data sets further
+    // on: in front of the region's start; the walk from there goes FORWARD to the next RSI start -- half an RSI on
+    // average -- and the count at the entry comes from the blocks in between)
+    p.back = 5u * (c.id_len + 1u + c.bps + c.bs * c.bps) + 128u;
+    lock_layout(p, nreg);
+    p.ok = true;
+    return p;
+}
 
 LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, uint32_t start_block)
 {
@@ -4300,7 +4699,8 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     // (an RSI of 128 zero blocks is two coded data sets, 26 bits; as many candidates per window as the tables of neither
     // kind have room for, and the serial walk took 64 ms for 64 MiB of a constant)
     const bool tiny = rsi_bits_hint != 0 && rsi_bits_hint <= tune("AEC_IDX_LOCK_TINY", 256u);
-    if (!tune("AEC_IDX_LOCK", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS) || (c.rsi > 32u && !tiny)) return p;
+    if (!tune("AEC_IDX_LOCK", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS)) return p;
+    if (c.rsi > 32u && !tiny) return lock_plan_p(c, total_bits, rsi_bits_hint);
     if (total_bits < (1u << 16)) return p;               // (a thousand coded data sets: the serial walker is as fast)
     uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 3;
     if (cds < 8) cds = 8;
@@ -4314,8 +4714,15 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     uint64_t lead = (uint64_t)tune("AEC_IDX_LOCK_LEAD", 2) * cds * cds * c.rsi;
     const uint64_t lmin = tune("AEC_IDX_LOCK_LMIN", 4096);
     if (lead < lmin) lead = lmin;
+    // (long coded data sets: a lead-in that is a good part of the stream is as good as a serial walk -- 1 MiB of 16-bit
+    // data in blocks of 32, rsi 16: 17 ms, five times the reference on one core -- where the options of real data tell
+    // the true chain from the others in a dozen coded data sets: mode 1)
+    if (cds >= 96 && lead * 8 > total_bits) {
+        const LockPlan q = lock_plan_p(c, total_bits, rsi_bits_hint);
+        if (q.ok) return q;
+    }
     // (long coded data sets: too far to lock, unless the stream is long enough for a number of such regions)
-    if (lead > (1u << 24) || (lead > (1u << 22) && total_bits < 4 * lead)) return p;
+    if (lead > (1u << 24) || (lead > (1u << 22) && total_bits < 4 * lead)) return lock_plan_p(c, total_bits, rsi_bits_hint);
     // (small streams: short regions -- the pass is as long as one lane's walk of a region, three times over)
     const uint64_t rmin = total_bits < (1u << 22) ? tune("AEC_IDX_LOCK_RMIN", 1024) : 16384;
     // (a region per wavefront now: regions a fraction of the lead-in, so that the walks -- one behind the other: count,
@@ -4325,25 +4732,20 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     region = (region + 1023) & ~1023ull;
     const uint64_t nreg = (total_bits + region - 1) / region;
     if (nreg > (1u << 24)) return p;
+    p.mode = 0;
+    p.back = 0;
     p.nreg = (uint32_t)nreg;
     p.region_bits = (uint32_t)region;
     p.lead = (uint32_t)lead;
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    size_t o = 0;
-    p.o_flags = o;  o = up(o + 64);
-    p.o_entry = o;  o = up(o + nreg * sizeof(LkState));
-    p.o_exit0 = o;  o = up(o + nreg * sizeof(LkState));
-    p.o_exit1 = o;  o = up(o + nreg * sizeof(LkState));
-    p.o_cnt = o;    o = up(o + nreg * 4);
-    p.o_base = o;   o = up(o + (nreg + 1) * 8);
-    p.bytes = o;
+    lock_layout(p, nreg);
     p.ok = true;
     return p;
 }
 
 void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
-                         uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot)
+                         uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
+                         bool serial_fallback = true)
 {
     const TrStream s{words, nwords, end_bit};
     LockTables t{};
@@ -4356,35 +4758,86 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
     t.nreg = p.nreg;
     t.region_bits = p.region_bits;
     t.lead = p.lead;
+    t.coop = p.mode == 1u ? 1u : 0u;
     t.lo = start_bit;
     (void)hipMemsetAsync(t.flags, 0, 64, st);
     // a wavefront per region (k_lock_*_w) -- unless the parameters are beyond its tables' look-ahead
-    const bool wave = tune("AEC_IDX_LOCK_WAVE", 1) != 0 && c.id_len + 1u + c.bps + c.bs * c.bps <= (kSwLookWords - 2u) * 32u;
+    const bool wave = p.mode == 1u ||
+                      (tune("AEC_IDX_LOCK_WAVE", 1) != 0 && c.id_len + 1u + c.bps + c.bs * c.bps <= (kSwLookWords - 2u) * 32u);
     const uint32_t wpw = 4;                                             // wavefronts per workgroup
     const size_t wlds = (size_t)wpw * kSwWaveWords * 4;
     if (wave) {
         LkState *ex[2] = {t.exit0, t.exit1};
-        if (p.nreg > 1)
+        if (p.nreg > 1 && p.mode == 1u)
+            hipLaunchKernelGGL(k_lock_guess_p, dim3(p.nreg - 1), dim3(64), (size_t)sw_wave_words(kLpPiece) * 4, st, c, s, t, p.back);
+        else if (p.nreg > 1)
             hipLaunchKernelGGL(k_lock_guess_w, dim3((p.nreg - 1 + wpw - 1) / wpw), dim3(64 * wpw), wlds, st, c, s, t);
         const uint32_t wg = (p.nreg + wpw - 1) / wpw;
-        hipLaunchKernelGGL(k_lock_walk_w, dim3(wg), dim3(64 * wpw), wlds, st, c, s, t, (const LkState *)nullptr, ex[0], 0u,
+        LkState *en[2] = {t.entry, reinterpret_cast<LkState *>(base + p.o_entry1)};
+        hipLaunchKernelGGL(k_lock_walk_w, dim3(wg), dim3(64 * wpw), wlds, st, c, s, t, (const LkState *)nullptr, ex[0], en[0], 0u,
                            start_bit, start_block);
+        if (p.mode == 1u) hipLaunchKernelGGL(k_lock_judge, dim3(1), dim3(1024), 0, st, t, (const LkState *)ex[0]);
+#ifdef AEC_TUNING
+        if (tune_set("AEC_IDX_DUMP")) {                    // (diagnostics: the guesses against the exits in front)
+            (void)hipStreamSynchronize(st);
+            std::vector<LkState> en0(p.nreg), ex0(p.nreg);
+            (void)hipMemcpy(en0.data(), en[0], p.nreg * sizeof(LkState), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(ex0.data(), ex[0], p.nreg * sizeof(LkState), hipMemcpyDeviceToHost);
+            uint32_t shown = 0;
+            for (uint32_t r = 1; r < p.nreg && shown < 24; r++) {
+                const bool mis = ex0[r - 1].pos != en0[r].pos || ex0[r - 1].b != en0[r].b;
+                if (!mis && r > 6) continue;
+                shown++;
+                fprintf(stderr, "  region %u (from bit %llu): guess (%llu, %u) | exit in front (%llu, %u, st %u)%s\n", r,
+                        (unsigned long long)(start_bit + (uint64_t)r * p.region_bits), (unsigned long long)en0[r].pos, en0[r].b,
+                        (unsigned long long)ex0[r - 1].pos, ex0[r - 1].b, ex0[r - 1].st, mis ? "  <-- differ" : "");
+            }
+        }
+#endif
         uint32_t cur = 0;
-        // (small streams: a dozen passes -- an idle pass is a launch of 5 us, 48 of them were a quarter of a millisecond
-        // on a 64 KiB chunk; a run of wrong guesses longer than that leaves the stream to the serial walker)
-        // a few parallel repair passes (each mends one region of every run of wrong guesses; an idle one is a launch of
-        // 5 us, and 48 of them were a quarter of a millisecond on a 64 KiB chunk), then one wavefront mends what is left
-        // run by run at the speed of the walk
-        const uint32_t passes = tune("AEC_IDX_LOCK_PASSES", 16u);
+        // a few parallel repair passes (each mends the first region of every run of regions in doubt; an idle one is a
+        // launch of 5 us, and 48 of them were a quarter of a millisecond on a 64 KiB chunk), then one wavefront mends
+        // what is left run by run at the speed of the walk
+        const uint32_t passes = tune("AEC_IDX_LOCK_PASSES", p.mode == 1u ? 8u : 16u);
         for (uint32_t k = 0; k < passes; k++) {
+            t.entry = en[cur];
             hipLaunchKernelGGL(k_lock_walk_w, dim3(wg), dim3(64 * wpw), wlds, st, c, s, t, (const LkState *)ex[cur], ex[cur ^ 1u],
-                               1u, start_bit, start_block);
+                               en[cur ^ 1u], 1u, start_bit, start_block);
             cur ^= 1u;
         }
+        t.entry = en[cur];
         hipLaunchKernelGGL(k_lock_fix_w, dim3(1), dim3(64), (size_t)kSwWaveWords * 4, st, c, s, t, ex[cur]);
         hipLaunchKernelGGL(k_lock_scan, dim3(1), dim3(1024), 0, st, t, (const LkState *)ex[cur]);
         hipLaunchKernelGGL(k_lock_fill_w, dim3(wg), dim3(64 * wpw), wlds, st, c, s, t, (const LkState *)ex[cur], words, nwords,
                            d_rsi_off, max_rsi, d_res, tail_slot, rsi_start, start_block);
+#ifdef AEC_TUNING
+        if (tune_set("AEC_IDX_STATS")) {                   // (diagnostics: synchronises)
+            (void)hipStreamSynchronize(st);
+            uint32_t fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipMemcpy(fl, t.flags, 32, hipMemcpyDeviceToHost);
+            std::vector<LkState> en(p.nreg), exs(p.nreg);
+            (void)hipMemcpy(en.data(), t.entry, p.nreg * sizeof(LkState), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(exs.data(), ex[cur], p.nreg * sizeof(LkState), hipMemcpyDeviceToHost);
+            uint32_t mism = 0;
+            for (uint32_t r = 1; r < p.nreg; r++) mism += exs[r - 1].st == 0 && (exs[r - 1].pos != en[r].pos || exs[r - 1].b != en[r].b);
+            if (p.mode == 1u) {
+                unsigned long long h[16];
+                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lp_prof), sizeof(h));
+                const double n = p.nreg > 1 ? p.nreg - 1 : 1, us = 1e-2;   // (100 MHz shader clock counter)
+                fprintf(stderr, "guesses, per region: %.1f us (anchors %.2f: %.1f us; walk %.0f steps with %.1f confirmations: %.1f us; "
+                        "all but the exact walk %.1f us), %.1f parses from device memory; RSI start found %.0f%%, in front of the "
+                        "region %.0f%% | the slowest: %.1f us (%.1f without the exact walk), most steps %llu, most new anchors %llu; chain lost %llu times\n",
+                        h[6] / n * us, h[1] / n, h[0] / n * us, h[5] / n, h[3] / n, h[2] / n * us, h[4] / n * us,
+                        h[7] / n, 100.0 * h[8] / n, 100.0 * h[9] / n, h[10] * us, h[13] * us, h[11], h[12], h[14]);
+                unsigned long long z[16] = {0};
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lp_prof), z, sizeof(z));
+            }
+            fprintf(stderr, "locked chains (mode %u): %u regions of %u bits | delivered %u, inconsistent %u, walk ended in region %u, "
+                    "abandoned %u | guesses that did not hold after the first walk: %u; entries that are not the exit in front "
+                    "after repairs: %u\n", p.mode, p.nreg, p.region_bits, fl[0], fl[1], fl[2], fl[3], fl[4], mism);
+        }
+#endif
+        if (!serial_fallback) return;                      // (the caller enqueues the trunk behind, skipped if this delivered)
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res,
                            (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start,
                            tail_slot, TwTables{}, (ChunkEntry *)nullptr, SparseTables{}, (uint32_t *)nullptr, (uint64_t)0,
@@ -4464,7 +4917,11 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
     const uint64_t end_bit = (uint64_t)in_bytes * 8;
     if (start_bit >= end_bit) return 0;
     const LockPlan lp = lock_plan(c, end_bit - start_bit, rsi_bits_hint, 0u);
-    if (lp.ok) return lp.bytes;
+    if (lp.ok && lp.mode == 0u) return lp.bytes;
+    if (lp.ok) {                                           // (mode 1: + the trunk behind it, for the streams it abandons)
+        const TrunkPlan tp = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, 0);
+        return lp.bytes + (tp.ok ? tp.bytes : 0);
+    }
     const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
     if (sp.ok) {
         // (many spans of windows: two sets of tables, so that the spans can be pipelined -- launch_index_sparse)
@@ -4487,9 +4944,22 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
     // else: the trunk.
     if (d_ws && ws_bytes && start_bit < end_bit && !d_seg_bits) {
         const LockPlan lp = lock_plan(c, end_bit - start_bit, rsi_bits_hint, start_block);
-        if (lp.ok && ws_bytes >= lp.bytes) {
+        if (lp.ok && lp.mode == 0u && ws_bytes >= lp.bytes) {
             launch_index_locked(c, lp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
                                 static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot);
+            return false;
+        }
+        if (lp.ok && lp.mode == 1u && ws_bytes >= lp.bytes) {
+            // entries by plausibility, the exact machinery of the phase-locked scheme behind them -- and behind that the
+            // trunk, every kernel of which returns at once if the stream has been delivered
+            uint8_t *wb = static_cast<uint8_t *>(d_ws);
+            const TrunkPlan tp = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, ws_bytes - lp.bytes);
+            launch_index_locked(c, lp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb, start_block,
+                                rsi_start, tail_slot, !tp.ok);
+            if (tp.ok)
+                launch_index_trunk(c, tp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb + lp.bytes,
+                                   start_block, rsi_start, tail_slot, nullptr,
+                                   reinterpret_cast<const uint32_t *>(wb + lp.o_flags));
             return false;
         }
     }

@@ -112,6 +112,7 @@ struct TrTables {
     uint32_t *park;            // [ncap]
     TrPoolEntry *pool;         // [pcap]
     uint32_t *pool_cnt;        // entries handed out (may run beyond pcap: then records were dropped)
+    const uint32_t *skip_if;   // (device kernels) non-null and *skip_if != 0: another scheme has delivered the index, return
 };
 
 AEC_HD uint32_t tr_word(const TrStream &s, uint64_t i)
