@@ -4391,6 +4391,9 @@ k_lock_guess_p(const Cfg c, const TrStream s, const LockTables t, uint32_t back_
     uint64_t cross = 0, S = 0;
     uint32_t steps = 0, nb_since = 0, reanch = 0;
     bool crossed = false, found = false, cnt_ok = true;
+    // (two RSIs: an RSI start is passed unseen now and then, see below, and the next one serves as well.  A budget of an
+    // RSI and a half made the slowest region, which is the kernel's duration, no faster to speak of and cost 1 GiB of the
+    // sample file's shape 10 ms: its regions are 8 RSIs long, and so is every repair of a guess that failed.)
     const uint32_t most = 2u * c.rsi + 64u;
     while (q && steps++ < most) {
         if (!crossed && q >= rstart) {
@@ -4424,7 +4427,7 @@ k_lock_guess_p(const Cfg c, const TrStream s, const LockTables t, uint32_t back_
             }
             if (verdict == 2u) {
                 LP_ADD(14, 1);
-                if (crossed || ++reanch > 3u) break;
+                if (crossed || ++reanch > 2u) break;
                 const unsigned long long lp_t4 = LP_NOW();
                 q = find_anchor(q);
                 LP_ADD(0, LP_NOW() - lp_t4);
@@ -4666,7 +4669,9 @@ static LockPlan lock_plan_p(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits
     LockPlan p{};
     if (!tune("AEC_IDX_LOCK_P", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS) || !rsi_bits_hint) return p;
     const uint64_t cds = rsi_bits_hint / c.rsi;
-    if (cds < 96 || c.rsi >= 8 * cds || c.segs_per_rsi >= 8u || total_bits < 4 * rsi_bits_hint) return p;
+    // (RSIs of fewer than 16 blocks: a scoring chain of 16 coded data sets passes an RSI start or three without their
+    // reference samples -- no anchor, every guess wrong)
+    if (cds < 96 || c.rsi < 16u || c.rsi >= 8 * cds || c.segs_per_rsi >= 8u || total_bits < 4 * rsi_bits_hint) return p;
     if (c.id_len + 1u + c.bps + c.bs * c.bps > (kSwLookWords - 2u) * 32u) return p;
     // regions of 1 .. 8 RSIs: large streams pay the guess (two RSIs walked per region) less often, small ones get
     // wavefronts to run
