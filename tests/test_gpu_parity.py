@@ -905,6 +905,63 @@ def test_streams_with_short_rsis(api, gpu):
                 assert dec_p == dec_o, (bps, bs, rsi, name)
 
 
+def test_long_coded_data_sets_in_short_rsis(api, gpu, typical_rz):
+    """The shape of the reference's sample file (16-bit, blocks of 64, rsi 256: coded data sets of ~650 bits, RSIs of
+    ~180 kbit): a chain needs longer than an RSI to find the true one, so neither table scheme of the index pass
+    applies and until round 5 the trunk walked such streams at 1 GiB per 110 ms.  Now the entries of the regions are
+    guessed by the PLAUSIBILITY of the options along a chain (aec_idx.hip: k_lock_guess_p) and checked, repaired and
+    judged by the kernels of the phase-locked scheme.  Offsets against the encoder's table; decoded bytes against the
+    oracle for whole, cut and garbage-tailed streams and for input in pieces (walks that resume inside an RSI); and a
+    stream whose options say nothing (a third of its blocks zero, the others noise of one size), where the guesses are
+    judged wrong and the trunk takes over: same results."""
+    import torch
+    import fuzz_stream_gpu
+    rng = np.random.default_rng(256)
+    flags = PP | MSB
+    rc, one = api.aec_buffer_decode(typical_rz, 16, 64, 256, flags, 1 << 20)
+    assert rc == AEC_OK
+    tiles = np.tile(np.frombuffer(one, dtype=np.uint8), 8)
+    fl2 = PP | MSB | SGN
+    walk = np.frombuffer(pack_samples(random_walk_samples(rng, 4 << 20, 16, fl2, scale=8.0, zero_frac=0.3), 16, fl2), dtype=np.uint8)
+    for name, bps, bs, rsi, fl, data in (("sample file x 8", 16, 64, 256, flags, tiles),
+                                         ("zero blocks and noise", 16, 32, 256, fl2, walk)):
+        n = data.size
+        codec = gpu.Codec(bps, bs, rsi, fl)
+        d_in = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+        d_out, nbytes, tb, _, d_off = codec.encode(d_in)
+        nr = codec.rsi_count(n)
+        hint = nbytes * 8 // max(nr, 1)
+        assert gpu.index_scheme(bps, bs, rsi, fl, nbytes, hint, 0) == 1, name
+        d_idx = torch.zeros(nr + 2, dtype=torch.int64, device="cuda")
+        d_res = torch.zeros(40, dtype=torch.uint8, device="cuda")
+        codec.index_async(d_out, nbytes, 0, d_idx, nr, d_res)
+        torch.cuda.synchronize()
+        res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.uint64)
+        whole = codec.block_count(n) // rsi
+        assert int(res[0]) in (nr, whole) and torch.equal(d_idx[:whole], d_off[:whole]), name
+        bound = whole // 3 + 1
+        d_idx.zero_()
+        codec.index_async(d_out, nbytes, 0, d_idx, bound, d_res)
+        torch.cuda.synchronize()
+        res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.uint64)
+        assert int(res[0]) == bound and int(res[1]) == 0 and int(res[2]) == int(d_off[bound]), (name, res[:3])
+        assert torch.equal(d_idx[:bound], d_off[:bound]), name
+        enc = d_out[:nbytes].cpu().numpy().tobytes()
+        rc_o, enc_o, *_ = oracle_encode(data, bps, bs, rsi, fl)
+        assert rc_o == AEC_OK and enc == enc_o, name
+        rc, got = fuzz_stream_gpu.drive(api.library(), "decode", enc, (bps, bs, rsi, fl),
+                                        [(1 << 20, 1 << 30), (300007, 1 << 30), (1 << 20, 1 << 30)], n)
+        assert rc == AEC_OK and got == data.tobytes(), (name, len(got))
+        for what, stream in (("whole", enc), ("cut", enc[: int(len(enc) * 0.61)]),
+                             ("cut + garbage", enc[: len(enc) // 3] + bytes(rng.integers(0, 256, 300, dtype=np.uint8).tolist())),
+                             ("garbage tail", enc + bytes(rng.integers(0, 256, 100, dtype=np.uint8).tolist()))):
+            rc_o, dec_o, _ = oracle_decode(stream, bps, bs, rsi, fl, n)
+            rc_p, dec_p = api.aec_buffer_decode(stream, bps, bs, rsi, fl, n)
+            assert rc_p == rc_o, (name, what, rc_p, rc_o)
+            if rc_o == AEC_OK:
+                assert dec_p == dec_o, (name, what)
+
+
 def test_large_one_shot_decode_of_damaged_streams(api):
     """aec_buffer_decode of 160 MiB runs as pipelined batches (index pass on a piece of the stream, copy-out of one batch
     beside the kernels of the next).  Damage in the first, a middle and the last batch, a cut
