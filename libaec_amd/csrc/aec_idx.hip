@@ -3714,6 +3714,7 @@ struct LockTables {
                            // [3] abandoned (plausibility guesses: too many did not hold; the trunk takes the stream)
     uint32_t nreg, region_bits, lead;
     uint32_t coop;         // long coded data sets: the walks parse one at a time (lk_walk_coop) instead of 64 bits at a time
+    const uint32_t *skip_if;   // != 0 there: a scheme in front has delivered the stream; every kernel returns at once
     uint64_t lo;           // bit position where region 0 begins (the caller's start)
 };
 
@@ -3740,6 +3741,7 @@ __device__ __forceinline__ void lk_step(const TrStream &s, const Cfg &c, LkState
 __global__ void __launch_bounds__(64)
 k_lock_guess(const Cfg c, const TrStream s, const LockTables t)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t lane = threadIdx.x;
     for (uint32_t r = 1u + blockIdx.x; r < t.nreg; r += gridDim.x) {
         const uint64_t rstart = t.lo + (uint64_t)r * t.region_bits;
@@ -3786,6 +3788,7 @@ __global__ void __launch_bounds__(64)
 k_lock_walk(const Cfg c, const TrStream s, const LockTables t, const LkState *exit_prev, LkState *exit_out, uint32_t mode,
             uint64_t start_bit, uint32_t start_block)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= t.nreg) return;
     LkState x;
@@ -3824,6 +3827,7 @@ k_lock_walk(const Cfg c, const TrStream s, const LockTables t, const LkState *ex
 __global__ void __launch_bounds__(1024)
 k_lock_scan(const LockTables t, const LkState *exit_last)
 {
+    if (t.skip_if && *t.skip_if) return;
     __shared__ uint64_t sh[1024];
     __shared__ uint32_t bad, first_end;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
@@ -3880,6 +3884,7 @@ k_lock_fill(const Cfg c, const TrStream s, const LockTables t, const LkState *ex
             uint64_t nwords, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res, uint32_t tail_slot,
             uint64_t rsi_start_in, uint32_t start_block)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= t.nreg || t.flags[1] || r > t.flags[2]) return;      // (not agreed, or behind the region that ended the walk)
     const uint64_t rend = r + 1u == t.nreg ? ~0ull : t.lo + (uint64_t)(r + 1u) * t.region_bits;
@@ -4068,6 +4073,7 @@ __device__ __forceinline__ void lk_walk_any(bool coop, WS &ws, const TrStream &s
 __global__ void __launch_bounds__(256)
 k_lock_guess_w(const Cfg c, const TrStream s, const LockTables t)
 {
+    if (t.skip_if && *t.skip_if) return;
     extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -4140,6 +4146,7 @@ __global__ void __launch_bounds__(256)
 k_lock_walk_w(const Cfg c, const TrStream s, const LockTables t, const LkState *exit_prev, LkState *exit_out, LkState *entry_out,
               uint32_t mode, uint64_t start_bit, uint32_t start_block)
 {
+    if (t.skip_if && *t.skip_if) return;
     extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -4222,6 +4229,7 @@ constexpr uint32_t kLpSteps = 16;          // coded data sets per scoring chain
 constexpr uint32_t kLpAccept = 8;          // options within 1 of their predecessor's (of kLpSteps - 1) that make a chain the true one
 constexpr uint32_t kLpConfirm = 8;         // coded data sets looked at where the walk doubts ...
 constexpr uint32_t kLpConfirmOk = 6;       // ... and how many of their options must lie within 2 of their predecessor's
+constexpr uint32_t kLpPhased = 16;         // RSIs of fewer blocks: the scoring chains carry the count of blocks (find_anchor_phased)
 constexpr uint32_t kLpLost = 3;            // fewer than this along the plain chain: the walk has lost the true one
 constexpr uint32_t kLpSpan = 10240;        // bits of the window in front of the walk (a confirmation's coded data sets)
 // (tests/emul-style check on the reference's sample file, 120 region starts: 116 entries right, 2 without an anchor in a
@@ -4247,6 +4255,7 @@ constexpr uint32_t kLpPiece = 16384;       // the guess's piece of the stream: 1
 __global__ void __launch_bounds__(64)
 k_lock_guess_p(const Cfg c, const TrStream s, const LockTables t, uint32_t back_bits)
 {
+    if (t.skip_if && *t.skip_if) return;
     extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t r = 1u + blockIdx.x;
@@ -4307,6 +4316,68 @@ k_lock_guess_p(const Cfg c, const TrStream s, const LockTables t, uint32_t back_
         }
         const uint64_t who = __ballot(best_sc == top);
         const uint64_t at = __shfl(best_at, (int)__builtin_ctzll(who));
+        return top >= kLpAccept ? at : 0ull;
+    };
+    // The same for RSIs of a few blocks (narrow scan lines; every few coded data sets hold a reference sample, and a
+    // scoring chain without them stands on nothing): every bit starts a chain for EVERY count of blocks it could stand
+    // at -- rsi times the chains; the one that scores stands on the true chain WITH the true count, which is the whole
+    // entry: no walk to an RSI start.  State after three coded data sets in (pos, b_out); 0: none is convincing.
+    auto find_anchor_phased = [&](uint64_t from, uint32_t &b_out) -> uint64_t {
+        uint32_t best_sc = 0, best_b = 0;
+        uint64_t best_at = 0;
+        uint64_t pbeg = 0, pend = 0;
+        if (fast) {
+            (void)ws.ensure(from, WS::kPiece / 2u);
+            pbeg = ws.base * 32u + ws.pc0;
+            pend = pbeg + WS::kPiece;
+        }
+        for (uint32_t phase = 0; phase < c.rsi; phase++) {
+            for (uint64_t q0 = from; q0 < from + maxbits + 64u; q0 += 64u) {
+                uint64_t q = q0 + lane, at3 = 0;
+                uint32_t sc = 0, prev = 0, b = phase, b3 = 0;
+                bool ok = true;
+                for (uint32_t i = 0; i < kLpSteps && ok; i++) {
+                    const uint32_t ref = (pp && b == 0u) ? 1u : 0u;
+                    uint32_t nz = 0, len = 0, id;
+                    if (q >= pbeg && q < pend) {
+                        const uint32_t rel = (uint32_t)(q - ws.base * 32u);
+                        const uint32_t e = ws.entry(c, rel, ref);
+                        len = e & 0xFFFu;
+                        if (e & kNxtZero) nz = len - c.id_len - 1u - ref * c.bps;
+                        id = ws.option(c, rel);
+                    } else {
+                        id = lp_id(s, c, q);
+                    }
+                    if (!len) len = tr_cds(s, c, q, ref, nz);
+                    const uint32_t nb = len ? tr_blocks(c, nz, b) : 0u;
+                    ok = nb != 0u;
+                    if (i && near1(id, prev)) sc++;
+                    prev = id;
+                    if (i == 3u) {
+                        at3 = q;
+                        b3 = b;
+                    }
+                    q += len;
+                    b += nb;
+                    if (b >= c.rsi) b = 0u;
+                }
+                if (!ok) sc = 0;
+                if (sc > best_sc) {
+                    best_sc = sc;
+                    best_at = at3;
+                    best_b = b3;
+                }
+            }
+        }
+        uint32_t top = best_sc;
+        for (int off = 32; off; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)top, off);
+            top = o > top ? o : top;
+        }
+        const uint64_t who = __ballot(best_sc == top);
+        const int src = (int)__builtin_ctzll(who);
+        const uint64_t at = __shfl(best_at, src);
+        b_out = (uint32_t)__shfl((int)best_b, src);
         return top >= kLpAccept ? at : 0ull;
     };
     // the coded data set that would begin at v, parsed by the lane's half of the wavefront out of the window (v and ref
@@ -4378,6 +4449,26 @@ k_lock_guess_p(const Cfg c, const TrStream s, const LockTables t, uint32_t back_
     };
     LkState guess{rstart, 0u, 0u};                      // (no guess: a wrong one, repaired or judged later)
     const unsigned long long lp_t0 = LP_NOW();
+    if (c.rsi < kLpPhased) {                            // RSIs of a few blocks: the anchor is the entry, walked on exactly
+        uint32_t b0 = 0;
+        const uint64_t at = find_anchor_phased(A, b0);
+        LP_ADD(0, LP_NOW() - lp_t0);
+        LP_ADD(1, 1);
+        if (at) {
+            LkState x{at, b0, 0u};
+            if (fast) {
+                lk_walk_coop(ws, s, c, x, rstart, [](const LkState &) { return true; });
+            } else {
+                while (x.pos < rstart && !x.st) lk_step(s, c, x);
+            }
+            if (!x.st && x.pos >= rstart) guess = x;
+            LP_ADD(8, 1);
+            LP_ADD(9, 1);
+        }
+        LP_ADD(6, LP_NOW() - lp_t0);
+        if (lane == 0) t.entry[r] = guess;
+        return;
+    }
     uint64_t q = find_anchor(A);
     LP_ADD(0, LP_NOW() - lp_t0);
     LP_ADD(1, 1);
@@ -4470,6 +4561,7 @@ k_lock_guess_p(const Cfg c, const TrStream s, const LockTables t, uint32_t back_
 __global__ void __launch_bounds__(1024)
 k_lock_judge(const LockTables t, const LkState *exit_last)
 {
+    if (t.skip_if && *t.skip_if) return;
     __shared__ uint32_t wrong;
     if (threadIdx.x == 0) wrong = 0;
     __syncthreads();
@@ -4487,6 +4579,12 @@ k_lock_judge(const LockTables t, const LkState *exit_last)
     }
 }
 
+// "delivered" of the scheme in front is "delivered" here too (the serial walker behind looks at these flags alone)
+__global__ void k_lock_merge(uint32_t *flags, const uint32_t *front)
+{
+    if (*front) flags[0] = 1u;
+}
+
 // What the parallel repair passes left: ONE wavefront goes through the regions in order and, wherever a region's entry is
 // not the exit of the region in front, walks on from that exit -- region after region, entries, counts and exits
 // rewritten -- until the walk stands on a stored entry again (from there on the stored walks hold).  A repair pass mends
@@ -4494,6 +4592,7 @@ k_lock_judge(const LockTables t, const LkState *exit_last)
 __global__ void __launch_bounds__(64)
 k_lock_fix_w(const Cfg c, const TrStream s, const LockTables t, LkState *ex)
 {
+    if (t.skip_if && *t.skip_if) return;
     extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
     const uint32_t lane = threadIdx.x & 63u;
     if (t.flags[3]) return;
@@ -4554,6 +4653,7 @@ k_lock_fill_w(const Cfg c, const TrStream s, const LockTables t, const LkState *
               uint64_t nwords, uint64_t *__restrict__ rsi_off, uint64_t max_rsi, DecResult *res, uint32_t tail_slot,
               uint64_t rsi_start_in, uint32_t start_block)
 {
+    if (t.skip_if && *t.skip_if) return;
     extern __shared__ __attribute__((aligned(16))) uint32_t lk_lds[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -4669,15 +4769,17 @@ static LockPlan lock_plan_p(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits
     LockPlan p{};
     if (!tune("AEC_IDX_LOCK_P", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS) || !rsi_bits_hint) return p;
     const uint64_t cds = rsi_bits_hint / c.rsi;
-    // (RSIs of fewer than 16 blocks: a scoring chain of 16 coded data sets passes an RSI start or three without their
-    // reference samples -- no anchor, every guess wrong)
-    if (cds < 96 || c.rsi < 16u || c.rsi >= 8 * cds || c.segs_per_rsi >= 8u || total_bits < 4 * rsi_bits_hint) return p;
+    // (RSIs of fewer than 16 blocks: a scoring chain of 16 coded data sets passes an RSI start or three -- there the
+    // chains carry the count of blocks, one set of chains per count: k_lock_guess_p, find_anchor_phased)
+    if (cds < 96 || c.rsi >= 8 * cds || c.segs_per_rsi >= 8u || total_bits < 4 * rsi_bits_hint) return p;
     if (c.id_len + 1u + c.bps + c.bs * c.bps > (kSwLookWords - 2u) * 32u) return p;
     // regions of 1 .. 8 RSIs: large streams pay the guess (two RSIs walked per region) less often, small ones get
     // wavefronts to run
+    // (RSIs of a few blocks: regions of 64 coded data sets at least -- the guess costs rsi x 18 x 16 parses)
     uint64_t region = (total_bits / 2048 + 1023) & ~1023ull;
-    if (region < rsi_bits_hint) region = rsi_bits_hint;
-    if (region > 8 * rsi_bits_hint) region = 8 * rsi_bits_hint;
+    const uint64_t rmin = rsi_bits_hint > 64 * cds ? rsi_bits_hint : 64 * cds;
+    if (region < rmin) region = rmin;
+    if (region > 8 * rmin) region = 8 * rmin;
     region = (region + 1023) & ~1023ull;
     const uint64_t nreg = (total_bits + region - 1) / region;
     if (nreg > (1u << 24) || region > 0xFFFFFFFFull) return p;
@@ -4694,7 +4796,9 @@ static LockPlan lock_plan_p(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits
     return p;
 }
 
-LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, uint32_t start_block)
+// allow_p = false: the plan of the 64 agreeing chains alone (what the dispatch runs behind entries by plausibility that
+// were judged wrong, before the trunk)
+LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, uint32_t start_block, bool allow_p = true)
 {
     LockPlan p{};
     // (without the preprocessor no coded data set holds a reference sample: nothing a chain could lock its count on)
@@ -4705,7 +4809,7 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     // kind have room for, and the serial walk took 64 ms for 64 MiB of a constant)
     const bool tiny = rsi_bits_hint != 0 && rsi_bits_hint <= tune("AEC_IDX_LOCK_TINY", 256u);
     if (!tune("AEC_IDX_LOCK", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS)) return p;
-    if (c.rsi > 32u && !tiny) return lock_plan_p(c, total_bits, rsi_bits_hint);
+    if (c.rsi > 32u && !tiny) return allow_p ? lock_plan_p(c, total_bits, rsi_bits_hint) : p;
     if (total_bits < (1u << 16)) return p;               // (a thousand coded data sets: the serial walker is as fast)
     uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 3;
     if (cds < 8) cds = 8;
@@ -4722,12 +4826,15 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     // (long coded data sets: a lead-in that is a good part of the stream is as good as a serial walk -- 1 MiB of 16-bit
     // data in blocks of 32, rsi 16: 17 ms, five times the reference on one core -- where the options of real data tell
     // the true chain from the others in a dozen coded data sets: mode 1)
-    if (cds >= 96 && lead * 8 > total_bits) {
+    // (and in RSIs of a few blocks whatever the size of the stream: 16 MiB of 24-bit data in blocks of 64 with rsi 1 took
+    // 122 ms with lead-ins of 1.3 Mbit per region)
+    if (allow_p && cds >= 96 && (lead * 8 > total_bits || c.rsi < kLpPhased)) {
         const LockPlan q = lock_plan_p(c, total_bits, rsi_bits_hint);
         if (q.ok) return q;
     }
     // (long coded data sets: too far to lock, unless the stream is long enough for a number of such regions)
-    if (lead > (1u << 24) || (lead > (1u << 22) && total_bits < 4 * lead)) return lock_plan_p(c, total_bits, rsi_bits_hint);
+    if (lead > (1u << 24) || (lead > (1u << 22) && total_bits < 4 * lead))
+        return allow_p ? lock_plan_p(c, total_bits, rsi_bits_hint) : p;
     // (small streams: short regions -- the pass is as long as one lane's walk of a region, three times over)
     const uint64_t rmin = total_bits < (1u << 22) ? tune("AEC_IDX_LOCK_RMIN", 1024) : 16384;
     // (a region per wavefront now: regions a fraction of the lead-in, so that the walks -- one behind the other: count,
@@ -4750,7 +4857,7 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
 void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
                          uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
-                         bool serial_fallback = true)
+                         bool serial_fallback = true, const uint32_t *skip_if = nullptr)
 {
     const TrStream s{words, nwords, end_bit};
     LockTables t{};
@@ -4764,6 +4871,7 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
     t.region_bits = p.region_bits;
     t.lead = p.lead;
     t.coop = p.mode == 1u ? 1u : 0u;
+    t.skip_if = skip_if;
     t.lo = start_bit;
     (void)hipMemsetAsync(t.flags, 0, 64, st);
     // a wavefront per region (k_lock_*_w) -- unless the parameters are beyond its tables' look-ahead
@@ -4842,6 +4950,7 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
                     "after repairs: %u\n", p.mode, p.nreg, p.region_bits, fl[0], fl[1], fl[2], fl[3], fl[4], mism);
         }
 #endif
+        if (skip_if) hipLaunchKernelGGL(k_lock_merge, dim3(1), dim3(1), 0, st, t.flags, skip_if);
         if (!serial_fallback) return;                      // (the caller enqueues the trunk behind, skipped if this delivered)
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res,
                            (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start,
@@ -4886,6 +4995,8 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
                 fl[1], fl[2], mism, ended, refused);
     }
 #endif
+    if (skip_if) hipLaunchKernelGGL(k_lock_merge, dim3(1), dim3(1), 0, st, t.flags, skip_if);
+    if (!serial_fallback) return;
     // whatever was not delivered: the serial walker, which returns at once otherwise
     hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res,
                        (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start,
@@ -4923,9 +5034,10 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
     if (start_bit >= end_bit) return 0;
     const LockPlan lp = lock_plan(c, end_bit - start_bit, rsi_bits_hint, 0u);
     if (lp.ok && lp.mode == 0u) return lp.bytes;
-    if (lp.ok) {                                           // (mode 1: + the trunk behind it, for the streams it abandons)
+    if (lp.ok) {                                           // (mode 1: + what runs behind it for the streams it abandons)
+        const LockPlan l0 = c.rsi < kLpPhased ? lock_plan(c, end_bit - start_bit, rsi_bits_hint, 0u, false) : LockPlan{};
         const TrunkPlan tp = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, 0);
-        return lp.bytes + (tp.ok ? tp.bytes : 0);
+        return lp.bytes + (l0.ok ? l0.bytes : 0) + (tp.ok ? tp.bytes : 0);
     }
     const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
     if (sp.ok) {
@@ -4955,16 +5067,30 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
             return false;
         }
         if (lp.ok && lp.mode == 1u && ws_bytes >= lp.bytes) {
-            // entries by plausibility, the exact machinery of the phase-locked scheme behind them -- and behind that the
-            // trunk, every kernel of which returns at once if the stream has been delivered
+            // entries by plausibility, the exact machinery of the phase-locked scheme behind them -- and behind that, for
+            // the streams whose options say nothing, what would have run without: the 64 agreeing chains where RSIs are
+            // short, then the trunk; every kernel of a later scheme returns at once if the stream has been delivered
             uint8_t *wb = static_cast<uint8_t *>(d_ws);
-            const TrunkPlan tp = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, ws_bytes - lp.bytes);
+            size_t used = lp.bytes;
+            // (the agreeing chains only for RSIs of a few blocks, where the trunk walks every RSI by itself -- 48 MiB with
+            // rsi 1: 1.5 s; with 16 .. 32 blocks and long coded data sets their lead-ins are megabits and the trunk is
+            // faster: 1 MiB of 16-bit data in blocks of 32, rsi 16: 17 against 7 ms)
+            const LockPlan l0 = c.rsi < kLpPhased ? lock_plan(c, end_bit - start_bit, rsi_bits_hint, start_block, false) : LockPlan{};
+            const bool have0 = l0.ok && ws_bytes >= used + l0.bytes;
+            const size_t off0 = used;
+            if (have0) used += l0.bytes;
+            const TrunkPlan tp = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, ws_bytes - used);
+            const uint32_t *done = reinterpret_cast<const uint32_t *>(wb + lp.o_flags);
             launch_index_locked(c, lp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb, start_block,
-                                rsi_start, tail_slot, !tp.ok);
+                                rsi_start, tail_slot, !tp.ok && !have0);
+            if (have0) {
+                launch_index_locked(c, l0, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb + off0,
+                                    start_block, rsi_start, tail_slot, !tp.ok, done);
+                done = reinterpret_cast<const uint32_t *>(wb + off0 + l0.o_flags);
+            }
             if (tp.ok)
-                launch_index_trunk(c, tp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb + lp.bytes,
-                                   start_block, rsi_start, tail_slot, nullptr,
-                                   reinterpret_cast<const uint32_t *>(wb + lp.o_flags));
+                launch_index_trunk(c, tp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb + used,
+                                   start_block, rsi_start, tail_slot, nullptr, done);
             return false;
         }
     }
