@@ -2789,7 +2789,17 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         }
         if (!done) {          // large blocks, or a code reaching beyond the register window
             if (coop) br.init(LdsWindowFetch{win, base}, end_bit, good);
-            const uint32_t st = skip_cds(br, c, ref, b, nblk);
+            uint32_t st = skip_cds(br, c, ref, b, nblk);
+            // (the window guarantees an encoder's longest coded data set; a foreign encoder's may be longer -- 12 800 bits
+            // in the tests -- and run out of the window, which reads as zeros up to the end of the stream: "input ended".
+            // From a window that begins at this coded data set it is read again; the window holds 131 kbit.)
+            if (st == DEC_NEED_INPUT && (good >> 5) > base + 4u && base + kIdxWindowWords < nwords) {
+                __syncthreads();
+                refill(good >> 5);
+                if (coop) load_regs(good >> 5);
+                br.init(LdsWindowFetch{win, base}, end_bit, good);
+                st = skip_cds(br, c, ref, b, nblk);
+            }
             if (st != DEC_OK) {
                 status = st;
                 break;
@@ -3713,6 +3723,7 @@ struct LockTables {
     uint32_t *flags;       // [0] done (k_index behind returns at once), [1] inconsistent, [2] region that ended the walk,
                            // [3] abandoned (plausibility guesses: too many did not hold; the trunk takes the stream)
     uint32_t nreg, region_bits, lead;
+    uint32_t gap;          // bits between the starts of the 64 chains of a guess (k_lock_guess_w)
     uint32_t coop;         // long coded data sets: the walks parse one at a time (lk_walk_coop) instead of 64 bits at a time
     const uint32_t *skip_if;   // != 0 there: a scheme in front has delivered the stream; every kernel returns at once
     uint64_t lo;           // bit position where region 0 begins (the caller's start)
@@ -3947,6 +3958,9 @@ k_lock_fill(const Cfg c, const TrStream s, const LockTables t, const LkState *ex
     // the walk ended here: only "the input ends inside this coded data set", confirmed by the sequential reader, is
     // delivered; anything else is the serial walker's to report
     if (x.st != 1u) return;
+    // (st 1 is also what a unary part beyond the parser's reach reports -- a foreign encoder's coded data set of 12 800
+    // bits: only within that reach of the end of the input does it mean that the input ended)
+    if (s.end_bit - x.pos > kTrMaxScan) return;
     {
         BitReaderT<QuadFetch> br;
         br.init(QuadFetch{words, nwords}, s.end_bit, x.pos);
@@ -4084,7 +4098,7 @@ k_lock_guess_w(const Cfg c, const TrStream s, const LockTables t)
     if (r >= t.nreg) return;
     const uint64_t rstart = t.lo + (uint64_t)r * t.region_bits;
     const uint64_t from = rstart > t.lo + t.lead ? rstart - t.lead : t.lo;
-    LkState x{from + (uint64_t)lane * 37u, 0u, 0u};
+    LkState x{from + (uint64_t)lane * t.gap, 0u, 0u};
     uint32_t steps = 0;
     const uint32_t most = 4u * (t.lead / (c.id_len + 1u) + 64u);
     bool ended = false;                                 // (no coded data set ends inside the input from here: out)
@@ -4719,6 +4733,9 @@ k_lock_fill_w(const Cfg c, const TrStream s, const LockTables t, const LkState *
         return;
     }
     if (x.st != 1u) return;
+    // (st 1 is also what a unary part beyond the parser's reach reports -- a foreign encoder's coded data set of 12 800
+    // bits: only within that reach of the end of the input does it mean that the input ended)
+    if (s.end_bit - x.pos > kTrMaxScan) return;
     {
         BitReaderT<QuadFetch> br;
         br.init(QuadFetch{words, nwords}, s.end_bit, x.pos);
@@ -4742,6 +4759,7 @@ struct LockPlan {
     uint32_t mode;            // 0: entries by 64 chains that agree (short RSIs); 1: by plausibility (k_lock_guess_p)
     uint32_t back;            // mode 1: how far in front of a region its guess begins (bits)
     uint32_t nreg, region_bits, lead;
+    uint32_t gap;             // mode 0: bits between the starts of a guess's 64 chains
     size_t o_entry, o_entry1, o_exit0, o_exit1, o_cnt, o_base, o_flags, bytes;
 };
 
@@ -4849,6 +4867,11 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     p.nreg = (uint32_t)nreg;
     p.region_bits = (uint32_t)region;
     p.lead = (uint32_t)lead;
+    // (the chains start a few RSIs apart in all -- 37 bits each were 2.4 kbit, more than the piece of the stream the
+    // wavefront's tables cover: with coded data sets of 24 bits in RSIs of 4 most chains waited most of the time, and
+    // the guesses of a 64 KiB chunk with scan lines of 32 pixels took 0.28 ms of its 0.59)
+    uint64_t gap = cds * (c.rsi < 4u ? 4u : c.rsi) / 16;
+    p.gap = (uint32_t)(gap < 3 ? 3 : gap > 37 ? 37 : gap);
     lock_layout(p, nreg);
     p.ok = true;
     return p;
@@ -4870,6 +4893,7 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
     t.nreg = p.nreg;
     t.region_bits = p.region_bits;
     t.lead = p.lead;
+    t.gap = p.gap ? p.gap : 37u;
     t.coop = p.mode == 1u ? 1u : 0u;
     t.skip_if = skip_if;
     t.lo = start_bit;
@@ -4911,7 +4935,10 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
         // a few parallel repair passes (each mends the first region of every run of regions in doubt; an idle one is a
         // launch of 5 us, and 48 of them were a quarter of a millisecond on a 64 KiB chunk), then one wavefront mends
         // what is left run by run at the speed of the walk
-        const uint32_t passes = tune("AEC_IDX_LOCK_PASSES", p.mode == 1u ? 8u : 16u);
+        // (a small chunk: four passes -- one costs as much as the walk of a region, which is what the wavefront behind
+        // them takes per region it mends; sixteen were 0.19 of the 0.59 ms of a 64 KiB chunk.  Not for 16 MiB: 16-bit
+        // data with rsi 32 went from 11 to 33 ms with four.)
+        const uint32_t passes = tune("AEC_IDX_LOCK_PASSES", p.mode == 1u ? 8u : p.nreg <= 256u ? 4u : 16u);
         for (uint32_t k = 0; k < passes; k++) {
             t.entry = en[cur];
             hipLaunchKernelGGL(k_lock_walk_w, dim3(wg), dim3(64 * wpw), wlds, st, c, s, t, (const LkState *)ex[cur], ex[cur ^ 1u],
@@ -5004,6 +5031,205 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
                        (const uint32_t *)t.flags);
 }
 
+// ---- small streams: EVERY bit parsed, the chain of RSI starts by pointer doubling ---------------------------------
+// A chunk of an HDF5 dataset is a call of its own (reference src/sz_compat.c:239): 64 KiB of pixels, a stream of 200
+// kbit.  Every scheme above pays lead-ins, repair passes or tables laid out for gigabits: 0.3 .. 1.7 ms for such a
+// chunk with RSIs of 1 .. 32 blocks, where the reference takes 0.1 .. 0.5 on one core.  A stream that small can be
+// parsed at EVERY bit by brute force -- 400 k parses are a few microseconds of this chip:
+//   1. k_small_parse: the coded data set that would begin at every bit, without and with a reference sample
+//      (nxt[] format, exact or 0);
+//   2. k_small_rsi:   from every bit one whole RSI (its first coded data set with a reference sample, the RSI's own
+//      bookkeeping of zero-block runs): where the NEXT RSI would start, J[q];
+//   3. k_small_double, log2(RSIs) times: the RSI starts 2^k .. 2^(k+1) - 1 from the first 2^k through J composed with
+//      itself k times, and J o J for the next round;
+//   4. k_small_finish: offsets, the walker's record, the trailing incomplete RSI walked by one lane -- anything out
+//      of the ordinary (a coded data set that does not parse, a run that does not fit) leaves the stream to the
+//      serial walker behind, as everywhere.
+// Works for any parameter set (no preprocessor, any rsi up to kSmMaxRsi), needs no guesses; 12 bytes of workspace per bit.
+constexpr uint64_t kSmMaxBits = 1ull << 22;      // 512 KiB of stream
+constexpr uint32_t kSmMaxRsi = 64;               // (step 2 is rsi dependent loads per bit)
+constexpr uint32_t kSmNone = 0xFFFFFFFFu;
+
+struct SmallPlan {
+    bool ok;
+    uint32_t nbits, scap, levels;
+    size_t o_e0, o_e1, o_ja, o_jb, o_s, o_flags, bytes;
+};
+
+static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi, uint32_t start_block)
+{
+    SmallPlan p{};
+    if (!tune("AEC_IDX_SMALL", 1) || start_block || !max_rsi || total_bits > kSmMaxBits || total_bits < 64 ||
+        c.rsi > kSmMaxRsi || (c.flags & F_PAD_RSI))
+        return p;
+    const uint64_t min_rsi_bits = (uint64_t)c.segs_per_rsi * (c.id_len + 2u) + ((c.flags & F_PREPROCESS) ? c.bps : 0u);
+    uint64_t most = total_bits / min_rsi_bits + 2;       // RSI starts the stream can hold ...
+    if (most > max_rsi + 1) most = max_rsi + 1;          // ... and the caller asks for (+ the one that clips)
+    uint32_t levels = 0;
+    while ((1ull << levels) < most) levels++;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    p.nbits = (uint32_t)total_bits;
+    p.scap = 1u << levels;
+    p.levels = levels;
+    size_t o = 0;
+    p.o_flags = o; o = up(o + 64);
+    p.o_e0 = o;    o = up(o + ((size_t)p.nbits + 1) * 2);
+    p.o_e1 = o;    o = up(o + ((size_t)p.nbits + 1) * 2);
+    p.o_ja = o;    o = up(o + ((size_t)p.nbits + 1) * 4);
+    p.o_jb = o;    o = up(o + ((size_t)p.nbits + 1) * 4);
+    p.o_s = o;     o = up(o + (size_t)p.scap * 4);
+    p.bytes = o;
+    p.ok = true;
+    return p;
+}
+
+__global__ void __launch_bounds__(256)
+k_small_parse(const Cfg c, const TrStream s, uint64_t start_bit, uint32_t nbits, uint16_t *__restrict__ e0,
+              uint16_t *__restrict__ e1)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nbits) return;
+    uint16_t a = 0, b = 0;
+    if (q < nbits) {
+        uint32_t nz;
+        TrWin W;
+        tr_win_load(s, start_bit + q, W);
+        uint32_t len = tr_cds(s, c, start_bit + q, 0u, nz, W);
+        if (len && len < 4096u) a = (uint16_t)(len | (nz ? kNxtZero : kNxtBlock));
+        b = a;
+        if (c.flags & F_PREPROCESS) {
+            len = tr_cds(s, c, start_bit + q, 1u, nz, W);
+            b = (len && len < 4096u) ? (uint16_t)(len | (nz ? kNxtZero : kNxtBlock)) : (uint16_t)0;
+        }
+    }
+    e0[q] = a;
+    e1[q] = b;
+}
+
+__global__ void __launch_bounds__(256)
+k_small_rsi(const Cfg c, uint32_t nbits, const uint16_t *__restrict__ e0, const uint16_t *__restrict__ e1,
+            uint32_t *__restrict__ j, uint32_t *__restrict__ sidx, uint32_t scap)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < scap) sidx[q] = q ? kSmNone : 0u;
+    if (q > nbits) return;
+    const uint32_t rfb = (c.flags & F_PREPROCESS) ? c.bps : 0u;
+    uint32_t pos = q, b = 0;
+    bool ok = q < nbits;
+    for (uint32_t i = 0; ok && i <= c.rsi && b < c.rsi; i++) {
+        const uint32_t e = b == 0u ? e1[pos] : e0[pos];
+        const uint32_t len = e & 0xFFFu;
+        const uint32_t nz = (e & kNxtZero) ? len - c.id_len - 1u - (b == 0u ? rfb : 0u) : 0u;
+        const uint32_t nb = e ? tr_blocks(c, nz, b) : 0u;
+        ok = nb != 0u && pos + len <= nbits;
+        pos += len;
+        b += nb;
+    }
+    j[q] = (ok && b == c.rsi) ? pos : kSmNone;
+}
+
+// round k: sidx[2^k + i] = j[sidx[i]] for i < 2^k, and jn = j o j
+__global__ void __launch_bounds__(256)
+k_small_double(uint32_t nbits, const uint32_t *__restrict__ j, uint32_t *__restrict__ jn, uint32_t *__restrict__ sidx,
+               uint32_t half, uint32_t scap, uint32_t last)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < half && half + q < scap) {
+        const uint32_t a = sidx[q];
+        sidx[half + q] = a == kSmNone ? kSmNone : j[a];
+    }
+    if (last || q > nbits) return;
+    const uint32_t v = j[q];
+    jn[q] = v == kSmNone ? kSmNone : j[v];
+}
+
+__global__ void __launch_bounds__(1024)
+k_small_finish(const Cfg c, const TrStream s, uint64_t start_bit, const uint32_t *__restrict__ sidx, uint32_t scap,
+               const uint32_t *__restrict__ words, uint64_t nwords, uint64_t *__restrict__ rsi_off, uint64_t max_rsi,
+               DecResult *res, uint32_t tail_slot, uint32_t *flags)
+{
+    __shared__ uint32_t first_none;
+    if (threadIdx.x == 0) first_none = scap;
+    __syncthreads();
+    uint32_t mine = scap;
+    for (uint32_t i = threadIdx.x; i < scap; i += blockDim.x)
+        if (sidx[i] == kSmNone) {
+            mine = i;
+            break;
+        }
+    if (mine < scap) atomicMin(&first_none, mine);
+    __syncthreads();
+    const uint32_t m = first_none;                      // RSI starts on the chain (the first is the caller's)
+    const uint64_t nout = m < max_rsi ? m : max_rsi;
+    for (uint64_t i = threadIdx.x; i < nout; i += blockDim.x) rsi_off[i] = start_bit + sidx[i];
+    if (threadIdx.x != 0) return;
+    if (m > max_rsi) {                                  // the caller's bound: ends on the start of RSI max_rsi
+        res->n_rsi = max_rsi;
+        res->tail_blocks = 0;
+        res->end_bit = start_bit + sidx[max_rsi];
+        res->status = DEC_OK;
+        res->pad = 0u;
+        res->bad_rsi = ~0ull;
+        if (tail_slot) rsi_off[max_rsi] = start_bit + sidx[max_rsi - 1u];
+        __threadfence();
+        flags[0] = 1u;
+        return;
+    }
+    // the RSI that does not end inside the input: walked to where the input ends (k_lock_fill's ending)
+    LkState x{start_bit + sidx[m - 1u], 0u, 0u};
+    for (uint32_t i = 0; i <= c.rsi && !x.st; i++) lk_step(s, c, x);
+    if (x.st != 1u) return;
+    // (st 1 is also what a unary part beyond the parser's reach reports -- a foreign encoder's coded data set of 12 800
+    // bits: only within that reach of the end of the input does it mean that the input ended)
+    if (s.end_bit - x.pos > kTrMaxScan) return;
+    {
+        BitReaderT<QuadFetch> br;
+        br.init(QuadFetch{words, nwords}, s.end_bit, x.pos);
+        uint32_t nblk = 1;
+        if (skip_cds(br, c, (x.b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u, x.b, nblk) != DEC_NEED_INPUT) return;
+    }
+    res->n_rsi = m - 1u;
+    res->tail_blocks = x.b;
+    res->end_bit = x.pos;
+    res->status = DEC_OK;
+    res->pad = 1u;
+    res->bad_rsi = ~0ull;
+    if (tail_slot) rsi_off[max_rsi] = start_bit + sidx[m - 1u];
+    __threadfence();
+    flags[0] = 1u;
+}
+
+static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
+                               uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
+                               uint8_t *base, uint64_t rsi_start, uint32_t tail_slot)
+{
+    const TrStream s{words, nwords, end_bit};
+    uint32_t *flags = reinterpret_cast<uint32_t *>(base + p.o_flags);
+    uint16_t *e0 = reinterpret_cast<uint16_t *>(base + p.o_e0), *e1 = reinterpret_cast<uint16_t *>(base + p.o_e1);
+    uint32_t *j[2] = {reinterpret_cast<uint32_t *>(base + p.o_ja), reinterpret_cast<uint32_t *>(base + p.o_jb)};
+    uint32_t *sidx = reinterpret_cast<uint32_t *>(base + p.o_s);
+    (void)hipMemsetAsync(flags, 0, 64, st);
+    const uint32_t grid = (p.nbits + 1u + 255u) / 256u;
+    const uint32_t sgrid = (p.scap + 255u) / 256u > grid ? (p.scap + 255u) / 256u : grid;
+    hipLaunchKernelGGL(k_small_parse, dim3(grid), dim3(256), 0, st, c, s, start_bit, p.nbits, e0, e1);
+    hipLaunchKernelGGL(k_small_rsi, dim3(sgrid), dim3(256), 0, st, c, p.nbits, (const uint16_t *)e0, (const uint16_t *)e1, j[0],
+                       sidx, p.scap);
+    for (uint32_t k = 0; k < p.levels; k++) {
+        const uint32_t half = 1u << k, last = k + 1u == p.levels ? 1u : 0u;
+        const uint32_t g = last ? (half + 255u) / 256u : ((half + 255u) / 256u > grid ? (half + 255u) / 256u : grid);
+        hipLaunchKernelGGL(k_small_double, dim3(g), dim3(256), 0, st, p.nbits, (const uint32_t *)j[k & 1u], j[(k & 1u) ^ 1u], sidx,
+                           half, p.scap, last);
+    }
+    if (tune("AEC_IDX_SMALL_FINISH", 1))
+    hipLaunchKernelGGL(k_small_finish, dim3(1), dim3(1024), 0, st, c, s, start_bit, (const uint32_t *)sidx, p.scap, words, nwords,
+                       d_rsi_off, max_rsi, d_res, tail_slot, flags);
+    // whatever was not delivered: the serial walker, which returns at once otherwise
+    hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res,
+                       (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, 0u, rsi_start, tail_slot,
+                       TwTables{}, (ChunkEntry *)nullptr, SparseTables{}, (uint32_t *)nullptr, (uint64_t)0,
+                       (const uint32_t *)flags);
+}
+
 }  // namespace
 
 // (tuning build: the A/B switches that live in device globals)
@@ -5023,12 +5249,25 @@ int index_scheme(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint, uint32_t
 {
     const uint64_t bits = (uint64_t)in_bytes * 8;
     if (!bits) return 0;
+    if (small_plan(c, bits, 1ull << 62, start_block).ok) return 4;
     if (lock_plan(c, bits, rsi_bits_hint, start_block).ok) return 1;
     if (sparse2_plan(c, bits, rsi_bits_hint).ok) return 2;
     return trunk_plan(c, bits, rsi_bits_hint, 0).ok ? 3 : 0;
 }
 
+static size_t index_workspace_bytes_large(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint);
+
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
+{
+    const uint64_t end_bit = (uint64_t)in_bytes * 8;
+    if (start_bit >= end_bit) return 0;
+    // (a small stream: the brute-force scheme for a walk from an RSI start, the others for one that resumes inside)
+    const SmallPlan sm = small_plan(c, end_bit - start_bit, 1ull << 62, 0u);
+    const size_t rest = index_workspace_bytes_large(c, in_bytes, start_bit, rsi_bits_hint);
+    return sm.ok && sm.bytes > rest ? sm.bytes : rest;
+}
+
+static size_t index_workspace_bytes_large(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
 {
     const uint64_t end_bit = (uint64_t)in_bytes * 8;
     if (start_bit >= end_bit) return 0;
@@ -5059,6 +5298,15 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
     idx_tuning_sync();
     // Low-entropy streams whose RSIs fit a window: candidates and RSI hypotheses per window (k_spec2); everything
     // else: the trunk.
+    // a small stream (a chunk of a dataset): every bit parsed, the RSI starts by pointer doubling
+    if (d_ws && ws_bytes && start_bit < end_bit && !d_seg_bits && !stop_near) {
+        const SmallPlan sm = small_plan(c, end_bit - start_bit, max_rsi, start_block);
+        if (sm.ok && ws_bytes >= sm.bytes) {
+            launch_index_small(c, sm, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
+                               static_cast<uint8_t *>(d_ws), rsi_start, tail_slot);
+            return false;
+        }
+    }
     if (d_ws && ws_bytes && start_bit < end_bit && !d_seg_bits) {
         const LockPlan lp = lock_plan(c, end_bit - start_bit, rsi_bits_hint, start_block);
         if (lp.ok && lp.mode == 0u && ws_bytes >= lp.bytes) {

@@ -20,20 +20,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size-mib", type=int, default=16)
+    ap.add_argument("--size-kib", type=int, default=0, help="a small chunk instead (what one SZIP call per chunk decodes): best of 50 calls")
+    ap.add_argument("--rsi", type=int, nargs="*", default=[1, 2, 4, 8, 16, 32, 64, 128])
     args = ap.parse_args()
     import torch  # noqa: F401
     from helpers import have_ref, ref_decode
     from libaec_amd import api
     from test_gpu_parity import gen
-    n = args.size_mib << 20
+    n = (args.size_kib << 10) if args.size_kib else (args.size_mib << 20)
+    size = f"{args.size_kib} KiB" if args.size_kib else f"{args.size_mib} MiB"
     for kind, bps, bs in ((2, 8, 8), (0, 16, 16)):
         data = gen(kind, n)
-        for rsi in (1, 2, 4, 8, 16, 32, 64, 128):
+        for rsi in args.rsi:
             flags = api.AEC_DATA_PREPROCESS
             rc, enc = api.aec_buffer_encode(data, bps, bs, rsi, flags)
             assert rc == 0
             best = 1e9
-            for _ in range(3):
+            for _ in range(50 if args.size_kib else 3):
                 t0 = time.perf_counter()
                 rc, dec = api.aec_buffer_decode(enc, bps, bs, rsi, flags, n)
                 best = min(best, time.perf_counter() - t0)
@@ -44,7 +47,7 @@ def main():
                 rc_r, dec_r = ref_decode(enc, bps, bs, rsi, flags, n)
                 ref = f"   reference on one core {(time.perf_counter() - t0) * 1e3:8.1f} ms"
                 assert dec_r == dec
-            print(f"{bps}-bit block {bs} rsi {rsi:3d}, {args.size_mib} MiB (stream {len(enc) >> 10} KiB): aec_buffer_decode "
+            print(f"{bps}-bit block {bs} rsi {rsi:3d}, {size} (stream {len(enc) >> 10} KiB): aec_buffer_decode "
                   f"{best * 1e3:8.2f} ms = {n / best / 1e9:6.2f} GB/s{ref}", flush=True)
 
 

@@ -17,6 +17,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
+    if "--only" in sys.argv:                    # --only <chunks> <chunk KiB> <scan line>: one shape alone (profiling)
+        i = sys.argv.index("--only")
+        run(int(sys.argv[i + 1]), int(sys.argv[i + 2]) << 10, int(sys.argv[i + 3]))
+        return
     run(64, 1 << 20)
     run(1024, 64 << 10)
     if "--narrow" in sys.argv:                  # (scan lines of 32 pixels: RSIs of 4 blocks)
