@@ -5045,8 +5045,8 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
 //   4. k_small_finish: offsets, the walker's record, the trailing incomplete RSI walked by one lane -- anything out
 //      of the ordinary (a coded data set that does not parse, a run that does not fit) leaves the stream to the
 //      serial walker behind, as everywhere.
-// Works for any parameter set (no preprocessor, any rsi up to kSmMaxRsi), needs no guesses; 12 bytes of workspace per bit.
-constexpr uint64_t kSmMaxBits = 1ull << 22;      // 512 KiB of stream
+// Works for any parameter set (no preprocessor, any rsi up to kSmMaxRsi), needs no guesses; 8 bytes of workspace per bit.
+constexpr uint64_t kSmMaxBits = 1ull << 24;      // 2 MiB of stream
 constexpr uint32_t kSmMaxRsi = 64;               // (step 2 is rsi dependent loads per bit)
 constexpr uint32_t kSmNone = 0xFFFFFFFFu;
 
@@ -5060,7 +5060,7 @@ static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi,
 {
     SmallPlan p{};
     if (!tune("AEC_IDX_SMALL", 1) || start_block || !max_rsi || total_bits > kSmMaxBits || total_bits < 64 ||
-        c.rsi > kSmMaxRsi || (c.flags & F_PAD_RSI))
+        c.rsi > (uint32_t)tune("AEC_IDX_SMALL_RSI", kSmMaxRsi) || (c.flags & F_PAD_RSI))
         return p;
     const uint64_t min_rsi_bits = (uint64_t)c.segs_per_rsi * (c.id_len + 2u) + ((c.flags & F_PREPROCESS) ? c.bps : 0u);
     uint64_t most = total_bits / min_rsi_bits + 2;       // RSI starts the stream can hold ...
@@ -5075,8 +5075,8 @@ static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi,
     p.o_flags = o; o = up(o + 64);
     p.o_e0 = o;    o = up(o + ((size_t)p.nbits + 1) * 2);
     p.o_e1 = o;    o = up(o + ((size_t)p.nbits + 1) * 2);
+    p.o_jb = p.o_e0;                                     // (the second table of the doubling: over the parses, done with by then)
     p.o_ja = o;    o = up(o + ((size_t)p.nbits + 1) * 4);
-    p.o_jb = o;    o = up(o + ((size_t)p.nbits + 1) * 4);
     p.o_s = o;     o = up(o + (size_t)p.scap * 4);
     p.bytes = o;
     p.ok = true;
@@ -5094,12 +5094,27 @@ k_small_parse(const Cfg c, const TrStream s, uint64_t start_bit, uint32_t nbits,
         uint32_t nz;
         TrWin W;
         tr_win_load(s, start_bit + q, W);
+        // (a second-extension code beyond the table is a data error to the reference, decode.c:589-616, and to the
+        // serial walker, skip_cds: such a coded data set does not parse here either -- the chain ends at its RSI and the
+        // walker behind gives the verdict)
+        const uint32_t il = c.id_len;
+        const uint32_t head = (uint32_t)(tr_peek64(s, start_bit + q) >> (63u - il));
+        const bool se = (head >> 1) == 0u && (head & 1u);
+        auto se_ok = [&](uint32_t ref) {
+            BitReaderT<QuadFetch> br;
+            br.init(QuadFetch{s.words, s.nwords}, s.end_bit, start_bit + q + il + 1u + ref * c.bps);
+            for (uint32_t k = 0; k < c.bs / 2u; k++) {
+                uint32_t m;
+                if (!br.unary(m) || m > 90u) return false;
+            }
+            return true;
+        };
         uint32_t len = tr_cds(s, c, start_bit + q, 0u, nz, W);
-        if (len && len < 4096u) a = (uint16_t)(len | (nz ? kNxtZero : kNxtBlock));
+        if (len && len < 4096u && (!se || se_ok(0u))) a = (uint16_t)(len | (nz ? kNxtZero : kNxtBlock));
         b = a;
         if (c.flags & F_PREPROCESS) {
             len = tr_cds(s, c, start_bit + q, 1u, nz, W);
-            b = (len && len < 4096u) ? (uint16_t)(len | (nz ? kNxtZero : kNxtBlock)) : (uint16_t)0;
+            b = (len && len < 4096u && (!se || se_ok(1u))) ? (uint16_t)(len | (nz ? kNxtZero : kNxtBlock)) : (uint16_t)0;
         }
     }
     e0[q] = a;
@@ -5175,19 +5190,22 @@ k_small_finish(const Cfg c, const TrStream s, uint64_t start_bit, const uint32_t
         flags[0] = 1u;
         return;
     }
-    // the RSI that does not end inside the input: walked to where the input ends (k_lock_fill's ending)
-    LkState x{start_bit + sidx[m - 1u], 0u, 0u};
-    for (uint32_t i = 0; i <= c.rsi && !x.st; i++) lk_step(s, c, x);
-    if (x.st != 1u) return;
-    // (st 1 is also what a unary part beyond the parser's reach reports -- a foreign encoder's coded data set of 12 800
-    // bits: only within that reach of the end of the input does it mean that the input ended)
-    if (s.end_bit - x.pos > kTrMaxScan) return;
-    {
-        BitReaderT<QuadFetch> br;
-        br.init(QuadFetch{words, nwords}, s.end_bit, x.pos);
+    // the RSI that does not end inside the input, walked as the serial walker walks it (skip_cds: the parse that also
+    // sees second-extension codes beyond the table); anything but "the input ends inside a coded data set" is its call
+    const uint64_t pos0 = start_bit + sidx[m - 1u];
+    BitReaderT<QuadFetch> br;
+    br.init(QuadFetch{words, nwords}, s.end_bit, pos0);
+    uint32_t b = 0, st = DEC_OK;
+    uint64_t good = pos0;
+    while (b < c.rsi) {
         uint32_t nblk = 1;
-        if (skip_cds(br, c, (x.b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u, x.b, nblk) != DEC_NEED_INPUT) return;
+        st = skip_cds(br, c, (b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u, b, nblk);
+        if (st != DEC_OK) break;
+        good = br.pos;
+        b += nblk;
     }
+    if (st != DEC_NEED_INPUT) return;
+    struct { uint64_t pos; uint32_t b; } x{good, b};
     res->n_rsi = m - 1u;
     res->tail_blocks = x.b;
     res->end_bit = x.pos;

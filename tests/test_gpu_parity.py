@@ -874,7 +874,8 @@ def test_streams_with_short_rsis(api, gpu):
         # the PATH, not a wall-clock bound (times: tests/bench_short_rsi.py): phase-locked chains, also
         # for a walk that resumes inside an RSI (streaming callers whose input arrives in pieces)
         hint = nbytes * 8 // max(nr, 1)
-        assert gpu.index_scheme(bps, bs, rsi, flags, nbytes, hint, 0) == 1, (bps, bs, rsi)
+        # (streams of at most 2 MiB walked from an RSI start: every bit parsed, test_small_streams_every_bit_parsed)
+        assert gpu.index_scheme(bps, bs, rsi, flags, nbytes, hint, 0) == (4 if nbytes <= 2 << 20 else 1), (bps, bs, rsi)
         assert gpu.index_scheme(bps, bs, rsi, flags, nbytes // 2, hint, 1) == 1, (bps, bs, rsi)
         # a caller's bound in the middle of the stream (what every batch but the last of a large decode asks for): ends
         # on the start of RSI number `bound`, which ONE region delivers (every region behind it is past the bound too)
@@ -960,6 +961,62 @@ def test_long_coded_data_sets_in_short_rsis(api, gpu, typical_rz):
             assert rc_p == rc_o, (name, what, rc_p, rc_o)
             if rc_o == AEC_OK:
                 assert dec_p == dec_o, (name, what)
+
+
+def test_small_streams_every_bit_parsed(api, gpu):
+    """A chunk of a dataset per call (reference src/sz_compat.c:239): streams of at most 2 MiB with RSIs of at most 64
+    blocks are parsed at EVERY bit and the chain of RSI starts is ranked by pointer doubling (aec_idx.hip:
+    launch_index_small) -- no preprocessor, zero-block runs to the end of a segment, a short last RSI, 8- to 32-bit
+    samples.  Offsets against the encoder's table, a caller's bound in the middle of the stream, decoded bytes against
+    the oracle for whole, cut and garbage-tailed streams."""
+    import torch
+    rng = np.random.default_rng(64)
+    shapes = [(8, 8, 1, PP, 65536), (8, 8, 4, PP, 65536), (8, 16, 1, 0, 200000), (16, 16, 16, PP | MSB, 300001),
+              (16, 64, 1, 0, 100000), (32, 16, 5, PP, 90000), (32, 32, 64, PP | SGN, 250000), (24, 8, 33, PP | MSB, 70001),
+              (12, 32, 3, PP, 1 << 20), (16, 8, 64, PP, 3), (8, 8, 64, 0, 1 << 19)]
+    for bps, bs, rsi, flags, n in shapes:
+        vals = random_walk_samples(rng, n, bps, flags, scale=float(rng.choice([0.3, 3.0, 60.0])),
+                                   zero_frac=float(rng.choice([0.0, 0.3, 0.7])))
+        raw = np.frombuffer(pack_samples(vals, bps, flags), dtype=np.uint8)
+        nb = bytes_per_sample(bps, flags)
+        rc, enc, _, offs, _ = oracle_encode(raw, bps, bs, rsi, flags)
+        assert rc == AEC_OK
+        nblk = (n + bs - 1) // bs
+        out = nblk * bs * nb
+        assert gpu.index_scheme(bps, bs, rsi, flags, len(enc), 0, 0) == (4 if len(enc) >= 8 else 0), (bps, bs, rsi)
+        codec = gpu.Codec(bps, bs, rsi, flags)
+        d_in = torch.from_numpy(np.frombuffer(enc, dtype=np.uint8).copy()).cuda()
+        d_off = torch.from_numpy(offs.astype(np.int64)).cuda()          # the oracle's table of RSI starts
+        nr = len(offs)
+        whole = nblk // rsi
+        d_res = torch.zeros(40, dtype=torch.uint8, device="cuda")
+        for bound in (nr, max(1, whole // 3 + 1), 1):
+            d_idx = torch.zeros(nr + 2, dtype=torch.int64, device="cuda")
+            codec.index_async(d_in, len(enc), 0, d_idx, bound, d_res)
+            torch.cuda.synchronize()
+            res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=np.uint64)
+            got = min(bound, whole)
+            if bound < whole:
+                assert int(res[0]) == bound and int(res[1]) == 0 and int(res[2]) == int(d_off[bound]), (bps, bs, rsi, bound, res[:3])
+            else:
+                assert int(res[0]) in (nr, whole), (bps, bs, rsi, bound, res[:3])
+            assert torch.equal(d_idx[:got], d_off[:got]), (bps, bs, rsi, bound)
+        for what, stream in (("whole", enc), ("cut", enc[: int(len(enc) * 0.61)]),
+                             ("cut + garbage", enc[: len(enc) // 3] + bytes(rng.integers(0, 256, 300, dtype=np.uint8).tolist())),
+                             ("garbage tail", enc + bytes(rng.integers(0, 256, 100, dtype=np.uint8).tolist()))):
+            # (garbage behind a short last RSI, room for exactly the samples: the reference stops with the room and
+            # returns AEC_OK; the oracle restates the decoder with ample room and meets the garbage -- the compiled
+            # reference is the arbiter where the two differ, as in tests/fuzz_corrupt_gpu.py)
+            if have_ref():
+                rc_o, dec_o = ref_decode(stream, bps, bs, rsi, flags, out)
+            elif what == "garbage tail" and nblk % rsi:
+                continue
+            else:
+                rc_o, dec_o, _ = oracle_decode(stream, bps, bs, rsi, flags, out)
+            rc_p, dec_p = api.aec_buffer_decode(stream, bps, bs, rsi, flags, out)
+            assert rc_p == rc_o, (bps, bs, rsi, what, rc_p, rc_o)
+            if rc_o == AEC_OK:
+                assert dec_p == dec_o, (bps, bs, rsi, what)
 
 
 def test_large_one_shot_decode_of_damaged_streams(api):
