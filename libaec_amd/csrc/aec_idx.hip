@@ -5040,8 +5040,8 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
 //      (nxt[] format, exact or 0);
 //   2. k_small_rsi:   from every bit one whole RSI (its first coded data set with a reference sample, the RSI's own
 //      bookkeeping of zero-block runs): where the NEXT RSI would start, J[q];
-//   3. k_small_double, log2(RSIs) times: the RSI starts 2^k .. 2^(k+1) - 1 from the first 2^k through J composed with
-//      itself k times, and J o J for the next round;
+//   3. k_small_double, log4(RSIs) times: the RSI starts 4^k .. 4^(k+1) - 1 from the first 4^k through J^(4^k) applied
+//      once, twice, three times, and its fourth power for the next round;
 //   4. k_small_finish: offsets, the walker's record, the trailing incomplete RSI walked by one lane -- anything out
 //      of the ordinary (a coded data set that does not parse, a run that does not fit) leaves the stream to the
 //      serial walker behind, as everywhere.
@@ -5065,11 +5065,11 @@ static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi,
     const uint64_t min_rsi_bits = (uint64_t)c.segs_per_rsi * (c.id_len + 2u) + ((c.flags & F_PREPROCESS) ? c.bps : 0u);
     uint64_t most = total_bits / min_rsi_bits + 2;       // RSI starts the stream can hold ...
     if (most > max_rsi + 1) most = max_rsi + 1;          // ... and the caller asks for (+ the one that clips)
-    uint32_t levels = 0;
-    while ((1ull << levels) < most) levels++;
+    uint32_t levels = 0;                                 // rounds of the doubling, each a factor of FOUR (a launch is 5 us)
+    while ((1ull << (2u * levels)) < most) levels++;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     p.nbits = (uint32_t)total_bits;
-    p.scap = 1u << levels;
+    p.scap = 1u << (2u * levels);
     p.levels = levels;
     size_t o = 0;
     p.o_flags = o; o = up(o + 64);
@@ -5143,19 +5143,23 @@ k_small_rsi(const Cfg c, uint32_t nbits, const uint16_t *__restrict__ e0, const 
     j[q] = (ok && b == c.rsi) ? pos : kSmNone;
 }
 
-// round k: sidx[2^k + i] = j[sidx[i]] for i < 2^k, and jn = j o j
+// round k, with quarter = 4^k known RSI starts: sidx[m * quarter + i] = j^m[sidx[i]] for m = 1 .. 3, and jn = j^4
 __global__ void __launch_bounds__(256)
 k_small_double(uint32_t nbits, const uint32_t *__restrict__ j, uint32_t *__restrict__ jn, uint32_t *__restrict__ sidx,
-               uint32_t half, uint32_t scap, uint32_t last)
+               uint32_t quarter, uint32_t scap, uint32_t last)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < half && half + q < scap) {
-        const uint32_t a = sidx[q];
-        sidx[half + q] = a == kSmNone ? kSmNone : j[a];
+    if (q < quarter) {
+        uint32_t a = sidx[q];
+        for (uint32_t m = 1; m < 4u; m++) {
+            a = a == kSmNone ? kSmNone : j[a];
+            if (m * quarter + q < scap) sidx[m * quarter + q] = a;
+        }
     }
     if (last || q > nbits) return;
-    const uint32_t v = j[q];
-    jn[q] = v == kSmNone ? kSmNone : j[v];
+    uint32_t v = j[q];
+    for (uint32_t m = 1; m < 4u && v != kSmNone; m++) v = j[v];
+    jn[q] = v;
 }
 
 __global__ void __launch_bounds__(1024)
@@ -5233,10 +5237,11 @@ static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t 
     hipLaunchKernelGGL(k_small_rsi, dim3(sgrid), dim3(256), 0, st, c, p.nbits, (const uint16_t *)e0, (const uint16_t *)e1, j[0],
                        sidx, p.scap);
     for (uint32_t k = 0; k < p.levels; k++) {
-        const uint32_t half = 1u << k, last = k + 1u == p.levels ? 1u : 0u;
-        const uint32_t g = last ? (half + 255u) / 256u : ((half + 255u) / 256u > grid ? (half + 255u) / 256u : grid);
+        const uint32_t quarter = 1u << (2u * k), last = k + 1u == p.levels ? 1u : 0u;
+        const uint32_t gq = (quarter + 255u) / 256u;
+        const uint32_t g = last ? gq : (gq > grid ? gq : grid);
         hipLaunchKernelGGL(k_small_double, dim3(g), dim3(256), 0, st, p.nbits, (const uint32_t *)j[k & 1u], j[(k & 1u) ^ 1u], sidx,
-                           half, p.scap, last);
+                           quarter, p.scap, last);
     }
     if (tune("AEC_IDX_SMALL_FINISH", 1))
     hipLaunchKernelGGL(k_small_finish, dim3(1), dim3(1024), 0, st, c, s, start_bit, (const uint32_t *)sidx, p.scap, words, nwords,
