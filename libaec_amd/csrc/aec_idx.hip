@@ -3725,6 +3725,7 @@ struct LockTables {
     uint32_t nreg, region_bits, lead;
     uint32_t gap;          // bits between the starts of the 64 chains of a guess (k_lock_guess_w)
     uint32_t coop;         // long coded data sets: the walks parse one at a time (lk_walk_coop) instead of 64 bits at a time
+    uint32_t mode;         // 1: the entries are guesses by plausibility (walks from wrong ones do not lock by themselves)
     const uint32_t *skip_if;   // != 0 there: a scheme in front has delivered the stream; every kernel returns at once
     uint64_t lo;           // bit position where region 0 begins (the caller's start)
 };
@@ -4188,7 +4189,7 @@ k_lock_walk_w(const Cfg c, const TrStream s, const LockTables t, const LkState *
         bool idle = prev.st || (prev.pos == mine.pos && prev.b == mine.b);
         // (Where 64 chains lock onto the phase -- short RSIs -- a walk from a wrong entry locks as well and its exit is
         // mostly right: there every region in doubt is walked again at once.)
-        if (!idle && r >= 2u && t.coop) {
+        if (!idle && r >= 2u && t.mode == 1u) {
             const LkState pp = exit_prev[r - 2u], pe = t.entry[r - 1u];
             idle = !pp.st && (pp.pos != pe.pos || pp.b != pe.b);
         }
@@ -4760,6 +4761,7 @@ struct LockPlan {
     uint32_t back;            // mode 1: how far in front of a region its guess begins (bits)
     uint32_t nreg, region_bits, lead;
     uint32_t gap;             // mode 0: bits between the starts of a guess's 64 chains
+    uint32_t coop;            // the walks parse one coded data set at a time (long ones) instead of 64 bits at a time
     size_t o_entry, o_entry1, o_exit0, o_exit1, o_cnt, o_base, o_flags, bytes;
 };
 
@@ -4789,7 +4791,9 @@ static LockPlan lock_plan_p(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits
     const uint64_t cds = rsi_bits_hint / c.rsi;
     // (RSIs of fewer than 16 blocks: a scoring chain of 16 coded data sets passes an RSI start or three -- there the
     // chains carry the count of blocks, one set of chains per count: k_lock_guess_p, find_anchor_phased)
-    if (cds < 96 || c.rsi >= 8 * cds || c.segs_per_rsi >= 8u || total_bits < 4 * rsi_bits_hint) return p;
+    const uint64_t cds_min = (c.rsi <= 32u && c.id_len >= 4u) ? (uint64_t)tune("AEC_IDX_LOCK_P_CDS", 32)
+                                                              : (uint64_t)tune("AEC_IDX_LOCK_P_CDS_LONG", 96);
+    if (cds < cds_min || c.rsi >= 8 * cds || c.segs_per_rsi >= 8u || total_bits < 4 * rsi_bits_hint) return p;
     if (c.id_len + 1u + c.bps + c.bs * c.bps > (kSwLookWords - 2u) * 32u) return p;
     // regions of 1 .. 8 RSIs: large streams pay the guess (two RSIs walked per region) less often, small ones get
     // wavefronts to run
@@ -4802,6 +4806,7 @@ static LockPlan lock_plan_p(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits
     const uint64_t nreg = (total_bits + region - 1) / region;
     if (nreg > (1u << 24) || region > 0xFFFFFFFFull) return p;
     p.mode = 1;
+    p.coop = cds >= (uint64_t)tune("AEC_IDX_LOCK_COOP_CDS", 96) ? 1u : 0u;
     p.nreg = (uint32_t)nreg;
     p.region_bits = (uint32_t)region;
     p.lead = 0;
@@ -4846,7 +4851,11 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     // the true chain from the others in a dozen coded data sets: mode 1)
     // (and in RSIs of a few blocks whatever the size of the stream: 16 MiB of 24-bit data in blocks of 64 with rsi 1 took
     // 122 ms with lead-ins of 1.3 Mbit per region)
-    if (allow_p && cds >= 96 && (lead * 8 > total_bits || c.rsi < kLpPhased)) {
+    // (and with 16 .. 32 blocks per RSI whatever the length of the coded data sets, where the options have four bits and
+    // more -- with three, 8-bit data, half of the guesses are wrong: 16 MiB of 16-bit data in blocks of 16, rsi 32: 11.3
+    // -> 3.2 ms, rsi 16: 6.4 -> 2.9; a walk to the next RSI start is 32 coded data sets at most)
+    if (allow_p && ((cds >= 96 && (lead * 8 > total_bits || c.rsi < kLpPhased)) ||
+                    (c.rsi >= kLpPhased && c.id_len >= 4u && cds >= (uint64_t)tune("AEC_IDX_LOCK_P_CDS", 32)))) {
         const LockPlan q = lock_plan_p(c, total_bits, rsi_bits_hint);
         if (q.ok) return q;
     }
@@ -4877,6 +4886,18 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     return p;
 }
 
+// What runs behind guesses by plausibility that were judged wrong, before the trunk: the 64 agreeing chains -- unless
+// their lead-in is a good part of the stream and RSIs have 16 blocks and more (long coded data sets: lead-ins of
+// megabits, the trunk is faster: 1 MiB of 16-bit data in blocks of 32, rsi 16: 17 against 7 ms; with fewer blocks the
+// trunk walks every RSI by itself -- 48 MiB with rsi 1: 1.5 s).
+static LockPlan lock_plan_alt(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, uint32_t start_block)
+{
+    if (c.rsi > 32u) return LockPlan{};
+    const LockPlan l0 = lock_plan(c, total_bits, rsi_bits_hint, start_block, false);
+    if (l0.ok && c.rsi >= kLpPhased && (uint64_t)l0.lead * 8u > total_bits) return LockPlan{};
+    return l0;
+}
+
 void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
                          uint8_t *base, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
@@ -4894,7 +4915,8 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
     t.region_bits = p.region_bits;
     t.lead = p.lead;
     t.gap = p.gap ? p.gap : 37u;
-    t.coop = p.mode == 1u ? 1u : 0u;
+    t.coop = p.coop;
+    t.mode = p.mode;
     t.skip_if = skip_if;
     t.lo = start_bit;
     (void)hipMemsetAsync(t.flags, 0, 64, st);
@@ -5297,7 +5319,7 @@ static size_t index_workspace_bytes_large(const Cfg &c, size_t in_bytes, uint64_
     const LockPlan lp = lock_plan(c, end_bit - start_bit, rsi_bits_hint, 0u);
     if (lp.ok && lp.mode == 0u) return lp.bytes;
     if (lp.ok) {                                           // (mode 1: + what runs behind it for the streams it abandons)
-        const LockPlan l0 = c.rsi < kLpPhased ? lock_plan(c, end_bit - start_bit, rsi_bits_hint, 0u, false) : LockPlan{};
+        const LockPlan l0 = lock_plan_alt(c, end_bit - start_bit, rsi_bits_hint, 0u);
         const TrunkPlan tp = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, 0);
         return lp.bytes + (l0.ok ? l0.bytes : 0) + (tp.ok ? tp.bytes : 0);
     }
@@ -5343,10 +5365,7 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
             // short, then the trunk; every kernel of a later scheme returns at once if the stream has been delivered
             uint8_t *wb = static_cast<uint8_t *>(d_ws);
             size_t used = lp.bytes;
-            // (the agreeing chains only for RSIs of a few blocks, where the trunk walks every RSI by itself -- 48 MiB with
-            // rsi 1: 1.5 s; with 16 .. 32 blocks and long coded data sets their lead-ins are megabits and the trunk is
-            // faster: 1 MiB of 16-bit data in blocks of 32, rsi 16: 17 against 7 ms)
-            const LockPlan l0 = c.rsi < kLpPhased ? lock_plan(c, end_bit - start_bit, rsi_bits_hint, start_block, false) : LockPlan{};
+            const LockPlan l0 = lock_plan_alt(c, end_bit - start_bit, rsi_bits_hint, start_block);
             const bool have0 = l0.ok && ws_bytes >= used + l0.bytes;
             const size_t off0 = used;
             if (have0) used += l0.bytes;
