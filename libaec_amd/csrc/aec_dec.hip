@@ -1466,8 +1466,11 @@ static bool dec_wave_wanted(const Cfg &c, uint64_t n_items)
     // per RSI, 205 us whatever the number, is through first -- 16 MiB of the 8-bit shape: 1.53 against 1.57 ms per call.
     // n_items is the MOST the index pass can have found where the counts come from its record: the streaming ABI asks
     // for room / RSI size + 2 of at least 4 MiB of room, 4098 for the 8-bit shape whatever the call holds)
+    // (RSIs of 64 .. 127 blocks: as many more as they are shorter -- the bound of a small call is 8194 for RSIs of 64
+    // blocks of 8 samples, which left a 64 KiB chunk of 128 RSIs to a lane per RSI: 102 us of the call's 260)
     const uint32_t most = tune("AEC_DEC_WAVE_MAX", 8192u), least = tune("AEC_DEC_WAVE_RSI", 16u);
-    return c.rsi >= least && n_items <= most;
+    const uint64_t scaled = c.rsi >= 64u && c.rsi < 128u ? (uint64_t)most * 128u / c.rsi : most;
+    return c.rsi >= least && n_items <= scaled;
 }
 
 template <bool SEG>

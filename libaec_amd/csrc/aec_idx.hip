@@ -5143,18 +5143,32 @@ k_small_parse(const Cfg c, const TrStream s, uint64_t start_bit, uint32_t nbits,
     e1[q] = b;
 }
 
-__global__ void __launch_bounds__(256)
+// (the walks of a workgroup begin at consecutive bits and stay within an RSI's length of them: the two tables of that
+// stretch are staged in LDS -- a step is an LDS read instead of a trip to the far end of the chip, 1.7 us measured, the
+// tables having just been written by workgroups on other XCDs; what leaves the stretch reads memory as before)
+constexpr uint32_t kSmRsiWg = 1024, kSmRsiSpan = 8192;
+
+__global__ void __launch_bounds__(kSmRsiWg)
 k_small_rsi(const Cfg c, uint32_t nbits, const uint16_t *__restrict__ e0, const uint16_t *__restrict__ e1,
             uint32_t *__restrict__ j, uint32_t *__restrict__ sidx, uint32_t scap)
 {
+    __shared__ uint16_t l0[kSmRsiWg + kSmRsiSpan], l1[kSmRsiWg + kSmRsiSpan];
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < scap) sidx[q] = q ? kSmNone : 0u;
+    const uint32_t w0 = blockIdx.x * blockDim.x;
+    const uint32_t wn = w0 > nbits ? 0u : (nbits + 1u - w0 < kSmRsiWg + kSmRsiSpan ? nbits + 1u - w0 : kSmRsiWg + kSmRsiSpan);
+    for (uint32_t i = threadIdx.x; i < wn; i += blockDim.x) {
+        l0[i] = e0[w0 + i];
+        l1[i] = e1[w0 + i];
+    }
+    __syncthreads();
     if (q > nbits) return;
     const uint32_t rfb = (c.flags & F_PREPROCESS) ? c.bps : 0u;
     uint32_t pos = q, b = 0;
     bool ok = q < nbits;
     for (uint32_t i = 0; ok && i <= c.rsi && b < c.rsi; i++) {
-        const uint32_t e = b == 0u ? e1[pos] : e0[pos];
+        const uint32_t rel = pos - w0;
+        const uint32_t e = rel < wn ? (b == 0u ? l1[rel] : l0[rel]) : (b == 0u ? e1[pos] : e0[pos]);
         const uint32_t len = e & 0xFFFu;
         const uint32_t nz = (e & kNxtZero) ? len - c.id_len - 1u - (b == 0u ? rfb : 0u) : 0u;
         const uint32_t nb = e ? tr_blocks(c, nz, b) : 0u;
@@ -5254,9 +5268,10 @@ static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t 
     uint32_t *sidx = reinterpret_cast<uint32_t *>(base + p.o_s);
     (void)hipMemsetAsync(flags, 0, 64, st);
     const uint32_t grid = (p.nbits + 1u + 255u) / 256u;
-    const uint32_t sgrid = (p.scap + 255u) / 256u > grid ? (p.scap + 255u) / 256u : grid;
+    const uint32_t rgrid = (p.nbits + 1u + kSmRsiWg - 1u) / kSmRsiWg;
+    const uint32_t sgrid = (p.scap + kSmRsiWg - 1u) / kSmRsiWg > rgrid ? (p.scap + kSmRsiWg - 1u) / kSmRsiWg : rgrid;
     hipLaunchKernelGGL(k_small_parse, dim3(grid), dim3(256), 0, st, c, s, start_bit, p.nbits, e0, e1);
-    hipLaunchKernelGGL(k_small_rsi, dim3(sgrid), dim3(256), 0, st, c, p.nbits, (const uint16_t *)e0, (const uint16_t *)e1, j[0],
+    hipLaunchKernelGGL(k_small_rsi, dim3(sgrid), dim3(kSmRsiWg), 0, st, c, p.nbits, (const uint16_t *)e0, (const uint16_t *)e1, j[0],
                        sidx, p.scap);
     for (uint32_t k = 0; k < p.levels; k++) {
         const uint32_t quarter = 1u << (2u * k), last = k + 1u == p.levels ? 1u : 0u;
