@@ -4240,6 +4240,10 @@ k_lock_walk_w(const Cfg c, const TrStream s, const LockTables t, const LkState *
 // Nothing rests on the guess: entries are checked against the exits of the regions in front, repaired and mended by the
 // kernels of the phase-locked scheme; k_lock_judge counts the guesses that did not hold after the first walk and, if they
 // are many (data whose options say nothing: noise in every block, periodic streams), hands the stream to the trunk.
+// RSIs of up to this many blocks take the phase-locked scheme.  32 until round 5: the window tables resolve RSIs that
+// short badly -- 16 MiB of 8-bit data with rsi 33: 72 ms, more than the reference on one core, rsi 40: 17 ms (16-bit: 18
+// and 6.7) -- and win from ~48 blocks on (5.5 / 3.1 ms; the chains' lead-in grows with rsi): tests/bench_short_rsi.py --edges
+constexpr uint32_t kLockMaxRsi = 44;
 constexpr uint32_t kLpSteps = 16;          // coded data sets per scoring chain
 constexpr uint32_t kLpAccept = 8;          // options within 1 of their predecessor's (of kLpSteps - 1) that make a chain the true one
 constexpr uint32_t kLpConfirm = 8;         // coded data sets looked at where the walk doubts ...
@@ -4791,7 +4795,7 @@ static LockPlan lock_plan_p(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits
     const uint64_t cds = rsi_bits_hint / c.rsi;
     // (RSIs of fewer than 16 blocks: a scoring chain of 16 coded data sets passes an RSI start or three -- there the
     // chains carry the count of blocks, one set of chains per count: k_lock_guess_p, find_anchor_phased)
-    const uint64_t cds_min = (c.rsi <= 32u && c.id_len >= 4u) ? (uint64_t)tune("AEC_IDX_LOCK_P_CDS", 32)
+    const uint64_t cds_min = (c.rsi <= kLockMaxRsi && c.id_len >= 4u) ? (uint64_t)tune("AEC_IDX_LOCK_P_CDS", 32)
                                                               : (uint64_t)tune("AEC_IDX_LOCK_P_CDS_LONG", 96);
     if (cds < cds_min || c.rsi >= 8 * cds || c.segs_per_rsi >= 8u || total_bits < 4 * rsi_bits_hint) return p;
     if (c.id_len + 1u + c.bps + c.bs * c.bps > (kSwLookWords - 2u) * 32u) return p;
@@ -4832,7 +4836,7 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
     // kind have room for, and the serial walk took 64 ms for 64 MiB of a constant)
     const bool tiny = rsi_bits_hint != 0 && rsi_bits_hint <= tune("AEC_IDX_LOCK_TINY", 256u);
     if (!tune("AEC_IDX_LOCK", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS)) return p;
-    if (c.rsi > 32u && !tiny) return allow_p ? lock_plan_p(c, total_bits, rsi_bits_hint) : p;
+    if (c.rsi > kLockMaxRsi && !tiny) return allow_p ? lock_plan_p(c, total_bits, rsi_bits_hint) : p;
     if (total_bits < (1u << 16)) return p;               // (a thousand coded data sets: the serial walker is as fast)
     uint64_t cds = rsi_bits_hint ? rsi_bits_hint / c.rsi : (uint64_t)(c.id_len + c.bs * c.bps) / 3;
     if (cds < 8) cds = 8;
@@ -4892,7 +4896,7 @@ LockPlan lock_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, ui
 // trunk walks every RSI by itself -- 48 MiB with rsi 1: 1.5 s).
 static LockPlan lock_plan_alt(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, uint32_t start_block)
 {
-    if (c.rsi > 32u) return LockPlan{};
+    if (c.rsi > kLockMaxRsi) return LockPlan{};
     const LockPlan l0 = lock_plan(c, total_bits, rsi_bits_hint, start_block, false);
     if (l0.ok && c.rsi >= kLpPhased && (uint64_t)l0.lead * 8u > total_bits) return LockPlan{};
     return l0;
@@ -5074,27 +5078,48 @@ constexpr uint32_t kSmNone = 0xFFFFFFFFu;
 
 struct SmallPlan {
     bool ok;
-    uint32_t nbits, scap, levels;
+    uint32_t nbits, scap, levels;     // bits of a piece (the whole stream if it is one), RSI starts of a piece, rounds
+    uint32_t npieces;
     size_t o_e0, o_e1, o_ja, o_jb, o_s, o_flags, bytes;
+};
+// Streams beyond kSmMaxBits go PIECE BY PIECE (without the preprocessor only: the other schemes' chains have nothing to
+// lock a count on there and such streams went over the trunk or to the serial walker -- 16 MiB of 16-bit data 31 .. 41
+// ms, three times the reference on one core): a piece ends on the start of the RSI it does not hold whole, the next
+// begins there; the cursor lives on the device, the launches of all pieces are enqueued at once.
+struct SmCursor {
+    uint64_t bit, idx, last_start;    // where the next piece begins, RSI starts delivered so far, the last one of them
+    uint32_t stop, pad;               // no further piece (delivered, or left to the serial walker)
 };
 
 static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi, uint32_t start_block)
 {
     SmallPlan p{};
-    if (!tune("AEC_IDX_SMALL", 1) || start_block || !max_rsi || total_bits > kSmMaxBits || total_bits < 64 ||
-        c.rsi > (uint32_t)tune("AEC_IDX_SMALL_RSI", kSmMaxRsi) || (c.flags & F_PAD_RSI))
+    if (!tune("AEC_IDX_SMALL", 1) || start_block || !max_rsi || total_bits < 64 || (c.flags & F_PAD_RSI)) return p;
+    const bool pp = c.flags & F_PREPROCESS;
+    // (pieces only with RSIs of at most 64 blocks: step 2 walks rsi coded data sets from every bit, and with 128 .. 256
+    // of 67 bits each a walk leaves the stretch that is staged in LDS -- 16 MiB of 8-bit data, rsi 256: 43 ms against 8)
+    if (total_bits > kSmMaxBits && (pp || c.rsi > kSmMaxRsi || !tune("AEC_IDX_SMALL_PIECES", 1) || total_bits >= (1ull << 40)))
         return p;
-    const uint64_t min_rsi_bits = (uint64_t)c.segs_per_rsi * (c.id_len + 2u) + ((c.flags & F_PREPROCESS) ? c.bps : 0u);
-    uint64_t most = total_bits / min_rsi_bits + 2;       // RSI starts the stream can hold ...
+    // (RSIs of up to 64 blocks; without the preprocessor -- no reference samples, nothing the other schemes' chains could
+    // lock a count on: such streams went to the serial walker, a 64 KiB chunk with rsi 128 in 2.5 ms -- up to 256: step 2
+    // is rsi LDS reads per bit)
+    if (c.rsi > (pp ? (uint32_t)tune("AEC_IDX_SMALL_RSI", kSmMaxRsi) : 256u)) return p;
+    const uint64_t piece = total_bits < kSmMaxBits ? total_bits : kSmMaxBits;
+    // (what an ENCODER makes of an RSI at most; a piece holds a few of them or the scheme is not for this stream)
+    const uint64_t worst = (uint64_t)c.rsi * (c.id_len + (uint64_t)c.bs * c.bps) + c.bps + 8;
+    if (total_bits > kSmMaxBits && worst * 4 > piece) return p;
+    const uint64_t min_rsi_bits = (uint64_t)c.segs_per_rsi * (c.id_len + 2u) + (pp ? c.bps : 0u);
+    uint64_t most = piece / min_rsi_bits + 2;            // RSI starts a piece can hold ...
     if (most > max_rsi + 1) most = max_rsi + 1;          // ... and the caller asks for (+ the one that clips)
     uint32_t levels = 0;                                 // rounds of the doubling, each a factor of FOUR (a launch is 5 us)
     while ((1ull << (2u * levels)) < most) levels++;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    p.nbits = (uint32_t)total_bits;
+    p.nbits = (uint32_t)piece;
     p.scap = 1u << (2u * levels);
     p.levels = levels;
+    p.npieces = total_bits <= kSmMaxBits ? 1u : (uint32_t)(total_bits / (piece - worst) + 2);
     size_t o = 0;
-    p.o_flags = o; o = up(o + 64);
+    p.o_flags = o; o = up(o + 64 + sizeof(SmCursor));
     p.o_e0 = o;    o = up(o + ((size_t)p.nbits + 1) * 2);
     p.o_e1 = o;    o = up(o + ((size_t)p.nbits + 1) * 2);
     p.o_jb = p.o_e0;                                     // (the second table of the doubling: over the parses, done with by then)
@@ -5105,10 +5130,23 @@ static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi,
     return p;
 }
 
+// the piece at hand: [start, start + nbits); false: nothing left to do
+__device__ __forceinline__ bool sm_piece(const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, uint64_t &start, uint32_t &nbits)
+{
+    if (cur->stop) return false;
+    start = cur->bit;
+    const uint64_t left = end_bit > start ? end_bit - start : 0u;
+    nbits = (uint32_t)(left < piece_bits ? left : piece_bits);
+    return true;
+}
+
 __global__ void __launch_bounds__(256)
-k_small_parse(const Cfg c, const TrStream s, uint64_t start_bit, uint32_t nbits, uint16_t *__restrict__ e0,
+k_small_parse(const Cfg c, const TrStream s, const SmCursor *cur, uint32_t piece_bits, uint16_t *__restrict__ e0,
               uint16_t *__restrict__ e1)
 {
+    uint64_t start_bit;
+    uint32_t nbits;
+    if (!sm_piece(cur, s.end_bit, piece_bits, start_bit, nbits)) return;
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > nbits) return;
     uint16_t a = 0, b = 0;
@@ -5144,15 +5182,17 @@ k_small_parse(const Cfg c, const TrStream s, uint64_t start_bit, uint32_t nbits,
 }
 
 // (the walks of a workgroup begin at consecutive bits and stay within an RSI's length of them: the two tables of that
-// stretch are staged in LDS -- a step is an LDS read instead of a trip to the far end of the chip, 1.7 us measured, the
-// tables having just been written by workgroups on other XCDs; what leaves the stretch reads memory as before)
+// stretch are staged in LDS; what leaves the stretch reads memory)
 constexpr uint32_t kSmRsiWg = 1024, kSmRsiSpan = 8192;
 
 __global__ void __launch_bounds__(kSmRsiWg)
-k_small_rsi(const Cfg c, uint32_t nbits, const uint16_t *__restrict__ e0, const uint16_t *__restrict__ e1,
-            uint32_t *__restrict__ j, uint32_t *__restrict__ sidx, uint32_t scap)
+k_small_rsi(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const uint16_t *__restrict__ e0,
+            const uint16_t *__restrict__ e1, uint32_t *__restrict__ j, uint32_t *__restrict__ sidx, uint32_t scap)
 {
     __shared__ uint16_t l0[kSmRsiWg + kSmRsiSpan], l1[kSmRsiWg + kSmRsiSpan];
+    uint64_t start_bit;
+    uint32_t nbits;
+    if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < scap) sidx[q] = q ? kSmNone : 0u;
     const uint32_t w0 = blockIdx.x * blockDim.x;
@@ -5181,9 +5221,12 @@ k_small_rsi(const Cfg c, uint32_t nbits, const uint16_t *__restrict__ e0, const 
 
 // round k, with quarter = 4^k known RSI starts: sidx[m * quarter + i] = j^m[sidx[i]] for m = 1 .. 3, and jn = j^4
 __global__ void __launch_bounds__(256)
-k_small_double(uint32_t nbits, const uint32_t *__restrict__ j, uint32_t *__restrict__ jn, uint32_t *__restrict__ sidx,
-               uint32_t quarter, uint32_t scap, uint32_t last)
+k_small_double(const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const uint32_t *__restrict__ j, uint32_t *__restrict__ jn,
+               uint32_t *__restrict__ sidx, uint32_t quarter, uint32_t scap, uint32_t last)
 {
+    uint64_t start_bit;
+    uint32_t nbits;
+    if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < quarter) {
         uint32_t a = sidx[q];
@@ -5199,11 +5242,15 @@ k_small_double(uint32_t nbits, const uint32_t *__restrict__ j, uint32_t *__restr
 }
 
 __global__ void __launch_bounds__(1024)
-k_small_finish(const Cfg c, const TrStream s, uint64_t start_bit, const uint32_t *__restrict__ sidx, uint32_t scap,
+k_small_finish(const Cfg c, const TrStream s, SmCursor *cur, uint32_t piece_bits, const uint32_t *__restrict__ sidx, uint32_t scap,
                const uint32_t *__restrict__ words, uint64_t nwords, uint64_t *__restrict__ rsi_off, uint64_t max_rsi,
                DecResult *res, uint32_t tail_slot, uint32_t *flags)
 {
     __shared__ uint32_t first_none;
+    uint64_t start_bit;
+    uint32_t nbits;
+    if (!sm_piece(cur, s.end_bit, piece_bits, start_bit, nbits)) return;
+    const uint64_t base = cur->idx, before = cur->last_start;
     if (threadIdx.x == 0) first_none = scap;
     __syncthreads();
     uint32_t mine = scap;
@@ -5214,22 +5261,40 @@ k_small_finish(const Cfg c, const TrStream s, uint64_t start_bit, const uint32_t
         }
     if (mine < scap) atomicMin(&first_none, mine);
     __syncthreads();
-    const uint32_t m = first_none;                      // RSI starts on the chain (the first is the caller's)
-    const uint64_t nout = m < max_rsi ? m : max_rsi;
-    for (uint64_t i = threadIdx.x; i < nout; i += blockDim.x) rsi_off[i] = start_bit + sidx[i];
+    const uint32_t m = first_none;                      // RSI starts of the chain in this piece (the first is its start)
+    const bool last_piece = start_bit + nbits >= s.end_bit;
+    const bool clips = base + m > max_rsi;              // the start of RSI max_rsi lies in this piece
+    // the starts this piece delivers: all it has -- but the last one is the next piece's first, if there is a next piece
+    uint64_t nout = (last_piece || clips) ? m : m - 1u;
+    if (base + nout > max_rsi) nout = max_rsi - base;
+    for (uint64_t i = threadIdx.x; i < nout; i += blockDim.x) rsi_off[base + i] = start_bit + sidx[i];
+    __syncthreads();
     if (threadIdx.x != 0) return;
-    if (m > max_rsi) {                                  // the caller's bound: ends on the start of RSI max_rsi
+    if (clips) {                                        // the caller's bound: ends on the start of RSI max_rsi
+        const uint32_t l = (uint32_t)(max_rsi - base);
         res->n_rsi = max_rsi;
         res->tail_blocks = 0;
-        res->end_bit = start_bit + sidx[max_rsi];
+        res->end_bit = start_bit + sidx[l];
         res->status = DEC_OK;
         res->pad = 0u;
         res->bad_rsi = ~0ull;
-        if (tail_slot) rsi_off[max_rsi] = start_bit + sidx[max_rsi - 1u];
+        if (tail_slot) rsi_off[max_rsi] = l ? start_bit + sidx[l - 1u] : before;
+        cur->stop = 1u;
         __threadfence();
         flags[0] = 1u;
         return;
     }
+    if (!last_piece) {
+        if (m < 2u) {                                   // (an RSI that a piece does not hold: the serial walker's)
+            cur->stop = 1u;
+            return;
+        }
+        cur->bit = start_bit + sidx[m - 1u];
+        cur->idx = base + m - 1u;
+        cur->last_start = start_bit + sidx[m - 2u];
+        return;
+    }
+    cur->stop = 1u;
     // the RSI that does not end inside the input, walked as the serial walker walks it (skip_cds: the parse that also
     // sees second-extension codes beyond the table); anything but "the input ends inside a coded data set" is its call
     const uint64_t pos0 = start_bit + sidx[m - 1u];
@@ -5245,16 +5310,25 @@ k_small_finish(const Cfg c, const TrStream s, uint64_t start_bit, const uint32_t
         b += nblk;
     }
     if (st != DEC_NEED_INPUT) return;
-    struct { uint64_t pos; uint32_t b; } x{good, b};
-    res->n_rsi = m - 1u;
-    res->tail_blocks = x.b;
-    res->end_bit = x.pos;
+    res->n_rsi = base + m - 1u;
+    res->tail_blocks = b;
+    res->end_bit = good;
     res->status = DEC_OK;
     res->pad = 1u;
     res->bad_rsi = ~0ull;
-    if (tail_slot) rsi_off[max_rsi] = start_bit + sidx[m - 1u];
+    if (tail_slot) rsi_off[max_rsi] = pos0;
     __threadfence();
     flags[0] = 1u;
+}
+
+__global__ void k_small_begin(uint32_t *flags, SmCursor *cur, uint64_t start_bit, uint64_t rsi_start)
+{
+    flags[0] = 0u;
+    cur->bit = start_bit;
+    cur->idx = 0u;
+    cur->last_start = rsi_start;
+    cur->stop = 0u;
+    cur->pad = 0u;
 }
 
 static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
@@ -5263,26 +5337,29 @@ static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t 
 {
     const TrStream s{words, nwords, end_bit};
     uint32_t *flags = reinterpret_cast<uint32_t *>(base + p.o_flags);
+    SmCursor *cur = reinterpret_cast<SmCursor *>(base + p.o_flags + 64);
     uint16_t *e0 = reinterpret_cast<uint16_t *>(base + p.o_e0), *e1 = reinterpret_cast<uint16_t *>(base + p.o_e1);
     uint32_t *j[2] = {reinterpret_cast<uint32_t *>(base + p.o_ja), reinterpret_cast<uint32_t *>(base + p.o_jb)};
     uint32_t *sidx = reinterpret_cast<uint32_t *>(base + p.o_s);
-    (void)hipMemsetAsync(flags, 0, 64, st);
+    hipLaunchKernelGGL(k_small_begin, dim3(1), dim3(1), 0, st, flags, cur, start_bit, rsi_start);
     const uint32_t grid = (p.nbits + 1u + 255u) / 256u;
     const uint32_t rgrid = (p.nbits + 1u + kSmRsiWg - 1u) / kSmRsiWg;
     const uint32_t sgrid = (p.scap + kSmRsiWg - 1u) / kSmRsiWg > rgrid ? (p.scap + kSmRsiWg - 1u) / kSmRsiWg : rgrid;
-    hipLaunchKernelGGL(k_small_parse, dim3(grid), dim3(256), 0, st, c, s, start_bit, p.nbits, e0, e1);
-    hipLaunchKernelGGL(k_small_rsi, dim3(sgrid), dim3(kSmRsiWg), 0, st, c, p.nbits, (const uint16_t *)e0, (const uint16_t *)e1, j[0],
-                       sidx, p.scap);
-    for (uint32_t k = 0; k < p.levels; k++) {
-        const uint32_t quarter = 1u << (2u * k), last = k + 1u == p.levels ? 1u : 0u;
-        const uint32_t gq = (quarter + 255u) / 256u;
-        const uint32_t g = last ? gq : (gq > grid ? gq : grid);
-        hipLaunchKernelGGL(k_small_double, dim3(g), dim3(256), 0, st, p.nbits, (const uint32_t *)j[k & 1u], j[(k & 1u) ^ 1u], sidx,
-                           quarter, p.scap, last);
+    for (uint32_t piece = 0; piece < p.npieces; piece++) {
+        hipLaunchKernelGGL(k_small_parse, dim3(grid), dim3(256), 0, st, c, s, (const SmCursor *)cur, p.nbits, e0, e1);
+        hipLaunchKernelGGL(k_small_rsi, dim3(sgrid), dim3(kSmRsiWg), 0, st, c, (const SmCursor *)cur, end_bit, p.nbits,
+                           (const uint16_t *)e0, (const uint16_t *)e1, j[0], sidx, p.scap);
+        for (uint32_t k = 0; k < p.levels; k++) {
+            const uint32_t quarter = 1u << (2u * k), last = k + 1u == p.levels ? 1u : 0u;
+            const uint32_t gq = (quarter + 255u) / 256u;
+            const uint32_t g = last ? gq : (gq > grid ? gq : grid);
+            hipLaunchKernelGGL(k_small_double, dim3(g), dim3(256), 0, st, (const SmCursor *)cur, end_bit, p.nbits,
+                               (const uint32_t *)j[k & 1u], j[(k & 1u) ^ 1u], sidx, quarter, p.scap, last);
+        }
+        if (tune("AEC_IDX_SMALL_FINISH", 1))
+            hipLaunchKernelGGL(k_small_finish, dim3(1), dim3(1024), 0, st, c, s, cur, p.nbits, (const uint32_t *)sidx, p.scap, words,
+                               nwords, d_rsi_off, max_rsi, d_res, tail_slot, flags);
     }
-    if (tune("AEC_IDX_SMALL_FINISH", 1))
-    hipLaunchKernelGGL(k_small_finish, dim3(1), dim3(1024), 0, st, c, s, start_bit, (const uint32_t *)sidx, p.scap, words, nwords,
-                       d_rsi_off, max_rsi, d_res, tail_slot, flags);
     // whatever was not delivered: the serial walker, which returns at once otherwise
     hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res,
                        (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, 0u, rsi_start, tail_slot,
@@ -5433,7 +5510,7 @@ size_t index_batch_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t n_chu
 {
     // (short RSIs: the window tables resolve none of them -- chunk by chunk through launch_index, whose phase-locked
     // chains do)
-    if (c.rsi <= 32u && (c.flags & F_PREPROCESS) && !(c.flags & F_PAD_RSI)) return 0;
+    if (c.rsi <= kLockMaxRsi && (c.flags & F_PREPROCESS) && !(c.flags & F_PAD_RSI)) return 0;
     const Sparse2Plan p = sparse2_plan(c, (uint64_t)in_bytes * 8, rsi_bits_hint);
     if (!p.ok || n_chunks == 0) return 0;
     const uint64_t nwin = ((uint64_t)in_bytes * 8 + p.g.core - 1) / p.g.core;

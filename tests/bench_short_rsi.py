@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--size-mib", type=int, default=16)
     ap.add_argument("--size-kib", type=int, default=0, help="a small chunk instead (what one SZIP call per chunk decodes): best of 50 calls")
     ap.add_argument("--rsi", type=int, nargs="*", default=[1, 2, 4, 8, 16, 32, 64, 128])
+    ap.add_argument("--edges", action="store_true", help="the shapes at the schemes' thresholds instead (ADVICE round 4): rsi 33 .. 63, "
+                    "no preprocessor")
     args = ap.parse_args()
     import torch  # noqa: F401
     from helpers import have_ref, ref_decode
@@ -29,10 +31,19 @@ def main():
     from test_gpu_parity import gen
     n = (args.size_kib << 10) if args.size_kib else (args.size_mib << 20)
     size = f"{args.size_kib} KiB" if args.size_kib else f"{args.size_mib} MiB"
-    for kind, bps, bs in ((2, 8, 8), (0, 16, 16)):
-        data = gen(kind, n)
-        for rsi in args.rsi:
-            flags = api.AEC_DATA_PREPROCESS
+    PP = api.AEC_DATA_PREPROCESS
+    plan = [(kind, bps, bs, rsi, PP) for kind, bps, bs in ((2, 8, 8), (0, 16, 16)) for rsi in args.rsi]
+    if args.edges:
+        plan = [(kind, bps, bs, rsi, fl) for kind, bps, bs in ((2, 8, 8), (0, 16, 16))
+                for rsi, fl in ((33, PP), (40, PP), (48, PP), (63, PP), (4, 0), (16, 0), (128, 0), (256, 0))]
+        # (AEC_PAD_RSI is not here: the reference does not decode what its encoder makes of these inputs with that flag --
+        # AEC_DATA_ERROR, and the product returns the same; tests/test_gpu_parity.py has the parity of that)
+    cache = {}
+    for kind, bps, bs, rsi, flags in plan:
+        if kind not in cache:
+            cache[kind] = gen(kind, n)
+        data = cache[kind]
+        for _ in (0,):
             rc, enc = api.aec_buffer_encode(data, bps, bs, rsi, flags)
             assert rc == 0
             best = 1e9
@@ -47,7 +58,8 @@ def main():
                 rc_r, dec_r = ref_decode(enc, bps, bs, rsi, flags, n)
                 ref = f"   reference on one core {(time.perf_counter() - t0) * 1e3:8.1f} ms"
                 assert dec_r == dec
-            print(f"{bps}-bit block {bs} rsi {rsi:3d}, {size} (stream {len(enc) >> 10} KiB): aec_buffer_decode "
+            what = "" if flags == PP else " no preprocessor"
+            print(f"{bps}-bit block {bs} rsi {rsi:3d}{what}, {size} (stream {len(enc) >> 10} KiB): aec_buffer_decode "
                   f"{best * 1e3:8.2f} ms = {n / best / 1e9:6.2f} GB/s{ref}", flush=True)
 
 
