@@ -5080,7 +5080,8 @@ struct SmallPlan {
     bool ok;
     uint32_t nbits, scap, levels;     // bits of a piece (the whole stream if it is one), RSI starts of a piece, rounds
     uint32_t npieces;
-    size_t o_e0, o_e1, o_ja, o_jb, o_s, o_flags, bytes;
+    uint32_t hops;                    // RSIs of more than 16 blocks: step 2 goes through a table of 8 coded data sets per entry
+    size_t o_e0, o_e1, o_ja, o_jb, o_s, o_h, o_flags, bytes;
 };
 // Streams beyond kSmMaxBits go PIECE BY PIECE (without the preprocessor only: the other schemes' chains have nothing to
 // lock a count on there and such streams went over the trunk or to the serial walker -- 16 MiB of 16-bit data 31 .. 41
@@ -5096,14 +5097,19 @@ static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi,
     SmallPlan p{};
     if (!tune("AEC_IDX_SMALL", 1) || start_block || !max_rsi || total_bits < 64 || (c.flags & F_PAD_RSI)) return p;
     const bool pp = c.flags & F_PREPROCESS;
-    // (pieces only with RSIs of at most 64 blocks: step 2 walks rsi coded data sets from every bit, and with 128 .. 256
-    // of 67 bits each a walk leaves the stretch that is staged in LDS -- 16 MiB of 8-bit data, rsi 256: 43 ms against 8)
-    if (total_bits > kSmMaxBits && (pp || c.rsi > kSmMaxRsi || !tune("AEC_IDX_SMALL_PIECES", 1) || total_bits >= (1ull << 40)))
+    // (pieces with RSIs of more than 64 blocks only for samples of more than 8 bits: 16 MiB with rsi 128 / 256 -- 16-bit 34 /
+    // 40 -> 12 / 14 ms, the reference 13; 8-bit 8.6 / 8.4 over the trunk against 11.8 / 13.7 here)
+    if (total_bits > kSmMaxBits && (pp || (c.rsi > kSmMaxRsi && c.bps <= 8u) || !tune("AEC_IDX_SMALL_PIECES", 1) ||
+                                    total_bits >= (1ull << 40)))
         return p;
     // (RSIs of up to 64 blocks; without the preprocessor -- no reference samples, nothing the other schemes' chains could
     // lock a count on: such streams went to the serial walker, a 64 KiB chunk with rsi 128 in 2.5 ms -- up to 256: step 2
     // is rsi LDS reads per bit)
-    if (c.rsi > (pp ? (uint32_t)tune("AEC_IDX_SMALL_RSI", kSmMaxRsi) : 256u)) return p;
+    // (with the preprocessor and more than 64 blocks only a chunk of up to 128 KiB of stream: the 8-bit SZIP shape, rsi
+    // 128, 64 KiB: 0.24 -> 0.20 ms; at 1 MiB the window tables are faster, 0.39 against 0.49)
+    if (c.rsi > 256u) return p;
+    if (pp && c.rsi > (uint32_t)tune("AEC_IDX_SMALL_RSI", kSmMaxRsi) && total_bits > (uint64_t)tune("AEC_IDX_SMALL_RSI_BITS", 1u << 20))
+        return p;
     const uint64_t piece = total_bits < kSmMaxBits ? total_bits : kSmMaxBits;
     // (what an ENCODER makes of an RSI at most; a piece holds a few of them or the scheme is not for this stream)
     const uint64_t worst = (uint64_t)c.rsi * (c.id_len + (uint64_t)c.bs * c.bps) + c.bps + 8;
@@ -5125,6 +5131,9 @@ static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi,
     p.o_jb = p.o_e0;                                     // (the second table of the doubling: over the parses, done with by then)
     p.o_ja = o;    o = up(o + ((size_t)p.nbits + 1) * 4);
     p.o_s = o;     o = up(o + (size_t)p.scap * 4);
+    p.hops = c.rsi > (uint32_t)tune("AEC_IDX_SMALL_HOP_RSI", 16) ? 1u : 0u;
+    p.o_h = o;
+    if (p.hops) o = up(o + ((size_t)p.nbits + 1) * 4);
     p.bytes = o;
     p.ok = true;
     return p;
@@ -5181,15 +5190,50 @@ k_small_parse(const Cfg c, const TrStream s, const SmCursor *cur, uint32_t piece
     e1[q] = b;
 }
 
-// (the walks of a workgroup begin at consecutive bits and stay within an RSI's length of them: the two tables of that
-// stretch are staged in LDS; what leaves the stretch reads memory)
+// Step 2 walks a whole RSI from every bit: rsi dependent reads.  For RSIs of more than 16 blocks a table of HOPS first:
+// from every bit up to 8 coded data sets without reference samples -- bits (15) and blocks (9 bits above) covered; a run
+// of zero blocks to the end of its segment (its length depends on where in the RSI it stands) ends a hop in front of it.
+// The walk then takes a hop wherever its blocks still fit the RSI and single coded data sets elsewhere (the first,
+// with its reference sample; rest-of-segment runs; the last few): rsi / 8 + a dozen reads instead of rsi.
+constexpr uint32_t kSmHopCds = 8;
+
+__global__ void __launch_bounds__(256)
+k_small_hop(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const uint16_t *__restrict__ e0,
+            uint32_t *__restrict__ hop)
+{
+    uint64_t start_bit;
+    uint32_t nbits;
+    if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nbits) return;
+    uint32_t pos = q, blocks = 0;
+    for (uint32_t i = 0; i < kSmHopCds && pos < nbits; i++) {
+        const uint32_t e = e0[pos];
+        const uint32_t len = e & 0xFFFu;
+        if (!e || pos + len > nbits) break;
+        uint32_t nb = 1;
+        if (e & kNxtZero) {
+            const uint32_t nz = len - c.id_len - 1u;
+            if (nz == 5u) break;
+            nb = nz > 5u ? nz - 1u : nz;
+        }
+        if (blocks + nb > 511u || pos + len - q > 32767u) break;
+        pos += len;
+        blocks += nb;
+    }
+    hop[q] = (pos - q) | (blocks << 15);
+}
+
+// (the walks of a workgroup begin at consecutive bits and stay within an RSI's length of them: the table they read at
+// every step -- the parses, or the hops -- is staged in LDS for that stretch; what leaves the stretch reads memory)
 constexpr uint32_t kSmRsiWg = 1024, kSmRsiSpan = 8192;
 
 __global__ void __launch_bounds__(kSmRsiWg)
 k_small_rsi(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const uint16_t *__restrict__ e0,
-            const uint16_t *__restrict__ e1, uint32_t *__restrict__ j, uint32_t *__restrict__ sidx, uint32_t scap)
+            const uint16_t *__restrict__ e1, const uint32_t *__restrict__ hop, uint32_t *__restrict__ j,
+            uint32_t *__restrict__ sidx, uint32_t scap)
 {
-    __shared__ uint16_t l0[kSmRsiWg + kSmRsiSpan], l1[kSmRsiWg + kSmRsiSpan];
+    __shared__ uint32_t lds[kSmRsiWg + kSmRsiSpan];
     uint64_t start_bit;
     uint32_t nbits;
     if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
@@ -5197,10 +5241,9 @@ k_small_rsi(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_b
     if (q < scap) sidx[q] = q ? kSmNone : 0u;
     const uint32_t w0 = blockIdx.x * blockDim.x;
     const uint32_t wn = w0 > nbits ? 0u : (nbits + 1u - w0 < kSmRsiWg + kSmRsiSpan ? nbits + 1u - w0 : kSmRsiWg + kSmRsiSpan);
-    for (uint32_t i = threadIdx.x; i < wn; i += blockDim.x) {
-        l0[i] = e0[w0 + i];
-        l1[i] = e1[w0 + i];
-    }
+    // (staged: the hops, or both parses of a position in one word)
+    for (uint32_t i = threadIdx.x; i < wn; i += blockDim.x)
+        lds[i] = hop ? hop[w0 + i] : ((uint32_t)e0[w0 + i] | ((uint32_t)e1[w0 + i] << 16));
     __syncthreads();
     if (q > nbits) return;
     const uint32_t rfb = (c.flags & F_PREPROCESS) ? c.bps : 0u;
@@ -5208,7 +5251,16 @@ k_small_rsi(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_b
     bool ok = q < nbits;
     for (uint32_t i = 0; ok && i <= c.rsi && b < c.rsi; i++) {
         const uint32_t rel = pos - w0;
-        const uint32_t e = rel < wn ? (b == 0u ? l1[rel] : l0[rel]) : (b == 0u ? e1[pos] : e0[pos]);
+        if (hop && b != 0u) {
+            const uint32_t h = rel < wn ? lds[rel] : hop[pos];
+            const uint32_t hb = h >> 15;
+            if (hb && b + hb <= c.rsi) {
+                pos += h & 0x7FFFu;
+                b += hb;
+                continue;
+            }
+        }
+        const uint32_t e = (!hop && rel < wn) ? (b == 0u ? lds[rel] >> 16 : lds[rel] & 0xFFFFu) : (b == 0u ? e1[pos] : e0[pos]);
         const uint32_t len = e & 0xFFFu;
         const uint32_t nz = (e & kNxtZero) ? len - c.id_len - 1u - (b == 0u ? rfb : 0u) : 0u;
         const uint32_t nb = e ? tr_blocks(c, nz, b) : 0u;
@@ -5341,14 +5393,19 @@ static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t 
     uint16_t *e0 = reinterpret_cast<uint16_t *>(base + p.o_e0), *e1 = reinterpret_cast<uint16_t *>(base + p.o_e1);
     uint32_t *j[2] = {reinterpret_cast<uint32_t *>(base + p.o_ja), reinterpret_cast<uint32_t *>(base + p.o_jb)};
     uint32_t *sidx = reinterpret_cast<uint32_t *>(base + p.o_s);
+    uint32_t *hop = reinterpret_cast<uint32_t *>(base + p.o_h);
     hipLaunchKernelGGL(k_small_begin, dim3(1), dim3(1), 0, st, flags, cur, start_bit, rsi_start);
     const uint32_t grid = (p.nbits + 1u + 255u) / 256u;
     const uint32_t rgrid = (p.nbits + 1u + kSmRsiWg - 1u) / kSmRsiWg;
     const uint32_t sgrid = (p.scap + kSmRsiWg - 1u) / kSmRsiWg > rgrid ? (p.scap + kSmRsiWg - 1u) / kSmRsiWg : rgrid;
     for (uint32_t piece = 0; piece < p.npieces; piece++) {
         hipLaunchKernelGGL(k_small_parse, dim3(grid), dim3(256), 0, st, c, s, (const SmCursor *)cur, p.nbits, e0, e1);
+        if (p.hops)
+            hipLaunchKernelGGL(k_small_hop, dim3(grid), dim3(256), 0, st, c, (const SmCursor *)cur, end_bit, p.nbits,
+                               (const uint16_t *)e0, hop);
         hipLaunchKernelGGL(k_small_rsi, dim3(sgrid), dim3(kSmRsiWg), 0, st, c, (const SmCursor *)cur, end_bit, p.nbits,
-                           (const uint16_t *)e0, (const uint16_t *)e1, j[0], sidx, p.scap);
+                           (const uint16_t *)e0, (const uint16_t *)e1, (const uint32_t *)(p.hops ? hop : nullptr), j[0], sidx,
+                           p.scap);
         for (uint32_t k = 0; k < p.levels; k++) {
             const uint32_t quarter = 1u << (2u * k), last = k + 1u == p.levels ? 1u : 0u;
             const uint32_t gq = (quarter + 255u) / 256u;
