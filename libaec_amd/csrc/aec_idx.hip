@@ -36,6 +36,7 @@
 #include "aec_trunk.h"
 #include "aec_coop.h"
 #include "aec_stretch.h"
+#include "aec_small.h"
 #include "aec_tune.h"
 
 namespace aec {
@@ -5074,7 +5075,6 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
 // Works for any parameter set (no preprocessor, any rsi up to kSmMaxRsi), needs no guesses; 8 bytes of workspace per bit.
 constexpr uint64_t kSmMaxBits = 1ull << 24;      // 2 MiB of stream
 constexpr uint32_t kSmMaxRsi = 64;               // (step 2 is rsi dependent loads per bit)
-constexpr uint32_t kSmNone = 0xFFFFFFFFu;
 
 struct SmallPlan {
     bool ok;
@@ -5159,33 +5159,7 @@ k_small_parse(const Cfg c, const TrStream s, const SmCursor *cur, uint32_t piece
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > nbits) return;
     uint16_t a = 0, b = 0;
-    if (q < nbits) {
-        uint32_t nz;
-        TrWin W;
-        tr_win_load(s, start_bit + q, W);
-        // (a second-extension code beyond the table is a data error to the reference, decode.c:589-616, and to the
-        // serial walker, skip_cds: such a coded data set does not parse here either -- the chain ends at its RSI and the
-        // walker behind gives the verdict)
-        const uint32_t il = c.id_len;
-        const uint32_t head = (uint32_t)(tr_peek64(s, start_bit + q) >> (63u - il));
-        const bool se = (head >> 1) == 0u && (head & 1u);
-        auto se_ok = [&](uint32_t ref) {
-            BitReaderT<QuadFetch> br;
-            br.init(QuadFetch{s.words, s.nwords}, s.end_bit, start_bit + q + il + 1u + ref * c.bps);
-            for (uint32_t k = 0; k < c.bs / 2u; k++) {
-                uint32_t m;
-                if (!br.unary(m) || m > 90u) return false;
-            }
-            return true;
-        };
-        uint32_t len = tr_cds(s, c, start_bit + q, 0u, nz, W);
-        if (len && len < 4096u && (!se || se_ok(0u))) a = (uint16_t)(len | (nz ? kNxtZero : kNxtBlock));
-        b = a;
-        if (c.flags & F_PREPROCESS) {
-            len = tr_cds(s, c, start_bit + q, 1u, nz, W);
-            b = (len && len < 4096u && (!se || se_ok(1u))) ? (uint16_t)(len | (nz ? kNxtZero : kNxtBlock)) : (uint16_t)0;
-        }
-    }
+    if (q < nbits) sm_parse(s, c, start_bit + q, a, b);
     e0[q] = a;
     e1[q] = b;
 }
@@ -5195,8 +5169,6 @@ k_small_parse(const Cfg c, const TrStream s, const SmCursor *cur, uint32_t piece
 // of zero blocks to the end of its segment (its length depends on where in the RSI it stands) ends a hop in front of it.
 // The walk then takes a hop wherever its blocks still fit the RSI and single coded data sets elsewhere (the first,
 // with its reference sample; rest-of-segment runs; the last few): rsi / 8 + a dozen reads instead of rsi.
-constexpr uint32_t kSmHopCds = 8;
-
 __global__ void __launch_bounds__(256)
 k_small_hop(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const uint16_t *__restrict__ e0,
             uint32_t *__restrict__ hop)
@@ -5206,22 +5178,7 @@ k_small_hop(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_b
     if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > nbits) return;
-    uint32_t pos = q, blocks = 0;
-    for (uint32_t i = 0; i < kSmHopCds && pos < nbits; i++) {
-        const uint32_t e = e0[pos];
-        const uint32_t len = e & 0xFFFu;
-        if (!e || pos + len > nbits) break;
-        uint32_t nb = 1;
-        if (e & kNxtZero) {
-            const uint32_t nz = len - c.id_len - 1u;
-            if (nz == 5u) break;
-            nb = nz > 5u ? nz - 1u : nz;
-        }
-        if (blocks + nb > 511u || pos + len - q > 32767u) break;
-        pos += len;
-        blocks += nb;
-    }
-    hop[q] = (pos - q) | (blocks << 15);
+    hop[q] = sm_hop(c, [&](uint32_t at) { return (uint32_t)e0[at]; }, q, nbits);
 }
 
 // (the walks of a workgroup begin at consecutive bits and stay within an RSI's length of them: the table they read at
@@ -5246,29 +5203,11 @@ k_small_rsi(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_b
         lds[i] = hop ? hop[w0 + i] : ((uint32_t)e0[w0 + i] | ((uint32_t)e1[w0 + i] << 16));
     __syncthreads();
     if (q > nbits) return;
-    const uint32_t rfb = (c.flags & F_PREPROCESS) ? c.bps : 0u;
-    uint32_t pos = q, b = 0;
-    bool ok = q < nbits;
-    for (uint32_t i = 0; ok && i <= c.rsi && b < c.rsi; i++) {
-        const uint32_t rel = pos - w0;
-        if (hop && b != 0u) {
-            const uint32_t h = rel < wn ? lds[rel] : hop[pos];
-            const uint32_t hb = h >> 15;
-            if (hb && b + hb <= c.rsi) {
-                pos += h & 0x7FFFu;
-                b += hb;
-                continue;
-            }
-        }
-        const uint32_t e = (!hop && rel < wn) ? (b == 0u ? lds[rel] >> 16 : lds[rel] & 0xFFFFu) : (b == 0u ? e1[pos] : e0[pos]);
-        const uint32_t len = e & 0xFFFu;
-        const uint32_t nz = (e & kNxtZero) ? len - c.id_len - 1u - (b == 0u ? rfb : 0u) : 0u;
-        const uint32_t nb = e ? tr_blocks(c, nz, b) : 0u;
-        ok = nb != 0u && pos + len <= nbits;
-        pos += len;
-        b += nb;
-    }
-    j[q] = (ok && b == c.rsi) ? pos : kSmNone;
+    // (what is staged comes out of LDS: the hops, or both parses of a position in one word)
+    auto r0 = [&](uint32_t at) { return (!hop && at - w0 < wn) ? (lds[at - w0] & 0xFFFFu) : (uint32_t)e0[at]; };
+    auto r1 = [&](uint32_t at) { return (!hop && at - w0 < wn) ? (lds[at - w0] >> 16) : (uint32_t)e1[at]; };
+    auto rh = [&](uint32_t at) { return at - w0 < wn ? lds[at - w0] : hop[at]; };
+    j[q] = sm_rsi(c, r0, r1, rh, hop != nullptr, q, nbits);
 }
 
 // round k, with quarter = 4^k known RSI starts: sidx[m * quarter + i] = j^m[sidx[i]] for m = 1 .. 3, and jn = j^4
@@ -5280,17 +5219,9 @@ k_small_double(const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const
     uint32_t nbits;
     if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < quarter) {
-        uint32_t a = sidx[q];
-        for (uint32_t m = 1; m < 4u; m++) {
-            a = a == kSmNone ? kSmNone : j[a];
-            if (m * quarter + q < scap) sidx[m * quarter + q] = a;
-        }
-    }
+    if (q < quarter) sm_double_starts(j, sidx, q, quarter, scap);
     if (last || q > nbits) return;
-    uint32_t v = j[q];
-    for (uint32_t m = 1; m < 4u && v != kSmNone; m++) v = j[v];
-    jn[q] = v;
+    jn[q] = sm_double_table(j, q);
 }
 
 __global__ void __launch_bounds__(1024)
