@@ -5081,7 +5081,8 @@ struct SmallPlan {
     uint32_t nbits, scap, levels;     // bits of a piece (the whole stream if it is one), RSI starts of a piece, rounds
     uint32_t npieces;
     uint32_t hops;                    // RSIs of more than 16 blocks: step 2 goes through a table of 8 coded data sets per entry
-    size_t o_e0, o_e1, o_ja, o_jb, o_s, o_h, o_flags, bytes;
+                                      // (2: and, for more than 256 blocks, through one of 8 such hops per entry)
+    size_t o_e0, o_e1, o_ja, o_jb, o_s, o_h, o_h2, o_flags, bytes;
 };
 // Streams beyond kSmMaxBits go PIECE BY PIECE (without the preprocessor only: the other schemes' chains have nothing to
 // lock a count on there and such streams went over the trunk or to the serial walker -- 16 MiB of 16-bit data 31 .. 41
@@ -5092,7 +5093,7 @@ struct SmCursor {
     uint32_t stop, pad;               // no further piece (delivered, or left to the serial walker)
 };
 
-static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi, uint32_t start_block)
+static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi, uint32_t start_block, uint64_t rsi_bits_hint)
 {
     SmallPlan p{};
     if (!tune("AEC_IDX_SMALL", 1) || start_block || !max_rsi || total_bits < 64 || (c.flags & F_PAD_RSI)) return p;
@@ -5107,8 +5108,12 @@ static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi,
     // is rsi LDS reads per bit)
     // (with the preprocessor and more than 64 blocks only a chunk of up to 128 KiB of stream: the 8-bit SZIP shape, rsi
     // 128, 64 KiB: 0.24 -> 0.20 ms; at 1 MiB the window tables are faster, 0.39 against 0.49)
-    if (c.rsi > 256u) return p;
-    if (pp && c.rsi > (uint32_t)tune("AEC_IDX_SMALL_RSI", kSmMaxRsi) && total_bits > (uint64_t)tune("AEC_IDX_SMALL_RSI_BITS", 1u << 20))
+    // (more than 256 blocks per RSI -- hops of hops: one piece only)
+    if (c.rsi > 256u && (total_bits > kSmMaxBits || !tune("AEC_IDX_SMALL_HOP2", 1))) return p;
+    // (... unless they would not serve the stream at all -- long coded data sets, high entropy: those go over the trunk,
+    // whose dozen launches cost a 1 MiB stream 4 .. 9 ms)
+    if (pp && c.rsi > (uint32_t)tune("AEC_IDX_SMALL_RSI", kSmMaxRsi) && total_bits > (uint64_t)tune("AEC_IDX_SMALL_RSI_BITS", 1u << 20) &&
+        (sparse2_plan(c, total_bits, rsi_bits_hint).ok || !tune("AEC_IDX_SMALL_FOR_TRUNK", 1)))
         return p;
     const uint64_t piece = total_bits < kSmMaxBits ? total_bits : kSmMaxBits;
     // (what an ENCODER makes of an RSI at most; a piece holds a few of them or the scheme is not for this stream)
@@ -5131,9 +5136,11 @@ static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi,
     p.o_jb = p.o_e0;                                     // (the second table of the doubling: over the parses, done with by then)
     p.o_ja = o;    o = up(o + ((size_t)p.nbits + 1) * 4);
     p.o_s = o;     o = up(o + (size_t)p.scap * 4);
-    p.hops = c.rsi > (uint32_t)tune("AEC_IDX_SMALL_HOP_RSI", 16) ? 1u : 0u;
+    p.hops = c.rsi > 256u ? 2u : (c.rsi > (uint32_t)tune("AEC_IDX_SMALL_HOP_RSI", 16) ? 1u : 0u);
     p.o_h = o;
     if (p.hops) o = up(o + ((size_t)p.nbits + 1) * 4);
+    p.o_h2 = o;
+    if (p.hops > 1u) o = up(o + ((size_t)p.nbits + 1) * 4);
     p.bytes = o;
     p.ok = true;
     return p;
@@ -5181,14 +5188,25 @@ k_small_hop(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_b
     hop[q] = sm_hop(c, [&](uint32_t at) { return (uint32_t)e0[at]; }, q, nbits);
 }
 
+__global__ void __launch_bounds__(256)
+k_small_hop2(const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const uint32_t *__restrict__ hop, uint32_t *__restrict__ hop2)
+{
+    uint64_t start_bit;
+    uint32_t nbits;
+    if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nbits) return;
+    hop2[q] = sm_hop2([&](uint32_t at) { return hop[at]; }, q, nbits);
+}
+
 // (the walks of a workgroup begin at consecutive bits and stay within an RSI's length of them: the table they read at
 // every step -- the parses, or the hops -- is staged in LDS for that stretch; what leaves the stretch reads memory)
 constexpr uint32_t kSmRsiWg = 1024, kSmRsiSpan = 8192;
 
 __global__ void __launch_bounds__(kSmRsiWg)
 k_small_rsi(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const uint16_t *__restrict__ e0,
-            const uint16_t *__restrict__ e1, const uint32_t *__restrict__ hop, uint32_t *__restrict__ j,
-            uint32_t *__restrict__ sidx, uint32_t scap)
+            const uint16_t *__restrict__ e1, const uint32_t *__restrict__ hop, const uint32_t *__restrict__ hop2,
+            uint32_t *__restrict__ j, uint32_t *__restrict__ sidx, uint32_t scap)
 {
     __shared__ uint32_t lds[kSmRsiWg + kSmRsiSpan];
     uint64_t start_bit;
@@ -5207,7 +5225,8 @@ k_small_rsi(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_b
     auto r0 = [&](uint32_t at) { return (!hop && at - w0 < wn) ? (lds[at - w0] & 0xFFFFu) : (uint32_t)e0[at]; };
     auto r1 = [&](uint32_t at) { return (!hop && at - w0 < wn) ? (lds[at - w0] >> 16) : (uint32_t)e1[at]; };
     auto rh = [&](uint32_t at) { return at - w0 < wn ? lds[at - w0] : hop[at]; };
-    j[q] = sm_rsi(c, r0, r1, rh, hop != nullptr, q, nbits);
+    auto rh2 = [&](uint32_t at) { return hop2[at]; };
+    j[q] = sm_rsi(c, r0, r1, rh, hop != nullptr, rh2, hop2 != nullptr, q, nbits);
 }
 
 // round k, with quarter = 4^k known RSI starts: sidx[m * quarter + i] = j^m[sidx[i]] for m = 1 .. 3, and jn = j^4
@@ -5324,7 +5343,7 @@ static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t 
     uint16_t *e0 = reinterpret_cast<uint16_t *>(base + p.o_e0), *e1 = reinterpret_cast<uint16_t *>(base + p.o_e1);
     uint32_t *j[2] = {reinterpret_cast<uint32_t *>(base + p.o_ja), reinterpret_cast<uint32_t *>(base + p.o_jb)};
     uint32_t *sidx = reinterpret_cast<uint32_t *>(base + p.o_s);
-    uint32_t *hop = reinterpret_cast<uint32_t *>(base + p.o_h);
+    uint32_t *hop = reinterpret_cast<uint32_t *>(base + p.o_h), *hop2 = reinterpret_cast<uint32_t *>(base + p.o_h2);
     hipLaunchKernelGGL(k_small_begin, dim3(1), dim3(1), 0, st, flags, cur, start_bit, rsi_start);
     const uint32_t grid = (p.nbits + 1u + 255u) / 256u;
     const uint32_t rgrid = (p.nbits + 1u + kSmRsiWg - 1u) / kSmRsiWg;
@@ -5334,9 +5353,12 @@ static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t 
         if (p.hops)
             hipLaunchKernelGGL(k_small_hop, dim3(grid), dim3(256), 0, st, c, (const SmCursor *)cur, end_bit, p.nbits,
                                (const uint16_t *)e0, hop);
+        if (p.hops > 1u)
+            hipLaunchKernelGGL(k_small_hop2, dim3(grid), dim3(256), 0, st, (const SmCursor *)cur, end_bit, p.nbits,
+                               (const uint32_t *)hop, hop2);
         hipLaunchKernelGGL(k_small_rsi, dim3(sgrid), dim3(kSmRsiWg), 0, st, c, (const SmCursor *)cur, end_bit, p.nbits,
-                           (const uint16_t *)e0, (const uint16_t *)e1, (const uint32_t *)(p.hops ? hop : nullptr), j[0], sidx,
-                           p.scap);
+                           (const uint16_t *)e0, (const uint16_t *)e1, (const uint32_t *)(p.hops ? hop : nullptr),
+                           (const uint32_t *)(p.hops > 1u ? hop2 : nullptr), j[0], sidx, p.scap);
         for (uint32_t k = 0; k < p.levels; k++) {
             const uint32_t quarter = 1u << (2u * k), last = k + 1u == p.levels ? 1u : 0u;
             const uint32_t gq = (quarter + 255u) / 256u;
@@ -5374,7 +5396,7 @@ int index_scheme(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint, uint32_t
 {
     const uint64_t bits = (uint64_t)in_bytes * 8;
     if (!bits) return 0;
-    if (small_plan(c, bits, 1ull << 62, start_block).ok) return 4;
+    if (small_plan(c, bits, 1ull << 62, start_block, rsi_bits_hint).ok) return 4;
     if (lock_plan(c, bits, rsi_bits_hint, start_block).ok) return 1;
     if (sparse2_plan(c, bits, rsi_bits_hint).ok) return 2;
     return trunk_plan(c, bits, rsi_bits_hint, 0).ok ? 3 : 0;
@@ -5387,7 +5409,7 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
     const uint64_t end_bit = (uint64_t)in_bytes * 8;
     if (start_bit >= end_bit) return 0;
     // (a small stream: the brute-force scheme for a walk from an RSI start, the others for one that resumes inside)
-    const SmallPlan sm = small_plan(c, end_bit - start_bit, 1ull << 62, 0u);
+    const SmallPlan sm = small_plan(c, end_bit - start_bit, 1ull << 62, 0u, rsi_bits_hint);
     const size_t rest = index_workspace_bytes_large(c, in_bytes, start_bit, rsi_bits_hint);
     return sm.ok && sm.bytes > rest ? sm.bytes : rest;
 }
@@ -5425,7 +5447,7 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
     // else: the trunk.
     // a small stream (a chunk of a dataset): every bit parsed, the RSI starts by pointer doubling
     if (d_ws && ws_bytes && start_bit < end_bit && !d_seg_bits && !stop_near) {
-        const SmallPlan sm = small_plan(c, end_bit - start_bit, max_rsi, start_block);
+        const SmallPlan sm = small_plan(c, end_bit - start_bit, max_rsi, start_block, rsi_bits_hint);
         if (sm.ok && ws_bytes >= sm.bytes) {
             launch_index_small(c, sm, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
                                static_cast<uint8_t *>(d_ws), rsi_start, tail_slot);

@@ -65,16 +65,41 @@ AEC_HD uint32_t sm_hop(const Cfg &c, const E0 &e0, uint32_t q, uint32_t nbits)
     return (pos - q) | (blocks << 15);
 }
 
+// Hops of hops, for RSIs of hundreds of blocks: up to 8 hops from bit q -- bits (18) and blocks (14 bits above).
+template <class H>
+AEC_HD uint32_t sm_hop2(const H &hop, uint32_t q, uint32_t nbits)
+{
+    uint32_t pos = q, blocks = 0;
+    for (uint32_t i = 0; i < 8u && pos < nbits; i++) {
+        const uint32_t h = hop(pos);
+        const uint32_t hb = h >> 15, hl = h & 0x7FFFu;
+        if (!hb || blocks + hb > 16383u || pos + hl - q > 262143u) break;
+        pos += hl;
+        blocks += hb;
+    }
+    return (pos - q) | (blocks << 18);
+}
+
 // Step 2: one whole RSI from bit q of the piece (its first coded data set with a reference sample, the RSI's own
 // bookkeeping of zero-block runs, reference decode.c:518-544): where the next RSI would start, or kSmNone.
-// e0 / e1: the parses of step 1; hop: the hops (has == false: none, every coded data set singly).
-template <class E0, class E1, class H>
-AEC_HD uint32_t sm_rsi(const Cfg &c, const E0 &e0, const E1 &e1, const H &hop, bool has, uint32_t q, uint32_t nbits)
+// e0 / e1: the parses of step 1; hop, hop2: the hops and the hops of hops (has, has2 == false: none).
+template <class E0, class E1, class H, class H2>
+AEC_HD uint32_t sm_rsi(const Cfg &c, const E0 &e0, const E1 &e1, const H &hop, bool has, const H2 &hop2, bool has2, uint32_t q,
+                       uint32_t nbits)
 {
     const uint32_t rfb = (c.flags & F_PREPROCESS) ? c.bps : 0u;
     uint32_t pos = q, b = 0;
     bool ok = q < nbits;
     for (uint32_t i = 0; ok && i <= c.rsi && b < c.rsi; i++) {
+        if (has2 && b != 0u) {
+            const uint32_t h = hop2(pos);
+            const uint32_t hb = h >> 18;
+            if (hb && b + hb <= c.rsi) {
+                pos += h & 0x3FFFFu;
+                b += hb;
+                continue;
+            }
+        }
         if (has && b != 0u) {
             const uint32_t h = hop(pos);
             const uint32_t hb = h >> 15;

@@ -28,11 +28,15 @@ extern "C" int emul_small(const uint32_t *prm, const uint8_t *stream, size_t nby
     if (use_hops)
         for (uint32_t q = 0; q <= nbits; q++) hop[q] = sm_hop(c, r0, q, nbits);
     auto rh = [&](uint32_t at) { return hop[at]; };
+    std::vector<uint32_t> hop2(nbits + 1, 0);
+    if (use_hops > 1)
+        for (uint32_t q = 0; q <= nbits; q++) hop2[q] = sm_hop2(rh, q, nbits);
+    auto rh2 = [&](uint32_t at) { return hop2[at]; };
     uint64_t differ = 0;
     for (uint32_t q = 0; q <= nbits; q++) {
-        ja[q] = sm_rsi(c, r0, r1, rh, use_hops != 0, q, nbits);
+        ja[q] = sm_rsi(c, r0, r1, rh, use_hops != 0, rh2, use_hops > 1, q, nbits);
         // (the walk through the hops must be the walk without them)
-        if (use_hops && ja[q] != sm_rsi(c, r0, r1, rh, false, q, nbits)) differ++;
+        if (use_hops && ja[q] != sm_rsi(c, r0, r1, rh, false, rh2, false, q, nbits)) differ++;
     }
     uint32_t levels = 0;
     while ((1ull << (2u * levels)) < nwant + 2) levels++;

@@ -40,6 +40,8 @@ def emul():
     (32, 16, 5, PP | SGN, 4000, 400.0, 0.1),
     (16, 16, 128, 0, 9000, 8.0, 0.5),          # no preprocessor, two segments per RSI
     (24, 32, 33, PP | MSB, 7000, 8.0, 0.3),
+    (16, 8, 1024, PP, 30000, 3.0, 0.5),        # RSIs of hundreds of blocks: hops of hops
+    (8, 8, 4096, 0, 70000, 1.0, 0.3),
 ])
 def test_every_bit_scheme_finds_the_encoders_rsi_starts(emul, bps, bs, rsi, flags, n, scale, zero_frac):
     rng = np.random.default_rng(bps * 1000 + rsi)
@@ -52,7 +54,7 @@ def test_every_bit_scheme_finds_the_encoders_rsi_starts(emul, bps, bs, rsi, flag
     want = np.asarray(offs, dtype=np.uint64)
     enc_a = np.frombuffer(enc, dtype=np.uint8)
     p = (C.c_uint32 * 4)(bps, bs, rsi, flags)
-    for hops in (0, 1):
+    for hops in (0, 1, 2):
         stats = np.zeros(4, dtype=np.uint64)
         rc = emul.emul_small(p, C.c_void_p(enc_a.ctypes.data), C.c_size_t(enc_a.size), C.c_void_p(want.ctypes.data),
                              C.c_uint64(len(want)), C.c_uint32(hops), C.c_void_p(stats.ctypes.data))
