@@ -176,8 +176,8 @@ AEC_GPU_API int aec_gpu_index_is_windowed(const aec_gpu_params *p, size_t in_byt
 /* Which scheme the index pass of such a stream takes, given the workspace it asks for: 0 = the serial walk alone,
  * 1 = phase-locked chains (RSIs of at most 44 blocks; entries by plausibility for long coded data sets), 2 = window
  * tables, 3 = the trunk, 4 = every bit parsed and the RSI starts by pointer doubling (walked from an RSI start: streams
- * of at most 2 MiB with RSIs of at most 64 blocks, chunks of at most 128 KiB with up to 256; without the preprocessor
- * streams of any size with RSIs of at most 256 blocks, piece by piece).  start_block != 0: a walk that
+ * of at most 2 MiB with RSIs of at most 64 blocks or that the window tables do not serve, chunks of at most 128 KiB with
+ * RSIs of up to 256 blocks; without the preprocessor streams of any size with RSIs of at most 256 blocks, piece by piece).  start_block != 0: a walk that
  * resumes inside an RSI (aec_gpu_index_resume_async).  Host arithmetic only; tests assert the path instead of a time. */
 AEC_GPU_API int aec_gpu_index_scheme(const aec_gpu_params *p, size_t in_bytes, uint64_t rsi_bits, unsigned int start_block);
 /* The NEXT index pass on ctx (one pass only) is handed a piece of a stream of which the caller holds more: an RSI
