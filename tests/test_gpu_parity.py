@@ -973,7 +973,11 @@ def test_small_streams_every_bit_parsed(api, gpu):
     rng = np.random.default_rng(64)
     shapes = [(8, 8, 1, PP, 65536), (8, 8, 4, PP, 65536), (8, 16, 1, 0, 200000), (16, 16, 16, PP | MSB, 300001),
               (16, 64, 1, 0, 100000), (32, 16, 5, PP, 90000), (32, 32, 64, PP | SGN, 250000), (24, 8, 33, PP | MSB, 70001),
-              (12, 32, 3, PP, 1 << 20), (16, 8, 64, PP, 3), (8, 8, 64, 0, 1 << 19)]
+              (12, 32, 3, PP, 1 << 20), (16, 8, 64, PP, 3), (8, 8, 64, 0, 1 << 19),
+              # the hops: RSIs of more than 16 blocks; hops of hops: more than 256 (where the window tables do not serve)
+              (8, 8, 128, PP, 65536), (16, 16, 256, 0, 40000), (32, 32, 4096, PP | MSB, 300000), (16, 8, 1024, PP, 200000),
+              # without the preprocessor piece by piece: a stream of 6 MB is three pieces of 16 Mbit
+              (16, 16, 16, 0, 3 << 20), (16, 16, 200, 0, (3 << 20) + 77)]
     for bps, bs, rsi, flags, n in shapes:
         vals = random_walk_samples(rng, n, bps, flags, scale=float(rng.choice([0.3, 3.0, 60.0])),
                                    zero_frac=float(rng.choice([0.0, 0.3, 0.7])))
