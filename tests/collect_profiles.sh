@@ -65,4 +65,5 @@ bash tests/prof_short_rsi.sh $1/shortrsi 16 > /dev/null 2>&1
 cp $OUT/shortrsi/kernel_stats_short_rsi.csv $OUT/kernel_stats_short_rsi.csv 2>/dev/null
 timeout 600 python3 tests/fuzz_index_gpu.py --cases 300 --seed 5001 --time 2>&1 | grep -A25 "slowest" > $OUT/fuzz_index_slowest_shapes.txt
 python3 -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/pytest_gpu.log
+rm -f $OUT/out.txt $OUT/summary.txt
 rm -rf $OUT/small $OUT/shortrsi $OUT/sq_c2 $OUT/stats_* $OUT/traffic_c2 $OUT/traffic_c3 $OUT/traffic_c5 $OUT/traffic_typical $OUT/idx $OUT/idxpmc_* $OUT/idxsq_*
