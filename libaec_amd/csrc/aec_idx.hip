@@ -5098,27 +5098,24 @@ static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi,
     SmallPlan p{};
     if (!tune("AEC_IDX_SMALL", 1) || start_block || !max_rsi || total_bits < 64 || (c.flags & F_PAD_RSI)) return p;
     const bool pp = c.flags & F_PREPROCESS;
-    // (pieces with RSIs of more than 64 blocks only for samples of more than 8 bits: 16 MiB with rsi 128 / 256 -- 16-bit 34 /
-    // 40 -> 12 / 14 ms, the reference 13; 8-bit 8.6 / 8.4 over the trunk against 11.8 / 13.7 here)
+    // Where the scheme runs, by measurement (tests/bench_short_rsi.py, --edges; tests/fuzz_index_gpu.py --time):
+    //  * more than one piece: only without the preprocessor (no reference samples: the other schemes' chains have nothing
+    //    to lock a count on) -- and with RSIs of more than 64 blocks only for samples of more than 8 bits (16 MiB with rsi
+    //    128 / 256: 16-bit 34 / 40 -> 12 / 14 ms, the reference 13; 8-bit 8.6 / 8.4 over the trunk against 11.8 / 13.7 here);
     if (total_bits > kSmMaxBits && (pp || (c.rsi > kSmMaxRsi && c.bps <= 8u) || !tune("AEC_IDX_SMALL_PIECES", 1) ||
                                     total_bits >= (1ull << 40)))
         return p;
-    // (RSIs of 45 .. 64 blocks with the preprocessor: the window tables' from 512 KiB of stream on -- 5 MiB of 8-bit
-    // data with rsi 64: 1.1 against 1.7 ms)
-    if (pp && c.rsi > kLockMaxRsi && c.rsi <= kSmMaxRsi && total_bits > (1u << 22) && sparse2_plan(c, total_bits, rsi_bits_hint).ok)
-        return p;
-    // (RSIs of up to 64 blocks; without the preprocessor -- no reference samples, nothing the other schemes' chains could
-    // lock a count on: such streams went to the serial walker, a 64 KiB chunk with rsi 128 in 2.5 ms -- up to 256: step 2
-    // is rsi LDS reads per bit)
-    // (with the preprocessor and more than 64 blocks only a chunk of up to 128 KiB of stream: the 8-bit SZIP shape, rsi
-    // 128, 64 KiB: 0.24 -> 0.20 ms; at 1 MiB the window tables are faster, 0.39 against 0.49)
-    // (more than 256 blocks per RSI -- hops of hops: one piece only)
+    //  * RSIs of more than 256 blocks (hops of hops): one piece;
     if (c.rsi > 256u && (total_bits > kSmMaxBits || !tune("AEC_IDX_SMALL_HOP2", 1))) return p;
-    // (... unless they would not serve the stream at all -- long coded data sets, high entropy: those go over the trunk,
-    // whose dozen launches cost a 1 MiB stream 4 .. 9 ms)
-    if (pp && c.rsi > (uint32_t)tune("AEC_IDX_SMALL_RSI", kSmMaxRsi) && total_bits > (uint64_t)tune("AEC_IDX_SMALL_RSI_BITS", 1u << 20) &&
-        (sparse2_plan(c, total_bits, rsi_bits_hint).ok || !tune("AEC_IDX_SMALL_FOR_TRUNK", 1)))
-        return p;
+    //  * with the preprocessor, where the window tables serve the stream: RSIs of up to 44 blocks always (the tables do
+    //    not resolve them); 45 .. 64 up to 512 KiB of stream (5 MiB of 8-bit data with rsi 64: 1.1 against 1.7 ms); more
+    //    than 64 up to 128 KiB (the 8-bit SZIP shape, rsi 128: 64 KiB 0.24 -> 0.19 ms, 1 MiB 0.39 against 0.49).  Where
+    //    the tables do not serve it -- long coded data sets, high entropy -- the stream would go over the trunk, whose
+    //    dozen launches cost a 1 MiB stream 4 .. 9 ms: here it stays.
+    if (pp && c.rsi > kLockMaxRsi) {
+        const uint64_t most_bits = c.rsi <= (uint32_t)tune("AEC_IDX_SMALL_RSI", kSmMaxRsi) ? (1u << 22) : (uint64_t)tune("AEC_IDX_SMALL_RSI_BITS", 1u << 20);
+        if (total_bits > most_bits && sparse2_plan(c, total_bits, rsi_bits_hint).ok) return p;
+    }
     const uint64_t piece = total_bits < kSmMaxBits ? total_bits : kSmMaxBits;
     // (what an ENCODER makes of an RSI at most; a piece holds a few of them or the scheme is not for this stream)
     const uint64_t worst = (uint64_t)c.rsi * (c.id_len + (uint64_t)c.bs * c.bps) + c.bps + 8;
