@@ -1,0 +1,40 @@
+"""Which scheme the index pass of a bare stream takes (libaec_amd/csrc/aec_idx.hip: launch_index) -- host arithmetic on
+the parameters, the size and the average coded RSI (aec_gpu_index_scheme), so it is pinned here without a GPU.  The table
+is the dispatch as DESIGN.md section 2 describes it and as tests/bench_short_rsi.py (--edges), tests/bench_index.py and
+tests/fuzz_index_gpu.py --time measured it; a change of a threshold shows up here first."""
+import pytest
+
+from libaec_amd import gpu
+
+PP, MSB = 8, 4
+SERIAL, LOCKED, TABLES, TRUNK, EVERY_BIT = range(5)
+
+CASES = [
+    # name, bits per sample, block, rsi, flags, stream bytes, bits per coded RSI, start block, scheme
+    ("a 64 KiB chunk with scan lines of 32 pixels", 8, 8, 4, PP, 24_000, 97, 0, EVERY_BIT),
+    ("the same, a walk that resumes inside an RSI", 8, 8, 4, PP, 24_000, 97, 1, LOCKED),
+    ("the 8-bit SZIP shape, a 64 KiB chunk", 8, 8, 128, PP, 23_700, 2960, 0, EVERY_BIT),
+    ("the 8-bit SZIP shape, 1 MiB", 8, 8, 128, PP, 379_000, 2960, 0, TABLES),
+    ("config 2, 1 GiB", 16, 16, 128, PP, 190_000_000, 5800, 0, TABLES),
+    ("config 3, 1 MiB: the tables do not serve it, the trunk's launches would cost 4.5 ms", 32, 32, 4096, PP, 260_000,
+     1_040_000, 0, EVERY_BIT),
+    ("config 3, 1 GiB", 32, 32, 4096, PP, 260_000_000, 1_040_000, 0, TRUNK),
+    ("the sample file's shape, 1 MiB", 16, 64, 256, PP | MSB, 737_000, 184_000, 0, EVERY_BIT),
+    ("the sample file's shape, 1 GiB: entries by plausibility", 16, 64, 256, PP | MSB, 755_000_000, 184_000, 0, LOCKED),
+    ("16 MiB of 8-bit data, rsi 32", 8, 8, 32, PP, 5_955_000, 762, 0, LOCKED),
+    ("16 MiB of 8-bit data, rsi 33: the tables resolve RSIs that short badly (72 ms)", 8, 8, 33, PP, 5_953_000, 786, 0, LOCKED),
+    ("16 MiB of 8-bit data, rsi 48", 8, 8, 48, PP, 5_940_000, 1140, 0, TABLES),
+    ("16 MiB of 16-bit data, rsi 32", 16, 16, 32, PP, 2_930_000, 1470, 0, LOCKED),
+    ("16 MiB without the preprocessor: piece by piece", 16, 16, 16, 0, 16_640_000, 4160, 0, EVERY_BIT),
+    ("16 MiB of 8-bit data without the preprocessor, rsi 128: the trunk is faster", 8, 8, 128, 0, 16_060_000, 8600, 0, TRUNK),
+    ("1 MiB with rsi 1 and long coded data sets", 16, 64, 1, PP, 790_000, 800, 0, EVERY_BIT),
+    ("16 MiB with rsi 1 and long coded data sets: scoring chains that carry the count", 24, 64, 1, PP, 7_800_000, 900, 0, LOCKED),
+    ("nothing to index", 16, 16, 128, PP, 0, 0, 0, SERIAL),
+]
+
+
+@pytest.mark.parametrize("name,bps,bs,rsi,flags,nbytes,hint,start_block,scheme", CASES, ids=[c[0] for c in CASES])
+def test_index_scheme(name, bps, bs, rsi, flags, nbytes, hint, start_block, scheme):
+    assert len(gpu.INDEX_SCHEMES) == 5
+    got = gpu.index_scheme(bps, bs, rsi, flags, nbytes, hint, start_block)
+    assert got == scheme, (name, gpu.INDEX_SCHEMES[got], gpu.INDEX_SCHEMES[scheme])
