@@ -103,6 +103,7 @@ struct SparseTables {
     // wide walker: per chunk of wpc windows, what every candidate of the chunk's first window leads to
     const uint4 *wide;         // [chunk * cap + index]: {exit lo, exit hi, RSIs, 1 = resolved}
     uint32_t wpc;
+    const uint32_t *skip_if = nullptr;   // != 0 there: a scheme in front has delivered the stream; the kernels return at once
 };
 
 // The DENSE tables (launch_index_sparse: windows with room for a candidate per four bits, built only where a window of
@@ -1145,6 +1146,7 @@ constexpr uint32_t kS2BridgeAfter = 16;      // RSIs the walker had to walk itse
 struct Spec2Geom {
     uint32_t lead, core, look, stride, burn, cap_lds, cap_core, fast, refill, uncrun;
     uint32_t v4;          // k_spec4 (a table of every position's coded data set) instead of k_spec2
+    const uint32_t *skip_if = nullptr;   // != 0 there: a scheme in front has delivered the stream; the kernel returns at once
 };
 
 __global__ void __launch_bounds__(1024)
@@ -1154,6 +1156,7 @@ k_spec2(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         unsigned long long *__restrict__ prof, const uint64_t *__restrict__ starts = nullptr, uint32_t nstarts = 0,
         uint32_t *__restrict__ blist = nullptr, uint32_t *__restrict__ blist_cnt = nullptr)
 {
+    if (g.skip_if && *g.skip_if) return;
     extern __shared__ __attribute__((aligned(16))) uint32_t spec_lds[];
     __shared__ uint32_t sh_total, sh_next[2], sh_part[16];
     // (diagnostic builds of the host pass `prof`: shader-clock stamps at the phase boundaries)
@@ -2031,6 +2034,7 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         const uint32_t *__restrict__ wlist = nullptr, const uint32_t *__restrict__ wcount = nullptr,
         const uint32_t *__restrict__ only_where_zero = nullptr, uint32_t other_core = 0, uint32_t other_nwin = 0)
 {
+    if (g.skip_if && *g.skip_if) return;
     // dense mode of a few windows (small inputs): every window looks itself whether an ordinary window over its core
     // gave up -- one launch instead of the list's two
     if (only_where_zero) {
@@ -2061,8 +2065,10 @@ k_spec4(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
 // which windows of the dense tables are to be built: those whose core lies over an ordinary window with a count of 0
 __global__ void __launch_bounds__(256)
 k_dense_pick(const uint32_t *__restrict__ sparse_ccnt, uint32_t sparse_core, uint32_t sparse_nwin, uint32_t dcore, uint32_t dnwin,
-             uint32_t *__restrict__ dccnt, uint32_t *__restrict__ wlist, uint32_t *__restrict__ wcount)
+             uint32_t *__restrict__ dccnt, uint32_t *__restrict__ wlist, uint32_t *__restrict__ wcount,
+             const uint32_t *__restrict__ skip_if = nullptr)
 {
+    if (skip_if && *skip_if) return;
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= dnwin) return;
     const uint64_t a = (uint64_t)w * dcore, b = a + dcore - 1u;
@@ -2219,6 +2225,7 @@ k_bridge(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
          uint2 *__restrict__ rec_out, const uint32_t *__restrict__ blist, const uint32_t *__restrict__ blist_cnt,
          const IdxCarry *__restrict__ carry, uint32_t first_span, uint32_t min_serial)
 {
+    if (t.skip_if && *t.skip_if) return;
     // Only for streams that need it: well-behaved streams have a dozen such hypotheses per window too (wrong phases
     // whose zero runs come out long), each a parse of several average RSIs for nothing.  The walker counts the
     // RSIs it had to walk itself; from kS2BridgeAfter of them on the rest of the stream is bridged.
@@ -2236,6 +2243,7 @@ k_bridge(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint6
 __global__ void __launch_bounds__(256)
 k_wide(const SparseTables t, uint32_t nwin, uint64_t end_bit, uint4 *__restrict__ wide)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t chunk = blockIdx.y;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t first = chunk * t.wpc;
@@ -2273,6 +2281,7 @@ k_rewalk(const SparseTables t, uint32_t nwin, uint32_t nchunks, uint64_t end_bit
          const ChunkEntry *__restrict__ entry, IdxHop *__restrict__ hops, uint32_t *__restrict__ nhops,
          uint64_t *__restrict__ rsi_off)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
     if (chunk >= nchunks) return;
     uint32_t n = 0;
@@ -2308,6 +2317,7 @@ __global__ void k_expand2(const SparseTables t, const IdxCarry *__restrict__ car
                           const uint32_t *__restrict__ nhops, uint32_t lists, uint32_t stride,
                           uint64_t *__restrict__ rsi_off, uint64_t rsi_stride = 0)
 {
+    if (t.skip_if && *t.skip_if) return;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     IdxHop h;
     if (lists == 0) {
@@ -3118,9 +3128,11 @@ void side_give(const SideStream &s)
 void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
                          uint8_t *base, size_t ws_bytes, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
-                         uint64_t stop_near)
+                         uint64_t stop_near, const uint32_t *skip_if = nullptr)
 {
     allow_big_lds2();
+    Spec2Geom geom = p.g, dgeom = p.dg;
+    geom.skip_if = dgeom.skip_if = skip_if;
     IdxCarry *carry = reinterpret_cast<IdxCarry *>(base);
     const uint64_t lo0 = start_bit / p.g.core * p.g.core;
     const uint64_t span = (uint64_t)p.nwin_max * p.g.core;
@@ -3156,6 +3168,7 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
         t.cap = p.g.cap_core;
         t.wide = reinterpret_cast<const uint4 *>(tb + p.o_wide);
         t.wpc = p.wpc;
+        t.skip_if = skip_if;
         ChunkEntry *centry = reinterpret_cast<ChunkEntry *>(tb + p.o_centry);
         IdxHop *hops = reinterpret_cast<IdxHop *>(tb + p.o_hops);
         IdxHop *rhops = reinterpret_cast<IdxHop *>(tb + p.o_rhops);
@@ -3165,12 +3178,12 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
         uint32_t *blist = reinterpret_cast<uint32_t *>(tb + p.o_blist), *blist_cnt = reinterpret_cast<uint32_t *>(tb + 56);
         (void)hipMemsetAsync(blist_cnt, 0, 8, ts);                  // (+ the count of the dense windows' list at offset 60)
         if (p.g.v4)
-            hipLaunchKernelGGL(k_spec4, dim3(nwin), dim3(1024), p.lds, ts, c, words, nwords, end_bit, lo, start_bit, p.g,
+            hipLaunchKernelGGL(k_spec4, dim3(nwin), dim3(1024), p.lds, ts, c, words, nwords, end_bit, lo, start_bit, geom,
                                const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
                                const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin),
                                (const uint64_t *)nullptr, 0u, blist, blist_cnt);
         else
-            hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, ts, c, words, nwords, end_bit, lo, start_bit, p.g,
+            hipLaunchKernelGGL(k_spec2, dim3(nwin), dim3(1024), p.lds, ts, c, words, nwords, end_bit, lo, start_bit, geom,
                                const_cast<uint32_t *>(t.bitmap), const_cast<uint16_t *>(t.pre), const_cast<uint2 *>(t.rec),
                                const_cast<uint16_t *>(t.cpos), const_cast<uint32_t *>(t.ccnt), spec2_prof_buffer(nwin),
                                (const uint64_t *)nullptr, 0u, blist, blist_cnt);
@@ -3189,18 +3202,19 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
             td.cap = p.dg.cap_core;
             td.wide = nullptr;
             td.wpc = 1;
+            td.skip_if = skip_if;
             uint32_t *dlist = reinterpret_cast<uint32_t *>(tb + p.od_list), *dcount = reinterpret_cast<uint32_t *>(tb + 60);
             if (dnwin <= 1024u)
-                hipLaunchKernelGGL(k_spec4, dim3(dnwin), dim3(1024), p.dlds, ts, c, words, nwords, end_bit, lo, start_bit, p.dg,
+                hipLaunchKernelGGL(k_spec4, dim3(dnwin), dim3(1024), p.dlds, ts, c, words, nwords, end_bit, lo, start_bit, dgeom,
                                    const_cast<uint32_t *>(td.bitmap), const_cast<uint16_t *>(td.pre), const_cast<uint2 *>(td.rec),
                                    const_cast<uint16_t *>(td.cpos), const_cast<uint32_t *>(td.ccnt), (unsigned long long *)nullptr,
                                    (const uint64_t *)nullptr, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
                                    (const uint32_t *)nullptr, t.ccnt, p.g.core, nwin);
             else {
             hipLaunchKernelGGL(k_dense_pick, dim3((dnwin + 255) / 256), dim3(256), 0, ts, t.ccnt, p.g.core, nwin, p.dg.core, dnwin,
-                               const_cast<uint32_t *>(td.ccnt), dlist, dcount);
+                               const_cast<uint32_t *>(td.ccnt), dlist, dcount, skip_if);
             hipLaunchKernelGGL(k_spec4, dim3(dnwin < 512u ? dnwin : 512u), dim3(1024), p.dlds, ts, c, words, nwords, end_bit, lo,
-                               start_bit, p.dg, const_cast<uint32_t *>(td.bitmap), const_cast<uint16_t *>(td.pre),
+                               start_bit, dgeom, const_cast<uint32_t *>(td.bitmap), const_cast<uint16_t *>(td.pre),
                                const_cast<uint2 *>(td.rec), const_cast<uint16_t *>(td.cpos), const_cast<uint32_t *>(td.ccnt),
                                (unsigned long long *)nullptr, (const uint64_t *)nullptr, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                (const uint32_t *)dlist, (const uint32_t *)dcount);
@@ -3244,7 +3258,7 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
                            d_res, (const uint64_t *)nullptr, hops, hop_cap, carry, first ? 1u : 0u, last ? 1u : 0u,
                            start_block, rsi_start, tail_slot, TwTables{}, centry, t, (uint32_t *)nullptr, last ? stop_near : 0ull,
-                           (const uint32_t *)nullptr, td);
+                           skip_if, td);
         if (!flat)
             hipLaunchKernelGGL(k_rewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, t, nwin, nchunks, end_bit, centry, rhops,
                                nhops, d_rsi_off);
@@ -5398,6 +5412,7 @@ int index_scheme(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint, uint32_t
     const uint64_t bits = (uint64_t)in_bytes * 8;
     if (!bits) return 0;
     if (small_plan(c, bits, 1ull << 62, start_block, rsi_bits_hint).ok) return 4;
+    if (region_plan(c, bits, rsi_bits_hint, false).ok) return 5;
     if (lock_plan(c, bits, rsi_bits_hint, start_block).ok) return 1;
     if (sparse2_plan(c, bits, rsi_bits_hint).ok) return 2;
     return trunk_plan(c, bits, rsi_bits_hint, 0).ok ? 3 : 0;
@@ -5411,7 +5426,9 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
     if (start_bit >= end_bit) return 0;
     // (a small stream: the brute-force scheme for a walk from an RSI start, the others for one that resumes inside)
     const SmallPlan sm = small_plan(c, end_bit - start_bit, 1ull << 62, 0u, rsi_bits_hint);
-    const size_t rest = index_workspace_bytes_large(c, in_bytes, start_bit, rsi_bits_hint);
+    // (the regions in front of whatever would run without them)
+    const RegionPlan rp = region_plan(c, end_bit - start_bit, rsi_bits_hint, false);
+    const size_t rest = index_workspace_bytes_large(c, in_bytes, start_bit, rsi_bits_hint) + (rp.ok ? rp.bytes : 0);
     return sm.ok && sm.bytes > rest ? sm.bytes : rest;
 }
 
@@ -5455,11 +5472,25 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
             return false;
         }
     }
+    // a large stream: regions walked from guessed entries; the schemes below are enqueued behind and return at once
+    // where it has delivered
+    const uint32_t *done = nullptr;
+    bool segs_filled = false;
+    if (d_ws && ws_bytes && start_bit < end_bit) {
+        const RegionPlan rp = region_plan(c, end_bit - start_bit, rsi_bits_hint, d_seg_bits != nullptr);
+        if (rp.ok && ws_bytes >= rp.bytes) {
+            done = launch_index_regions(c, rp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
+                                        static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot, d_seg_bits);
+            d_ws = static_cast<uint8_t *>(d_ws) + rp.bytes;
+            ws_bytes -= rp.bytes;
+            segs_filled = d_seg_bits != nullptr;
+        }
+    }
     if (d_ws && ws_bytes && start_bit < end_bit && !d_seg_bits) {
         const LockPlan lp = lock_plan(c, end_bit - start_bit, rsi_bits_hint, start_block);
         if (lp.ok && lp.mode == 0u && ws_bytes >= lp.bytes) {
             launch_index_locked(c, lp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
-                                static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot);
+                                static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot, true, done);
             return false;
         }
         if (lp.ok && lp.mode == 1u && ws_bytes >= lp.bytes) {
@@ -5473,9 +5504,9 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
             const size_t off0 = used;
             if (have0) used += l0.bytes;
             const TrunkPlan tp = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, ws_bytes - used);
-            const uint32_t *done = reinterpret_cast<const uint32_t *>(wb + lp.o_flags);
             launch_index_locked(c, lp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb, start_block,
-                                rsi_start, tail_slot, !tp.ok && !have0);
+                                rsi_start, tail_slot, !tp.ok && !have0, done);
+            done = reinterpret_cast<const uint32_t *>(wb + lp.o_flags);
             if (have0) {
                 launch_index_locked(c, l0, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb + off0,
                                     start_block, rsi_start, tail_slot, !tp.ok, done);
@@ -5491,8 +5522,9 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
         const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
         if (sp.ok && ws_bytes >= sp.bytes) {
             launch_index_sparse(c, sp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
-                                static_cast<uint8_t *>(d_ws), ws_bytes, start_block, rsi_start, tail_slot, stop_near);
-            return false;
+                                static_cast<uint8_t *>(d_ws), ws_bytes, start_block, rsi_start, tail_slot, stop_near, done);
+            // (segment starts the regions did not deliver stay ~0: such RSIs are decoded by one lane each)
+            return segs_filled;
         }
     }
     TrunkPlan p{};
@@ -5500,13 +5532,14 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
     if (!p.ok) {                                       // serial walk only
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off,
                            max_rsi, d_res, (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u,
-                           1u, start_block, rsi_start, tail_slot, TwTables{}, (ChunkEntry *)nullptr, SparseTables{});
-        return false;
+                           1u, start_block, rsi_start, tail_slot, TwTables{}, (ChunkEntry *)nullptr, SparseTables{},
+                           (uint32_t *)nullptr, (uint64_t)0, done);
+        return segs_filled;
     }
     // (segment starts: the caller has set the table to ~0; the RSI the walk resumes in has none -- its first
     // blocks lie in front of the walk)
     launch_index_trunk(c, p, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
-                       static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot, d_seg_bits);
+                       static_cast<uint8_t *>(d_ws), start_block, rsi_start, tail_slot, d_seg_bits, done);
     return d_seg_bits != nullptr;
 }
 

@@ -151,7 +151,8 @@ bool launch_decode_bare(const Cfg &c, const uint8_t *d_in, size_t in_bytes, cons
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint);
 bool index_is_windowed(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint);
 // the scheme launch_index takes with the workspace index_workspace_bytes asks for: 0 serial walk, 1 phase-locked
-// chains, 2 window tables, 3 trunk
+// chains, 2 window tables, 3 trunk, 4 every bit parsed (small streams), 5 regions walked from guessed entries (large
+// streams; what it does not deliver is left to the scheme this function would name without it)
 int index_scheme(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint, uint32_t start_block);
 // d_seg_bits (optional; (max_rsi + 1) * segs_per_rsi entries, set to ~0 by the caller): where the index runs over
 // the trunk tables it also leaves the start bit of every segment of the RSIs it finds (launch_decode_bare); the
@@ -164,6 +165,22 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
                   void *d_ws = nullptr, size_t ws_bytes = 0, uint64_t rsi_bits_hint = 0,
                   uint32_t start_block = 0, uint64_t rsi_start = 0, uint32_t tail_slot = 0,
                   uint64_t *d_seg_bits = nullptr, uint64_t stop_near = 0);
+
+// The region index (aec_region.hip): large preprocessed streams -- a lane per region guesses the first RSI start behind
+// the region's first bit from the options around it, lanes walk the regions from their entries, every entry is checked
+// against the walk in front and mended; delivers only if all agree.  Returns the device flag that is != 0 once the
+// stream has been delivered (the skip_if of the schemes enqueued behind).
+struct RegionPlan {
+    bool ok;
+    uint32_t nreg, budget, passes, avg_cds;
+    uint64_t region_bits;
+    size_t o_flags, o_found, o_entry[2], o_exit[2], o_cnt[2], o_base, bytes;
+};
+RegionPlan region_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, bool want_segments);
+const uint32_t *launch_index_regions(const Cfg &c, const RegionPlan &p, const uint32_t *words, uint64_t nwords,
+                                     uint64_t end_bit, uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi,
+                                     DecResult *d_res, hipStream_t st, uint8_t *base, uint32_t start_block, uint64_t rsi_start,
+                                     uint32_t tail_slot, uint64_t *d_seg_bits, const uint32_t *skip_if = nullptr);
 
 // Index pass over many independent streams stored in one buffer (e.g. the chunks of an HDF5
 // dataset): stream s occupies bytes [chunk_off[s], chunk_off[s+1]) (chunk_off 4-byte aligned values,

@@ -99,7 +99,8 @@ def stitch_async(d_gathered, slot, d_plans, world, d_stream, d_total=None, strea
         raise RuntimeError(f"aec_gpu_stitch_async failed ({rc})")
 
 
-INDEX_SCHEMES = ("serial walk", "phase-locked chains", "window tables", "trunk", "every bit parsed (small streams)")
+INDEX_SCHEMES = ("serial walk", "phase-locked chains", "window tables", "trunk", "every bit parsed (small streams)",
+                 "regions walked from guessed entries (large streams)")
 
 
 def index_scheme(bits_per_sample, block_size, rsi, flags, in_bytes, rsi_bits=0, start_block=0):

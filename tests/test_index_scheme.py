@@ -7,7 +7,7 @@ import pytest
 from libaec_amd import gpu
 
 PP, MSB = 8, 4
-SERIAL, LOCKED, TABLES, TRUNK, EVERY_BIT = range(5)
+SERIAL, LOCKED, TABLES, TRUNK, EVERY_BIT, REGIONS = range(6)
 
 CASES = [
     # name, bits per sample, block, rsi, flags, stream bytes, bits per coded RSI, start block, scheme
@@ -15,7 +15,8 @@ CASES = [
     ("the same, a walk that resumes inside an RSI", 8, 8, 4, PP, 24_000, 97, 1, LOCKED),
     ("the 8-bit SZIP shape, a 64 KiB chunk", 8, 8, 128, PP, 23_700, 2960, 0, EVERY_BIT),
     ("the 8-bit SZIP shape, 1 MiB", 8, 8, 128, PP, 379_000, 2960, 0, TABLES),
-    ("config 2, 1 GiB", 16, 16, 128, PP, 190_000_000, 5800, 0, TABLES),
+    ("config 2, 1 GiB: regions (what they do not deliver is left to the window tables)", 16, 16, 128, PP, 190_000_000, 5800, 0, REGIONS),
+    ("config 2, 4 MiB: the window tables", 16, 16, 128, PP, 745_000, 5800, 0, TABLES),
     ("config 3, 1 MiB: the tables do not serve it, the trunk's launches would cost 4.5 ms", 32, 32, 4096, PP, 260_000,
      1_040_000, 0, EVERY_BIT),
     ("config 3, 1 GiB", 32, 32, 4096, PP, 260_000_000, 1_040_000, 0, TRUNK),
@@ -23,7 +24,7 @@ CASES = [
     ("the sample file's shape, 1 GiB: entries by plausibility", 16, 64, 256, PP | MSB, 755_000_000, 184_000, 0, LOCKED),
     ("16 MiB of 8-bit data, rsi 32", 8, 8, 32, PP, 5_955_000, 762, 0, LOCKED),
     ("16 MiB of 8-bit data, rsi 33: the tables resolve RSIs that short badly (72 ms)", 8, 8, 33, PP, 5_953_000, 786, 0, LOCKED),
-    ("16 MiB of 8-bit data, rsi 48", 8, 8, 48, PP, 5_940_000, 1140, 0, TABLES),
+    ("16 MiB of 8-bit data, rsi 48", 8, 8, 48, PP, 5_940_000, 1140, 0, REGIONS),
     ("16 MiB of 16-bit data, rsi 32", 16, 16, 32, PP, 2_930_000, 1470, 0, LOCKED),
     ("16 MiB without the preprocessor: piece by piece", 16, 16, 16, 0, 16_640_000, 4160, 0, EVERY_BIT),
     ("16 MiB of 8-bit data without the preprocessor, rsi 128: the trunk is faster", 8, 8, 128, 0, 16_060_000, 8600, 0, TRUNK),
@@ -35,6 +36,6 @@ CASES = [
 
 @pytest.mark.parametrize("name,bps,bs,rsi,flags,nbytes,hint,start_block,scheme", CASES, ids=[c[0] for c in CASES])
 def test_index_scheme(name, bps, bs, rsi, flags, nbytes, hint, start_block, scheme):
-    assert len(gpu.INDEX_SCHEMES) == 5
+    assert len(gpu.INDEX_SCHEMES) == 6
     got = gpu.index_scheme(bps, bs, rsi, flags, nbytes, hint, start_block)
     assert got == scheme, (name, gpu.INDEX_SCHEMES[got], gpu.INDEX_SCHEMES[scheme])
