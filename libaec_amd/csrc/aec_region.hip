@@ -49,9 +49,9 @@ struct RgTables {
 // the lane's ring: a column of the workgroup's LDS (one wavefront per workgroup)
 #define RG_RING(ps)                                                             \
     extern __shared__ __attribute__((aligned(16))) uint32_t rg_lds[];          \
-    RgRingParser ps{s, c};                                                      \
+    RgRing ps{s, c};                                                            \
     ps.init(rg_lds + (threadIdx.x & 63u), 64u, t.period)
-constexpr size_t kRgLds = (size_t)kRgRingWords * 64u * 4u;
+constexpr size_t kRgLds = (size_t)kRgRingRows * 64u * 4u;
 
 __device__ __forceinline__ bool rg_off(const RgTables &t)
 {
@@ -68,8 +68,8 @@ k_rg_guess(const Cfg c, const TrStream s, const RgTables t)
     const uint32_t lane = threadIdx.x & 63u;
     RgGuess g;
     g.init(0);
-    uint32_t r = 0;
-    uint64_t limit = 0;
+    uint32_t r = 0, r0 = 0;
+    const uint32_t limit = (uint32_t)(2u * t.region_bits);
     bool have = false, dry = false;
     for (;;) {
         const uint64_t want = __ballot(!have && !dry);
@@ -82,10 +82,10 @@ k_rg_guess(const Cfg c, const TrStream s, const RgTables t)
                 r = 1u + first + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
                 if (r < t.nreg) {
                     const uint64_t from = t.lo + (uint64_t)r * t.region_bits;
-                    limit = from + 2u * t.region_bits;
-                    g.init(from);
-                    if (from + c.id_len >= s.end_bit) g.mode = RgGuess::NONE;
                     ps.seat(from);
+                    r0 = ps.rel_of(from);
+                    g.init(r0);
+                    if (!(r0 < ps.end_rel && ps.end_rel - r0 > c.id_len)) g.mode = RgGuess::NONE;
                     have = true;
                 } else {
                     dry = true;
@@ -94,13 +94,13 @@ k_rg_guess(const Cfg c, const TrStream s, const RgTables t)
         }
         if (!__any(have)) break;
         if (have) {
-            if (g.busy() && g.parses < t.budget && !(g.mode <= RgGuess::WALK && g.q >= limit)) {
+            if (g.busy() && g.parses < t.budget && !(g.mode <= RgGuess::WALK && g.q - r0 >= limit)) {
                 uint32_t id, nz;
                 const uint32_t len = ps.cds(g.q, g.ref, id, nz);
-                g.step(c, s.end_bit, len, id, nz);
+                g.step(c, ps.end_rel, len, id, nz);
             } else {
                 const bool got = g.mode == RgGuess::FOUND;
-                t.found[r] = RgEntry{got ? g.found : 0u, 0u, got ? 1u : 0u};
+                t.found[r] = RgEntry{got ? ps.pos_of(g.found) : 0u, 0u, got ? 1u : 0u};
                 have = false;
             }
         }
@@ -350,7 +350,7 @@ k_rg_fill(const Cfg c, const TrStream s, const RgTables t, uint32_t cur, uint64_
     auto start_in_front = [&]() -> uint64_t {
         for (uint32_t q = r; q-- > 0u;) {
             if (!e[q].live || !t.cnt[cur][q]) continue;
-            RgRingParser &pq = ps;                       // (this lane's own walk is over)
+            RgRing &pq = ps;                             // (this lane's own walk is over)
             RgState y{e[q].pos, e[q].b, 0u};
             uint64_t lastpos = rsi_start_in;
             const uint32_t qn = rg_next_live(e, q, t.nreg);

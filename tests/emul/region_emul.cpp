@@ -17,11 +17,8 @@ using namespace aec;
 namespace {
 struct HostRing {                       // the lane's ring as plain memory (stride 1)
     std::vector<uint32_t> mem;
-    RgRingParser ps;
-    HostRing(const TrStream &s, const Cfg &c, uint32_t period) : mem(kRgRingWords, 0u), ps{s, c}
-    {
-        ps.init(mem.data(), 1u, period);
-    }
+    RgRing ps;
+    HostRing(const TrStream &s, const Cfg &c) : mem(kRgRingRows, 0u), ps{s, c} { ps.init(mem.data(), 1u, 5u); }
 };
 }  // namespace
 
@@ -38,16 +35,14 @@ int emul_region_guess(const uint32_t *params, const uint8_t *stream, size_t nbyt
     std::vector<uint32_t> words((nbytes + 3) / 4 + 16, 0u);
     std::memcpy(words.data(), stream, nbytes);
     const TrStream s{words.data(), (nbytes + 3) / 4, (uint64_t)nbytes * 8};
-    HostRing hr(s, c, rg_ring_period(s.end_bit / (n_off ? n_off : 1) / c.rsi));
-    RgRingParser &ps = hr.ps;
+    HostRing hr(s, c);
     std::vector<uint64_t> offs(rsi_off, rsi_off + n_off);
     std::sort(offs.begin(), offs.end());
-    uint64_t regions = 0, right = 0, none = 0, wrong = 0, dist = 0;
-    RgGuessStats gs{};
+    uint64_t regions = 0, right = 0, none = 0, wrong = 0, dist = 0, parses = 0;
     for (uint64_t from = region_bits; from + 64 < s.end_bit; from += region_bits) {
         regions++;
         uint64_t at = 0;
-        const bool got = rg_guess(ps, c, from, from + 2 * region_bits, s.end_bit, budget, at, &gs);
+        const bool got = rg_guess(hr.ps, c, from, (uint32_t)(2 * region_bits), budget, at, &parses);
         if (guesses) guesses[regions - 1] = got ? at : ~0ull;
         if (!got) {
             none++;
@@ -64,7 +59,7 @@ int emul_region_guess(const uint32_t *params, const uint8_t *stream, size_t nbyt
     stats[1] = right;
     stats[2] = none;
     stats[3] = wrong;
-    stats[4] = gs.parses;
+    stats[4] = parses;
     stats[5] = 0;
     stats[6] = 0;
     stats[7] = 0;
@@ -72,9 +67,9 @@ int emul_region_guess(const uint32_t *params, const uint8_t *stream, size_t nbyt
     return 0;
 }
 
-// rg_cds (the lane's register window) against tr_cds (from memory) at EVERY bit of the stream, without and with a
-// reference sample, in the order a walk would ask (increasing positions) and jumping about; returns the first bit where
-// they differ + 1, 0 = none
+// RgRing::cds (the lane's ring) against tr_cds (from memory) at EVERY bit of the stream, without and with a reference
+// sample, in the order a walk would ask (increasing positions) and jumping about as the tests of the guess do; returns the
+// first bit where they differ + 1, 0 = none
 uint64_t emul_region_parser(const uint32_t *params, const uint8_t *stream, size_t nbytes, uint64_t stride)
 {
     Cfg c{};
@@ -82,27 +77,25 @@ uint64_t emul_region_parser(const uint32_t *params, const uint8_t *stream, size_
     std::vector<uint32_t> words((nbytes + 3) / 4 + 16, 0u);
     std::memcpy(words.data(), stream, nbytes);
     const TrStream s{words.data(), (nbytes + 3) / 4, (uint64_t)nbytes * 8};
-    RgLaneParser ps{s, c, RgWin{}};
     RgMemParser pm{s, c};
-    HostRing hr(s, c, 3u);
-    ps.seat(0);
+    HostRing hr(s, c);
     hr.ps.seat(0);
+    auto same = [&](uint64_t q, uint32_t ref) {
+        uint32_t id0, nz0, id2, nz2;
+        const uint32_t l0 = pm.cds(q, ref, id0, nz0), l2 = hr.ps.cds(hr.ps.rel_of(q), ref, id2, nz2);
+        return l0 == l2 && (!l0 || (id0 == id2 && nz0 == nz2));
+    };
     for (uint64_t q = 0; q < s.end_bit; q += stride) {
-        for (uint32_t ref = 0; ref < 2; ref++) {
-            uint32_t id0, nz0, id1, nz1, id2, nz2;
-            const uint32_t l0 = pm.cds(q, ref, id0, nz0), l1 = ps.cds(q, ref, id1, nz1), l2 = hr.ps.cds(q, ref, id2, nz2);
-            if (l0 != l1 || (l0 && (id0 != id1 || nz0 != nz1))) return q + 1;
-            if (l0 != l2 || (l0 && (id0 != id2 || nz0 != nz2))) return q + 1;
-        }
-        if ((q & 1023u) == 0u) {              // (jumps back and forth, as the tests of the guess do)
+        for (uint32_t ref = 0; ref < 2; ref++)
+            if (!same(q, ref)) return q + 1;
+        if ((q & 1023u) == 0u) {
             for (uint64_t d : {700ull, 300ull, 5000ull}) {
                 const uint64_t back = q > d ? q - d : 0;
-                uint32_t id0, nz0, id1, nz1, id2, nz2;
-                const uint32_t l0 = pm.cds(back, 1u, id0, nz0), l1 = ps.cds(back, 1u, id1, nz1), l2 = hr.ps.cds(back, 1u, id2, nz2);
-                if (l0 != l1 || (l0 && (id0 != id1 || nz0 != nz1))) return back + 1;
-                if (l0 != l2 || (l0 && (id0 != id2 || nz0 != nz2))) return back + 1;
+                if (back < hr.ps.base_bits) continue;    // (a ring serves positions from its base on)
+                if (!same(back, 1u)) return back + 1;
             }
         }
+        if ((q & 16383u) == 8191u) hr.ps.seat(q + 1);    // (a new base, as every walk has its own)
     }
     return 0;
 }
@@ -125,11 +118,10 @@ int emul_region_index(const uint32_t *params, const uint8_t *stream, size_t nbyt
     std::vector<RgEntry> found(nreg), entry(nreg);
     found[0] = RgEntry{0, 0, 1};
     for (uint64_t r = 1; r < nreg; r++) {
-        HostRing hr(s, c, 5u);
-        RgRingParser &ps = hr.ps;
+        HostRing hr(s, c);
         uint64_t at = 0;
         const uint64_t from = r * region_bits;
-        const bool got = rg_guess(ps, c, from, from + 2 * region_bits, s.end_bit, budget, at);
+        const bool got = rg_guess(hr.ps, c, from, (uint32_t)(2 * region_bits), budget, at);
         found[r] = RgEntry{got ? at : 0, 0, got ? 1u : 0u};
         if (got && sabotage_every && r % sabotage_every == 0) found[r].pos = (uint64_t)((int64_t)at + sabotage_shift);
     }
@@ -154,8 +146,8 @@ int emul_region_index(const uint32_t *params, const uint8_t *stream, size_t nbyt
     std::vector<RgState> ex(nreg);
     std::vector<uint32_t> cnt(nreg, 0);
     auto walk = [&](uint64_t r) {
-        HostRing hr(s, c, 7u);
-        RgRingParser &ps = hr.ps;
+        HostRing hr(s, c);
+        RgRing &ps = hr.ps;
         RgState x{entry[r].pos, entry[r].b, 0};
         const uint64_t nl = next_live(r);
         uint32_t n = 0;
@@ -217,7 +209,8 @@ int emul_region_index(const uint32_t *params, const uint8_t *stream, size_t nbyt
     RgState x{};
     for (uint64_t r = 0; r <= last; r++) {
         if (!entry[r].live) continue;
-        RgLaneParser ps{s, c, RgWin{}};
+        HostRing hr(s, c);
+        RgRing &ps = hr.ps;
         x = RgState{entry[r].pos, entry[r].b, 0};
         const uint64_t nl = next_live(r);
         rg_walk(ps, c, x, nl < nreg && r != last ? entry[nl].pos : ~0ull, ~0ull,
