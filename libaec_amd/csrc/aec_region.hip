@@ -406,7 +406,9 @@ RegionPlan region_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint
     if (!tune("AEC_IDX_REGIONS", 1)) return p;
     // the guess looks for the coded data set that holds a reference sample and reads the options around it
     if (!(c.flags & F_PREPROCESS) || (c.flags & F_PAD_RSI) || c.id_len < 3u || !rsi_bits_hint) return p;
-    if (total_bits < (uint64_t)tune("AEC_IDX_REGIONS_MIN", 1u << 23)) return p;
+    // (large streams: the passes are as long as one lane's guess and walks -- a few milliseconds whatever the size -- and
+    // below half a gigabit of stream the window tables, which cost 3 ms per 100 MiB of input, are through first)
+    if (total_bits < (uint64_t)tune("AEC_IDX_REGIONS_MIN", 1u << 29)) return p;
     // RSIs beyond the phase-locked scheme's; short coded data sets: a lane takes one per step whatever its length, and with
     // hundreds of bits per coded data set (config 3, the sample file) a region of one RSI is too long a walk for one lane
     // -- the trunk and the plausibility scheme of aec_idx.hip, which put a wavefront on such a region, are faster
@@ -427,8 +429,8 @@ RegionPlan region_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint
     p.nreg = (uint32_t)nreg;
     p.region_bits = region;
     p.avg_cds = (uint32_t)(rsi_bits_hint / c.rsi);
-    p.budget = tune("AEC_IDX_REGION_BUDGET", (c.rsi <= kRgVerifyMaxRsi ? 4u : 2u) * c.rsi + 640u);
-    p.passes = tune("AEC_IDX_REGION_PASSES", 12);
+    p.budget = tune("AEC_IDX_REGION_BUDGET", (c.rsi <= kRgVerifyMaxRsi ? 3u : 2u) * c.rsi + 384u);
+    p.passes = tune("AEC_IDX_REGION_PASSES", 8);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t o = 0;
     p.o_flags = o;  o = up(o + 64);

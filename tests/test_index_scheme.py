@@ -24,7 +24,8 @@ CASES = [
     ("the sample file's shape, 1 GiB: entries by plausibility", 16, 64, 256, PP | MSB, 755_000_000, 184_000, 0, LOCKED),
     ("16 MiB of 8-bit data, rsi 32", 8, 8, 32, PP, 5_955_000, 762, 0, LOCKED),
     ("16 MiB of 8-bit data, rsi 33: the tables resolve RSIs that short badly (72 ms)", 8, 8, 33, PP, 5_953_000, 786, 0, LOCKED),
-    ("16 MiB of 8-bit data, rsi 48", 8, 8, 48, PP, 5_940_000, 1140, 0, REGIONS),
+    ("16 MiB of 8-bit data, rsi 48", 8, 8, 48, PP, 5_940_000, 1140, 0, TABLES),
+    ("config 2, 256 MiB: below half a gigabit of stream the window tables are through first", 16, 16, 128, PP, 47_700_000, 5800, 0, TABLES),
     ("16 MiB of 16-bit data, rsi 32", 16, 16, 32, PP, 2_930_000, 1470, 0, LOCKED),
     ("16 MiB without the preprocessor: piece by piece", 16, 16, 16, 0, 16_640_000, 4160, 0, EVERY_BIT),
     ("16 MiB of 8-bit data without the preprocessor, rsi 128: the trunk is faster", 8, 8, 128, 0, 16_060_000, 8600, 0, TRUNK),
