@@ -672,6 +672,22 @@ def test_fused_encoder_edges(env):
     assert out.returncode == 0 and "fused edges ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 
 
+def test_every_index_scheme_on_the_same_streams():
+    """tests/cross_scheme.py: ~40 streams across the dispatch thresholds of launch_index (RSIs of 1 .. 4096 blocks, 100 KiB ..
+    20 MiB, with and without the preprocessor), each through EVERY scheme that may legally take it -- the tuning build's
+    switches take the schemes away one after the other: every bit parsed, regions, phase-locked chains, window tables,
+    trunk -- against the oracle encoder's RSI starts and the oracle's bytes: whole, cut short, with the caller's bound in
+    front of the end, and resumed inside an RSI."""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e["AEC_AMD_LIB"] = os.path.join(ROOT, "libaec_amd", "lib", "tuning", "libaec.so.0")
+    assert os.path.exists(e["AEC_AMD_LIB"])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "cross_scheme.py")], env=e, capture_output=True,
+                         text=True, timeout=1500)
+    assert out.returncode == 0 and "cross scheme ok" in out.stdout, (out.stdout[-3000:], out.stderr[-3000:])
+
+
 @pytest.mark.parametrize("bps,bs,rsi,n_rsi,long_hi", [
     (16, 16, 8, 200, 120),      # coded data sets of up to 1900 bits where the encoder's bound is 277
     (8, 8, 128, 20, 200),
