@@ -781,8 +781,10 @@ int decode_call(struct aec_stream *strm, int flush)
             size_t n = strm->avail_in < backlog_max ? strm->avail_in : backlog_max;
             if (n >= kDecDirectMin && s->stage.empty()) {
                 rc = upload(s, strm->next_in, n);
-                // (a one-shot caller's whole stream did not fit beside its output and the index workspace: in pieces
-                // of the ordinary backlog, as before round 4 -- only then AEC_MEM_ERROR)
+                // (the staging buffer for a one-shot caller's whole stream could not be allocated: in pieces of the
+                // ordinary backlog, as before round 4 -- only then AEC_MEM_ERROR.  A stream that goes up whole and then
+                // finds no memory for its output or its index workspace is NOT retried here: decode_run reports it, or
+                // the index pass falls back to a smaller workspace / the serial walk: aec_gpu.hip index_common)
                 if (rc == AEC_MEM_ERROR && n > kBacklogMax) {
                     (void)hipGetLastError();
                     n = kBacklogMax;

@@ -329,8 +329,16 @@ static int index_common(aec_gpu_ctx *ctx, const aec_gpu_params *p, const void *d
         ctx->idx_ws = nullptr;
         ctx->idx_ws_bytes = 0;
         const size_t want = need + need / 16;
-        if (hipMalloc(&ctx->idx_ws, want) == hipSuccess) ctx->idx_ws_bytes = want;
-        else (void)hipGetLastError();
+        if (hipMalloc(&ctx->idx_ws, want) == hipSuccess) {
+            ctx->idx_ws_bytes = want;
+        } else {
+            // (the every-bit scheme's tables are the largest by far for what they serve -- up to 270 MB for a 2 MiB
+            // stream: without them before the serial walk)
+            (void)hipGetLastError();
+            const size_t less = index_workspace_bytes_large(c, in_bytes, start_bit, hint);
+            if (less && less < need && hipMalloc(&ctx->idx_ws, less) == hipSuccess) ctx->idx_ws_bytes = less;
+            else (void)hipGetLastError();
+        }
     }
     ctx->idx_used_hint = hint;
     if (d_seg_bits && !decode_bare_supported(c)) d_seg_bits = nullptr;

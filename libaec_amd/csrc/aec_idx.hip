@@ -2502,7 +2502,9 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
             const uint32_t incl = wave_incl_sum_dpp(pc);
             if (i < pwords) prank[i + 1u] = (uint16_t)(carry + incl);
             uint32_t at = carry + incl - pc, bits = word;
-            const uint32_t bbase = wi * 32u + 1u;
+            // (positions relative to the piece: the window has 131 072 bits, the table 16 bits per entry -- window
+            // positions wrapped in the upper half of every window and no entry there resolved: ADVICE round 5)
+            const uint32_t bbase = i * 32u + 1u;
             while (bits) {
                 const uint32_t z = (uint32_t)__builtin_clz(bits);
                 bits &= ~(0x80000000u >> z);
@@ -2531,7 +2533,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         const uint32_t pi = w1 - (pc0 >> 5);
         const uint32_t r1 = (uint32_t)prank[pi < kIdxPieceWords ? pi : kIdxPieceWords] + (sh1 ? (uint32_t)__builtin_popcount(win[w1c] >> (32u - sh1)) : 0u);
         const uint32_t k = r1 + n - 1u;
-        const uint32_t e = (k < tcnt && n != 0u) ? (uint32_t)ones[k] : 0u;
+        const uint32_t e = (k < tcnt && n != 0u) ? pc0 + (uint32_t)ones[k] : 0u;
         const uint32_t add = low ? 0u : n * (id - 1u);
         const uint32_t end = unc ? q + il + c.bs * c.bps : e + add;
         const bool ok = (unc || e != 0u) && q1 < plim && end <= plim && end - q < 4096u;
@@ -5418,7 +5420,6 @@ int index_scheme(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint, uint32_t
     return trunk_plan(c, bits, rsi_bits_hint, 0).ok ? 3 : 0;
 }
 
-static size_t index_workspace_bytes_large(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint);
 
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
 {
@@ -5427,12 +5428,12 @@ size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, 
     // (a small stream: the brute-force scheme for a walk from an RSI start, the others for one that resumes inside)
     const SmallPlan sm = small_plan(c, end_bit - start_bit, 1ull << 62, 0u, rsi_bits_hint);
     // (the regions in front of whatever would run without them)
-    const RegionPlan rp = region_plan(c, end_bit - start_bit, rsi_bits_hint, false);
+    const RegionPlan rp = region_plan(c, end_bit - start_bit, rsi_bits_hint, decode_bare_supported(c));
     const size_t rest = index_workspace_bytes_large(c, in_bytes, start_bit, rsi_bits_hint) + (rp.ok ? rp.bytes : 0);
     return sm.ok && sm.bytes > rest ? sm.bytes : rest;
 }
 
-static size_t index_workspace_bytes_large(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
+size_t index_workspace_bytes_large(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint)
 {
     const uint64_t end_bit = (uint64_t)in_bytes * 8;
     if (start_bit >= end_bit) return 0;

@@ -149,10 +149,15 @@ bool launch_decode_bare(const Cfg &c, const uint8_t *d_in, size_t in_bytes, cons
 // less than that means more, smaller spans) the walk hops over the trunk tables built by all CUs (aec_idx.hip).
 // rsi_bits_hint: estimate of the coded size of one RSI (0 = unknown); it sizes burn-in, regions and records.
 size_t index_workspace_bytes(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint);
+// ... without the every-bit scheme's tables (8 .. 16 bytes per bit of a small stream): what to ask for when the full
+// size cannot be had -- launch_index takes whatever scheme the workspace it is given has room for
+size_t index_workspace_bytes_large(const Cfg &c, size_t in_bytes, uint64_t start_bit, uint64_t rsi_bits_hint);
 bool index_is_windowed(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint);
 // the scheme launch_index takes with the workspace index_workspace_bytes asks for: 0 serial walk, 1 phase-locked
 // chains, 2 window tables, 3 trunk, 4 every bit parsed (small streams), 5 regions walked from guessed entries (large
-// streams; what it does not deliver is left to the scheme this function would name without it)
+// streams; what it does not deliver is left to the scheme this function would name without it).  It describes the plain
+// index pass (aec_gpu_index_async / aec_gpu_index_resume_async): with segment starts (d_seg_bits) or as a piece of a
+// longer stream (stop_near) launch_index skips schemes 4 and 1, which deliver neither.
 int index_scheme(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint, uint32_t start_block);
 // d_seg_bits (optional; (max_rsi + 1) * segs_per_rsi entries, set to ~0 by the caller): where the index runs over
 // the trunk tables it also leaves the start bit of every segment of the RSIs it finds (launch_decode_bare); the
@@ -172,9 +177,9 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
 // stream has been delivered (the skip_if of the schemes enqueued behind).
 struct RegionPlan {
     bool ok;
-    uint32_t nreg, budget, passes, avg_cds;
+    uint32_t nreg, budget, passes, avg_cds, K;
     uint64_t region_bits;
-    size_t o_flags, o_found, o_entry[2], o_exit[2], o_cnt[2], o_base, bytes;
+    size_t o_flags, o_found, o_entry[2], o_exit[2], o_cnt[2], o_base, o_list, o_slist, bytes;
 };
 RegionPlan region_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, bool want_segments);
 const uint32_t *launch_index_regions(const Cfg &c, const RegionPlan &p, const uint32_t *words, uint64_t nwords,

@@ -38,6 +38,9 @@ struct RgTables {
     RgState *exit[2];          // [nreg] where the walk of the region arrived
     uint32_t *cnt[2];          // [nreg] RSI starts the walk met
     uint64_t *base;            // [nreg + 1] ... in front of the region
+    uint64_t *list;            // [nreg * K] the first K of them, as the region's last walk met them
+    uint64_t *slist;           // [nreg * K * segments per RSI] and their segment starts (null: not asked for)
+    uint32_t K;
     uint32_t *flags;           // [0] delivered, [1] entries do not agree, [2] region in which the input ended,
                                // [3] stepped aside, [4] live regions, [5] regions mended (all passes), [6] the guesses' queue,
                                // [7] first region whose entry is not where the walk in front arrived
@@ -164,12 +167,25 @@ __device__ __forceinline__ void rg_walk_region(const Cfg &c, const TrStream &s, 
     RgState x{mine.pos, mine.b, 0u};
     const uint32_t nl = rg_next_live(e, r, t.nreg);
     uint32_t n = 0;
+    const uint32_t spr = c.segs_per_rsi;
+    uint64_t *list = t.list + (size_t)r * t.K, *slist = t.slist ? t.slist + (size_t)r * t.K * spr : nullptr;
+    // (the RSI starts go to the region's list as they are met, so that the last pass need not walk again: k_rg_fill)
     rg_walk(ps, c, x, nl < t.nreg ? e[nl].pos : ~0ull, nl < t.nreg ? t.max_walk : ~0ull,
-            [&](uint64_t) {
+            [&](uint64_t pos) {
+                if (n < t.K) {
+                    list[n] = pos;
+                    if (slist) {
+                        slist[(size_t)n * spr] = pos;
+                        for (uint32_t k = 1; k < spr; k++) slist[(size_t)n * spr + k] = ~0ull;
+                    }
+                }
                 n++;
                 return true;
             },
-            [](uint32_t, uint64_t) {});
+            [&](uint32_t b, uint64_t pos) {
+                // (the RSI a walk resumed in has no entries: its first blocks lie in front of the input)
+                if (slist && n && n <= t.K) slist[(size_t)(n - 1u) * spr + (b >> 6)] = pos;
+            });
     cnt_out[r] = n;
     ex_out[r] = x;
 }
@@ -322,11 +338,73 @@ k_rg_fill(const Cfg c, const TrStream s, const RgTables t, uint32_t cur, uint64_
     if (idx > max_rsi) return;                       // (behind the caller's bound)
     const bool last = r == t.flags[2];
     const uint32_t nl = rg_next_live(e, r, t.nreg);
+    const uint32_t spr = c.segs_per_rsi;
+    if (mycnt <= t.K && (!seg_bits || t.slist)) {
+        // the region's RSI starts lie in its list: no walk
+        const uint64_t *list = t.list + (size_t)r * t.K;
+        const uint64_t *slist = t.slist ? t.slist + (size_t)r * t.K * spr : nullptr;
+        // the last RSI start in front of this region, from the lists of the regions in front (a region whose list is
+        // not whole: the caller's, as a walk would find it -- only asked by the lane that writes the record)
+        auto start_in_front = [&]() -> uint64_t {
+            for (uint32_t q = r; q-- > 0u;) {
+                if (!e[q].live || !t.cnt[cur][q]) continue;
+                const uint32_t nq = t.cnt[cur][q];
+                if (nq <= t.K) return t.list[(size_t)q * t.K + nq - 1u];
+                break;
+            }
+            return rsi_start_in;
+        };
+        uint32_t i = 0;
+        bool clipped = false;
+        for (; i < mycnt; i++) {
+            if (idx == max_rsi) {                    // the caller's bound: the pass ends on this RSI start
+                clipped = true;
+                break;
+            }
+            rsi_off[idx] = list[i];
+            if (seg_bits)
+                for (uint32_t k = 0; k < spr; k++) seg_bits[idx * spr + k] = slist[(size_t)i * spr + k];
+            idx++;
+        }
+        const RgState x = t.exit[cur][r];
+        if (!clipped && !(last && x.st)) return;     // the walk goes on in the next region
+        // (an RSI start the next region begins on is that region's: a bound met there is met there)
+        if (clipped) {
+            res->n_rsi = max_rsi;
+            res->tail_blocks = 0;
+            res->end_bit = list[i];
+            res->status = DEC_OK;
+            res->pad = 0u;
+            res->bad_rsi = ~0ull;
+            if (tail_slot) rsi_off[max_rsi] = i ? list[i - 1u] : start_in_front();
+            __threadfence();
+            t.flags[0] = 1u;
+            return;
+        }
+        if (x.st != 1u || s.end_bit - x.pos > kTrMaxScan) return;
+        {
+            BitReader br;
+            br.init(s.words, s.nwords, s.end_bit, x.pos);
+            uint32_t nblk = 1;
+            if (skip_cds(br, c, (x.b == 0u && (c.flags & F_PREPROCESS)) ? 1u : 0u, x.b, nblk) != DEC_NEED_INPUT) return;
+        }
+        if (idx == 0) return;
+        res->n_rsi = idx - 1u;
+        res->tail_blocks = x.b;
+        res->end_bit = x.pos;
+        res->status = DEC_OK;
+        res->pad = 1u;
+        res->bad_rsi = ~0ull;
+        if (tail_slot) rsi_off[max_rsi] = mycnt ? list[mycnt - 1u] : start_in_front();
+        __threadfence();
+        t.flags[0] = 1u;
+        return;
+    }
+    // a region with more RSI starts than its list holds (a constant stretch: an RSI in a few dozen bits): walked again
     RG_RING(ps);
     RgState x{mine.pos, mine.b, 0u};
     uint64_t cur_start = 0;
     bool met = false, clipped = false;
-    const uint32_t spr = c.segs_per_rsi;
     rg_walk(ps, c, x, (nl < t.nreg && !last) ? e[nl].pos : ~0ull, ~0ull,
             [&](uint64_t pos) {
                 if (idx == max_rsi) {                // the caller's bound: the pass ends on this RSI start
@@ -402,19 +480,15 @@ k_rg_fill(const Cfg c, const TrStream s, const RgTables t, uint32_t cur, uint64_
 RegionPlan region_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint, bool want_segments)
 {
     RegionPlan p{};
-    (void)want_segments;
     if (!tune("AEC_IDX_REGIONS", 1)) return p;
     // the guess looks for the coded data set that holds a reference sample and reads the options around it
     if (!(c.flags & F_PREPROCESS) || (c.flags & F_PAD_RSI) || c.id_len < 3u || !rsi_bits_hint) return p;
     // (large streams: the passes are as long as one lane's guess and walks -- a few milliseconds whatever the size -- and
     // below half a gigabit of stream the window tables, which cost 3 ms per 100 MiB of input, are through first)
     if (total_bits < (uint64_t)tune("AEC_IDX_REGIONS_MIN", 1u << 29)) return p;
-    // RSIs beyond the phase-locked scheme's; short coded data sets: a lane takes one per step whatever its length, and with
-    // hundreds of bits per coded data set (config 3, the sample file) a region of one RSI is too long a walk for one lane
-    // -- the trunk and the plausibility scheme of aec_idx.hip, which put a wavefront on such a region, are faster
+    // RSIs beyond the phase-locked scheme's
     const uint64_t cds = rsi_bits_hint / c.rsi;
-    if (c.rsi < 48u || cds < 8u || cds > (uint64_t)tune("AEC_IDX_REGIONS_MAXCDS", 128)) return p;
-    // regions of a few RSIs, 32 kbit at least: the guess walks up to an RSI or two whatever the region's size
+    if (c.rsi < 48u || cds < 8u) return p;
     // regions: enough of them to fill the chip's lanes a few times over (the passes are as long as one lane's walk), but
     // of a few RSIs, 16 kbit at least: the guess walks an RSI or two whatever the region's size
     uint64_t region = (uint64_t)tune("AEC_IDX_REGION_BITS", 0);
@@ -425,11 +499,18 @@ RegionPlan region_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint
     }
     region = (region + 63) & ~63ull;
     const uint64_t nreg = (total_bits + region - 1) / region;
-    if (nreg < 16 || nreg > (1u << 22)) return p;
+    // (long coded data sets -- config 3, the sample file: a region is an RSI and a lane's walk of it takes milliseconds
+    // whatever the size of the stream; from a few thousand RSIs on that is less than the trunk's 20 ms per GiB)
+    // (and only where RSIs have eight segments and more: shorter ones with long coded data sets -- the sample file -- are
+    // the plausibility scheme's of aec_idx.hip, a wavefront per region: 16 against 24 ms per GiB)
+    if (cds > 128u && c.segs_per_rsi < 8u) return p;
+    if (nreg < (cds > 128u ? (uint64_t)tune("AEC_IDX_REGIONS_LONG", 3072) : 16u) || nreg > (1u << 22)) return p;
     p.nreg = (uint32_t)nreg;
     p.region_bits = region;
     p.avg_cds = (uint32_t)(rsi_bits_hint / c.rsi);
-    p.budget = tune("AEC_IDX_REGION_BUDGET", (c.rsi <= kRgVerifyMaxRsi ? 3u : 2u) * c.rsi + 384u);
+    // (the guess: an anchor -- two parses per bit of a coded data set --, the walk to an RSI start, tests, and the
+    // candidate's RSI once more where RSIs are short; three-bit options say less: more of it)
+    p.budget = tune("AEC_IDX_REGION_BUDGET", (uint32_t)((c.rsi <= kRgVerifyMaxRsi ? (c.id_len <= 3u ? 4u : 3u) : 2u) * c.rsi + 384u + 3u * cds));
     p.passes = tune("AEC_IDX_REGION_PASSES", 8);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t o = 0;
@@ -441,6 +522,12 @@ RegionPlan region_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint
         p.o_cnt[k] = o;   o = up(o + nreg * 4);
     }
     p.o_base = o;   o = up(o + (nreg + 1) * 8);
+    // the RSI starts a region's walk meets: room for four times what the hint expects (a walk takes the regions without
+    // an entry behind it along) and a few
+    p.K = (uint32_t)(4u * (region / rsi_bits_hint) + 8u);
+    p.o_list = o;   o = up(o + nreg * p.K * 8);
+    p.o_slist = o;
+    if (want_segments) o = up(o + nreg * p.K * (size_t)c.segs_per_rsi * 8);
     p.bytes = o;
     p.ok = true;
     return p;
@@ -461,6 +548,9 @@ const uint32_t *launch_index_regions(const Cfg &c, const RegionPlan &p, const ui
         t.cnt[k] = reinterpret_cast<uint32_t *>(base + p.o_cnt[k]);
     }
     t.base = reinterpret_cast<uint64_t *>(base + p.o_base);
+    t.list = reinterpret_cast<uint64_t *>(base + p.o_list);
+    t.slist = (d_seg_bits && p.o_slist != p.bytes) ? reinterpret_cast<uint64_t *>(base + p.o_slist) : nullptr;
+    t.K = p.K;
     t.nreg = p.nreg;
     t.budget = p.budget;
     t.period = rg_ring_period(p.avg_cds);

@@ -20,6 +20,7 @@ CASES = [
     ("config 3, 1 MiB: the tables do not serve it, the trunk's launches would cost 4.5 ms", 32, 32, 4096, PP, 260_000,
      1_040_000, 0, EVERY_BIT),
     ("config 3, 1 GiB", 32, 32, 4096, PP, 260_000_000, 1_040_000, 0, TRUNK),
+    ("config 3, 4 GiB: a lane per RSI", 32, 32, 4096, PP, 1_037_000_000, 1_013_000, 0, REGIONS),
     ("the sample file's shape, 1 MiB", 16, 64, 256, PP | MSB, 737_000, 184_000, 0, EVERY_BIT),
     ("the sample file's shape, 1 GiB: entries by plausibility", 16, 64, 256, PP | MSB, 755_000_000, 184_000, 0, LOCKED),
     ("16 MiB of 8-bit data, rsi 32", 8, 8, 32, PP, 5_955_000, 762, 0, LOCKED),
