@@ -95,18 +95,23 @@ AEC_HD uint32_t rg_select32(uint32_t v, uint32_t n)
 // few steps one of them is short.)  The ring keeps kRgRingBack words behind the parse (the guess goes back a few coded
 // data sets for its tests); a lane that jumps out of its ring, or consumed faster than the top-ups bring, fills up at
 // once and the wavefront waits.
-constexpr uint32_t kRgRingWords = 64, kRgRingMirror = 8, kRgRingBack = 16, kRgRingChunks = 8;
-constexpr uint32_t kRgRingRows = kRgRingWords + kRgRingMirror;
+constexpr uint32_t kRgRingMirror = 8, kRgRingChunks = 8;
+// (WORDS: the ring's size, 32 or 64 -- the LDS it takes decides how many wavefronts a CU holds, and the walks of short
+// coded data sets, which go forward only, do with the smaller; a quarter of it stays behind the parse)
+constexpr uint32_t rg_ring_rows(uint32_t words) { return words + kRgRingMirror; }
 
 struct RgChunk {
     uint32_t a, b, c, d;      // four stream words as they lie in memory
 };
 
-struct RgRing {
+// STRIDE: words between two rows of a lane's column (64 in LDS: a row holds the 64 lanes' words; 1 in the emulator)
+template <uint32_t STRIDE, uint32_t WORDS = 64u>
+struct RgRingT {
+    static constexpr uint32_t stride = STRIDE, kRgRingWords = WORDS, kRgRingBack = WORDS / 4u;
+    static_assert(WORDS == 32u || WORDS == 64u, "a power of two that holds a parse's seven words and the top-up's chunks");
     const TrStream &s;
     const Cfg &c;
     uint32_t *ring;
-    uint32_t stride;
     uint64_t base_bits;        // positions are base_bits + rel; a multiple of 128
     uint32_t wbase;            // low bits of base_bits / 32 (the slot of relative word 0)
     uint32_t lo, hi;           // relative words [lo, hi) are in the ring; multiples of 4, hi - lo <= kRgRingWords
@@ -116,10 +121,9 @@ struct RgRing {
     uint32_t pv;               // chunks in flight: relative words [hi, hi + 4 pv)
     RgChunk p0, p1, p2, p3, p4, p5, p6, p7;      // (named: see RgGuess::hp0)
 
-    AEC_HD void init(uint32_t *ring_, uint32_t stride_, uint32_t period_)
+    AEC_HD void init(uint32_t *ring_, uint32_t period_)
     {
         ring = ring_;
-        stride = stride_;
         period = period_ ? period_ : 1u;
         aligned16 = (reinterpret_cast<uintptr_t>(s.words) & 15u) == 0u;
         seat(0);
@@ -190,6 +194,22 @@ struct RgRing {
         const uint32_t room = (kRgRingWords - (hi - lo)) >> 2;
         const uint32_t n = room < kRgRingChunks ? room : kRgRingChunks;
         pv = n;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (all of them inside the buffer, which begins on a 16-byte boundary -- the rule: one address, eight loads)
+        const uint64_t w = (base_bits >> 5) + hi;
+        if (aligned16 && w + 4u * n <= s.nwords) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(s.words + w);
+            if (n > 0u) { const uint4 v = src[0]; p0 = RgChunk{v.x, v.y, v.z, v.w}; }
+            if (n > 1u) { const uint4 v = src[1]; p1 = RgChunk{v.x, v.y, v.z, v.w}; }
+            if (n > 2u) { const uint4 v = src[2]; p2 = RgChunk{v.x, v.y, v.z, v.w}; }
+            if (n > 3u) { const uint4 v = src[3]; p3 = RgChunk{v.x, v.y, v.z, v.w}; }
+            if (n > 4u) { const uint4 v = src[4]; p4 = RgChunk{v.x, v.y, v.z, v.w}; }
+            if (n > 5u) { const uint4 v = src[5]; p5 = RgChunk{v.x, v.y, v.z, v.w}; }
+            if (n > 6u) { const uint4 v = src[6]; p6 = RgChunk{v.x, v.y, v.z, v.w}; }
+            if (n > 7u) { const uint4 v = src[7]; p7 = RgChunk{v.x, v.y, v.z, v.w}; }
+            return;
+        }
+#endif
         if (n > 0u) p0 = load_chunk(hi);
         if (n > 1u) p1 = load_chunk(hi + 4u);
         if (n > 2u) p2 = load_chunk(hi + 8u);
@@ -236,8 +256,7 @@ struct RgRing {
         }
         if (!in) return 0;
         const uint32_t *q = ring + (size_t)((wbase + rw) & (kRgRingWords - 1u)) * stride;
-        const uint32_t w0 = q[0], w1 = q[stride], w2 = q[2u * stride], w3 = q[3u * stride], w4 = q[4u * stride],
-                       w5 = q[5u * stride], w6 = q[6u * stride];
+        const uint32_t w0 = q[0], w1 = q[stride];
         const uint32_t left = end_rel - rel;
         const uint32_t sh = rel & 31u;
         const uint32_t h = spec_shl_hi(w0, w1, sh);
@@ -248,9 +267,10 @@ struct RgRing {
         const uint32_t need = low ? (selbit ? c.bs / 2u : 1u) : c.bs - ref;
         const uint32_t add = low ? 0u : need * (id - 1u);
         const uint32_t o2 = sh + hdr, i = o2 >> 5, t2 = o2 & 31u;               // o2 < 70: i <= 2
-        const uint32_t a0 = i == 0u ? w0 : (i == 1u ? w1 : w2), a1 = i == 0u ? w1 : (i == 1u ? w2 : w3),
-                       a2 = i == 0u ? w2 : (i == 1u ? w3 : w4), a3 = i == 0u ? w3 : (i == 1u ? w4 : w5),
-                       a4 = i == 0u ? w4 : (i == 1u ? w5 : w6);
+        // (the five words the unary part begins in: a second read at their own row -- cheaper than picking them out of
+        // seven by i; rows up to 6 behind the first: the mirror rows serve them)
+        const uint32_t *qa = q + (size_t)i * stride;
+        const uint32_t a0 = qa[0], a1 = qa[stride], a2 = qa[2u * stride], a3 = qa[3u * stride], a4 = qa[4u * stride];
         // 128 bits of unary part in four pieces; their running counts of 1-bits say which holds the need-th
         const uint32_t u0 = spec_shl_hi(a0, a1, t2), u1 = spec_shl_hi(a1, a2, t2), u2 = spec_shl_hi(a2, a3, t2),
                        u3 = spec_shl_hi(a3, a4, t2);
@@ -571,7 +591,8 @@ struct RgGuess {
 
 // The first RSI start the guess from bit `from` recognises within `budget` coded data sets, in front of `limit` bits
 // from there (the walk of the guess does not go beyond).
-AEC_HD bool rg_guess(RgRing &ps, const Cfg &c, uint64_t from, uint32_t limit, uint32_t budget, uint64_t &rsi_start,
+template <class RING>
+AEC_HD bool rg_guess(RING &ps, const Cfg &c, uint64_t from, uint32_t limit, uint32_t budget, uint64_t &rsi_start,
                      uint64_t *parses = nullptr)
 {
     ps.seat(from);
@@ -608,8 +629,8 @@ struct RgEntry {
 // AEC_PAD_RSI the next RSI begins on a byte, decode.c:407-408).  at_rsi(pos) is called at every RSI start in front of
 // the target, BEFORE the step; false ends the walk there.  at_seg(b, pos): at every other coded data set that begins on
 // a multiple of 64 blocks (the segment starts).  Cut short (st 3) after max_bits.
-template <class FR, class FS>
-AEC_HD void rg_walk(RgRing &ps, const Cfg &c, RgState &x, uint64_t target, uint64_t max_bits, FR at_rsi, FS at_seg)
+template <class RING, class FR, class FS>
+AEC_HD void rg_walk(RING &ps, const Cfg &c, RgState &x, uint64_t target, uint64_t max_bits, FR at_rsi, FS at_seg)
 {
     ps.seat(x.pos);
     const uint64_t base = ps.base_bits;

@@ -50,11 +50,11 @@ struct RgTables {
 };
 
 // the lane's ring: a column of the workgroup's LDS (one wavefront per workgroup)
-#define RG_RING(ps)                                                             \
+#define RG_RING(ps, W)                                                          \
     extern __shared__ __attribute__((aligned(16))) uint32_t rg_lds[];          \
-    RgRing ps{s, c};                                                            \
-    ps.init(rg_lds + (threadIdx.x & 63u), 64u, t.period)
-constexpr size_t kRgLds = (size_t)kRgRingRows * 64u * 4u;
+    RgRingT<64u, W> ps{s, c};                                                   \
+    ps.init(rg_lds + (threadIdx.x & 63u), t.period)
+constexpr size_t rg_lds_bytes(uint32_t words) { return (size_t)rg_ring_rows(words) * 64u * 4u; }
 
 __device__ __forceinline__ bool rg_off(const RgTables &t)
 {
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(64)
 k_rg_guess(const Cfg c, const TrStream s, const RgTables t)
 {
     if (t.skip_if && *t.skip_if) return;
-    RG_RING(ps);
+    RG_RING(ps, 64u);
     const uint32_t lane = threadIdx.x & 63u;
     RgGuess g;
     g.init(0);
@@ -160,10 +160,11 @@ __device__ __forceinline__ bool rg_differs(const RgEntry *e, const RgState *ex, 
     return p.st != 0u || p.pos != m.pos || p.b != m.b;
 }
 
+template <uint32_t W>
 __device__ __forceinline__ void rg_walk_region(const Cfg &c, const TrStream &s, const RgTables &t, const RgEntry *e, uint32_t r,
                                                RgEntry mine, RgState *ex_out, uint32_t *cnt_out)
 {
-    RG_RING(ps);
+    RG_RING(ps, W);
     RgState x{mine.pos, mine.b, 0u};
     const uint32_t nl = rg_next_live(e, r, t.nreg);
     uint32_t n = 0;
@@ -190,6 +191,8 @@ __device__ __forceinline__ void rg_walk_region(const Cfg &c, const TrStream &s, 
     ex_out[r] = x;
 }
 
+// W: the lanes' rings (32 words where coded data sets are short: twice the wavefronts per CU)
+template <uint32_t W>
 __global__ void __launch_bounds__(64)
 k_rg_walk(const Cfg c, const TrStream s, const RgTables t)
 {
@@ -202,10 +205,11 @@ k_rg_walk(const Cfg c, const TrStream s, const RgTables t)
         t.cnt[0][r] = 0u;
         return;
     }
-    rg_walk_region(c, s, t, t.entry[0], r, mine, t.exit[0], t.cnt[0]);
+    rg_walk_region<W>(c, s, t, t.entry[0], r, mine, t.exit[0], t.cnt[0]);
 }
 
 // one mending pass, from the tables `cur` into the tables `cur ^ 1`
+template <uint32_t W>
 __global__ void __launch_bounds__(64)
 k_rg_mend(const Cfg c, const TrStream s, const RgTables t, uint32_t cur)
 {
@@ -232,7 +236,7 @@ k_rg_mend(const Cfg c, const TrStream s, const RgTables t, uint32_t cur)
     atomicAdd(&t.flags[5], 1u);
     // (the entries of the regions behind are the same in both sets unless they are mended in this pass -- and then the one
     // in front of them was in doubt: the walk's target is the entry the NEXT pass will compare with)
-    rg_walk_region(c, s, t, e, r, mine, t.exit[cur ^ 1u], t.cnt[cur ^ 1u]);
+    rg_walk_region<W>(c, s, t, e, r, mine, t.exit[cur ^ 1u], t.cnt[cur ^ 1u]);
 }
 
 __global__ void k_rg_prep(const RgTables t)
@@ -401,7 +405,7 @@ k_rg_fill(const Cfg c, const TrStream s, const RgTables t, uint32_t cur, uint64_
         return;
     }
     // a region with more RSI starts than its list holds (a constant stretch: an RSI in a few dozen bits): walked again
-    RG_RING(ps);
+    RG_RING(ps, 64u);
     RgState x{mine.pos, mine.b, 0u};
     uint64_t cur_start = 0;
     bool met = false, clipped = false;
@@ -428,7 +432,7 @@ k_rg_fill(const Cfg c, const TrStream s, const RgTables t, uint32_t cur, uint64_
     auto start_in_front = [&]() -> uint64_t {
         for (uint32_t q = r; q-- > 0u;) {
             if (!e[q].live || !t.cnt[cur][q]) continue;
-            RgRing &pq = ps;                             // (this lane's own walk is over)
+            auto &pq = ps;                               // (this lane's own walk is over)
             RgState y{e[q].pos, e[q].b, 0u};
             uint64_t lastpos = rsi_start_in;
             const uint32_t qn = rg_next_live(e, q, t.nreg);
@@ -561,20 +565,23 @@ const uint32_t *launch_index_regions(const Cfg &c, const RegionPlan &p, const ui
     (void)hipMemsetAsync(t.flags, 0, 64, st);
     const uint32_t wg = (p.nreg + 63u) / 64u;
     const uint32_t gwg = wg < 2560u ? wg : 2560u;        // (the guesses come from a queue: as many wavefronts as the chip holds)
-    hipLaunchKernelGGL(k_rg_guess, dim3(gwg), dim3(64), kRgLds, st, c, s, t);
+    const bool small_ring = p.avg_cds <= (uint32_t)tune("AEC_IDX_REGION_RING32", 32);
+    hipLaunchKernelGGL(k_rg_guess, dim3(gwg), dim3(64), rg_lds_bytes(64u), st, c, s, t);
     hipLaunchKernelGGL(k_rg_link, dim3((p.nreg + 255u) / 256u), dim3(256), 0, st, t, start_bit, start_block);
     hipLaunchKernelGGL(k_rg_judge, dim3(1), dim3(1), 0, st, t);
-    hipLaunchKernelGGL(k_rg_walk, dim3(wg), dim3(64), kRgLds, st, c, s, t);
+    if (small_ring) hipLaunchKernelGGL(k_rg_walk<32u>, dim3(wg), dim3(64), rg_lds_bytes(32u), st, c, s, t);
+    else hipLaunchKernelGGL(k_rg_walk<64u>, dim3(wg), dim3(64), rg_lds_bytes(64u), st, c, s, t);
     uint32_t cur = 0;
     for (uint32_t k = 0; k < p.passes; k++) {
-        hipLaunchKernelGGL(k_rg_mend, dim3(wg), dim3(64), kRgLds, st, c, s, t, cur);
+        if (small_ring) hipLaunchKernelGGL(k_rg_mend<32u>, dim3(wg), dim3(64), rg_lds_bytes(32u), st, c, s, t, cur);
+        else hipLaunchKernelGGL(k_rg_mend<64u>, dim3(wg), dim3(64), rg_lds_bytes(64u), st, c, s, t, cur);
         cur ^= 1u;
     }
     hipLaunchKernelGGL(k_rg_prep, dim3(1), dim3(1), 0, st, t);
     hipLaunchKernelGGL(k_rg_check, dim3((p.nreg + 255u) / 256u), dim3(256), 0, st, t, cur);
     hipLaunchKernelGGL(k_rg_sums, dim3(wg), dim3(64), 0, st, t, cur);
     hipLaunchKernelGGL(k_rg_scan, dim3(1), dim3(1024), 0, st, t, cur);
-    hipLaunchKernelGGL(k_rg_fill, dim3(wg), dim3(64), kRgLds, st, c, s, t, cur, d_rsi_off, max_rsi, d_res, tail_slot, rsi_start,
+    hipLaunchKernelGGL(k_rg_fill, dim3(wg), dim3(64), rg_lds_bytes(64u), st, c, s, t, cur, d_rsi_off, max_rsi, d_res, tail_slot, rsi_start,
                        start_block, d_seg_bits);
 #ifdef AEC_TUNING
     if (tune_set("AEC_IDX_STATS")) {                       // (diagnostics: synchronises)

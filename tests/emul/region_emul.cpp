@@ -17,8 +17,8 @@ using namespace aec;
 namespace {
 struct HostRing {                       // the lane's ring as plain memory (stride 1)
     std::vector<uint32_t> mem;
-    RgRing ps;
-    HostRing(const TrStream &s, const Cfg &c) : mem(kRgRingRows, 0u), ps{s, c} { ps.init(mem.data(), 1u, 5u); }
+    RgRingT<1u, 64u> ps;
+    HostRing(const TrStream &s, const Cfg &c) : mem(rg_ring_rows(64u), 0u), ps{s, c} { ps.init(mem.data(), 5u); }
 };
 }  // namespace
 
@@ -80,10 +80,16 @@ uint64_t emul_region_parser(const uint32_t *params, const uint8_t *stream, size_
     RgMemParser pm{s, c};
     HostRing hr(s, c);
     hr.ps.seat(0);
+    std::vector<uint32_t> mem32(rg_ring_rows(32u), 0u);      // (the walks' smaller ring beside it)
+    RgRingT<1u, 32u> small{s, c};
+    small.init(mem32.data(), 3u);
+    small.seat(0);
     auto same = [&](uint64_t q, uint32_t ref) {
-        uint32_t id0, nz0, id2, nz2;
+        uint32_t id0, nz0, id2, nz2, id3, nz3;
         const uint32_t l0 = pm.cds(q, ref, id0, nz0), l2 = hr.ps.cds(hr.ps.rel_of(q), ref, id2, nz2);
-        return l0 == l2 && (!l0 || (id0 == id2 && nz0 == nz2));
+        if (small.base_bits != hr.ps.base_bits) small.seat(hr.ps.base_bits);
+        const uint32_t l3 = small.cds(small.rel_of(q), ref, id3, nz3);
+        return l0 == l2 && (!l0 || (id0 == id2 && nz0 == nz2)) && l0 == l3 && (!l0 || (id0 == id3 && nz0 == nz3));
     };
     for (uint64_t q = 0; q < s.end_bit; q += stride) {
         for (uint32_t ref = 0; ref < 2; ref++)
@@ -147,7 +153,7 @@ int emul_region_index(const uint32_t *params, const uint8_t *stream, size_t nbyt
     std::vector<uint32_t> cnt(nreg, 0);
     auto walk = [&](uint64_t r) {
         HostRing hr(s, c);
-        RgRing &ps = hr.ps;
+        auto &ps = hr.ps;
         RgState x{entry[r].pos, entry[r].b, 0};
         const uint64_t nl = next_live(r);
         uint32_t n = 0;
@@ -210,7 +216,7 @@ int emul_region_index(const uint32_t *params, const uint8_t *stream, size_t nbyt
     for (uint64_t r = 0; r <= last; r++) {
         if (!entry[r].live) continue;
         HostRing hr(s, c);
-        RgRing &ps = hr.ps;
+        auto &ps = hr.ps;
         x = RgState{entry[r].pos, entry[r].b, 0};
         const uint64_t nl = next_live(r);
         rg_walk(ps, c, x, nl < nreg && r != last ? entry[nl].pos : ~0ull, ~0ull,
