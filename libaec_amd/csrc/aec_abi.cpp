@@ -28,6 +28,7 @@
 #include <ctime>
 #include <mutex>
 #include <new>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -878,14 +879,17 @@ thread_local bool t_in_part = false;          // this thread is one of run_parts
 
 // Waiting for a kit's stream inside the batch paths.  With several host threads each waiting on a stream of its own,
 // hipStreamSynchronize was measured to return up to 9 ms late now and then (2.4 ms batches taking 10); polling the
-// stream does not.
+// stream does not.  The poll yields for the first few dozen microseconds -- a small batch is through by then -- and then
+// sleeps between two looks (round 6: a part thread burnt a core for the whole of its batch; the timer's slack, ~60 us,
+// is a few per cent of the milliseconds such a batch takes).
 hipError_t batch_sync(hipStream_t st)
 {
     if (!t_in_part) return hipStreamSynchronize(st);
-    for (;;) {
+    for (unsigned spins = 0;; spins++) {
         const hipError_t e = hipStreamQuery(st);
         if (e != hipErrorNotReady) return e;
-        std::this_thread::yield();
+        if (spins < 256u) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(25));
     }
 }
 
@@ -1111,10 +1115,11 @@ int decode_batch(const struct aec_stream *prm, size_t n, const void *const *src,
     };
     auto landed = [&](size_t piece) -> bool {
         if (!t_in_part) return hipEventSynchronize(k.ev_copied[piece & 1]) == hipSuccess;
-        for (;;) {                                   // (polling, as batch_sync does)
+        for (unsigned spins = 0;; spins++) {         // (polling, as batch_sync does)
             const hipError_t e = hipEventQuery(k.ev_copied[piece & 1]);
             if (e != hipErrorNotReady) return e == hipSuccess;
-            std::this_thread::yield();
+            if (spins < 256u) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(25));
         }
     };
     if (staged && !fetch(0)) return AEC_FAIL(AEC_MEM_ERROR);

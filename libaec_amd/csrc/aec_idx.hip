@@ -5112,7 +5112,10 @@ struct SmCursor {
 static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi, uint32_t start_block, uint64_t rsi_bits_hint)
 {
     SmallPlan p{};
-    if (!tune("AEC_IDX_SMALL", 1) || start_block || !max_rsi || total_bits < 64 || (c.flags & F_PAD_RSI)) return p;
+    if (!tune("AEC_IDX_SMALL", 1) || !max_rsi || total_bits < 64) return p;
+    // (round 6: AEC_PAD_RSI -- the next RSI begins on a byte: sm_rsi rounds up -- and walks that resume inside an RSI --
+    // the first walk begins with start_block blocks done -- are this scheme's too; the latter in one piece)
+    if (start_block && total_bits > kSmMaxBits) return p;
     const bool pp = c.flags & F_PREPROCESS;
     // Where the scheme runs, by measurement (tests/bench_short_rsi.py, --edges; tests/fuzz_index_gpu.py --time):
     //  * more than one piece: only without the preprocessor (no reference samples: the other schemes' chains have nothing
@@ -5223,14 +5226,15 @@ constexpr uint32_t kSmRsiWg = 1024, kSmRsiSpan = 8192;
 __global__ void __launch_bounds__(kSmRsiWg)
 k_small_rsi(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const uint16_t *__restrict__ e0,
             const uint16_t *__restrict__ e1, const uint32_t *__restrict__ hop, const uint32_t *__restrict__ hop2,
-            uint32_t *__restrict__ j, uint32_t *__restrict__ sidx, uint32_t scap)
+            uint32_t *__restrict__ j, uint32_t *__restrict__ sidx, uint32_t scap, uint32_t start_block)
 {
     __shared__ uint32_t lds[kSmRsiWg + kSmRsiSpan];
     uint64_t start_bit;
     uint32_t nbits;
     if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < scap) sidx[q] = q ? kSmNone : 0u;
+    const uint32_t pad = (c.flags & F_PAD_RSI) ? 1u + (uint32_t)(start_bit & 7u) : 0u;
+    if (q < scap && (q || !start_block)) sidx[q] = q ? kSmNone : 0u;
     const uint32_t w0 = blockIdx.x * blockDim.x;
     const uint32_t wn = w0 > nbits ? 0u : (nbits + 1u - w0 < kSmRsiWg + kSmRsiSpan ? nbits + 1u - w0 : kSmRsiWg + kSmRsiSpan);
     // (staged: the hops, or both parses of a position in one word)
@@ -5243,7 +5247,9 @@ k_small_rsi(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_b
     auto r1 = [&](uint32_t at) { return (!hop && at - w0 < wn) ? (lds[at - w0] >> 16) : (uint32_t)e1[at]; };
     auto rh = [&](uint32_t at) { return at - w0 < wn ? lds[at - w0] : hop[at]; };
     auto rh2 = [&](uint32_t at) { return hop2[at]; };
-    j[q] = sm_rsi(c, r0, r1, rh, hop != nullptr, rh2, hop2 != nullptr, q, nbits);
+    j[q] = sm_rsi(c, r0, r1, rh, hop != nullptr, rh2, hop2 != nullptr, q, nbits, 0u, pad);
+    // a walk that resumes inside an RSI: the first RSI start of the chain is where THAT RSI ends
+    if (q == 0u && start_block) sidx[0] = sm_rsi(c, r0, r1, rh, hop != nullptr, rh2, hop2 != nullptr, 0u, nbits, start_block, pad);
 }
 
 // round k, with quarter = 4^k known RSI starts: sidx[m * quarter + i] = j^m[sidx[i]] for m = 1 .. 3, and jn = j^4
@@ -5263,7 +5269,7 @@ k_small_double(const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const
 __global__ void __launch_bounds__(1024)
 k_small_finish(const Cfg c, const TrStream s, SmCursor *cur, uint32_t piece_bits, const uint32_t *__restrict__ sidx, uint32_t scap,
                const uint32_t *__restrict__ words, uint64_t nwords, uint64_t *__restrict__ rsi_off, uint64_t max_rsi,
-               DecResult *res, uint32_t tail_slot, uint32_t *flags)
+               DecResult *res, uint32_t tail_slot, uint32_t *flags, uint32_t start_block)
 {
     __shared__ uint32_t first_none;
     uint64_t start_bit;
@@ -5316,10 +5322,11 @@ k_small_finish(const Cfg c, const TrStream s, SmCursor *cur, uint32_t piece_bits
     cur->stop = 1u;
     // the RSI that does not end inside the input, walked as the serial walker walks it (skip_cds: the parse that also
     // sees second-extension codes beyond the table); anything but "the input ends inside a coded data set" is its call
-    const uint64_t pos0 = start_bit + sidx[m - 1u];
+    // (m == 0: the RSI the walk resumed in does not end inside the input itself)
+    const uint64_t pos0 = m ? start_bit + sidx[m - 1u] : start_bit;
     BitReaderT<QuadFetch> br;
     br.init(QuadFetch{words, nwords}, s.end_bit, pos0);
-    uint32_t b = 0, st = DEC_OK;
+    uint32_t b = m ? 0u : start_block, st = DEC_OK;
     uint64_t good = pos0;
     while (b < c.rsi) {
         uint32_t nblk = 1;
@@ -5335,16 +5342,20 @@ k_small_finish(const Cfg c, const TrStream s, SmCursor *cur, uint32_t piece_bits
     res->status = DEC_OK;
     res->pad = 1u;
     res->bad_rsi = ~0ull;
-    if (tail_slot) rsi_off[max_rsi] = pos0;
+    if (tail_slot) rsi_off[max_rsi] = m ? pos0 : before;
     __threadfence();
     flags[0] = 1u;
 }
 
-__global__ void k_small_begin(uint32_t *flags, SmCursor *cur, uint64_t start_bit, uint64_t rsi_start)
+// (a walk that resumes inside an RSI: that RSI is number 0 and began at rsi_start, the first RSI start the chain meets is
+// number 1 -- as k_index counts)
+__global__ void k_small_begin(uint32_t *flags, SmCursor *cur, uint64_t start_bit, uint64_t rsi_start, uint32_t start_block,
+                              uint64_t *rsi_off, uint64_t max_rsi)
 {
     flags[0] = 0u;
     cur->bit = start_bit;
-    cur->idx = 0u;
+    cur->idx = start_block ? 1u : 0u;
+    if (start_block && max_rsi) rsi_off[0] = rsi_start;
     cur->last_start = rsi_start;
     cur->stop = 0u;
     cur->pad = 0u;
@@ -5352,7 +5363,7 @@ __global__ void k_small_begin(uint32_t *flags, SmCursor *cur, uint64_t start_bit
 
 static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                                uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
-                               uint8_t *base, uint64_t rsi_start, uint32_t tail_slot)
+                               uint8_t *base, uint64_t rsi_start, uint32_t tail_slot, uint32_t start_block = 0)
 {
     const TrStream s{words, nwords, end_bit};
     uint32_t *flags = reinterpret_cast<uint32_t *>(base + p.o_flags);
@@ -5361,7 +5372,7 @@ static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t 
     uint32_t *j[2] = {reinterpret_cast<uint32_t *>(base + p.o_ja), reinterpret_cast<uint32_t *>(base + p.o_jb)};
     uint32_t *sidx = reinterpret_cast<uint32_t *>(base + p.o_s);
     uint32_t *hop = reinterpret_cast<uint32_t *>(base + p.o_h), *hop2 = reinterpret_cast<uint32_t *>(base + p.o_h2);
-    hipLaunchKernelGGL(k_small_begin, dim3(1), dim3(1), 0, st, flags, cur, start_bit, rsi_start);
+    hipLaunchKernelGGL(k_small_begin, dim3(1), dim3(1), 0, st, flags, cur, start_bit, rsi_start, start_block, d_rsi_off, max_rsi);
     const uint32_t grid = (p.nbits + 1u + 255u) / 256u;
     const uint32_t rgrid = (p.nbits + 1u + kSmRsiWg - 1u) / kSmRsiWg;
     const uint32_t sgrid = (p.scap + kSmRsiWg - 1u) / kSmRsiWg > rgrid ? (p.scap + kSmRsiWg - 1u) / kSmRsiWg : rgrid;
@@ -5375,7 +5386,7 @@ static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t 
                                (const uint32_t *)hop, hop2);
         hipLaunchKernelGGL(k_small_rsi, dim3(sgrid), dim3(kSmRsiWg), 0, st, c, (const SmCursor *)cur, end_bit, p.nbits,
                            (const uint16_t *)e0, (const uint16_t *)e1, (const uint32_t *)(p.hops ? hop : nullptr),
-                           (const uint32_t *)(p.hops > 1u ? hop2 : nullptr), j[0], sidx, p.scap);
+                           (const uint32_t *)(p.hops > 1u ? hop2 : nullptr), j[0], sidx, p.scap, start_block);
         for (uint32_t k = 0; k < p.levels; k++) {
             const uint32_t quarter = 1u << (2u * k), last = k + 1u == p.levels ? 1u : 0u;
             const uint32_t gq = (quarter + 255u) / 256u;
@@ -5385,11 +5396,11 @@ static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t 
         }
         if (tune("AEC_IDX_SMALL_FINISH", 1))
             hipLaunchKernelGGL(k_small_finish, dim3(1), dim3(1024), 0, st, c, s, cur, p.nbits, (const uint32_t *)sidx, p.scap, words,
-                               nwords, d_rsi_off, max_rsi, d_res, tail_slot, flags);
+                               nwords, d_rsi_off, max_rsi, d_res, tail_slot, flags, start_block);
     }
     // whatever was not delivered: the serial walker, which returns at once otherwise
     hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res,
-                       (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, 0u, rsi_start, tail_slot,
+                       (const uint64_t *)nullptr, (IdxHop *)nullptr, 0u, (IdxCarry *)nullptr, 1u, 1u, start_block, rsi_start, tail_slot,
                        TwTables{}, (ChunkEntry *)nullptr, SparseTables{}, (uint32_t *)nullptr, (uint64_t)0,
                        (const uint32_t *)flags);
 }
@@ -5469,7 +5480,7 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
         const SmallPlan sm = small_plan(c, end_bit - start_bit, max_rsi, start_block, rsi_bits_hint);
         if (sm.ok && ws_bytes >= sm.bytes) {
             launch_index_small(c, sm, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
-                               static_cast<uint8_t *>(d_ws), rsi_start, tail_slot);
+                               static_cast<uint8_t *>(d_ws), rsi_start, tail_slot, start_block);
             return false;
         }
     }

@@ -83,12 +83,14 @@ AEC_HD uint32_t sm_hop2(const H &hop, uint32_t q, uint32_t nbits)
 // Step 2: one whole RSI from bit q of the piece (its first coded data set with a reference sample, the RSI's own
 // bookkeeping of zero-block runs, reference decode.c:518-544): where the next RSI would start, or kSmNone.
 // e0 / e1: the parses of step 1; hop, hop2: the hops and the hops of hops (has, has2 == false: none).
+// b0: blocks of the RSI that lie in front of q (a walk that resumes inside an RSI; 0: q begins one).
+// pad: AEC_PAD_RSI -- the next RSI begins on a byte (decode.c:407-408): 1 + (the piece's first bit modulo 8), 0: no padding.
 template <class E0, class E1, class H, class H2>
 AEC_HD uint32_t sm_rsi(const Cfg &c, const E0 &e0, const E1 &e1, const H &hop, bool has, const H2 &hop2, bool has2, uint32_t q,
-                       uint32_t nbits)
+                       uint32_t nbits, uint32_t b0 = 0, uint32_t pad = 0)
 {
     const uint32_t rfb = (c.flags & F_PREPROCESS) ? c.bps : 0u;
-    uint32_t pos = q, b = 0;
+    uint32_t pos = q, b = b0;
     bool ok = q < nbits;
     for (uint32_t i = 0; ok && i <= c.rsi && b < c.rsi; i++) {
         if (has2 && b != 0u) {
@@ -116,6 +118,10 @@ AEC_HD uint32_t sm_rsi(const Cfg &c, const E0 &e0, const E1 &e1, const H &hop, b
         ok = nb != 0u && pos + len <= nbits;
         pos += len;
         b += nb;
+    }
+    if (ok && b == c.rsi && pad) {
+        pos = ((pos + pad - 1u + 7u) & ~7u) - (pad - 1u);
+        ok = pos <= nbits;
     }
     return (ok && b == c.rsi) ? pos : kSmNone;
 }

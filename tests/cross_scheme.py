@@ -48,10 +48,32 @@ def smooth(rng, n, bps, signed, scale, zero_frac=0.05, jump_frac=0.0005):
     return x
 
 
+PAD = H.AEC_PAD_RSI
+
+
 def make_stream(rng, bps, bs, rsi, flags, nbytes, scale):
     nb = H.bytes_per_sample(bps, flags)
     n = nbytes // nb // bs * bs                          # whole blocks
     data = H.pack_samples(smooth(rng, n, bps, bool(flags & SGN), scale), bps, flags)
+    if flags & PAD:
+        # AEC_PAD_RSI is the DECODER's flag (reference decode.c:407-408; the encoder's padding is dead code, encode.c:499-505):
+        # a stream whose RSIs begin on bytes is the RSIs coded one by one, each padded to a byte
+        rb = bs * rsi * nb
+        parts, traces, offs, pos = [], [], [], 0
+        for i in range(0, data.size, rb):
+            rc, e, t, _, b = H.oracle_encode(data[i:i + rb], bps, bs, rsi, flags & ~PAD, want_trace=True)
+            assert rc == H.AEC_OK
+            t = t.copy()
+            # (the padding counts as the last coded data set's -- the last block may lie inside a run of zero blocks)
+            t["bits"][np.flatnonzero(t["bits"])[-1]] += (-b) % 8
+            parts.append(e)
+            traces.append(t)
+            offs.append(pos)
+            pos += len(e) * 8
+        tr = np.concatenate(traces)
+        # (the walk ends behind the last coded data set -- on the next byte, if that completed an RSI: decode.c:407-408)
+        last_bits = pos if (n // bs) % rsi == 0 else pos - (-b) % 8
+        return np.ascontiguousarray(data), b"".join(parts), tr, np.array(offs, dtype=np.uint64), last_bits
     rc, enc, tr, offs, bits = H.oracle_encode(data, bps, bs, rsi, flags, want_trace=True)
     assert rc == H.AEC_OK
     return np.ascontiguousarray(data), enc, tr, offs, bits
@@ -84,6 +106,8 @@ def main():
     # without the preprocessor, and the benchmark's own shapes at a size where the region index may be forced
     shapes += [(16, 16, 16, 0, 600 * KiB, 30.0), (8, 8, 128, 0, 3 * MiB, 3.0), (16, 16, 128, PP, 20 * MiB, 2.0),
                (8, 8, 128, PP, 20 * MiB, 1.2), (16, 64, 256, PP | MSB, 20 * MiB, 40.0)]
+    # AEC_PAD_RSI: every RSI begins on a byte (the every-bit scheme from round 6 on, the trunk, the serial walker)
+    shapes += [(16, 16, 8, PP | PAD, 100 * KiB, 2.0), (8, 8, 64, PP | PAD | MSB, 600 * KiB, 1.2), (16, 16, 128, PAD, 600 * KiB, 30.0)]
     ran = {s: 0 for s in range(6)}
     for (bps, bs, rsi, flags, size, scale) in shapes:
         data, enc, tr, offs, bits = make_stream(rng, bps, bs, rsi, flags, size, scale)

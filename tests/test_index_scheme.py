@@ -12,7 +12,8 @@ SERIAL, LOCKED, TABLES, TRUNK, EVERY_BIT, REGIONS = range(6)
 CASES = [
     # name, bits per sample, block, rsi, flags, stream bytes, bits per coded RSI, start block, scheme
     ("a 64 KiB chunk with scan lines of 32 pixels", 8, 8, 4, PP, 24_000, 97, 0, EVERY_BIT),
-    ("the same, a walk that resumes inside an RSI", 8, 8, 4, PP, 24_000, 97, 1, LOCKED),
+    ("the same, a walk that resumes inside an RSI (round 6: the every-bit scheme's too)", 8, 8, 4, PP, 24_000, 97, 1, EVERY_BIT),
+    ("AEC_PAD_RSI, a 64 KiB chunk (round 6)", 8, 8, 4, PP | 32, 24_000, 97, 0, EVERY_BIT),
     ("the 8-bit SZIP shape, a 64 KiB chunk", 8, 8, 128, PP, 23_700, 2960, 0, EVERY_BIT),
     ("the 8-bit SZIP shape, 1 MiB", 8, 8, 128, PP, 379_000, 2960, 0, TABLES),
     ("config 2, 1 GiB: regions (what they do not deliver is left to the window tables)", 16, 16, 128, PP, 190_000_000, 5800, 0, REGIONS),
