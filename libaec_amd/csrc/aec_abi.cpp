@@ -56,6 +56,17 @@ int fail_at(int code, int line)
 }
 #define AEC_FAIL(code) fail_at((code), __LINE__)
 
+// What the index pass is told about the coded RSIs: a look-ahead of 1.5 means (the window tables are sized from it) --
+// except for RSIs of uncompressed blocks, where the pass is told the mean itself so that it leaves out the schemes that
+// look for reference samples (aec_kernels.h: index_incompressible), and a look-ahead that happens to fall into that
+// band is moved beyond it.
+uint64_t index_hint_of(const Cfg &c, uint64_t mean)
+{
+    if (index_incompressible(c, mean)) return mean;
+    const uint64_t h = mean + mean / 2;
+    return index_incompressible(c, h) ? (uint64_t)c.rsi * (c.id_len + (uint64_t)c.bs * c.bps) + 65 : h;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -519,7 +530,7 @@ int decode_run(internal_state *s, struct aec_stream *strm)
 
     aec_gpu_dec_result *d_idx = static_cast<aec_gpu_dec_result *>(s->d_res.p), *d_dec = d_idx + 1;
     uint64_t *d_off = static_cast<uint64_t *>(s->d_off.p);
-    aec_gpu_set_index_hint(s->ctx, hint + hint / 2);
+    aec_gpu_set_index_hint(s->ctx, index_hint_of(c, hint));
     if (piece) aec_gpu_set_index_piece(s->ctx, 6 * hint + 8192);
     int rc = d_seg ? aec_gpu_index_segments_async(s->ctx, &s->prm, s->d_in.p, in_bytes, walk_rel, s->walk_blocks, rsi_rel,
                                                   d_off, d_seg, max_rsi, d_idx, s->stream)
@@ -777,7 +788,13 @@ int decode_call(struct aec_stream *strm, int flush)
         // (a caller that offers more room than that may bring as much input: the stream of a one-shot decode goes up
         // whole and is indexed in one pass -- in pieces of 64 MiB a 180 MB stream of the reference's sample shape paid
         // the fixed phases of the trunk index three times, 71 ms instead of 48 for 256 MiB)
-        const size_t backlog_max = strm->avail_out > kBacklogMax ? strm->avail_out : kBacklogMax;
+        // (as much input as that output can take at most -- incompressible data is longer coded than decoded, and a
+        // stream cut at the size of its output had its last few per cent indexed and decoded as a second batch, with
+        // an average coded RSI for the first that was too low to tell what kind of stream it is)
+        const size_t rsi_out = (size_t)s->cfg.rsi * s->cfg.bs * bytes;
+        const size_t in_for_out = (size_t)((strm->avail_out / rsi_out + 2) * worst_rsi_bytes(s->cfg));
+        const size_t backlog_max = strm->avail_out >= kBacklogMax ? (in_for_out > strm->avail_out ? in_for_out : strm->avail_out)
+                                                                  : kBacklogMax;
         if (strm->avail_in && s->d_len - (size_t)((s->walk_bit / 8) - s->base) < backlog_max) {
             size_t n = strm->avail_in < backlog_max ? strm->avail_in : backlog_max;
             if (n >= kDecDirectMin && s->stage.empty()) {

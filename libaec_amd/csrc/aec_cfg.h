@@ -78,4 +78,16 @@ inline size_t max_encoded_bytes(const Cfg &c)
     return (size_t)((c.total_blocks * (uint64_t)(c.id_len + c.bs * c.bps + 2) + 7) / 8) + 16;
 }
 
+// A stream whose RSIs are as long as RSIs of uncompressed blocks (within 1/32): incompressible data.  An uncompressed
+// block with a reference sample looks like one without (the reference is its first sample), so nothing in such a stream
+// marks an RSI start and the schemes that guess entries from the options around a reference sample (regions, the chains
+// by plausibility) only cost their passes before the trunk's block counts deliver -- 64 MiB of 8-bit noise: 22 ms of 60.
+// (no RSI an encoder writes is longer than that: a hint beyond is a look-ahead, not a mean -- aec_abi.cpp passes 1.5 means
+// and keeps out of this band unless the mean is in it)
+inline bool index_incompressible(const Cfg &c, uint64_t rsi_bits_hint)
+{
+    const uint64_t raw = (uint64_t)c.rsi * (c.id_len + (uint64_t)c.bs * c.bps);
+    return rsi_bits_hint + raw / 32 >= raw && rsi_bits_hint <= raw + 64;
+}
+
 }  // namespace aec

@@ -4809,6 +4809,7 @@ static LockPlan lock_plan_p(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits
 {
     LockPlan p{};
     if (!tune("AEC_IDX_LOCK_P", 1) || (c.flags & F_PAD_RSI) || !(c.flags & F_PREPROCESS) || !rsi_bits_hint) return p;
+    if (index_incompressible(c, rsi_bits_hint)) return p;
     const uint64_t cds = rsi_bits_hint / c.rsi;
     // (RSIs of fewer than 16 blocks: a scoring chain of 16 coded data sets passes an RSI start or three -- there the
     // chains carry the count of blocks, one set of chains per count: k_lock_guess_p, find_anchor_phased)

@@ -487,6 +487,7 @@ RegionPlan region_plan(const Cfg &c, uint64_t total_bits, uint64_t rsi_bits_hint
     if (!tune("AEC_IDX_REGIONS", 1)) return p;
     // the guess looks for the coded data set that holds a reference sample and reads the options around it
     if (!(c.flags & F_PREPROCESS) || (c.flags & F_PAD_RSI) || c.id_len < 3u || !rsi_bits_hint) return p;
+    if (index_incompressible(c, rsi_bits_hint)) return p;
     // (large streams: the passes are as long as one lane's guess and walks -- a few milliseconds whatever the size -- and
     // below half a gigabit of stream the window tables, which cost 3 ms per 100 MiB of input, are through first)
     if (total_bits < (uint64_t)tune("AEC_IDX_REGIONS_MIN", 1u << 29)) return p;
