@@ -2373,9 +2373,15 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         uint32_t first, uint32_t last, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
         const TwTables sp, ChunkEntry *__restrict__ centry, const SparseTables s2,
         uint32_t *__restrict__ batch_nhops = nullptr, uint64_t stop_near = 0,
-        const uint32_t *__restrict__ skip_if = nullptr, const SparseTables s2d = SparseTables{})
+        const uint32_t *__restrict__ skip_if = nullptr, const SparseTables s2d = SparseTables{},
+        uint32_t serial_cap = 0, uint32_t *__restrict__ delivered = nullptr)
 {
     if (skip_if && *skip_if) return;                 // (the phase-locked chains have delivered everything: launch_index_locked)
+    // serial_cap / delivered (launch_index_sparse, a small stream in one span): the tables resolve most RSIs of the streams
+    // they are made for and next to none of others -- very compressible data, runs of zero blocks -- and this walk is
+    // then 50 ns per block on ONE wavefront (16 MiB of 12-bit data in blocks of 8: 54 ms).  After serial_cap blocks
+    // walked serially the walk gives up: *delivered stays 0 and the every-bit scheme enqueued behind takes the stream
+    // (0.9 ms for that one); else *delivered = 1 and that scheme's kernels return at once.
     // stop_near (bits; callers that index a stream piece by piece and have more of it than they hand in): an RSI the
     // tables do not resolve within this many bits of the end of the input is not walked serially -- the tables end
     // there for lack of look-ahead, the caller's next piece resolves it -- the pass ends in front of it
@@ -2558,7 +2564,13 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
     for (;;) {
         bool hopped = false;
         if (b == 0) {
-            if (r >= max_rsi) break;
+            if (r >= max_rsi) {
+                // (the caller's bound: the walk ends on the START of RSI max_rsi -- with AEC_PAD_RSI on the byte it begins
+                // on, as the other schemes report it: the next batch's walk starts there, and the every-bit scheme parses
+                // from exactly where it is told to)
+                if ((c.flags & F_PAD_RSI) && (good & 7u) && good > start_bit) good = (good + 7u) & ~7ull;
+                break;
+            }
             // Fast hops over the speculative tables (k_spec): at an RSI start one lookup gives the
             // end of a chain of whole RSIs leaving the window (Xb/Xc; the RSI starts inside the hop
             // are filled in by k_expand), or of this RSI alone (T).  An entry of 0 = not resolved
@@ -2666,7 +2678,10 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                 r += k1;
                 hopped = true;
             }
-            if (r >= max_rsi) break;
+            if (r >= max_rsi) {
+                if ((c.flags & F_PAD_RSI) && (good & 7u) && good > start_bit) good = (good + 7u) & ~7ull;   // (as above)
+                break;
+            }
             if (carry && !last && good >= (s2.bitmap ? s2.hi : sp.hi)) {       // the next span continues from here
                 if (lane == 0) {
                     carry->good = good;
@@ -2683,6 +2698,13 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
                 hopped = true;
             }
             if (stop_near && end_bit - good < stop_near && (hopped || r != 0)) break;   // (status OK, b = 0: ends on an RSI start)
+            if (serial_cap && (uint64_t)n_serial * c.rsi > serial_cap) {
+                if (lane == 0 && carry) {
+                    carry->active = 0;
+                    carry->n_hops = 0;
+                }
+                return;
+            }
             if (lane == 0) rsi_off[r] = good;
             cur_start = good;
             n_serial++;
@@ -2832,6 +2854,7 @@ k_index(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, uint64
         carry->n_lookups = n_lookups;
     }
     if (lane == 0 && chunk_off && batch_nhops) batch_nhops[blockIdx.x] = nh;
+    if (lane == 0 && delivered) *delivered = 1u;
     if (lane == 0) {
         // streaming callers: where the trailing partial RSI began, in a slot of its own behind the table
         if (tail_slot && !chunk_off) rsi_off[max_rsi] = cur_start;
@@ -3130,7 +3153,8 @@ void side_give(const SideStream &s)
 void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
                          uint8_t *base, size_t ws_bytes, uint32_t start_block, uint64_t rsi_start, uint32_t tail_slot,
-                         uint64_t stop_near, const uint32_t *skip_if = nullptr)
+                         uint64_t stop_near, const uint32_t *skip_if = nullptr, uint32_t serial_cap = 0,
+                         uint32_t *delivered = nullptr)
 {
     allow_big_lds2();
     Spec2Geom geom = p.g, dgeom = p.dg;
@@ -3260,7 +3284,7 @@ void launch_index_sparse(const Cfg &c, const Sparse2Plan &p, const uint32_t *wor
         hipLaunchKernelGGL(k_index, dim3(1), dim3(64), 0, st, c, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi,
                            d_res, (const uint64_t *)nullptr, hops, hop_cap, carry, first ? 1u : 0u, last ? 1u : 0u,
                            start_block, rsi_start, tail_slot, TwTables{}, centry, t, (uint32_t *)nullptr, last ? stop_near : 0ull,
-                           skip_if, td);
+                           skip_if, td, (first && last) ? serial_cap : 0u, (first && last) ? delivered : (uint32_t *)nullptr);
         if (!flat)
             hipLaunchKernelGGL(k_rewalk, dim3((nchunks + 63) / 64), dim3(64), 0, st, t, nwin, nchunks, end_bit, centry, rhops,
                                nhops, d_rsi_off);
@@ -5092,6 +5116,7 @@ void launch_index_locked(const Cfg &c, const LockPlan &p, const uint32_t *words,
 // Works for any parameter set (no preprocessor, any rsi up to kSmMaxRsi), needs no guesses; 8 bytes of workspace per bit.
 constexpr uint64_t kSmMaxBits = 1ull << 24;      // 2 MiB of stream
 constexpr uint32_t kSmMaxRsi = 64;               // (step 2 is rsi dependent loads per bit)
+constexpr uint32_t kSmGrid = 4096;               // most workgroups of 256 per launch (16 per CU); the kernels stride
 
 struct SmallPlan {
     bool ok;
@@ -5110,7 +5135,11 @@ struct SmCursor {
     uint32_t stop, pad;               // no further piece (delivered, or left to the serial walker)
 };
 
-static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi, uint32_t start_block, uint64_t rsi_bits_hint)
+// forced: the plan as the FALLBACK behind a scheme that may give a stream up (the chains by plausibility whose entries
+// were judged wrong, the window tables that resolve too few RSIs: launch_index) -- the limits of the scheme itself
+// without the rules about where another scheme is faster, since that scheme has just failed.
+static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi, uint32_t start_block, uint64_t rsi_bits_hint,
+                            bool forced = false)
 {
     SmallPlan p{};
     if (!tune("AEC_IDX_SMALL", 1) || !max_rsi || total_bits < 64) return p;
@@ -5122,7 +5151,14 @@ static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi,
     //  * more than one piece: only without the preprocessor (no reference samples: the other schemes' chains have nothing
     //    to lock a count on) -- and with RSIs of more than 64 blocks only for samples of more than 8 bits (16 MiB with rsi
     //    128 / 256: 16-bit 34 / 40 -> 12 / 14 ms, the reference 13; 8-bit 8.6 / 8.4 over the trunk against 11.8 / 13.7 here);
-    if (total_bits > kSmMaxBits && (pp || (c.rsi > kSmMaxRsi && c.bps <= 8u) || !tune("AEC_IDX_SMALL_PIECES", 1) ||
+    //    -- and, with it, streams of up to 4 MiB whose entries would be guessed by plausibility: the guesses alone take as
+    //    long as this scheme's pass (4 MiB of 16-bit data, rsi 256: 4.2 of 7.2 ms when they are judged wrong, 5.4 against
+    //    3.0 when they hold; 1 MiB of 8-bit data in blocks of 32, rsi 64: 1.5 against 0.45)
+    //    (RSIs of more than 32 blocks; with 16 .. 32 the guesses are cheap: 16 MiB of 16-bit data, rsi 32: 2.9 against 3.5 ms)
+    const bool by_plausibility = pp && c.rsi > kLockMaxRsi && total_bits <= (uint64_t)tune("AEC_IDX_SMALL_PP_BITS", 1u << 25) &&
+                                 lock_plan(c, total_bits, rsi_bits_hint, start_block).mode == 1u;
+    const bool pp_pieces = pp && (forced || by_plausibility);
+    if (total_bits > kSmMaxBits && ((pp && !pp_pieces) || (c.rsi > kSmMaxRsi && c.bps <= 8u) || !tune("AEC_IDX_SMALL_PIECES", 1) ||
                                     total_bits >= (1ull << 40)))
         return p;
     //  * RSIs of more than 256 blocks (hops of hops): one piece;
@@ -5132,7 +5168,7 @@ static SmallPlan small_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi,
     //    than 64 up to 128 KiB (the 8-bit SZIP shape, rsi 128: 64 KiB 0.24 -> 0.19 ms, 1 MiB 0.39 against 0.49).  Where
     //    the tables do not serve it -- long coded data sets, high entropy -- the stream would go over the trunk, whose
     //    dozen launches cost a 1 MiB stream 4 .. 9 ms: here it stays.
-    if (pp && c.rsi > kLockMaxRsi) {
+    if (pp && c.rsi > kLockMaxRsi && !forced && !by_plausibility) {
         const uint64_t most_bits = c.rsi <= (uint32_t)tune("AEC_IDX_SMALL_RSI", kSmMaxRsi) ? (1u << 22) : (uint64_t)tune("AEC_IDX_SMALL_RSI_BITS", 1u << 20);
         if (total_bits > most_bits && sparse2_plan(c, total_bits, rsi_bits_hint).ok) return p;
     }
@@ -5184,12 +5220,14 @@ k_small_parse(const Cfg c, const TrStream s, const SmCursor *cur, uint32_t piece
     uint64_t start_bit;
     uint32_t nbits;
     if (!sm_piece(cur, s.end_bit, piece_bits, start_bit, nbits)) return;
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q > nbits) return;
-    uint16_t a = 0, b = 0;
-    if (q < nbits) sm_parse(s, c, start_bit + q, a, b);
-    e0[q] = a;
-    e1[q] = b;
+    // (the grids of this scheme's kernels are capped and the kernels stride: a piece that does not run -- the cursor says
+    // stop, or the scheme in front has delivered -- costs a launch of kSmGrid workgroups that return, not of 65 536)
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q <= nbits; q += gridDim.x * blockDim.x) {
+        uint16_t a = 0, b = 0;
+        if (q < nbits) sm_parse(s, c, start_bit + q, a, b);
+        e0[q] = a;
+        e1[q] = b;
+    }
 }
 
 // Step 2 walks a whole RSI from every bit: rsi dependent reads.  For RSIs of more than 16 blocks a table of HOPS first:
@@ -5204,9 +5242,8 @@ k_small_hop(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_b
     uint64_t start_bit;
     uint32_t nbits;
     if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q > nbits) return;
-    hop[q] = sm_hop(c, [&](uint32_t at) { return (uint32_t)e0[at]; }, q, nbits);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q <= nbits; q += gridDim.x * blockDim.x)
+        hop[q] = sm_hop(c, [&](uint32_t at) { return (uint32_t)e0[at]; }, q, nbits);
 }
 
 __global__ void __launch_bounds__(256)
@@ -5215,9 +5252,8 @@ k_small_hop2(const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const u
     uint64_t start_bit;
     uint32_t nbits;
     if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q > nbits) return;
-    hop2[q] = sm_hop2([&](uint32_t at) { return hop[at]; }, q, nbits);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q <= nbits; q += gridDim.x * blockDim.x)
+        hop2[q] = sm_hop2([&](uint32_t at) { return hop[at]; }, q, nbits);
 }
 
 // (the walks of a workgroup begin at consecutive bits and stay within an RSI's length of them: the table they read at
@@ -5233,24 +5269,27 @@ k_small_rsi(const Cfg c, const SmCursor *cur, uint64_t end_bit, uint32_t piece_b
     uint64_t start_bit;
     uint32_t nbits;
     if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t pad = (c.flags & F_PAD_RSI) ? 1u + (uint32_t)(start_bit & 7u) : 0u;
-    if (q < scap && (q || !start_block)) sidx[q] = q ? kSmNone : 0u;
-    const uint32_t w0 = blockIdx.x * blockDim.x;
-    const uint32_t wn = w0 > nbits ? 0u : (nbits + 1u - w0 < kSmRsiWg + kSmRsiSpan ? nbits + 1u - w0 : kSmRsiWg + kSmRsiSpan);
-    // (staged: the hops, or both parses of a position in one word)
-    for (uint32_t i = threadIdx.x; i < wn; i += blockDim.x)
-        lds[i] = hop ? hop[w0 + i] : ((uint32_t)e0[w0 + i] | ((uint32_t)e1[w0 + i] << 16));
-    __syncthreads();
-    if (q > nbits) return;
-    // (what is staged comes out of LDS: the hops, or both parses of a position in one word)
-    auto r0 = [&](uint32_t at) { return (!hop && at - w0 < wn) ? (lds[at - w0] & 0xFFFFu) : (uint32_t)e0[at]; };
-    auto r1 = [&](uint32_t at) { return (!hop && at - w0 < wn) ? (lds[at - w0] >> 16) : (uint32_t)e1[at]; };
-    auto rh = [&](uint32_t at) { return at - w0 < wn ? lds[at - w0] : hop[at]; };
-    auto rh2 = [&](uint32_t at) { return hop2[at]; };
-    j[q] = sm_rsi(c, r0, r1, rh, hop != nullptr, rh2, hop2 != nullptr, q, nbits, 0u, pad);
-    // a walk that resumes inside an RSI: the first RSI start of the chain is where THAT RSI ends
-    if (q == 0u && start_block) sidx[0] = sm_rsi(c, r0, r1, rh, hop != nullptr, rh2, hop2 != nullptr, 0u, nbits, start_block, pad);
+    const uint32_t most = nbits + 1u > scap ? nbits + 1u : scap;
+    for (uint32_t w0 = blockIdx.x * blockDim.x; w0 < most; w0 += gridDim.x * blockDim.x) {
+        const uint32_t q = w0 + threadIdx.x;
+        if (q < scap && (q || !start_block)) sidx[q] = q ? kSmNone : 0u;
+        const uint32_t wn = w0 > nbits ? 0u : (nbits + 1u - w0 < kSmRsiWg + kSmRsiSpan ? nbits + 1u - w0 : kSmRsiWg + kSmRsiSpan);
+        // (staged: the hops, or both parses of a position in one word)
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < wn; i += blockDim.x)
+            lds[i] = hop ? hop[w0 + i] : ((uint32_t)e0[w0 + i] | ((uint32_t)e1[w0 + i] << 16));
+        __syncthreads();
+        if (q > nbits) continue;
+        // (what is staged comes out of LDS: the hops, or both parses of a position in one word)
+        auto r0 = [&](uint32_t at) { return (!hop && at - w0 < wn) ? (lds[at - w0] & 0xFFFFu) : (uint32_t)e0[at]; };
+        auto r1 = [&](uint32_t at) { return (!hop && at - w0 < wn) ? (lds[at - w0] >> 16) : (uint32_t)e1[at]; };
+        auto rh = [&](uint32_t at) { return at - w0 < wn ? lds[at - w0] : hop[at]; };
+        auto rh2 = [&](uint32_t at) { return hop2[at]; };
+        j[q] = sm_rsi(c, r0, r1, rh, hop != nullptr, rh2, hop2 != nullptr, q, nbits, 0u, pad);
+        // a walk that resumes inside an RSI: the first RSI start of the chain is where THAT RSI ends
+        if (q == 0u && start_block) sidx[0] = sm_rsi(c, r0, r1, rh, hop != nullptr, rh2, hop2 != nullptr, 0u, nbits, start_block, pad);
+    }
 }
 
 // round k, with quarter = 4^k known RSI starts: sidx[m * quarter + i] = j^m[sidx[i]] for m = 1 .. 3, and jn = j^4
@@ -5261,10 +5300,11 @@ k_small_double(const SmCursor *cur, uint64_t end_bit, uint32_t piece_bits, const
     uint64_t start_bit;
     uint32_t nbits;
     if (!sm_piece(cur, end_bit, piece_bits, start_bit, nbits)) return;
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < quarter) sm_double_starts(j, sidx, q, quarter, scap);
-    if (last || q > nbits) return;
-    jn[q] = sm_double_table(j, q);
+    const uint32_t most = last ? quarter : (nbits + 1u > quarter ? nbits + 1u : quarter);
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < most; q += gridDim.x * blockDim.x) {
+        if (q < quarter) sm_double_starts(j, sidx, q, quarter, scap);
+        if (!last && q <= nbits) jn[q] = sm_double_table(j, q);
+    }
 }
 
 __global__ void __launch_bounds__(1024)
@@ -5350,21 +5390,24 @@ k_small_finish(const Cfg c, const TrStream s, SmCursor *cur, uint32_t piece_bits
 
 // (a walk that resumes inside an RSI: that RSI is number 0 and began at rsi_start, the first RSI start the chain meets is
 // number 1 -- as k_index counts)
+// (skip_if: the scheme in front has delivered -- no piece runs, and the serial walker behind the pieces returns at once)
 __global__ void k_small_begin(uint32_t *flags, SmCursor *cur, uint64_t start_bit, uint64_t rsi_start, uint32_t start_block,
-                              uint64_t *rsi_off, uint64_t max_rsi)
+                              uint64_t *rsi_off, uint64_t max_rsi, const uint32_t *skip_if)
 {
-    flags[0] = 0u;
+    const bool skip = skip_if && *skip_if;
+    flags[0] = skip ? 1u : 0u;
     cur->bit = start_bit;
     cur->idx = start_block ? 1u : 0u;
-    if (start_block && max_rsi) rsi_off[0] = rsi_start;
+    if (start_block && max_rsi && !skip) rsi_off[0] = rsi_start;
     cur->last_start = rsi_start;
-    cur->stop = 0u;
+    cur->stop = skip ? 1u : 0u;
     cur->pad = 0u;
 }
 
 static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                                uint64_t start_bit, uint64_t *d_rsi_off, uint64_t max_rsi, DecResult *d_res, hipStream_t st,
-                               uint8_t *base, uint64_t rsi_start, uint32_t tail_slot, uint32_t start_block = 0)
+                               uint8_t *base, uint64_t rsi_start, uint32_t tail_slot, uint32_t start_block = 0,
+                               const uint32_t *skip_if = nullptr)
 {
     const TrStream s{words, nwords, end_bit};
     uint32_t *flags = reinterpret_cast<uint32_t *>(base + p.o_flags);
@@ -5373,10 +5416,14 @@ static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t 
     uint32_t *j[2] = {reinterpret_cast<uint32_t *>(base + p.o_ja), reinterpret_cast<uint32_t *>(base + p.o_jb)};
     uint32_t *sidx = reinterpret_cast<uint32_t *>(base + p.o_s);
     uint32_t *hop = reinterpret_cast<uint32_t *>(base + p.o_h), *hop2 = reinterpret_cast<uint32_t *>(base + p.o_h2);
-    hipLaunchKernelGGL(k_small_begin, dim3(1), dim3(1), 0, st, flags, cur, start_bit, rsi_start, start_block, d_rsi_off, max_rsi);
-    const uint32_t grid = (p.nbits + 1u + 255u) / 256u;
+    hipLaunchKernelGGL(k_small_begin, dim3(1), dim3(1), 0, st, flags, cur, start_bit, rsi_start, start_block, d_rsi_off, max_rsi,
+                       skip_if);
+    // (capped only where the scheme is enqueued as a fallback: a workgroup per 256 bits, retiring as it goes, is 10 - 18 %
+    // faster than striding ones where the scheme does run -- 1 MiB streams: 0.37 against 0.47 ms)
+    auto capped = [&](uint32_t g, uint32_t most) { return (!skip_if || g < most) ? g : most; };
+    const uint32_t grid = capped((p.nbits + 1u + 255u) / 256u, kSmGrid);
     const uint32_t rgrid = (p.nbits + 1u + kSmRsiWg - 1u) / kSmRsiWg;
-    const uint32_t sgrid = (p.scap + kSmRsiWg - 1u) / kSmRsiWg > rgrid ? (p.scap + kSmRsiWg - 1u) / kSmRsiWg : rgrid;
+    const uint32_t sgrid = capped((p.scap + kSmRsiWg - 1u) / kSmRsiWg > rgrid ? (p.scap + kSmRsiWg - 1u) / kSmRsiWg : rgrid, kSmGrid / 4u);
     for (uint32_t piece = 0; piece < p.npieces; piece++) {
         hipLaunchKernelGGL(k_small_parse, dim3(grid), dim3(256), 0, st, c, s, (const SmCursor *)cur, p.nbits, e0, e1);
         if (p.hops)
@@ -5390,7 +5437,7 @@ static void launch_index_small(const Cfg &c, const SmallPlan &p, const uint32_t 
                            (const uint32_t *)(p.hops > 1u ? hop2 : nullptr), j[0], sidx, p.scap, start_block);
         for (uint32_t k = 0; k < p.levels; k++) {
             const uint32_t quarter = 1u << (2u * k), last = k + 1u == p.levels ? 1u : 0u;
-            const uint32_t gq = (quarter + 255u) / 256u;
+            const uint32_t gq = capped((quarter + 255u) / 256u, kSmGrid);
             const uint32_t g = last ? gq : (gq > grid ? gq : grid);
             hipLaunchKernelGGL(k_small_double, dim3(g), dim3(256), 0, st, (const SmCursor *)cur, end_bit, p.nbits,
                                (const uint32_t *)j[k & 1u], j[(k & 1u) ^ 1u], sidx, quarter, p.scap, last);
@@ -5419,6 +5466,28 @@ static void idx_tuning_sync()
     if (dev < 0 || dev >= 64) dev = 0;
     std::call_once(once[dev], [] { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_idx_no_stretch), &no_stretch, sizeof(int)); });
 #endif
+}
+
+// The every-bit scheme as the FALLBACK behind a scheme that may give a stream up (round 6; tests/fuzz_index_gpu.py --time
+// listed thirteen shapes of 300 below 0.6 GB/s, all of them such streams):
+//  * behind the chains by plausibility (lock_plan mode 1), in place of the 64 agreeing chains and the trunk, which took
+//    57 and 115 ms for 4 and 16 MiB of data in blocks of 64 with RSIs of 5 and 1 blocks whose guesses were judged wrong
+//    (the every-bit pieces: 2.0 and 4.9 ms) -- streams of up to 2^28 bits, of up to 2^25 where RSIs have 64 blocks and more;
+//  * behind the window tables of a stream of one piece (2^24 bits), whose walker gives up after kSparseSerialCap blocks
+//    walked serially (k_index: serial_cap).
+// 256 bytes in front of its workspace hold the flag "the scheme in front has delivered".
+constexpr uint32_t kSparseSerialCap = 2048;
+static SmallPlan small_fallback_plan(const Cfg &c, uint64_t total_bits, uint64_t max_rsi, uint32_t start_block,
+                                     uint64_t rsi_bits_hint, bool behind_tables)
+{
+    if (!tune("AEC_IDX_SMALL_FALLBACK", 1)) return SmallPlan{};
+    // (behind the chains by plausibility: RSIs of 64 blocks and more are the trunk's from 4 MiB of stream on -- its
+    // block counts take 27 MiB with rsi 64 in 3 ms, the pieces 21 -- and below that its dozen launches cost more than
+    // the pieces: 4 MiB of 16-bit data with rsi 256: 9.9 against 3.0 ms)
+    const uint64_t most = behind_tables ? kSmMaxBits
+                          : (c.rsi < 64u ? (uint64_t)tune("AEC_IDX_SMALL_FB_BITS", 1u << 28) : (uint64_t)tune("AEC_IDX_SMALL_FB_BITS_LONG", 1u << 25));
+    if (total_bits > most) return SmallPlan{};
+    return small_plan(c, total_bits, max_rsi, start_block, rsi_bits_hint, true);
 }
 
 int index_scheme(const Cfg &c, size_t in_bytes, uint64_t rsi_bits_hint, uint32_t start_block)
@@ -5452,6 +5521,8 @@ size_t index_workspace_bytes_large(const Cfg &c, size_t in_bytes, uint64_t start
     const LockPlan lp = lock_plan(c, end_bit - start_bit, rsi_bits_hint, 0u);
     if (lp.ok && lp.mode == 0u) return lp.bytes;
     if (lp.ok) {                                           // (mode 1: + what runs behind it for the streams it abandons)
+        const SmallPlan fb = small_fallback_plan(c, end_bit - start_bit, 1ull << 62, 0u, rsi_bits_hint, false);
+        if (fb.ok) return lp.bytes + 256 + fb.bytes;
         const LockPlan l0 = lock_plan_alt(c, end_bit - start_bit, rsi_bits_hint, 0u);
         const TrunkPlan tp = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, 0);
         return lp.bytes + (l0.ok ? l0.bytes : 0) + (tp.ok ? tp.bytes : 0);
@@ -5460,7 +5531,8 @@ size_t index_workspace_bytes_large(const Cfg &c, size_t in_bytes, uint64_t start
     if (sp.ok) {
         // (many spans of windows: two sets of tables, so that the spans can be pipelined -- launch_index_sparse)
         const uint64_t span = (uint64_t)sp.nwin_max * sp.g.core;
-        return end_bit - start_bit > (kS2PipeSpans - 1) * span ? 2 * sp.bytes : sp.bytes;
+        const SmallPlan fb = small_fallback_plan(c, end_bit - start_bit, 1ull << 62, 0u, rsi_bits_hint, true);
+        return (end_bit - start_bit > (kS2PipeSpans - 1) * span ? 2 * sp.bytes : sp.bytes) + (fb.ok ? 256 + fb.bytes : 0);
     }
     const TrunkPlan p = trunk_plan(c, end_bit - start_bit, rsi_bits_hint, 0);
     return p.ok ? p.bytes : 0;
@@ -5512,6 +5584,16 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
             // short, then the trunk; every kernel of a later scheme returns at once if the stream has been delivered
             uint8_t *wb = static_cast<uint8_t *>(d_ws);
             size_t used = lp.bytes;
+            // (streams of up to 2^28 bits: the every-bit scheme piece by piece in place of both -- small_fallback_plan)
+            const SmallPlan fb = stop_near ? SmallPlan{}
+                                           : small_fallback_plan(c, end_bit - start_bit, max_rsi, start_block, rsi_bits_hint, false);
+            if (fb.ok && ws_bytes >= used + 256 + fb.bytes) {
+                launch_index_locked(c, lp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb, start_block,
+                                    rsi_start, tail_slot, false, done);
+                launch_index_small(c, fb, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb + used + 256,
+                                   rsi_start, tail_slot, start_block, reinterpret_cast<const uint32_t *>(wb + lp.o_flags));
+                return false;
+            }
             const LockPlan l0 = lock_plan_alt(c, end_bit - start_bit, rsi_bits_hint, start_block);
             const bool have0 = l0.ok && ws_bytes >= used + l0.bytes;
             const size_t off0 = used;
@@ -5533,6 +5615,22 @@ bool launch_index(const Cfg &c, const uint8_t *d_in, size_t in_bytes, uint64_t s
     }
     if (d_ws && ws_bytes && start_bit < end_bit) {
         const Sparse2Plan sp = sparse2_plan(c, end_bit - start_bit, rsi_bits_hint);
+        const SmallPlan fb = (sp.ok && !stop_near && !done)
+                                 ? small_fallback_plan(c, end_bit - start_bit, max_rsi, start_block, rsi_bits_hint, true)
+                                 : SmallPlan{};
+        if (sp.ok && fb.ok && ws_bytes >= sp.bytes + 256 + fb.bytes &&
+            end_bit - start_bit / sp.g.core * sp.g.core <= (uint64_t)sp.nwin_max * sp.g.core) {
+            // (one span of tables: the walker may give the stream up, the every-bit scheme behind it takes it then)
+            uint8_t *wb = static_cast<uint8_t *>(d_ws);
+            uint32_t *delivered = reinterpret_cast<uint32_t *>(wb + sp.bytes);
+            (void)hipMemsetAsync(delivered, 0, 4, st);
+            launch_index_sparse(c, sp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb, sp.bytes,
+                                start_block, rsi_start, tail_slot, 0ull, nullptr, (uint32_t)tune("AEC_IDX_SPARSE_SERIAL_CAP", kSparseSerialCap),
+                                delivered);
+            launch_index_small(c, fb, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st, wb + sp.bytes + 256,
+                               rsi_start, tail_slot, start_block, delivered);
+            return segs_filled;
+        }
         if (sp.ok && ws_bytes >= sp.bytes) {
             launch_index_sparse(c, sp, words, nwords, end_bit, start_bit, d_rsi_off, max_rsi, d_res, st,
                                 static_cast<uint8_t *>(d_ws), ws_bytes, start_block, rsi_start, tail_slot, stop_near, done);

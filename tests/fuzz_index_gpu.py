@@ -21,8 +21,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--only", type=int, default=-1, help="run this case alone (the others only draw their random numbers)")
+    ap.add_argument("--only", default="", help="run these cases alone, e.g. 22,212 (the others only draw their random numbers)")
     ap.add_argument("--time", action="store_true", help="time a second index pass per case and list the slowest shapes")
+    ap.add_argument("--list", type=int, default=25, help="with --time: how many of the slowest to list")
     return run(ap.parse_args())
 
 
@@ -30,6 +31,7 @@ def run(args):
     import torch
     from libaec_amd import gpu
     rng = np.random.default_rng(args.seed)
+    only = {int(x) for x in args.only.split(",") if x != ""}
     bad = 0
     slow = []
     for case in range(args.cases):
@@ -60,7 +62,7 @@ def run(args):
                 cnt = min(ln, data.size - o) // nb
                 lo, hi = (-(1 << (bps - 1)), 1 << (bps - 1)) if flags & AEC_DATA_SIGNED else (0, 1 << bps)
                 data[o:o + cnt * nb] = pack_samples(rng.integers(lo, hi, cnt), bps, flags)    # (valid samples only)
-        if args.only >= 0 and case != args.only:
+        if only and case not in only:
             continue
         codec = gpu.Codec(bps, bs, rsi, flags)
         d_in = torch.from_numpy(data).cuda()
@@ -101,15 +103,16 @@ def run(args):
             codec.index_async(d_out, nbytes, 0, d_idx, nr, d_res)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) * 1e3
+            scheme = gpu.INDEX_SCHEMES[gpu.index_scheme(bps, bs, rsi, flags, nbytes, nbytes * 8 // max(nr, 1))]
             slow.append((data.size / ms / 1e6, f"case {case}: bps {bps} bs {bs} rsi {rsi} flags {flags} {data.size >> 20} MiB scale {scale} "
-                                                 f"ratio {data.size / nbytes:.2f}: index {ms:.2f} ms = {data.size / ms / 1e6:.2f} GB/s"))
+                                                 f"ratio {data.size / nbytes:.2f}: index {ms:.2f} ms = {data.size / ms / 1e6:.2f} GB/s [{scheme}]"))
         print(f"case {case}: bps {bps} bs {bs} rsi {rsi} flags {flags} n {n} scale {scale} ratio "
               f"{data.size / nbytes:.2f}: {'ok' if ok else 'MISMATCH ' + why}", flush=True)
         bad += 0 if ok else 1
         del d_in, d_out, d_off, d_idx
     if args.time:
         print("slowest index passes (decoded bytes per second of index time):")
-        for _, line in sorted(slow)[:25]:
+        for _, line in sorted(slow)[:getattr(args, 'list', 25)]:
             print("  " + line)
     print("mismatches:", bad)
     return 1 if bad else 0

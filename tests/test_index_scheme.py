@@ -29,6 +29,8 @@ CASES = [
     ("16 MiB of 8-bit data, rsi 48", 8, 8, 48, PP, 5_940_000, 1140, 0, TABLES),
     ("config 2, 256 MiB: below half a gigabit of stream the window tables are through first", 16, 16, 128, PP, 47_700_000, 5800, 0, TABLES),
     ("16 MiB of 16-bit data, rsi 32", 16, 16, 32, PP, 2_930_000, 1470, 0, LOCKED),
+    ("4 MiB of the sample file's shape: up to 4 MiB of stream every bit parsed, piece by piece (round 6)", 16, 64, 256, PP | MSB, 2_950_000, 184_000, 0, EVERY_BIT),
+    ("8 MiB of the sample file's shape: entries by plausibility", 16, 64, 256, PP | MSB, 5_900_000, 184_000, 0, LOCKED),
     ("16 MiB without the preprocessor: piece by piece", 16, 16, 16, 0, 16_640_000, 4160, 0, EVERY_BIT),
     ("16 MiB of 8-bit data without the preprocessor, rsi 128: the trunk is faster", 8, 8, 128, 0, 16_060_000, 8600, 0, TRUNK),
     ("1 MiB with rsi 1 and long coded data sets", 16, 64, 1, PP, 790_000, 800, 0, EVERY_BIT),
