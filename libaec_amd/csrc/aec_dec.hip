@@ -40,22 +40,56 @@ __device__ __forceinline__ uint32_t wave_incl_sum_dpp(uint32_t v)
 }
 
 // Inverse predictor + byte-order store of one block (BS > 0: registers, vector stores).
+//
+// The predictor (reference decode.c:91-135): x += d / 2 or x -= (d + 1) / 2 as long as the step's size fits the room on
+// both sides of x, something else where it does not.  Every sample of a block takes the first branch if the SUM of the
+// block's mapped residuals fits the room on both sides of the sample in front of the block (a step is at most its
+// residual, and x moves by at most the steps taken so far): one test per block, wave-wide, and then a sample is a
+// shift, a sign, an exclusive or and an add (4.5 vector instructions with the sum, against 13 for the exact step; the
+// predictor was a third of the kernel's 39 instructions per sample, profiles/r06/k_decode_isa.txt).  A wavefront with
+// a lane whose block does not pass -- samples near the ends of the range -- takes the exact steps for that block.
 template <int BS, int BYTES>
 __device__ __forceinline__ void store_block(uint8_t *dst, const uint32_t *d, const Cfg &c, bool ref,
                                             uint32_t &x)
 {
     const bool pp = c.flags & F_PREPROCESS, sgn = c.flags & F_SIGNED, msb = c.flags & F_MSB;
     uint32_t v[BS];
+    if (!pp) {
 #pragma unroll
-    for (int i = 0; i < BS; i++) {
-        if (!pp) {
-            v[i] = d[i];
-        } else if (i == 0 && ref) {
-            x = sgn ? sign_extend(d[0], c.bps) : d[0];           // decode.c:78-86
-            v[i] = x;
+        for (int i = 0; i < BS; i++) v[i] = d[i];
+    } else {
+        // (the first block of an RSI: its first sample is the reference sample itself, decode.c:78-86)
+        const uint32_t x0 = ref ? (sgn ? sign_extend(d[0], c.bps) : d[0]) : x;
+        const uint32_t d0 = ref ? 0u : d[0];
+        uint32_t sum = d0, any = 0;
+#pragma unroll
+        for (int i = 1; i + 1 < BS; i += 2) sum += d[i] + d[i + 1];
+        if (BS % 2 == 0) sum += d[BS - 1];
+        if (BYTES == 4) {                          // (the sum of 64 residuals of up to 32 bits: none above 26 bits)
+#pragma unroll
+            for (int i = 0; i < BS; i++) any |= i == 0 ? d0 : d[i];
+        }
+        const uint32_t below = sgn ? x0 + c.xmax + 1u : x0, above = c.xmax - x0;      // x0 - xmin, xmax - x0
+        const bool fits = sum <= below && sum <= above && (BYTES != 4 || (any >> 26) == 0u);
+        if (!__any(!fits)) {
+            uint32_t xx = x0;
+#pragma unroll
+            for (int i = 0; i < BS; i++) {
+                const uint32_t di = i == 0 ? d0 : d[i];
+                xx += (di >> 1) ^ (uint32_t)__builtin_amdgcn_sbfe((int)di, 0u, 1u);     // + d / 2, or - (d + 1) / 2
+                v[i] = xx;
+            }
+            x = xx;
         } else {
-            x = sgn ? unpp_signed(x, d[i], c.xmax) : unpp_unsigned(x, d[i], c.xmax);
-            v[i] = x;
+#pragma unroll
+            for (int i = 0; i < BS; i++) {
+                if (i == 0 && ref) {
+                    x = x0;
+                } else {
+                    x = sgn ? unpp_signed(x, d[i], c.xmax) : unpp_unsigned(x, d[i], c.xmax);
+                }
+                v[i] = x;
+            }
         }
     }
     if (BYTES == 4) {
@@ -68,27 +102,23 @@ __device__ __forceinline__ void store_block(uint8_t *dst, const uint32_t *d, con
             o[q] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     } else if (BYTES == 2) {
+        // two samples per word, one byte permute each: low halves side by side, or their bytes swapped
+        const uint32_t sel = msb ? 0x04050001u : 0x05040100u;
         uint32_t w[BS / 2];
 #pragma unroll
-        for (int j = 0; j < BS / 2; j++) {
-            uint32_t a = v[2 * j] & 0xFFFFu, b = v[2 * j + 1] & 0xFFFFu;
-            if (msb) {
-                a = (a >> 8) | ((a & 0xFFu) << 8);
-                b = (b >> 8) | ((b & 0xFFu) << 8);
-            }
-            w[j] = a | (b << 16);
-        }
+        for (int j = 0; j < BS / 2; j++) w[j] = __builtin_amdgcn_perm(v[2 * j + 1], v[2 * j], sel);
         if (BS >= 8) {
             uint4 *o = reinterpret_cast<uint4 *>(dst);
 #pragma unroll
             for (int q = 0; q < BS / 8; q++) o[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
         }
     } else if (BYTES == 1) {
+        // four samples per word: their low bytes, two permutes and an or
         uint32_t w[BS / 4];
 #pragma unroll
         for (int j = 0; j < BS / 4; j++)
-            w[j] = (v[4 * j] & 0xFFu) | ((v[4 * j + 1] & 0xFFu) << 8) | ((v[4 * j + 2] & 0xFFu) << 16) |
-                   (v[4 * j + 3] << 24);
+            w[j] = __builtin_amdgcn_perm(v[4 * j + 1], v[4 * j], 0x0c0c0400u) |
+                   __builtin_amdgcn_perm(v[4 * j + 3], v[4 * j + 2], 0x04000c0cu);
         uint2 *o = reinterpret_cast<uint2 *>(dst);
 #pragma unroll
         for (int q = 0; q < BS / 8; q++) o[q] = make_uint2(w[2 * q], w[2 * q + 1]);

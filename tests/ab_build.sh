@@ -8,7 +8,7 @@ name=$1; flags=$2; shift 2; files=${@:-aec_dec.hip}
 R=$(cd $(dirname $0)/.. && pwd); O=$R/build/ab/$name; mkdir -p $O
 make -s -C $R/libaec_amd/csrc > /dev/null
 objs=""
-for o in aec_enc aec_dec aec_idx aec_shard aec_gpu aec_abi; do
+for o in aec_enc aec_dec aec_idx aec_region aec_shard aec_gpu aec_abi; do
   src=""; for f in $files; do [ "${f%.*}" = "$o" ] && src=$f; done
   if [ -n "$src" ]; then
     x=""; [ "${src##*.}" = "cpp" ] && x="-x hip"
