@@ -35,6 +35,11 @@ CASES = [
     ("16 MiB of 8-bit data without the preprocessor, rsi 128: the trunk is faster", 8, 8, 128, 0, 16_060_000, 8600, 0, TRUNK),
     ("1 MiB with rsi 1 and long coded data sets", 16, 64, 1, PP, 790_000, 800, 0, EVERY_BIT),
     ("16 MiB with rsi 1 and long coded data sets: scoring chains that carry the count", 24, 64, 1, PP, 7_800_000, 900, 0, LOCKED),
+    ("64 MiB of 8-bit noise: RSIs of uncompressed blocks mark no RSI start -- past the schemes that look for reference samples "
+     "(round 6); runs of uncompressed coded data sets start chains of their own in the window tables: 11 ms against the "
+     "trunk's 25", 8, 8, 128, PP, 70_178_074, 8566, 0, TABLES),
+    ("the same stream with a hint that is a look-ahead, not a mean (1.5 means: the ABI's): regions", 8, 8, 128, PP, 70_178_074, 12849, 0, REGIONS),
+    ("64 MiB of 16-bit noise", 16, 16, 128, PP, 68_154_718, 33278, 0, TRUNK),
     ("nothing to index", 16, 16, 128, PP, 0, 0, 0, SERIAL),
 ]
 
