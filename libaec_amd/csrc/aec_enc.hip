@@ -201,6 +201,49 @@ __device__ __forceinline__ uint32_t pp_unsigned_pk(uint32_t prev, uint32_t cur, 
     return unpk(__builtin_elementwise_min(folded, room + d));
 }
 
+// The mapped residuals of NW words of sample pairs in stream order (pw; `before` holds the sample in front of them in its
+// upper half).  Where nothing can clip -- every step of the stretch is at most the distance between its smallest and its
+// largest sample, R, and R fits the room between those and the ends of the range: one test per stretch, wave-wide -- a
+// residual is the zigzag of the difference (subtract, shift, sign, exclusive or: 4 packed instructions per pair against
+// 11 for pp_unsigned_pk, which the wavefronts with a lane near the ends of the range run as before).  |difference| <= R <=
+// xmax / 2 < 2^15, so the difference is exact as a signed 16-bit value and twice it fits 16 bits.
+// (try_fast: wave-uniform, the caller's; a stretch that does not pass ends the tests for the caller's remaining stretches
+// -- data that lives near an end of its range pays one test per segment, not one per stretch)
+template <uint32_t NW>
+__device__ __forceinline__ void pp_words_pk(const uint32_t *pw, uint32_t before, uint32_t xm, bool act, uint32_t *out,
+                                            bool &try_fast)
+{
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    if (!try_fast) {
+#pragma unroll
+        for (uint32_t j = 0; j < NW; j++)
+            out[j] = pp_unsigned_pk(__builtin_amdgcn_alignbit(pw[j], j ? pw[j - 1] : before, 16), pw[j], xm);
+        return;
+    }
+    u16x2 lo = pk((before >> 16) * 0x00010001u), hi = lo;
+#pragma unroll
+    for (uint32_t j = 0; j < NW; j++) {
+        lo = __builtin_elementwise_min(lo, pk(pw[j]));
+        hi = __builtin_elementwise_max(hi, pk(pw[j]));
+    }
+    const uint32_t lo_s = lo.x < lo.y ? lo.x : lo.y, hi_s = hi.x > hi.y ? hi.x : hi.y, range = hi_s - lo_s;
+    const bool fits = range <= lo_s && range <= (xm & 0xFFFFu) - hi_s;
+    if (!__any(act && !fits)) {
+        const u16x2 one = {1, 1}, fifteen = {15, 15};
+#pragma unroll
+        for (uint32_t j = 0; j < NW; j++) {
+            const u16x2 d = pk(pw[j]) - pk(__builtin_amdgcn_alignbit(pw[j], j ? pw[j - 1] : before, 16));
+            const i16x2 sign = __builtin_bit_cast(i16x2, d) >> __builtin_bit_cast(i16x2, fifteen);
+            out[j] = unpk(d << one) ^ (uint32_t)__builtin_bit_cast(uint32_t, sign);
+        }
+        return;
+    }
+    try_fast = false;
+#pragma unroll
+    for (uint32_t j = 0; j < NW; j++)
+        out[j] = pp_unsigned_pk(__builtin_amdgcn_alignbit(pw[j], j ? pw[j - 1] : before, 16), pw[j], xm);
+}
+
 template <int BS, int BYTES>
 struct FastSeg {
     static constexpr uint32_t CHUNKS = (uint32_t)BS * BYTES * 64u / 16u;       // per full segment
@@ -236,6 +279,7 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
     const bool msb = c.flags & F_MSB, pp = c.flags & F_PREPROCESS;
     const uint32_t nchunks = g.nv * (uint32_t)BS * BYTES / 16u;
     uint32_t carry = sample_byte_order<BYTES>(f.carry, msb);
+    bool try_fast = true;                          // (pp_words_pk)
 
 #pragma unroll
     for (uint32_t it = 0; it < FastSeg<BS, BYTES>::NIT; it++) {
@@ -274,12 +318,10 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
             const uint32_t before = wave_shr1(pw[NW - 1], cbias << 16);
             carry = wave_last(pw[NW - 1]) >> 16;
             if (sgn) carry ^= 1u << (c.bps - 1);       // back to the raw form the next round expects
+            const uint32_t xm = (sgn ? full : c.xmax) * 0x00010001u;
+            uint32_t dw[NW];
+            pp_words_pk<NW>(pw, before, xm, act, dw, try_fast);
             if (act) {
-                const uint32_t xm = (sgn ? full : c.xmax) * 0x00010001u;
-                uint32_t dw[NW];
-#pragma unroll
-                for (uint32_t j = 0; j < NW; j++)
-                    dw[j] = pp_unsigned_pk(__builtin_amdgcn_alignbit(pw[j], j ? pw[j - 1] : before, 16), pw[j], xm);
                 if (g.b0 == 0 && ci == 0) dw[0] &= 0xFFFF0000u;      // reference sample slot, encode.c:254
 #pragma unroll
                 for (uint32_t q = 0; q < NW / 4; q++) {
@@ -416,9 +458,8 @@ __device__ __forceinline__ void direct_finish(const Cfg &c, const Seg &g, const 
     }
     const uint32_t before = wave_shr1(pw[NW - 1], carry << 16);
     const uint32_t xm = (sgn ? full : c.xmax) * 0x00010001u;
-#pragma unroll
-    for (uint32_t j = 0; j < NW; j++)
-        w[j] = pp_unsigned_pk(__builtin_amdgcn_alignbit(pw[j], j ? pw[j - 1] : before, 16), pw[j], xm);
+    bool try_fast = true;
+    pp_words_pk<NW>(pw, before, xm, lane < g.nv, w, try_fast);
     if (g.b0 == 0 && lane == 0) w[0] &= 0xFFFF0000u;      // reference sample slot, encode.c:254
 }
 
