@@ -357,17 +357,44 @@ __device__ __forceinline__ void fast_finish(const Cfg &c, const Seg &g, const Fa
             if (!pp) {
 #pragma unroll
                 for (uint32_t j = 0; j < SPC; j++) dd[j] = x[j];
-            } else if (c.flags & F_SIGNED) {
-                uint32_t pv = sign_extend(prev, c.bps);
-#pragma unroll
-                for (uint32_t j = 0; j < SPC; j++) {
-                    const uint32_t cv = sign_extend(x[j], c.bps);
-                    dd[j] = pp_signed(pv, cv, c.xmin, c.xmax);
-                    pv = cv;
-                }
             } else {
+                // as pp_words_pk, for samples of more than 16 bits: the values as distances from xmin, their smallest and
+                // largest, the zigzag of the differences where nothing can clip (|difference| <= the stretch's range <=
+                // half the sample range < 2^31), the exact mapping otherwise -- and then for the rest of the segment
+                const bool sgn = c.flags & F_SIGNED;
+                bool fast = try_fast;
+                uint32_t u[SPC];
+                const uint32_t up = sgn ? sign_extend(prev, c.bps) - c.xmin : prev;
+                if (fast) {
+                    uint32_t lo = up, hi = up;
 #pragma unroll
-                for (uint32_t j = 0; j < SPC; j++) dd[j] = pp_unsigned(j ? x[j - 1] : prev, x[j], c.xmax);
+                    for (uint32_t j = 0; j < SPC; j++) {
+                        u[j] = sgn ? sign_extend(x[j], c.bps) - c.xmin : x[j];
+                        lo = u[j] < lo ? u[j] : lo;
+                        hi = u[j] > hi ? u[j] : hi;
+                    }
+                    const uint32_t range = hi - lo;
+                    fast = !__any(!(range <= lo && range <= (c.xmax - c.xmin) - hi));
+                    try_fast = fast;
+                }
+                if (fast) {
+#pragma unroll
+                    for (uint32_t j = 0; j < SPC; j++) {
+                        const uint32_t diff = u[j] - (j ? u[j - 1] : up);
+                        dd[j] = (diff << 1) ^ (uint32_t)((int32_t)diff >> 31);
+                    }
+                } else if (sgn) {
+                    uint32_t pv = sign_extend(prev, c.bps);
+#pragma unroll
+                    for (uint32_t j = 0; j < SPC; j++) {
+                        const uint32_t cv = sign_extend(x[j], c.bps);
+                        dd[j] = pp_signed(pv, cv, c.xmin, c.xmax);
+                        pv = cv;
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < SPC; j++) dd[j] = pp_unsigned(j ? x[j - 1] : prev, x[j], c.xmax);
+                }
             }
             if (pp && g.b0 == 0 && ci == 0) dd[0] = 0;   // reference sample slot, encode.c:254
             if (Rows<BS, BYTES>::HALF) {
