@@ -16,6 +16,13 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
+def held(codec):
+    """aec_gpu_held_bytes: device memory the context holds for its own purposes (index tables, encoder workspace)"""
+    import ctypes as C
+    codec.lib.aec_gpu_held_bytes.restype = C.c_size_t
+    return int(codec.lib.aec_gpu_held_bytes(codec.ctx))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c2")
@@ -63,7 +70,8 @@ def main():
         ok = bool(torch.equal(d_idx[:nr], d_off[:nr])) and int(res["n_rsi"]) == nr and int(res["end_bit"]) == bits
         print(f"{args.config} {mib} MiB: index {dt * 1e3:.3f} ms = {n / dt / 1e9:.3f} GB/s decoded-equivalent "
               f"({cbytes / dt / 1e9:.3f} GB/s of stream), n_rsi {int(res['n_rsi'])}/{nr}, "
-              f"status {int(res['status'])}, offsets {'OK' if ok else 'MISMATCH'}", flush=True)
+              f"status {int(res['status'])}, offsets {'OK' if ok else 'MISMATCH'}; the context holds "
+              f"{held(codec) / 2 ** 20:.0f} MiB (index tables and workspaces)", flush=True)
         assert ok
 
 
