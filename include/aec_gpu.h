@@ -165,8 +165,8 @@ AEC_GPU_API int aec_gpu_decode_segments_async(aec_gpu_ctx *ctx, const aec_gpu_pa
  * (about 20 kbit coded), cut by the end of the input or malformed are walked serially, so the
  * result never depends on the tables.  The look-ahead is sized from the expected coded RSI:
  * (input bits / max_rsi) unless aec_gpu_set_index_hint gave a better estimate (0 = back to default).
- * The call may allocate table workspace (768 MiB, for large streams up to six times the stream and 4 GiB; larger
- * inputs are indexed span by span).
+ * The call may allocate table workspace in the context (aec_gpu_held_bytes tells how much: 0.4 GB for 64 MiB, 2.3 GB for
+ * 4 GiB of 16-bit data, up to 4.5 GB for 4 GiB of 32-bit data; larger inputs are indexed span by span within that).
  */
 AEC_GPU_API void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits);
 /* 1 when the index pass of a stream of in_bytes whose coded RSIs average rsi_bits runs over the window tables
