@@ -173,12 +173,17 @@ AEC_GPU_API void aec_gpu_set_index_hint(aec_gpu_ctx *ctx, uint64_t rsi_bits);
  * (low-entropy streams, RSIs inside a 64-kbit window): cheap per call also for pieces of a few MiB, so a caller
  * may decode such a stream piece by piece and overlap one piece's transfers with the next one's kernels. */
 AEC_GPU_API int aec_gpu_index_is_windowed(const aec_gpu_params *p, size_t in_bytes, uint64_t rsi_bits);
-/* Which scheme the index pass of such a stream takes, given the workspace it asks for: 0 = the serial walk alone,
- * 1 = phase-locked chains (RSIs of at most 44 blocks; entries by plausibility for long coded data sets), 2 = window
- * tables, 3 = the trunk, 4 = every bit parsed and the RSI starts by pointer doubling (walked from an RSI start: streams
- * of at most 2 MiB with RSIs of at most 64 blocks or that the window tables do not serve, chunks of at most 128 KiB with
- * RSIs of up to 256 blocks; without the preprocessor streams of any size with RSIs of at most 256 blocks, piece by piece).  start_block != 0: a walk that
- * resumes inside an RSI (aec_gpu_index_resume_async).  Host arithmetic only; tests assert the path instead of a time. */
+/* Which scheme the index pass of such a stream takes FIRST, given the workspace it asks for (aec_gpu_index_async /
+ * aec_gpu_index_resume_async; with segment starts or as a piece of a longer stream schemes 4 and 1 are skipped):
+ * 0 = the serial walk alone, 1 = phase-locked chains (RSIs of at most 44 blocks; entries by plausibility for long coded
+ * data sets), 2 = window tables, 3 = the trunk, 4 = every bit parsed and the RSI starts by pointer doubling (streams of
+ * at most 2 MiB with RSIs of at most 64 blocks or that the window tables do not serve, chunks of at most 128 KiB with RSIs
+ * of up to 256 blocks, AEC_PAD_RSI and walks that resume inside an RSI included; without the preprocessor streams of any
+ * size with RSIs of at most 256 blocks, piece by piece; with it up to 4 MiB where entries would be guessed by
+ * plausibility), 5 = regions walked from guessed entries (large preprocessed streams).  A scheme that gives a stream up
+ * on the device (guesses judged wrong, tables that resolve too little) is followed by the next one enqueued behind it --
+ * scheme 4 behind 1 and 2 for streams of moderate size, then the serial walk -- which this function does not tell.
+ * start_block != 0: a walk that resumes inside an RSI.  Host arithmetic only; tests assert the path instead of a time. */
 AEC_GPU_API int aec_gpu_index_scheme(const aec_gpu_params *p, size_t in_bytes, uint64_t rsi_bits, unsigned int start_block);
 /* The NEXT index pass on ctx (one pass only) is handed a piece of a stream of which the caller holds more: an RSI
  * that the window tables leave unresolved within stop_near_bits of the end of the piece -- they end there for lack
