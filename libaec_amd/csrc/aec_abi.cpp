@@ -547,12 +547,22 @@ int decode_run(internal_state *s, struct aec_stream *strm)
     const uint8_t *d_bytes = static_cast<const uint8_t *>(obuf.p) + skip;
     size_t spec = max_rsi * rsi_bytes - skip;
     if (spec > kBounce) spec = kBounce;
+    const auto t_enq = std::chrono::steady_clock::now();                // (AEC_ABI_TRACE: where a batch's time goes)
     if (hipMemcpyAsync(s->h_res, d_idx, 2 * sizeof(aec_gpu_dec_result), hipMemcpyDeviceToHost, s->stream) !=
             hipSuccess ||
         hipMemcpyAsync(s->h_res + 128, d_off + max_rsi, 8, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
         hipMemcpyAsync(bounce, d_bytes, spec, hipMemcpyDeviceToHost, s->stream) != hipSuccess ||
         hipStreamSynchronize(s->stream) != hipSuccess)
         return AEC_FAIL(AEC_MEM_ERROR);
+    if (trace_on()) {
+        static thread_local std::chrono::steady_clock::time_point t_prev = t_enq;
+        const auto t_done = std::chrono::steady_clock::now();
+        fprintf(stderr, "libaec (MI355X): decode batch: %.3f ms since the batch in front was through, of which %.3f ms "
+                "waiting for this one's kernels after the last launch\n",
+                std::chrono::duration<double, std::milli>(t_done - t_prev).count(),
+                std::chrono::duration<double, std::milli>(t_done - t_enq).count());
+        t_prev = t_done;
+    }
     const aec_gpu_dec_result idx = reinterpret_cast<aec_gpu_dec_result *>(s->h_res)[0];
     const aec_gpu_dec_result dec = reinterpret_cast<aec_gpu_dec_result *>(s->h_res)[1];
     if (trace_on())
