@@ -12,6 +12,11 @@
 //             blocks of 16 or 32 bytes leave through LDS rows written out transposed, as whole
 //             64-byte sectors -- per-lane 16-byte stores 2 KiB apart bounded the kernel.
 //   (the index pass for streams that arrive without an offset table lives in aec_idx.hip)
+//
+// This file is compiled once per templated block size with -DAEC_DEC_PART=<0|8|16|32|64> (the kernels of that block size:
+// objects aec_dec_bs<N>.o) and once without (everything that does not depend on the block size, and the dispatch): a
+// process loads the code object of the block size it decodes, a fifth of the whole, with its first decode, and the five
+// parts compile side by side.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -24,6 +29,43 @@
 #include "aec_tune.h"
 
 namespace aec {
+
+// ---- decoding a bare stream segment by segment (launch_decode_bare) ---------------------------------------
+// What the summing pass leaves per segment.  With u = (sample in front of the segment) - xmin:  the samples of the
+// segment are u + (prefix sums of the steps) exactly when lo <= u <= hi, and then the sample behind the segment is
+// u + sum.  (For the first segment of an RSI u is the reference sample `ref` itself and the sums start behind it.)
+struct SegSum {
+    int64_t sum, lo, hi;
+    uint64_t end;          // bit behind the segment's last coded data set
+    uint32_t ref;          // first segment of an RSI: the reference sample (raw)
+    uint32_t ok;           // 1 = all blocks parsed, the segment ends on a coded data set
+};
+
+// what launch_decode_bare adds to a launch: the summing pass's output, or the list of RSIs to take
+struct BareArgs {
+    SegSum *sums = nullptr;
+    const uint32_t *list = nullptr, *list_cnt = nullptr;
+    uint64_t avg_hint = 0;         // bits per coded data set where the counts come from an index record
+};
+
+// The launch of one block size's kernels (defined in the object compiled with -DAEC_DEC_PART=BS, see the head of the file)
+struct DecLaunch {
+    const Cfg *c;
+    const uint32_t *words;
+    uint64_t nwords, end_bit;
+    const uint64_t *rsi_off;
+    const SegEntry *seg_table;
+    uint64_t n_items, total_blocks;
+    uint8_t *out;
+    DecResult *res;
+    hipStream_t st;
+    uint8_t *dump;
+    const DecResult *idx, *batch;
+    uint32_t rpc;
+    BareArgs ba;
+};
+template <int BS> void dec_part_bytes(bool seg, bool sums, const DecLaunch &a);      // k_decode<BS, ...>
+template <int BS> void dec_part_wave(const DecLaunch &a);                             // k_decode_wave<BS, ...>
 
 namespace {
 
@@ -234,17 +276,6 @@ __device__ __forceinline__ void ring_put4(uint32_t *col, uint32_t slot0, uint32_
         col[(mask + 2u) * 64u] = y;
     }
 }
-
-// ---- decoding a bare stream segment by segment (launch_decode_bare) ---------------------------------------
-// What the summing pass leaves per segment.  With u = (sample in front of the segment) - xmin:  the samples of the
-// segment are u + (prefix sums of the steps) exactly when lo <= u <= hi, and then the sample behind the segment is
-// u + sum.  (For the first segment of an RSI u is the reference sample `ref` itself and the sums start behind it.)
-struct SegSum {
-    int64_t sum, lo, hi;
-    uint64_t end;          // bit behind the segment's last coded data set
-    uint32_t ref;          // first segment of an RSI: the reference sample (raw)
-    uint32_t ok;           // 1 = all blocks parsed, the segment ends on a coded data set
-};
 
 // accumulator of the summing pass: 32 bits carry a segment of up to 4096 samples of at most 16 bits
 template <int BYTES>
@@ -1275,6 +1306,7 @@ k_decode_wave(const Cfg c, const uint32_t *__restrict__ words, uint64_t nwords, 
     if (lane == 0 && r + 1 == n_rsi) res->end_bit = pp ? xcarry : 0u;
 }
 
+#ifndef AEC_DEC_PART                  // (what does not depend on the block size: the one object without a part)
 // ---- the coded data set the input ends in ------------------------------------------------------------
 // The reference's resumable readers release every sample whose bits have arrived, also from a coded
 // data set that is cut by the end of the input (reference src/decode.c:342-400 bits_ask / fs_ask,
@@ -1384,6 +1416,7 @@ uint8_t *dump_buffer()
     }
     return buf[dev];
 }
+#endif
 
 struct DecGeom {
     uint32_t ring_words, maxw, needw, waves, grid;
@@ -1438,13 +1471,6 @@ DecGeom dec_geom(const Cfg &c, uint64_t n_rsi, uint64_t avg_cds_bits, uint32_t s
     return g;
 }
 
-// what launch_decode_bare adds to a launch: the summing pass's output, or the list of RSIs to take
-struct BareArgs {
-    SegSum *sums = nullptr;
-    const uint32_t *list = nullptr, *list_cnt = nullptr;
-    uint64_t avg_hint = 0;         // bits per coded data set where the counts come from an index record
-};
-
 template <int BS, bool SEG, bool SUMS = false>
 void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, uint64_t end_bit,
                          const uint64_t *rsi_off, const SegEntry *seg_table, uint64_t n_rsi,
@@ -1486,6 +1512,103 @@ void launch_decode_bytes(const Cfg &c, const uint32_t *words, uint64_t nwords, u
 
 }  // namespace
 
+#ifdef AEC_DEC_PART
+// ---- the kernels of ONE block size (this object: -DAEC_DEC_PART=<block size>, 0 = any other) --------------------------------
+template <int BS>
+void dec_part_bytes(bool seg, bool sums, const DecLaunch &a)
+{
+    const Cfg &c = *a.c;
+    if constexpr (BS == 0) {
+        // generic block sizes and containers: the sample-by-sample reader has no second attempt: full ring
+        const DecGeom g = dec_geom(c, a.n_items, 0, 0u);
+        if (seg)
+            hipLaunchKernelGGL((k_decode<0, 0, true, 2>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, a.st, c, a.words, a.nwords,
+                               a.end_bit, a.rsi_off, a.seg_table, a.n_items, a.total_blocks, a.out, a.res, g.ring_words, g.maxw,
+                               g.needw, a.dump, a.idx, a.batch, a.rpc, (SegSum *)nullptr, (const uint32_t *)nullptr,
+                               (const uint32_t *)nullptr);
+        else
+            hipLaunchKernelGGL((k_decode<0, 0, false, 2>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, a.st, c, a.words, a.nwords,
+                               a.end_bit, a.rsi_off, a.seg_table, a.n_items, a.total_blocks, a.out, a.res, g.ring_words, g.maxw,
+                               g.needw, a.dump, a.idx, a.batch, a.rpc, (SegSum *)nullptr, (const uint32_t *)nullptr,
+                               (const uint32_t *)nullptr);
+    } else if (sums) {
+        launch_decode_bytes<BS, true, true>(c, a.words, a.nwords, a.end_bit, a.rsi_off, a.seg_table, a.n_items, a.total_blocks,
+                                            a.out, a.res, a.st, a.dump, a.idx, a.batch, a.rpc, a.ba);
+    } else if (seg) {
+        launch_decode_bytes<BS, true, false>(c, a.words, a.nwords, a.end_bit, a.rsi_off, a.seg_table, a.n_items, a.total_blocks,
+                                             a.out, a.res, a.st, a.dump, a.idx, a.batch, a.rpc, a.ba);
+    } else {
+        launch_decode_bytes<BS, false, false>(c, a.words, a.nwords, a.end_bit, a.rsi_off, a.seg_table, a.n_items, a.total_blocks,
+                                              a.out, a.res, a.st, a.dump, a.idx, a.batch, a.rpc, a.ba);
+    }
+}
+
+template <int BS>
+void dec_part_wave(const DecLaunch &a)
+{
+    const Cfg &c = *a.c;
+    constexpr int B = BS;
+    const uint32_t waves = 2;                            // (~24 KB of LDS per wavefront: six of them on a CU)
+    const dim3 grid((uint32_t)((a.n_items + waves - 1) / waves)), block(64 * waves);
+    const size_t lds = (size_t)waves * dw_wave_words(c) * 4;
+#define AEC_WV2(BY)                                                                                                     \
+    hipLaunchKernelGGL((k_decode_wave<B, BY>), grid, block, lds, a.st, c, a.words, a.nwords, a.end_bit, a.rsi_off, a.n_items, \
+                       a.total_blocks, a.out, a.res, a.dump, a.idx, a.batch, a.rpc)
+#ifdef AEC_TUNING
+    static const bool dw_prof = tune("AEC_DW_PROF", 0) != 0;
+    if (dw_prof) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dw_prof), z, sizeof(z), 0, hipMemcpyHostToDevice, a.st);
+    }
+#endif
+    switch (c.bytes) {
+    case 1: AEC_WV2(1); break;
+    case 2: AEC_WV2(2); break;
+    case 3: AEC_WV2(3); break;
+    default: AEC_WV2(4); break;
+    }
+#undef AEC_WV2
+#ifdef AEC_TUNING
+    if (dw_prof) {
+        static int reports = 0;
+        if (reports++ < 6) {
+            unsigned long long h[8];
+            (void)hipStreamSynchronize(a.st);
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dw_prof), sizeof(h));
+            fprintf(stderr, "k_decode_wave, RSI 0 (s_memtime ticks): refills %llu | pieces %llu | walk incl. those %llu | "
+                    "+ decode %llu | + predictor, store %llu\n", h[0], h[1], h[2], h[3], h[4]);
+        }
+    }
+#endif
+}
+
+template void dec_part_bytes<AEC_DEC_PART>(bool, bool, const DecLaunch &);
+#if AEC_DEC_PART != 0
+template void dec_part_wave<AEC_DEC_PART>(const DecLaunch &);
+#endif
+
+#else       // ---- the object without a part: dispatch, and what does not depend on the block size ---------------------
+extern template void dec_part_bytes<0>(bool, bool, const DecLaunch &);
+extern template void dec_part_bytes<8>(bool, bool, const DecLaunch &);
+extern template void dec_part_bytes<16>(bool, bool, const DecLaunch &);
+extern template void dec_part_bytes<32>(bool, bool, const DecLaunch &);
+extern template void dec_part_bytes<64>(bool, bool, const DecLaunch &);
+extern template void dec_part_wave<8>(const DecLaunch &);
+extern template void dec_part_wave<16>(const DecLaunch &);
+extern template void dec_part_wave<32>(const DecLaunch &);
+extern template void dec_part_wave<64>(const DecLaunch &);
+
+static void dec_part_bytes_bs(uint32_t bs, bool seg, bool sums, const DecLaunch &a)
+{
+    switch (bs) {
+    case 8: dec_part_bytes<8>(seg, sums, a); break;
+    case 16: dec_part_bytes<16>(seg, sums, a); break;
+    case 32: dec_part_bytes<32>(seg, sums, a); break;
+    case 64: dec_part_bytes<64>(seg, sums, a); break;
+    default: dec_part_bytes<0>(seg, sums, a); break;
+    }
+}
+
 // Few RSIs, each long enough to keep a wavefront's lanes busy: a wavefront per RSI (k_decode_wave) instead of a lane.
 // A lane per RSI needs ~260 000 RSIs to fill the chip and takes as long as ONE RSI's serial chain however few there
 // are; a wavefront per RSI costs ~7 times the instructions per RSI, which only matters once the chip is full.
@@ -1520,61 +1643,17 @@ static bool launch_decode_any(const Cfg &c, const uint8_t *d_in, size_t in_bytes
     // vector stores need 16-byte aligned blocks
     const bool vec_ok = (reinterpret_cast<uintptr_t>(d_out) & 15u) == 0;
     const uint32_t bs = vec_ok ? c.bs : 0;
+    DecLaunch a{&c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc,
+                BareArgs()};
     if (!SEG && bs && dec_wave_wanted(c, n_items)) {
-        const uint32_t waves = 2;                            // (~24 KB of LDS per wavefront: six of them on a CU)
-        const dim3 grid((uint32_t)((n_items + waves - 1) / waves)), block(64 * waves);
-        const size_t lds = (size_t)waves * dw_wave_words(c) * 4;
-#define AEC_WV2(BSV, B)                                                                                              \
-    hipLaunchKernelGGL((k_decode_wave<BSV, B>), grid, block, lds, st, c, words, nwords, end_bit, d_rsi_off, n_items, \
-                       total_blocks, d_out, d_res, dump, d_idx, d_batch, rpc)
-#define AEC_WV(BSV)                                                                                                  \
-    switch (c.bytes) {                                                                                               \
-    case 1: AEC_WV2(BSV, 1); break;                                                                                  \
-    case 2: AEC_WV2(BSV, 2); break;                                                                                  \
-    case 3: AEC_WV2(BSV, 3); break;                                                                                  \
-    default: AEC_WV2(BSV, 4); break;                                                                                 \
-    }
-#ifdef AEC_TUNING
-        static const bool dw_prof = tune("AEC_DW_PROF", 0) != 0;
-        if (dw_prof) {
-            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dw_prof), z, sizeof(z), 0, hipMemcpyHostToDevice, st);
-        }
-#endif
         switch (bs) {
-        case 8: AEC_WV(8); break;
-        case 16: AEC_WV(16); break;
-        case 32: AEC_WV(32); break;
-        default: AEC_WV(64); break;
+        case 8: dec_part_wave<8>(a); break;
+        case 16: dec_part_wave<16>(a); break;
+        case 32: dec_part_wave<32>(a); break;
+        default: dec_part_wave<64>(a); break;
         }
-#undef AEC_WV
-#undef AEC_WV2
-#ifdef AEC_TUNING
-        if (dw_prof) {
-            static int reports = 0;
-            if (reports++ < 6) {
-                unsigned long long h[8];
-                (void)hipStreamSynchronize(st);
-                (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dw_prof), sizeof(h));
-                fprintf(stderr, "k_decode_wave, RSI 0 (s_memtime ticks): refills %llu | pieces %llu | walk incl. those %llu | "
-                        "+ decode %llu | + predictor, store %llu\n", h[0], h[1], h[2], h[3], h[4]);
-            }
-        }
-#endif
-    } else
-    switch (bs) {
-    case 8: launch_decode_bytes<8, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc); break;
-    case 16: launch_decode_bytes<16, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc); break;
-    case 32: launch_decode_bytes<32, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc); break;
-    case 64: launch_decode_bytes<64, SEG>(c, words, nwords, end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, st, dump, d_idx, d_batch, rpc); break;
-    default:
-    {
-        const DecGeom g = dec_geom(c, n_items, 0, 0u);   // the sample-by-sample reader has no second attempt: full ring
-        hipLaunchKernelGGL((k_decode<0, 0, SEG, 2>), dim3(g.grid), dim3(64 * g.waves), g.lds_bytes, st, c, words, nwords,
-                           end_bit, d_rsi_off, d_seg, n_items, total_blocks, d_out, d_res, g.ring_words, g.maxw, g.needw, dump, d_idx, d_batch, rpc,
-                           (SegSum *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
-        break;
-    }
+    } else {
+        dec_part_bytes_bs(bs, SEG, false, a);
     }
     if (prof) (void)hipEventRecord(prof->ev[6], st);
     // (behind the timed kernel: returns at once unless k_decode raised kDecRedo)
@@ -1709,22 +1788,22 @@ bool launch_decode_bare(const Cfg &c, const uint8_t *d_in, size_t in_bytes, cons
     a_list.list = list;
     a_list.list_cnt = list_cnt;
     a_sum.avg_hint = a_seg.avg_hint = a_list.avg_hint = avg_cds_hint;
-#define AEC_BARE(BS)                                                                                                   \
-    launch_decode_bytes<BS, true, true>(c, words, nwords, end_bit, d_seg_bits, nullptr, n_items, total_blocks, nullptr, \
-                                        d_res, st, dump, d_idx, nullptr, 0u, a_sum);                                   \
-    hipLaunchKernelGGL(k_seg_scan, dim3((uint32_t)((n_rsi + 255) / 256)), dim3(256), 0, st, c, d_rsi_off, d_seg_bits,  \
-                       sums, n_rsi, total_blocks, d_idx, table, list, list_cnt);                                       \
-    launch_decode_bytes<BS, true, false>(c, words, nwords, end_bit, nullptr, table, n_items, total_blocks, d_out,      \
-                                         d_res, st, dump, d_idx, nullptr, 0u, a_seg);                                  \
-    launch_decode_bytes<BS, false, false>(c, words, nwords, end_bit, d_rsi_off, nullptr, n_rsi, total_blocks, d_out,   \
-                                          d_res, st, dump, d_idx, nullptr, 0u, a_list)
-    switch (c.bs) {
-    case 8: AEC_BARE(8); break;
-    case 16: AEC_BARE(16); break;
-    case 32: AEC_BARE(32); break;
-    default: AEC_BARE(64); break;
-    }
-#undef AEC_BARE
+    // (summing pass over the segments, scan per RSI, a lane per segment, a lane per RSI of the list)
+    DecLaunch l{&c, words, nwords, end_bit, d_seg_bits, nullptr, n_items, total_blocks, nullptr, d_res, st, dump, d_idx, nullptr, 0u,
+                a_sum};
+    dec_part_bytes_bs(c.bs, true, true, l);
+    hipLaunchKernelGGL(k_seg_scan, dim3((uint32_t)((n_rsi + 255) / 256)), dim3(256), 0, st, c, d_rsi_off, d_seg_bits,
+                       sums, n_rsi, total_blocks, d_idx, table, list, list_cnt);
+    l.rsi_off = nullptr;
+    l.seg_table = table;
+    l.out = d_out;
+    l.ba = a_seg;
+    dec_part_bytes_bs(c.bs, true, false, l);
+    l.rsi_off = d_rsi_off;
+    l.seg_table = nullptr;
+    l.n_items = n_rsi;
+    l.ba = a_list;
+    dec_part_bytes_bs(c.bs, false, false, l);
     if (prof) (void)hipEventRecord(prof->ev[6], st);
     // (behind the timed kernels: return at once unless a k_decode raised kDecRedo)
     const uint64_t w_seg = (n_items + 63) / 64, w_rsi = (n_rsi + 63) / 64;
@@ -1744,5 +1823,6 @@ bool launch_decode_segments(const Cfg &c, const uint8_t *d_in, size_t in_bytes, 
     return launch_decode_any<true>(c, d_in, in_bytes, nullptr, d_seg_table, n_seg, total_blocks, d_out, d_res, st,
                                    prof);
 }
+#endif      // AEC_DEC_PART
 
 }  // namespace aec

@@ -20,6 +20,9 @@
 //
 // HBM traffic per input byte: 2 reads of the input + 4/(bs*bytes) summary write+read
 // + 1 write of the compressed stream.  Algorithmic bytes are N + C.
+//
+// Compiled once per templated block size with -DAEC_ENC_PART=<0|8|16|32|64> (k_analyze / k_pack / k_encode_fused of that
+// block size: objects aec_enc_bs<N>.o) and once without (scans, batch kernels, dispatch), as aec_dec.hip is.
 #include <hip/hip_runtime.h>
 
 #include "aec_kernels.h"
@@ -31,6 +34,17 @@
 #define AEC_ENC_GRP64 0
 #endif
 namespace aec {
+
+struct FusedGeom {
+    uint32_t waves, segs, nparts, parts_per_wg, grid, obuf_words;
+    size_t lds_bytes;
+};
+// The launches of one block size's kernels (defined in the object compiled with -DAEC_ENC_PART=BS)
+template <int BS> void enc_part(bool pack, const Cfg &c, const uint8_t *in, const EncWorkspace &ws, uint32_t *out_words,
+                                uint64_t cap_words, uint32_t fast_ok, hipStream_t st);
+template <int BS> void enc_part_fused(const Cfg &c, const uint8_t *in, uint32_t *out_words, uint64_t cap_words,
+                                      const FusedGeom &g, void *ctl, uint32_t start_bit, uint32_t k_in, uint64_t *rsi_off,
+                                      SegEntry *seg_table, EncResult *res, uint32_t fast_ok, hipStream_t st);
 
 namespace {
 
@@ -857,6 +871,7 @@ __device__ __forceinline__ ScanVal block_excl_scan(ScanVal v, ScanVal &total, Sc
     return scan_then(wprefix, exc);
 }
 
+#ifndef AEC_ENC_PART                  // (what does not depend on the block size)
 constexpr uint32_t kScanItems = 8;   // kScanChunk = 256 * 8
 
 __global__ void __launch_bounds__(256)
@@ -1063,6 +1078,7 @@ k_seg_table(const Cfg c, const uint8_t *__restrict__ in, const uint64_t *__restr
     }
     table[sg] = SegEntry{seg_start[sg], prev, 0u};
 }
+#endif
 
 // Emission of one segment into its LDS image (rows in LDS, block summaries in registers): offsets
 // inside the segment by a DPP prefix sum of the lengths, k by the DPP clamp scan from the k carried
@@ -1665,26 +1681,6 @@ void dispatch_bytes(bool pack, const Cfg &c, const uint8_t *in, const EncWorkspa
 #undef AEC_GO
 }
 
-void dispatch(bool pack, const Cfg &c, const uint8_t *in, const EncWorkspace &ws, uint32_t *out_words,
-              uint64_t cap_words, uint32_t fast_ok, hipStream_t st)
-{
-    switch (c.bs) {
-    case 8: dispatch_bytes<8>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
-    case 16: dispatch_bytes<16>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
-    case 32: dispatch_bytes<32>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
-    case 64: dispatch_bytes<64>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
-    default:
-        if (pack) launch_pack_t<0, 0>(c, in, ws, out_words, cap_words, 0, st);
-        else launch_analyze_t<0, 0>(c, in, ws, 0, st);
-        break;
-    }
-}
-
-struct FusedGeom {
-    uint32_t waves, segs, nparts, parts_per_wg, grid, obuf_words;
-    size_t lds_bytes;
-};
-
 // waves per workgroup and segments per wave of the fused kernel: as many segments per wave as keep
 // three or more workgroups on a CU (the look-back costs per partition), at least one
 FusedGeom fused_geom(const Cfg &c)
@@ -1766,6 +1762,57 @@ void launch_fused_bytes(const Cfg &c, const uint8_t *in, uint32_t *out_words, ui
 
 }  // namespace
 
+#ifdef AEC_ENC_PART
+// ---- the kernels of ONE block size (this object: -DAEC_ENC_PART=<block size>, 0 = any other) --------------------------------
+template <int BS>
+void enc_part(bool pack, const Cfg &c, const uint8_t *in, const EncWorkspace &ws, uint32_t *out_words, uint64_t cap_words,
+              uint32_t fast_ok, hipStream_t st)
+{
+    if constexpr (BS == 0) {
+        if (pack) launch_pack_t<0, 0>(c, in, ws, out_words, cap_words, 0, st);
+        else launch_analyze_t<0, 0>(c, in, ws, 0, st);
+    } else {
+        dispatch_bytes<BS>(pack, c, in, ws, out_words, cap_words, fast_ok, st);
+    }
+}
+template <int BS>
+void enc_part_fused(const Cfg &c, const uint8_t *in, uint32_t *out_words, uint64_t cap_words, const FusedGeom &g, void *ctl,
+                    uint32_t start_bit, uint32_t k_in, uint64_t *rsi_off, SegEntry *seg_table, EncResult *res,
+                    uint32_t fast_ok, hipStream_t st)
+{
+    launch_fused_bytes<BS>(c, in, out_words, cap_words, g, ctl, start_bit, k_in, rsi_off, seg_table, res, fast_ok, st);
+}
+template void enc_part<AEC_ENC_PART>(bool, const Cfg &, const uint8_t *, const EncWorkspace &, uint32_t *, uint64_t, uint32_t,
+                                     hipStream_t);
+#if AEC_ENC_PART != 0
+template void enc_part_fused<AEC_ENC_PART>(const Cfg &, const uint8_t *, uint32_t *, uint64_t, const FusedGeom &, void *,
+                                           uint32_t, uint32_t, uint64_t *, SegEntry *, EncResult *, uint32_t, hipStream_t);
+#endif
+
+#else       // ---- the object without a part ------------------------------------------------------------------------
+#define AEC_ENC_EXTERN(BS)                                                                                                  \
+    extern template void enc_part<BS>(bool, const Cfg &, const uint8_t *, const EncWorkspace &, uint32_t *, uint64_t, uint32_t, \
+                                      hipStream_t);
+AEC_ENC_EXTERN(0) AEC_ENC_EXTERN(8) AEC_ENC_EXTERN(16) AEC_ENC_EXTERN(32) AEC_ENC_EXTERN(64)
+#undef AEC_ENC_EXTERN
+#define AEC_ENC_EXTERN(BS)                                                                                                  \
+    extern template void enc_part_fused<BS>(const Cfg &, const uint8_t *, uint32_t *, uint64_t, const FusedGeom &, void *,    \
+                                            uint32_t, uint32_t, uint64_t *, SegEntry *, EncResult *, uint32_t, hipStream_t);
+AEC_ENC_EXTERN(8) AEC_ENC_EXTERN(16) AEC_ENC_EXTERN(32) AEC_ENC_EXTERN(64)
+#undef AEC_ENC_EXTERN
+
+static void dispatch(bool pack, const Cfg &c, const uint8_t *in, const EncWorkspace &ws, uint32_t *out_words,
+                     uint64_t cap_words, uint32_t fast_ok, hipStream_t st)
+{
+    switch (c.bs) {
+    case 8: enc_part<8>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
+    case 16: enc_part<16>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
+    case 32: enc_part<32>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
+    case 64: enc_part<64>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
+    default: enc_part<0>(pack, c, in, ws, out_words, cap_words, fast_ok, st); break;
+    }
+}
+
 // The single-pass kernel is bit-exact (tests/fused_edges.py, and the whole 4 GiB stream of the bench
 // against the CPU reference) but SLOWER than the analyze / scan / pack trio on MI355X: 5.5 ms against
 // 3.74 ms at C2 (4 GiB; 6.9 ms with 4 segments per wave, 7.4 ms with 1).  Keeping the rows of a wave's
@@ -1825,10 +1872,10 @@ void launch_encode(const Cfg &c, const uint8_t *d_in, uint8_t *d_out, size_t out
         mark(2);
         mark(3);
         switch (c.bs) {
-        case 8: launch_fused_bytes<8>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
-        case 16: launch_fused_bytes<16>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
-        case 32: launch_fused_bytes<32>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
-        default: launch_fused_bytes<64>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
+        case 8: enc_part_fused<8>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
+        case 16: enc_part_fused<16>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
+        case 32: enc_part_fused<32>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
+        default: enc_part_fused<64>(c, d_in, out_words, cap_words, g, ws.fused_ctl, start_bit, k_in, d_rsi_off, d_seg_table, d_res, fast_ok, st); break;
         }
         mark(4);
         return;
@@ -1886,5 +1933,7 @@ void launch_encode_uniform_batch(const Cfg &c, const uint8_t *d_in, uint64_t seg
                        d_chunks, ws.seg_start, ws.seg_kin, out_words, cap_words, make_geom(c, true).segs_per_wave);
     dispatch(true, c, d_in, ws, out_words, cap_words, fast_ok, st);
 }
+
+#endif      // AEC_ENC_PART
 
 }  // namespace aec
