@@ -56,6 +56,9 @@ for c in c2 c3 c5 typical; do python3 tests/bench_abi_large.py --config $c 2>&1 
 python3 tests/bench_sz_chunks.py 2>&1 | grep -v amdgpu > $OUT/bench_sz_chunks.txt
 python3 tests/bench_sz_chunks.py --narrow 2>&1 | grep -v amdgpu >> $OUT/bench_sz_chunks.txt
 python3 tests/bench_short_rsi.py 2>&1 | grep -v amdgpu > $OUT/bench_short_rsi.txt
+python3 tests/bench_short_rsi.py --size-kib 64 --rsi 1 4 16 32 64 128 2>&1 | grep -v amdgpu >> $OUT/bench_short_rsi.txt
+python3 tests/bench_short_rsi.py --size-mib 1 2>&1 | grep -v amdgpu >> $OUT/bench_short_rsi.txt
+python3 tests/bench_short_rsi.py --edges 2>&1 | grep -v amdgpu > $OUT/bench_short_rsi_edges.txt
 python3 tests/bench_degenerate.py --size-mib 64 2>&1 | grep -v amdgpu > $OUT/bench_degenerate.txt
 # kernel trace of small one-shot decodes (which kernels a 64 KiB call is made of) and the wave-per-RSI decoder's phases
 bash tests/prof_small.sh $1/small > /dev/null 2>&1
