@@ -136,6 +136,59 @@ def phases_decode(src_dir):
     return t
 
 
+def phases_encode(src_dir):
+    """(file, first line, last line, phase, hot) for k_analyze / k_pack: by function (the steady-state path is the packed
+    16-bit one of the templated block sizes; the generic loaders and writers are listed as rare)."""
+    enc = open(os.path.join(src_dir, "aec_enc.hip")).read().split("\n")
+    lane = open(os.path.join(src_dir, "aec_lane.h")).read().split("\n")
+    E = lambda p, s=0: find(enc, p, s)
+    L = lambda p, s=0: find(lane, p, s)
+    t = []
+
+    def fn(lines, fname, start_pat, phase, hot, table):
+        a = find(lines, start_pat)
+        b = a
+        depth = 0
+        seen = False
+        for i in range(a - 1, len(lines)):                 # to the closing brace of the function
+            depth += lines[i].count("{") - lines[i].count("}")
+            seen = seen or "{" in lines[i]
+            if seen and depth == 0:
+                b = i + 1
+                break
+        table.append((fname, a, b, phase, hot))
+
+    A = "phase A: loads, byte order, mapped residuals (predictor), rows to LDS"
+    fn(enc, "aec_enc.hip", r"void wave_lds_fence\(", "LDS fences, wave scans (DPP)", True, t)
+    fn(enc, "aec_enc.hip", r"uint32_t wave_scan_dpp\(", "LDS fences, wave scans (DPP)", True, t)
+    fn(enc, "aec_enc.hip", r"__forceinline__ Seg seg_geom\(", "segment geometry (64-bit divisions, once per segment)", True, t)
+    fn(enc, "aec_enc.hip", r"uint32_t pp_unsigned_pk\(", "rare: the exact mapping (stretches near the ends of the range)", False, t)
+    fn(enc, "aec_enc.hip", r"void pp_words_pk\(", A, True, t)
+    fn(enc, "aec_enc.hip", r"void fast_issue\(", A, True, t)
+    fn(enc, "aec_enc.hip", r"void fast_finish\(", A, True, t)
+    fn(enc, "aec_enc.hip", r"void direct_issue\(", A, True, t)
+    fn(enc, "aec_enc.hip", r"void direct_finish\(", A, True, t)
+    fn(enc, "aec_enc.hip", r"void load_segment_generic\(", "rare: generic loader (ragged ends, odd block sizes)", False, t)
+    fn(enc, "aec_enc.hip", r"^struct Feeder \{", A, True, t)
+    fn(enc, "aec_enc.hip", r"^struct BlockRegs \{", "block out of its LDS row into registers", True, t)
+    fn(enc, "aec_enc.hip", r"bool block_is_zero\(", "option selection (fs(k) by packed shifts and dot products, second extension, choice)", True, t)
+    fn(enc, "aec_enc.hip", r"BlockChoice choose_option_pk\(", "option selection (fs(k) by packed shifts and dot products, second extension, choice)", True, t)
+    fn(enc, "aec_enc.hip", r"uint32_t analyze_segment\(", "segment: zero runs by ballot, lengths, k clamps, summaries", True, t)
+    fn(enc, "aec_enc.hip", r"void emit_segment\(", "segment: prefix sum of lengths, k per block, emission control", True, t)
+    for pat, ph, hot in ((r"AEC_HD void assess_split_with\(", "option selection (fs(k) by packed shifts and dot products, second extension, choice)", True),
+                         (r"AEC_HD BlockChoice choose_from\(", "option selection (fs(k) by packed shifts and dot products, second extension, choice)", True),
+                         (r"AEC_HD uint32_t zero_run_at\(", "segment: zero runs by ballot, lengths, k clamps, summaries", True),
+                         (r"^struct BitWriter \{", "bit writer (LDS image of the segment: shifts, atomic or)", True),
+                         (r"AEC_HD void emit_block\(", "rare: emission code by code (blocks of more than 16 samples, long codes)", False),
+                         (r"AEC_HD bool small_eligible\(", "emission of a block of up to 16 samples: unary and field regions in two 64-bit registers", True),
+                         (r"AEC_HD void emit_small\(", "emission of a block of up to 16 samples: unary and field regions in two 64-bit registers", True)):
+        fn(lane, "aec_lane.h", pat, ph, hot, t)
+    # kernels' own bodies
+    fn(enc, "aec_enc.hip", r"^k_analyze\(const Cfg c", "kernel loop: segments of a wave, prefetch of the next, summaries out", True, t)
+    fn(enc, "aec_enc.hip", r"^k_pack\(const Cfg c", "kernel loop: segments of a wave, LDS image copied out byte-swapped, shared words", True, t)
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("asm")
@@ -143,6 +196,7 @@ def main():
     ap.add_argument("--samples", type=int, default=32, help="samples the steady-state loop body covers")
     ap.add_argument("--lines", action="store_true", help="list the counts per source line as well")
     ap.add_argument("--src", default=CSRC, help="directory of the sources the listing was compiled from")
+    ap.add_argument("--encoder", action="store_true", help="the phase table of k_analyze / k_pack instead of k_decode's")
     args = ap.parse_args()
     files = {}
     body = []
@@ -160,7 +214,7 @@ def main():
                     break
     if not body:
         raise SystemExit("kernel not found")
-    table = phases_decode(args.src)
+    table = phases_encode(args.src) if args.encoder else phases_decode(args.src)
     instr = re.compile(r"^\t([vsd]_[a-z0-9_]+|ds_[a-z0-9_]+|global_[a-z0-9_]+|buffer_[a-z0-9_]+|flat_[a-z0-9_]+)\s")
 
     def phase_of(loc):
