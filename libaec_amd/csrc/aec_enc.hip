@@ -668,18 +668,24 @@ __device__ __forceinline__ BlockChoice choose_option_pk(const uint32_t *w, const
     if (c.id_len > 1) assess_split_with(fs, n, c.kmax, klo, khi, split_len);
     // second extension (aec_lane.h assess_se): a pair is the two halves of a word; their sum stays
     // below 2^17, so the reference's 64-bit wrap case cannot occur here
+    // (round 6) The reference adds (a + b)(a + b + 1) / 2 + b + 1 pair by pair and gives up once the length passes the
+    // limit (encode.c:412-434); the terms are positive, so that is "the whole sum passes the limit", and the whole sum is
+    // 1 + (sum of s^2 + sum of s) / 2 + sum of b + pairs with s = a + b: per pair two dot products, a multiply-add, an or
+    // and an add instead of a dozen instructions with their compares and selects.  A pair sum of 2^13 and more is beyond
+    // any limit (<= 64 x 16 bits) by itself -- the or of all pair sums tells -- and below that nothing overflows 32 bits.
     const uint32_t limit = n * c.bps;
-    uint32_t len = 1;
-    bool over = false;
+    const u16x2 second = {0, 1};
+    uint32_t s_all = 0, s_sq = 0, s_b = 0, s_or = 0;
 #pragma unroll
     for (int j = 0; j < BS / 2; j++) {
-        const uint32_t b = w[j] >> 16;
         const uint32_t sum = __builtin_amdgcn_udot2(pk(w[j]), ones, 0u, false);
-        const uint32_t add = sum * (sum + 1u) / 2u + b + 1u;        // only used while sum < 2^15
-        const bool bad = sum >= 32768u || len + add > limit;
-        len = (over || bad) ? len : len + add;
-        over = over || bad;
+        s_or |= sum;
+        s_all += sum;
+        s_sq += __umul24(sum, sum);                                   // (sum < 2^13 wherever the result is used)
+        s_b = __builtin_amdgcn_udot2(pk(w[j]), second, s_b, false);
     }
+    const uint32_t len = 1u + (s_sq + s_all) / 2u + s_b + (uint32_t)BS / 2u;
+    const bool over = (s_or >> 13) != 0u || len > limit;
     return choose_from(c, (uint32_t)BS, ref, split_len, over ? 0xFFFFFFFFu : len, klo, khi);
 }
 
